@@ -1,0 +1,94 @@
+"""ctypes binding of libemgraph_hip.so (include/emgraph_hip.h).
+
+The HIP library IS the product's compute path.  There is no CPU fallback: if the shared object is
+missing or a call fails this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libemgraph_hip.so")
+
+# ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
+ABI_VERSION = 1
+TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE = range(5)
+SIDE_S, SIDE_O, SIDE_SO = range(3)
+LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
+OPT_SGD, OPT_MOMENTUM, OPT_ADAGRAD, OPT_ADAM, OPT_ADAM_LAZY = range(5)
+SCORE_FINAL, SCORE_PARTIAL = 0, 1
+EVAL_S, EVAL_O, EVAL_SPO, EVAL_S_O = range(4)
+
+LOSS_IDS = {"pairwise": LOSS_PAIRWISE, "nll": LOSS_NLL, "absolute_margin": LOSS_ABSOLUTE_MARGIN,
+            "self_adversarial": LOSS_SELF_ADVERSARIAL, "multiclass_nll": LOSS_MULTICLASS_NLL}
+OPT_IDS = {"sgd": OPT_SGD, "momentum": OPT_MOMENTUM, "adagrad": OPT_ADAGRAD, "adam": OPT_ADAM,
+           "adam_lazy": OPT_ADAM_LAZY}
+SIDE_IDS = {"s": SIDE_S, "o": SIDE_O, "s+o": SIDE_SO, "s,o": SIDE_SO}
+EVAL_SIDE_IDS = {"s": EVAL_S, "o": EVAL_O, "s+o": EVAL_SPO, "s,o": EVAL_S_O}
+
+
+class EmgError(RuntimeError):
+    """A libemgraph_hip call returned a non-zero code."""
+
+
+_p = C.c_void_p
+_i32, _i64, _u64, _f32 = C.c_int32, C.c_int64, C.c_uint64, C.c_float
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/emgraph_hip.h declares
+SIGNATURES = {
+    "emg_version": (_int, []),
+    "emg_last_error": (C.c_char_p, []),
+    "emg_target": (C.c_char_p, []),
+    "emg_score_triples": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _p, _p]),
+    "emg_finalize_scores": (_int, [_int, _f32, _p, _i64, _p]),
+    "emg_corrupt_codes": (_int, [_i64, _i32, _int, _i64, _p, _u64, _u64, _p, _p, _p, _p]),
+    "emg_corrupt_expand": (_int, [_p, _i64, _i32, _p, _p, _p]),
+    "emg_train_forward": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _p, _i32, _p, _p, _p]),
+    "emg_loss": (_int, [_int, _p, _p, _i64, _i32, _i32, _f32, _f32, _p, _p, _p, _p]),
+    "emg_train_backward": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _p, _p, _p,
+                                  _p, _p, _i64, _p, _p, _p]),
+    "emg_apply_workspace_bytes": (_i64, [_i64, _i64]),
+    "emg_apply_rows": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64,
+                              C.POINTER(_f32), _p, _i64, _p]),
+    "emg_lp_regularizer": (_int, [_p, _i64, _i64, _i32, _f32, _i32, _f32, _p, _p]),
+    "emg_clip_rows": (_int, [_p, _i64, _i64, _i32, _f32, _p]),
+    "emg_eval_build_queries": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _int, _p, _i64,
+                                      _p, _p]),
+    "emg_eval_count": (_int, [_int, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i32, _f32, _int, _p, _i64, _p, _p, _p]),
+    "emg_eval_filter_count": (_int, [_int, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _int, _p, _p,
+                                     _p, _p, _p]),
+    "emg_eval_scores_dense": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _int, _p, _i64, _p,
+                                     _i64, _p]),
+    "emg_to_bf16": (_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EmgError(
+            "libemgraph_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or emgraph_amd/csrc/build.sh.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.emg_version()
+    if ver != ABI_VERSION:
+        raise EmgError("libemgraph_hip ABI version %d != expected %d" % (ver, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().emg_last_error().decode("utf-8", "replace")
+        raise EmgError("%s failed (code %d): %s" % (what or "libemgraph_hip call", rc, msg))

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Build libemgraph_hip.so for gfx950 (MI355X), in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../lib"
+OBJ="${HERE}/_obj"
+mkdir -p "${OUT}" "${OBJ}"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function)
+pids=()
+for f in emg_abi emg_score emg_train emg_apply emg_rank; do
+  src="${HERE}/${f}.hip"; obj="${OBJ}/${f}.o"
+  if [[ ! -f "${obj}" || "${src}" -nt "${obj}" || "${HERE}/emg_common.hpp" -nt "${obj}" || "${HERE}/../../include/emgraph_hip.h" -nt "${obj}" ]]; then
+    "${HIPCC}" "${FLAGS[@]}" -c "${src}" -o "${obj}" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "${p}" ]] && wait "${p}"; done
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}/libemgraph_hip.so" "${OBJ}"/emg_*.o
+echo "built ${OUT}/libemgraph_hip.so"

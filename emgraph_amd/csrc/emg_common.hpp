@@ -1,0 +1,128 @@
+// emg_common.hpp — shared host/device helpers for libemgraph_hip.so (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "emgraph_hip.h"
+
+namespace emg {
+
+int fail(int code, const char* fmt, ...);
+
+#define EMG_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ::emg::fail(EMG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),   \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define EMG_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::emg::fail(EMG_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define EMG_LAUNCH_CHECK() EMG_HIP(hipGetLastError())
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Bit-for-bit the generator restated in
+// oracle/emgraph_oracle.py::philox4x32_10 and oracle/emg_oracle.c.
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// draws for corruption row j: keep_subject bit and an index in [0, n_choices)
+__host__ __device__ __forceinline__ void corruption_draw(uint64_t seed, uint64_t counter, uint64_t j,
+                                                         uint64_t n_choices, uint32_t* keep_subject,
+                                                         uint32_t* idx) {
+    const Philox4 o = philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), (uint32_t)counter, (uint32_t)(counter >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    *keep_subject = o.v[0] & 1u;
+    const uint64_t r64 = ((uint64_t)o.v[2] << 32) | (uint64_t)o.v[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    *idx = (uint32_t)__umul64hi(r64, n_choices);
+#else
+    *idx = (uint32_t)(((unsigned __int128)r64 * n_choices) >> 64);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register tile of one embedding row slice held by a lane group.
+//   W  = floats per chunk (4: 16-byte global_load_dwordx4; 1: scalar fallback)
+//   NV = chunks per lane;  a group of LPG lanes covers LPG*NV chunks.
+// chunk c of a lane: c = lg + it*LPG  (lg = lane in group)  -> floats [c*W, c*W+W)
+// ---------------------------------------------------------------------------------------------
+template <int W, int NV>
+struct RowTile {
+    float x[W * NV];
+};
+
+template <int W, int NV, int LPG>
+__device__ __forceinline__ void load_tile(RowTile<W, NV>& t, const float* __restrict__ row, int lg, int nchunks) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int c = lg + it * LPG;
+        if (c < nchunks) {
+            if constexpr (W == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * c);
+                t.x[4 * it + 0] = v.x; t.x[4 * it + 1] = v.y; t.x[4 * it + 2] = v.z; t.x[4 * it + 3] = v.w;
+            } else {
+                t.x[it] = row[c];
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; ++w) t.x[W * it + w] = 0.f;
+        }
+    }
+}
+
+template <int W, int NV, int LPG>
+__device__ __forceinline__ void store_tile(const RowTile<W, NV>& t, float* __restrict__ row, int lg, int nchunks) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int c = lg + it * LPG;
+        if (c < nchunks) {
+            if constexpr (W == 4) {
+                *reinterpret_cast<float4*>(row + 4 * c) =
+                    make_float4(t.x[4 * it + 0], t.x[4 * it + 1], t.x[4 * it + 2], t.x[4 * it + 3]);
+            } else {
+                row[c] = t.x[it];
+            }
+        }
+    }
+}
+
+template <int LPG>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPG / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sgnf(float d) { return (float)(d > 0.f) - (float)(d < 0.f); }
+
+}  // namespace emg

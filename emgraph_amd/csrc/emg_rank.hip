@@ -1,0 +1,544 @@
+// emg_rank.hip — filtered 1-vs-all ranking (K10-K13).
+//
+// Replaces, per test triple, generate_corruptions_for_eval (protocol.py:448-528: a [2|E|,3] int
+// array), three gathers of [2|E|,k] rows + _fn over them (EmbeddingModel.py:1856-1866),
+// perform_comparision (:1989-2033) and the filter gathers (:1942-1963).  Nothing of that is
+// materialised: DistMult/ComplEx/HolE become a [rows x k_int]·[k_int x |E|] contraction on the
+// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain) with the
+// int32(score*1e5) comparison against the positive fused into the epilogue, so only two int32
+// counters per query row ever reach HBM.  TransE (not a contraction) is an LDS-tiled VALU kernel.
+//
+// CANONICAL ORDER (what makes ranks bit-exact against oracle/emg_oracle.c): every score is the
+// chain acc_{k+1} = fmaf(q_k, e_k, acc_k), k ascending from acc_0 = +0 (TransE-L1:
+// acc + |q_k - e_k|; L2: fmaf(d,d,acc)).  The MFMA kernel, the positive scorer and the filter
+// scorer all produce exactly that chain, so the test entity and every filter entity compare
+// identically wherever they are scored.
+#include "emg_common.hpp"
+
+// The canonical order below is only canonical if the compiler never fuses a*b+c on its own:
+// every fused multiply-add in this file is an explicit __fmaf_rn / MFMA.
+#pragma clang fp contract(off)
+
+namespace emg {
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int cmp_int(float score) { return (int)__fmul_rn(score, 100000.0f); }  // EmbeddingModel.py:2010-2014
+
+__device__ __forceinline__ bool is_dot_model(int model) { return model >= EMG_DISTMULT; }
+
+// ---------------------------------------------------------------------------------------------
+// query construction
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_to_query(int64_t r, int64_t n_q, int side_mode, int64_t* qi, bool* obj_side) {
+    if (side_mode == EMG_EVAL_S) { *qi = r; *obj_side = false; }
+    else if (side_mode == EMG_EVAL_O) { *qi = r; *obj_side = true; }
+    else { *obj_side = r < n_q; *qi = r < n_q ? r : r - n_q; }
+}
+
+__global__ void build_queries_kernel(int model, const float* __restrict__ ent, int64_t ld_ent,
+                                     const float* __restrict__ rel, int64_t ld_rel, int k_int,
+                                     const int32_t* __restrict__ test, int64_t n_q, int64_t n_rows, int side_mode,
+                                     float* __restrict__ Q, int64_t ldq) {
+    const bool cplx = (model == EMG_COMPLEX || model == EMG_HOLE);
+    const int n = cplx ? k_int / 2 : k_int;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * n) return;
+    const int64_t r = t / n;
+    const int c = (int)(t - r * n);
+    int64_t qi; bool obj;
+    row_to_query(r, n_q, side_mode, &qi, &obj);
+    const int32_t s = test[3 * qi + 0], p = test[3 * qi + 1], o = test[3 * qi + 2];
+    const float* x = ent + (int64_t)(obj ? s : o) * ld_ent;  // the KEPT entity
+    const float* pr = rel + (int64_t)p * ld_rel;
+    float* q = Q + r * ldq;
+    if (model == EMG_TRANSE_L1 || model == EMG_TRANSE_L2) {
+        // object side: |(s+p) - e| ; subject side: |(e+p) - o| = |e - (o-p)|
+        q[c] = obj ? __fadd_rn(x[c], pr[c]) : __fsub_rn(x[c], pr[c]);
+    } else if (model == EMG_DISTMULT) {
+        q[c] = __fmul_rn(pr[c], x[c]);
+    } else {
+        const float p_r = pr[c], p_i = pr[n + c], x_r = x[c], x_i = x[n + c];
+        if (obj) {  // <[p_r s_r - p_i s_i | p_r s_i + p_i s_r], [e_r | e_i]>
+            q[c] = __fmaf_rn(p_r, x_r, -__fmul_rn(p_i, x_i));
+            q[n + c] = __fmaf_rn(p_r, x_i, __fmul_rn(p_i, x_r));
+        } else {    // <[p_r o_r + p_i o_i | p_r o_i - p_i o_r], [e_r | e_i]>
+            q[c] = __fmaf_rn(p_r, x_r, __fmul_rn(p_i, x_i));
+            q[n + c] = __fmaf_rn(p_r, x_i, -__fmul_rn(p_i, x_r));
+        }
+    }
+}
+
+// canonical chain of one (query row, entity row) pair
+__device__ __forceinline__ float chain_score(int model, const float* __restrict__ q, const float* __restrict__ e, int k_int,
+                                             float scale) {
+    float acc = 0.f;
+    if (model == EMG_TRANSE_L1) {
+        for (int k = 0; k < k_int; ++k) acc = __fadd_rn(acc, fabsf(__fsub_rn(q[k], e[k])));
+        return -acc;
+    }
+    if (model == EMG_TRANSE_L2) {
+        for (int k = 0; k < k_int; ++k) {
+            const float d = __fsub_rn(q[k], e[k]);
+            acc = __fmaf_rn(d, d, acc);
+        }
+        return -sqrtf(acc);
+    }
+    for (int k = 0; k < k_int; ++k) acc = __fmaf_rn(q[k], e[k], acc);
+    return model == EMG_HOLE ? __fmul_rn(acc, scale) : acc;
+}
+
+__global__ void pos_int_kernel(int model, const float* __restrict__ ent, int64_t ld_ent, int k_int, float scale,
+                               const int32_t* __restrict__ test, int64_t n_q, int64_t n_rows, int side_mode,
+                               const float* __restrict__ Q, int64_t ldq, int32_t* __restrict__ pos_int) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t qi; bool obj;
+    row_to_query(r, n_q, side_mode, &qi, &obj);
+    const int32_t tgt = obj ? test[3 * qi + 2] : test[3 * qi + 0];  // the TRUE entity on the corrupted side
+    pos_int[r] = cmp_int(chain_score(model, Q + r * ldq, ent + (int64_t)tgt * ld_ent, k_int, scale));
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 MFMA count kernel (DistMult / ComplEx / HolE)
+// ---------------------------------------------------------------------------------------------
+struct CountParams {
+    const float* Q; int64_t ldq; const int32_t* pos_int; int64_t n_rows;
+    const float* ent; int64_t n_cand; int64_t ld_ent; const int32_t* cand;
+    int32_t k_int; float scale; int32_t model;
+    int32_t* cnt_gt; int32_t* cnt_eq;
+    float* S; int64_t lds;
+    int64_t n_qb; int64_t n_cb; int64_t n_tiles; int32_t tiles_per_chunk;
+};
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 1;
+
+template <bool VEC>
+__device__ __forceinline__ void load_frag4(float (&v)[4], const float* __restrict__ row, bool row_ok, int kbase, int k_int) {
+    if constexpr (VEC) {
+        if (row_ok && kbase < k_int) {
+            const float4 t = *reinterpret_cast<const float4*>(row + kbase);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (row_ok && kbase + c < k_int) ? row[kbase + c] : 0.f;
+    }
+}
+
+template <bool VEC, bool DENSE>
+__global__ __launch_bounds__(256) void count_mfma_kernel(const CountParams P) {
+    __shared__ float As[BM * LDT];
+    __shared__ float Bs[BN * LDT];
+    __shared__ int pos_s[BM];
+
+    // XCD-aware decode: blocks on one XCD (id % 8) walk the query tiles of the SAME entity chunk,
+    // so an entity tile is fetched from HBM once per XCD and re-read from that XCD's L2.
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot = id >> 3;
+    const int64_t qb = slot % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = tid >> 2, kq = tid & 3;  // loader: rows lrow, lrow+64 ; floats [4kq,4kq+4)
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    if (tid < BM) {
+        const int64_t qr = qb * BM + tid;
+        pos_s[tid] = (!DENSE && qr < P.n_rows) ? P.pos_int[qr] : 0x7fffffff;
+    }
+
+    const float* arow[2];
+    bool aok[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t qr = qb * BM + lrow + 64 * r;
+        aok[r] = qr < P.n_rows;
+        arow[r] = P.Q + (aok[r] ? qr : 0) * P.ldq;
+    }
+
+    unsigned cnt[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt[a][r] = 0u;
+
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int64_t tile1 = min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles);
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const float* brow[2];
+        bool bok[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t el = tile * BN + lrow + 64 * r;
+            bok[r] = el < P.n_cand;
+            const int64_t erow = bok[r] ? (P.cand ? (int64_t)P.cand[el] : el) : 0;
+            brow[r] = P.ent + erow * P.ld_ent;
+        }
+        float16v acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        for (int k0 = 0; k0 < P.k_int; k0 += BK) {
+            float av[2][4], bv[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                load_frag4<VEC>(av[r], arow[r], aok[r], k0 + 4 * kq, P.k_int);
+                load_frag4<VEC>(bv[r], brow[r], bok[r], k0 + 4 * kq, P.k_int);
+            }
+            __syncthreads();  // previous k-step's LDS reads done
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    As[(lrow + 64 * r) * LDT + 4 * kq + c] = av[r][c];
+                    Bs[(lrow + 64 * r) * LDT + 4 * kq + c] = bv[r][c];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int k = 2 * kk + lhi;  // A[i][k=lane>>5], B[k=lane>>5][j]
+                float a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = As[(wr * 64 + t * 32 + l31) * LDT + k];
+                    b[t] = Bs[(wc * 64 + t * 32 + l31) * LDT + k];
+                }
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+        // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int64_t ecol = tile * BN + wc * 64 + tb * 32 + l31;
+                const bool cok = ecol < P.n_cand;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[ta][tb][r];
+                    if (P.model == EMG_HOLE) v = __fmul_rn(v, P.scale);
+                    if constexpr (DENSE) {
+                        const int64_t qr = qb * BM + rl;
+                        if (cok && qr < P.n_rows) P.S[qr * P.lds + ecol] = v;
+                    } else {
+                        const int ci = cmp_int(v);
+                        const int p = pos_s[rl];
+                        cnt[ta][r] += (unsigned)(cok && ci > p) + ((unsigned)(cok && ci == p) << 16);
+                    }
+                }
+            }
+    }
+    if constexpr (!DENSE) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned c = cnt[ta][r];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+                if (l31 == 0) {
+                    const int rl = wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int64_t qr = qb * BM + rl;
+                    if (qr < P.n_rows) {
+                        if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+                        if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+                    }
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransE count kernel (f32 VALU, LDS-tiled): 64 queries x 64 entities per block, 4x4 per thread
+// ---------------------------------------------------------------------------------------------
+constexpr int TQ = 64, TE = 64, TK = 32;
+
+template <bool L2, bool DENSE>
+__global__ __launch_bounds__(256) void count_transe_kernel(const CountParams P) {
+    __shared__ __attribute__((aligned(16))) float Qs[TK * TQ];
+    __shared__ __attribute__((aligned(16))) float Es[TK * TE];
+    __shared__ int pos_s[TQ];
+    __shared__ unsigned cnt_s[TQ];
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot = id >> 3;
+    const int64_t qb = slot % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x;
+    const int tq = tid & 15, te = tid >> 4;
+    const int lrow = tid & 63, lkq = tid >> 6;  // loader: row lrow, float4 slots lkq and lkq+4 of the k-tile
+
+    if (tid < TQ) {
+        const int64_t qr = qb * TQ + tid;
+        pos_s[tid] = (!DENSE && qr < P.n_rows) ? P.pos_int[qr] : 0x7fffffff;
+        cnt_s[tid] = 0u;
+    }
+    const int64_t qrow_g = qb * TQ + lrow;
+    const bool qok = qrow_g < P.n_rows;
+    const float* qptr = P.Q + (qok ? qrow_g : 0) * P.ldq;
+
+    unsigned cnt[4] = {0u, 0u, 0u, 0u};
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int64_t tile1 = min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles);
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const int64_t el = tile * TE + lrow;
+        const bool eok = el < P.n_cand;
+        const float* eptr = P.ent + (eok ? (P.cand ? (int64_t)P.cand[el] : el) : 0) * P.ld_ent;
+        float acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+        for (int k0 = 0; k0 < P.k_int; k0 += TK) {
+            float qv[2][4], ev[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kb = k0 + 4 * (lkq + 4 * h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    qv[h][c] = (qok && kb + c < P.k_int) ? qptr[kb + c] : 0.f;
+                    ev[h][c] = (eok && kb + c < P.k_int) ? eptr[kb + c] : 0.f;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int kl = 4 * (lkq + 4 * h) + c;
+                    Qs[kl * TQ + lrow] = qv[h][c];
+                    Es[kl * TE + lrow] = ev[h][c];
+                }
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < TK; ++k) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&Qs[k * TQ + 4 * tq]);
+                const float4 e4 = *reinterpret_cast<const float4*>(&Es[k * TE + 4 * te]);
+                const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                const float e[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float d = __fsub_rn(q[a], e[b]);
+                        if constexpr (L2) acc[a][b] = __fmaf_rn(d, d, acc[a][b]);
+                        else acc[a][b] = __fadd_rn(acc[a][b], fabsf(d));
+                    }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ql = 4 * tq + a;
+            const int p = pos_s[ql];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int64_t ecol = tile * TE + 4 * te + b;
+                const bool cok = ecol < P.n_cand;
+                const float v = L2 ? -sqrtf(acc[a][b]) : -acc[a][b];
+                if constexpr (DENSE) {
+                    const int64_t qr = qb * TQ + ql;
+                    if (cok && qr < P.n_rows) P.S[qr * P.lds + ecol] = v;
+                } else {
+                    const int ci = cmp_int(v);
+                    cnt[a] += (unsigned)(cok && ci > p) + ((unsigned)(cok && ci == p) << 16);
+                }
+            }
+        }
+    }
+    if constexpr (!DENSE) {
+        // per thread <= 4*tiles_per_chunk per field; 16 threads share a query row
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (cnt[a]) atomicAdd(&cnt_s[4 * tq + a], cnt[a]);
+        __syncthreads();
+        if (tid < TQ) {
+            const int64_t qr = qb * TQ + tid;
+            const unsigned c = cnt_s[tid];
+            if (qr < P.n_rows) {
+                if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+                if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter counts: one wave per query row, one lane per filter entry, canonical chain
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void filter_count_kernel(int model, const float* __restrict__ Q, int64_t ldq,
+                                                           const int32_t* __restrict__ pos_int, int64_t n_rows,
+                                                           const float* __restrict__ ent, int64_t n_local,
+                                                           int64_t ld_ent, int64_t ent_offset, int k_int, float scale,
+                                                           const int64_t* __restrict__ fptr,
+                                                           const int32_t* __restrict__ fidx,
+                                                           int32_t* __restrict__ fgt, int32_t* __restrict__ feq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const int p = pos_int[r];
+    const float* q = Q + r * ldq;
+    int gt = 0, eq = 0;
+    for (int64_t u = fptr[r] + lane; u < fptr[r + 1]; u += 64) {
+        const int64_t e = (int64_t)fidx[u] - ent_offset;
+        if (e < 0 || e >= n_local) continue;
+        const int ci = cmp_int(chain_score(model, q, ent + e * ld_ent, k_int, scale));
+        gt += ci > p;
+        eq += ci == p;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        gt += __shfl_xor(gt, off, 64);
+        eq += __shfl_xor(eq, off, 64);
+    }
+    if (lane == 0) {
+        if (gt) atomicAdd(&fgt[r], gt);
+        if (eq) atomicAdd(&feq[r], eq);
+    }
+}
+
+__global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
+                               uint16_t* __restrict__ dst, int64_t ld_dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * ld_dst) return;
+    const int64_t r = t / ld_dst;
+    const int c = (int)(t - r * ld_dst);
+    uint16_t out = 0;
+    if (c < k_int) {
+        const uint32_t u = __float_as_uint(src[r * ld_src + c]);
+        if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x7fffffu)) out = (uint16_t)((u >> 16) | 0x40u);  // NaN
+        else out = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                                  // RNE
+    }
+    dst[t] = out;
+}
+
+static int launch_count(bool dense, int model, CountParams& P, int precision, hipStream_t st) {
+    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "unknown model id %d", model);
+    if (precision != 0) return fail(EMG_ENOSUP, "eval precision mode %d is not built in this version", precision);
+    if (P.n_rows == 0 || P.n_cand == 0) return EMG_OK;
+    const bool transe = model <= EMG_TRANSE_L2;
+    const int bm = transe ? TQ : BM, bn = transe ? TE : BN;
+    P.n_qb = cdiv(P.n_rows, bm);
+    P.n_tiles = cdiv(P.n_cand, bn);
+    P.tiles_per_chunk = dense ? 4 : (transe ? 64 : 32);  // packed 16-bit per-lane counters stay < 65536
+    P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
+    const int64_t blocks = 8 * P.n_qb * cdiv(P.n_cb, 8);
+    EMG_REQUIRE(blocks < ((int64_t)1 << 31), "emg_eval_count: grid too large");
+    const dim3 grid((unsigned)blocks), block(256);
+    if (transe) {
+        if (model == EMG_TRANSE_L1) {
+            if (dense) hipLaunchKernelGGL((count_transe_kernel<false, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_transe_kernel<false, false>), grid, block, 0, st, P);
+        } else {
+            if (dense) hipLaunchKernelGGL((count_transe_kernel<true, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_transe_kernel<true, false>), grid, block, 0, st, P);
+        }
+    } else {
+        const bool vec = (P.k_int % 4 == 0) && (P.ldq % 4 == 0) && (P.ld_ent % 4 == 0) && aligned16(P.Q) && aligned16(P.ent);
+        if (vec) {
+            if (dense) hipLaunchKernelGGL((count_mfma_kernel<true, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_mfma_kernel<true, false>), grid, block, 0, st, P);
+        } else {
+            if (dense) hipLaunchKernelGGL((count_mfma_kernel<false, true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_mfma_kernel<false, false>), grid, block, 0, st, P);
+        }
+    }
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+}  // namespace emg
+
+using namespace emg;
+
+extern "C" int emg_eval_build_queries(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel,
+                                      int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale,
+                                      const int32_t* test_spo, int64_t n_q, int side_mode, float* Q, int64_t ldq,
+                                      int32_t* pos_int, void* stream) {
+    (void)n_ent; (void)n_rel;
+    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "emg_eval_build_queries: unknown model %d", model);
+    EMG_REQUIRE(side_mode >= EMG_EVAL_S && side_mode <= EMG_EVAL_S_O, "emg_eval_build_queries: bad side_mode %d", side_mode);
+    EMG_REQUIRE(k_int > 0 && ld_ent >= k_int && ld_rel >= k_int && ldq >= k_int, "emg_eval_build_queries: bad strides");
+    const bool cplx = (model == EMG_COMPLEX || model == EMG_HOLE);
+    EMG_REQUIRE(!cplx || k_int % 2 == 0, "emg_eval_build_queries: odd k_int for a complex model");
+    if (n_q == 0) return EMG_OK;
+    EMG_REQUIRE(ent && rel && test_spo && Q && pos_int, "emg_eval_build_queries: null pointer");
+    const int64_t n_rows = (side_mode >= EMG_EVAL_SPO) ? 2 * n_q : n_q;
+    const int n = cplx ? k_int / 2 : k_int;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(build_queries_kernel, dim3((unsigned)cdiv(n_rows * n, 256)), dim3(256), 0, st, model, ent, ld_ent,
+                       rel, ld_rel, (int)k_int, test_spo, n_q, n_rows, side_mode, Q, ldq);
+    EMG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pos_int_kernel, dim3((unsigned)cdiv(n_rows, 64)), dim3(64), 0, st, model, ent, ld_ent, (int)k_int,
+                       scale, test_spo, n_q, n_rows, side_mode, Q, ldq, pos_int);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_eval_count(int model, const float* Q, int64_t ldq, const int32_t* pos_int, int64_t n_rows,
+                              const float* ent, int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_int,
+                              float scale, int precision, const void* ent_bf16, int64_t ld_bf16, int32_t* cnt_gt,
+                              int32_t* cnt_eq, void* stream) {
+    (void)ent_bf16; (void)ld_bf16;
+    EMG_REQUIRE(n_rows >= 0 && n_cand >= 0 && k_int > 0 && ldq >= k_int && ld_ent >= k_int, "emg_eval_count: bad sizes");
+    EMG_REQUIRE((n_rows == 0 || n_cand == 0) || (Q && pos_int && ent && cnt_gt && cnt_eq), "emg_eval_count: null pointer");
+    CountParams P{};
+    P.Q = Q; P.ldq = ldq; P.pos_int = pos_int; P.n_rows = n_rows; P.ent = ent; P.n_cand = n_cand; P.ld_ent = ld_ent;
+    P.cand = cand; P.k_int = k_int; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
+    return launch_count(false, model, P, precision, (hipStream_t)stream);
+}
+
+extern "C" int emg_eval_scores_dense(int model, const float* Q, int64_t ldq, int64_t n_rows, const float* ent,
+                                     int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_int, float scale,
+                                     int precision, const void* ent_bf16, int64_t ld_bf16, float* S, int64_t lds,
+                                     void* stream) {
+    (void)ent_bf16; (void)ld_bf16;
+    EMG_REQUIRE(n_rows >= 0 && n_cand >= 0 && k_int > 0 && ldq >= k_int && ld_ent >= k_int && lds >= n_cand,
+                "emg_eval_scores_dense: bad sizes");
+    EMG_REQUIRE((n_rows == 0 || n_cand == 0) || (Q && ent && S), "emg_eval_scores_dense: null pointer");
+    CountParams P{};
+    P.Q = Q; P.ldq = ldq; P.n_rows = n_rows; P.ent = ent; P.n_cand = n_cand; P.ld_ent = ld_ent; P.cand = cand;
+    P.k_int = k_int; P.scale = scale; P.model = model; P.S = S; P.lds = lds;
+    return launch_count(true, model, P, precision, (hipStream_t)stream);
+}
+
+extern "C" int emg_eval_filter_count(int model, const float* Q, int64_t ldq, const int32_t* pos_int, int64_t n_rows,
+                                     const float* ent, int64_t n_local, int64_t ld_ent, int64_t ent_offset,
+                                     int32_t k_int, float scale, int precision, const int64_t* filt_ptr,
+                                     const int32_t* filt_idx, int32_t* fcnt_gt, int32_t* fcnt_eq, void* stream) {
+    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "emg_eval_filter_count: unknown model %d", model);
+    if (precision != 0) return fail(EMG_ENOSUP, "eval precision mode %d is not built in this version", precision);
+    EMG_REQUIRE(n_rows >= 0 && k_int > 0 && ldq >= k_int && ld_ent >= k_int, "emg_eval_filter_count: bad sizes");
+    if (n_rows == 0) return EMG_OK;
+    EMG_REQUIRE(Q && pos_int && ent && filt_ptr && fcnt_gt && fcnt_eq, "emg_eval_filter_count: null pointer");
+    hipLaunchKernelGGL(filter_count_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                       model, Q, ldq, pos_int, n_rows, ent, n_local, ld_ent, ent_offset, (int)k_int, scale, filt_ptr,
+                       filt_idx, fcnt_gt, fcnt_eq);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, void* dst_bf16,
+                           int64_t ld_dst, void* stream) {
+    EMG_REQUIRE(src && dst_bf16 && n_rows >= 0 && ld_src >= k_int && ld_dst >= k_int, "emg_to_bf16: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)cdiv(n_rows * ld_dst, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       n_rows, ld_src, (int)k_int, (uint16_t*)dst_bf16, ld_dst);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}

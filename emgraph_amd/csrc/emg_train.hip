@@ -1,0 +1,266 @@
+// emg_train.hip — corruption draws (K3/K14), loss + dL/dscore (K5), LP regulariser (K6), row clip (K9).
+#include "emg_common.hpp"
+
+namespace emg {
+
+// ---------------------------------------------------------------------------------------------
+// K3/K14: codes[j] = replacement | keep_subject<<31   (protocol.py:598-641)
+// ---------------------------------------------------------------------------------------------
+__global__ void corrupt_codes_kernel(int64_t n, int side, uint64_t n_choices, const int32_t* __restrict__ entities_list,
+                                     uint64_t seed, uint64_t counter, const int32_t* __restrict__ inj_mask,
+                                     const int32_t* __restrict__ inj_repl, int32_t* __restrict__ codes) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t keep, idx;
+    if (inj_repl) {
+        idx = (uint32_t)inj_repl[j];
+        keep = inj_mask ? (uint32_t)(inj_mask[j] != 0) : 0u;
+    } else {
+        corruption_draw(seed, counter, (uint64_t)j, n_choices, &keep, &idx);
+    }
+    if (side == EMG_SIDE_O) keep = 1u;       // protocol.py:606 keep subject, corrupt object
+    else if (side == EMG_SIDE_S) keep = 0u;  // :607-608
+    const uint32_t repl = entities_list ? (uint32_t)entities_list[idx] : idx;  // :616-619 / :635-641
+    codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
+}
+
+// protocol.py:643-656: subjects = keep_s*s + keep_o*repl ; objects = keep_o*o + keep_s*repl
+__global__ void corrupt_expand_kernel(const int32_t* __restrict__ pos, int64_t B, int64_t n,
+                                      const int32_t* __restrict__ codes, int32_t* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t i = j % B;
+    const int32_t code = codes[j];
+    const int32_t repl = code & 0x7fffffff;
+    const bool keep_s = code < 0;
+    out[3 * j + 0] = keep_s ? pos[3 * i + 0] : repl;
+    out[3 * j + 1] = pos[3 * i + 1];
+    out[3 * j + 2] = keep_s ? repl : pos[3 * i + 2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 losses.  One thread per positive i; negatives of i are rows (sd*eta + j)*B + i.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clip75(float v) { return fminf(fmaxf(v, -75.0f), 75.0f); }  // losses/utils.py:44-53
+__device__ __forceinline__ float in75(float v) { return (v >= -75.0f && v <= 75.0f) ? 1.f : 0.f; }
+__device__ __forceinline__ float log1pexp_naive(float x) { return logf(1.0f + expf(x)); }  // nll.py:59 literal form
+__device__ __forceinline__ float log_sigmoid(float x) {  // tf.math.log_sigmoid = -softplus(-x)
+    return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp, const float* __restrict__ sn,
+                                                   int64_t B, int eta, int n_sides, float margin, float alpha,
+                                                   double* __restrict__ loss_accum, float* __restrict__ g_pos,
+                                                   float* __restrict__ g_neg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    if (i < B) {
+        const float pos = sp[i];
+        float gp = 0.f;
+        for (int sd = 0; sd < n_sides; ++sd) {
+            const float* snp = sn + (int64_t)sd * eta * B + i;
+            float* gnp = g_neg + (int64_t)sd * eta * B + i;
+            if constexpr (LOSS == EMG_LOSS_PAIRWISE) {  // pairwise.py:69
+                for (int j = 0; j < eta; ++j) {
+                    const float v = margin - pos + snp[(int64_t)j * B];
+                    const float act = v >= 0.f ? 1.f : 0.f;  // TF MaximumGrad: x >= y takes the gradient
+                    loss += fmaxf(v, 0.f);
+                    gnp[(int64_t)j * B] = act;
+                    gp -= act;
+                }
+            } else if constexpr (LOSS == EMG_LOSS_NLL) {  // nll.py:55-59, positives tiled eta times
+                const float pc = clip75(pos);
+                const float lp = log1pexp_naive(-pc);
+                const float gpp = -in75(pos) * sigmoidf(-pc);
+                for (int j = 0; j < eta; ++j) {
+                    const float nv = snp[(int64_t)j * B];
+                    const float nc = clip75(nv);
+                    loss += lp + log1pexp_naive(nc);
+                    gnp[(int64_t)j * B] = in75(nv) * sigmoidf(nc);
+                    gp += gpp;
+                }
+            } else if constexpr (LOSS == EMG_LOSS_ABSOLUTE_MARGIN) {  // absolute_margin.py:69
+                for (int j = 0; j < eta; ++j) {
+                    const float v = margin + snp[(int64_t)j * B];
+                    loss += fmaxf(v, 0.f) - pos;
+                    gnp[(int64_t)j * B] = v >= 0.f ? 1.f : 0.f;
+                    gp -= 1.f;
+                }
+            } else if constexpr (LOSS == EMG_LOSS_SELF_ADVERSARIAL) {  // self_adversarial.py:98-110
+                loss += -log_sigmoid(margin + pos);
+                gp += -sigmoidf(-(margin + pos));
+                float mx = -INFINITY;
+                for (int j = 0; j < eta; ++j) mx = fmaxf(mx, alpha * snp[(int64_t)j * B]);
+                float den = 0.f, wsum = 0.f;
+                for (int j = 0; j < eta; ++j) {
+                    const float nv = snp[(int64_t)j * B];
+                    const float w = expf(alpha * nv - mx);
+                    den += w;
+                    wsum += w * log_sigmoid(-nv - margin);
+                }
+                const float sbar = wsum / den;  // sum_j p_j * ell_j
+                loss -= sbar;
+                for (int j = 0; j < eta; ++j) {
+                    const float nv = snp[(int64_t)j * B];
+                    const float w = expf(alpha * nv - mx) / den;
+                    const float ell = log_sigmoid(-nv - margin);
+                    const float dell = -sigmoidf(nv + margin);
+                    gnp[(int64_t)j * B] = -(w * dell + alpha * w * (ell - sbar));  // softmax not stop-gradiented
+                }
+            } else {  // multiclass_nll: nll_multiclass.py:70-81
+                const float pc = clip75(pos);
+                const float pe = expf(pc);
+                float den = pe;
+                for (int j = 0; j < eta; ++j) den += expf(clip75(snp[(int64_t)j * B]));
+                loss += -logf(pe / den);
+                gp += -(1.f - pe / den) * in75(pos);
+                for (int j = 0; j < eta; ++j) {
+                    const float nv = snp[(int64_t)j * B];
+                    gnp[(int64_t)j * B] = in75(nv) * expf(clip75(nv)) / den;
+                }
+            }
+        }
+        g_pos[i] = gp;
+    }
+    // block reduction of the loss (double), one atomic per block
+    double v = (double)loss;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = part[0] + part[1] + part[2] + part[3];
+        if (t != 0.0) atomicAdd(loss_accum, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: LP regulariser over a full table (regularizers/lp.py:107-113)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float powi_abs(float a, int p) {
+    if (p == 1) return a;
+    if (p == 2) return a * a;
+    if (p == 3) return a * a * a;
+    return powf(a, (float)p);
+}
+
+__global__ __launch_bounds__(256) void lp_kernel(float* __restrict__ w, int64_t n_rows, int64_t ld, int k_int,
+                                                 float lambda, int p, float step, double* __restrict__ loss_accum) {
+    double acc = 0.0;
+    const int64_t total = n_rows * (int64_t)k_int;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / k_int;
+        const int c = (int)(t - r * k_int);
+        float* ptr = w + r * ld + c;
+        const float x = *ptr;
+        const float a = fabsf(x);
+        acc += (double)powi_abs(a, p);
+        if (step != 0.f) {
+            // d/dx lambda*|x|^p = lambda*p*|x|^(p-1)*sign(x)
+            const float g = lambda * (float)p * (p == 1 ? 1.f : powi_abs(a, p - 1)) * sgnf(x);
+            *ptr = x - step * g;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_accum) atomicAdd(loss_accum, (double)lambda * (part[0] + part[1] + part[2] + part[3]));
+}
+
+// K9: tf.clip_by_norm(W, clip_norm, axes=1): rows with ||row|| > c are scaled by c/||row||
+__global__ __launch_bounds__(256) void clip_rows_kernel(float* __restrict__ w, int64_t n_rows, int64_t ld, int k_int,
+                                                        float max_norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    float* row = w + r * ld;
+    float acc = 0.f;
+    for (int c = lane; c < k_int; c += 64) acc = fmaf(row[c], row[c], acc);
+    acc = group_sum<64>(acc);
+    const float nrm = sqrtf(acc);
+    if (nrm > max_norm) {
+        const float f = max_norm / nrm;
+        for (int c = lane; c < k_int; c += 64) row[c] *= f;
+    }
+}
+
+}  // namespace emg
+
+using namespace emg;
+
+extern "C" int emg_corrupt_codes(int64_t B, int32_t eta, int side, int64_t n_choices, const int32_t* entities_list,
+                                 uint64_t seed, uint64_t draw_counter, const int32_t* inj_mask,
+                                 const int32_t* inj_repl, int32_t* codes, void* stream) {
+    EMG_REQUIRE(side >= EMG_SIDE_S && side <= EMG_SIDE_SO, "emg_corrupt_codes: bad side %d", side);
+    EMG_REQUIRE(B >= 0 && eta >= 0, "emg_corrupt_codes: negative sizes");
+    const int64_t n = B * eta;
+    if (n == 0) return EMG_OK;
+    EMG_REQUIRE(codes, "emg_corrupt_codes: null codes");
+    EMG_REQUIRE(n_choices > 0 && n_choices < ((int64_t)1 << 31), "emg_corrupt_codes: n_choices=%lld out of range",
+                (long long)n_choices);
+    EMG_REQUIRE(!(side == EMG_SIDE_SO && inj_repl && !inj_mask), "emg_corrupt_codes: injected 's+o' needs inj_mask");
+    hipLaunchKernelGGL(corrupt_codes_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, side,
+                       (uint64_t)n_choices, entities_list, seed, draw_counter, inj_mask, inj_repl, codes);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_corrupt_expand(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes, int32_t* out_spo,
+                                  void* stream) {
+    const int64_t n = B * eta;
+    if (n <= 0) return EMG_OK;
+    EMG_REQUIRE(pos && codes && out_spo, "emg_corrupt_expand: null pointer");
+    hipLaunchKernelGGL(corrupt_expand_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pos, B, n,
+                       codes, out_spo);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_loss(int loss, const float* scores_pos, const float* scores_neg, int64_t B, int32_t eta,
+                        int32_t n_sides, float margin, float alpha, double* loss_accum, float* g_pos, float* g_neg,
+                        void* stream) {
+    EMG_REQUIRE(loss >= EMG_LOSS_PAIRWISE && loss <= EMG_LOSS_MULTICLASS_NLL, "emg_loss: unknown loss %d", loss);
+    EMG_REQUIRE(B >= 0 && eta >= 1 && n_sides >= 1, "emg_loss: bad sizes");
+    if (B == 0) return EMG_OK;
+    EMG_REQUIRE(scores_pos && scores_neg && loss_accum && g_pos && g_neg, "emg_loss: null pointer");
+    const dim3 grid((unsigned)cdiv(B, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define EMG_LAUNCH_LOSS(L) \
+    hipLaunchKernelGGL(loss_kernel<L>, grid, block, 0, st, scores_pos, scores_neg, B, eta, n_sides, margin, alpha, loss_accum, g_pos, g_neg)
+    switch (loss) {
+        case EMG_LOSS_PAIRWISE: EMG_LAUNCH_LOSS(EMG_LOSS_PAIRWISE); break;
+        case EMG_LOSS_NLL: EMG_LAUNCH_LOSS(EMG_LOSS_NLL); break;
+        case EMG_LOSS_ABSOLUTE_MARGIN: EMG_LAUNCH_LOSS(EMG_LOSS_ABSOLUTE_MARGIN); break;
+        case EMG_LOSS_SELF_ADVERSARIAL: EMG_LAUNCH_LOSS(EMG_LOSS_SELF_ADVERSARIAL); break;
+        default: EMG_LAUNCH_LOSS(EMG_LOSS_MULTICLASS_NLL); break;
+    }
+#undef EMG_LAUNCH_LOSS
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_lp_regularizer(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float lambda, int32_t p,
+                                  float grad_scale_lr, double* loss_accum, void* stream) {
+    EMG_REQUIRE(table && n_rows >= 0 && ld >= k_int && k_int > 0 && p >= 1, "emg_lp_regularizer: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    const int64_t total = n_rows * (int64_t)k_int;
+    const unsigned grid = (unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, n_rows, ld, (int)k_int, lambda,
+                       (int)p, grad_scale_lr, loss_accum);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream) {
+    EMG_REQUIRE(table && n_rows >= 0 && ld >= k_int && k_int > 0, "emg_clip_rows: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    hipLaunchKernelGGL(clip_rows_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, table,
+                       n_rows, ld, (int)k_int, max_norm);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}

@@ -1,0 +1,241 @@
+"""Thin typed wrappers: PyTorch-ROCm tensors (device-memory holders + stream provider) -> C-ABI calls.
+
+No arithmetic happens here; every function forwards pointers and sizes to libemgraph_hip.so on the
+current torch stream.  Tables are 2-D float32 tensors with unit column stride; their row stride is
+passed as ``ld``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise L.EmgError("emgraph_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback.")
+    L.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_table(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError("%s must be a 2-D float32 CUDA tensor with unit column stride" % name)
+    return t.data_ptr(), t.shape[0], t.stride(0)
+
+
+def _chk_vec(t, dtype, name, n=None):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous %s CUDA tensor" % (name, dtype))
+    if n is not None and t.numel() != n:
+        raise ValueError("%s has %d elements, expected %d" % (name, t.numel(), n))
+    return t.data_ptr()
+
+
+def score_triples(model_id, ent, rel, k_int, scale, spo, flags=L.SCORE_FINAL, out=None):
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    n = spo.shape[0]
+    ps = _chk_vec(spo, torch.int32, "spo", 3 * n)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=ent.device)
+    L.check(lib.emg_score_triples(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale, ps, n, flags,
+                                  _chk_vec(out, torch.float32, "out", n), _stream()), "emg_score_triples")
+    return out
+
+
+def finalize_scores(model_id, scale, scores):
+    lib = L.load()
+    L.check(lib.emg_finalize_scores(model_id, scale, _chk_vec(scores, torch.float32, "scores"), scores.numel(),
+                                    _stream()), "emg_finalize_scores")
+    return scores
+
+
+def corrupt_codes(B, eta, side, n_choices, device, entities_list=None, seed=0, counter=0, inj_mask=None,
+                  inj_repl=None, out=None):
+    lib = L.load()
+    n = B * eta
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=device)
+    L.check(lib.emg_corrupt_codes(B, eta, side, n_choices, _chk_vec(entities_list, torch.int32, "entities_list"),
+                                  seed & 0xFFFFFFFFFFFFFFFF, counter & 0xFFFFFFFFFFFFFFFF,
+                                  _chk_vec(inj_mask, torch.int32, "inj_mask", n if inj_mask is not None else None),
+                                  _chk_vec(inj_repl, torch.int32, "inj_repl", n if inj_repl is not None else None),
+                                  _chk_vec(out, torch.int32, "codes", n), _stream()), "emg_corrupt_codes")
+    return out
+
+
+def corrupt_expand(pos, eta, codes):
+    lib = L.load()
+    B = pos.shape[0]
+    out = torch.empty((B * eta, 3), dtype=torch.int32, device=pos.device)
+    L.check(lib.emg_corrupt_expand(_chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
+                                   _chk_vec(codes, torch.int32, "codes", B * eta), out.data_ptr(), _stream()),
+            "emg_corrupt_expand")
+    return out
+
+
+def train_forward(model_id, ent, rel, k_int, scale, pos, eta, codes, flags=L.SCORE_FINAL, scores_pos=None,
+                  scores_neg=None):
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    B = pos.shape[0]
+    if scores_pos is None:
+        scores_pos = torch.empty(B, dtype=torch.float32, device=ent.device)
+    if scores_neg is None:
+        scores_neg = torch.empty(B * eta, dtype=torch.float32, device=ent.device)
+    L.check(lib.emg_train_forward(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
+                                  _chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
+                                  _chk_vec(codes, torch.int32, "codes", B * eta) if eta else None, flags,
+                                  _chk_vec(scores_pos, torch.float32, "scores_pos", B),
+                                  _chk_vec(scores_neg, torch.float32, "scores_neg", B * eta) if eta else None,
+                                  _stream()), "emg_train_forward")
+    return scores_pos, scores_neg
+
+
+def loss(loss_id, scores_pos, scores_neg, B, eta, n_sides, margin, alpha, loss_accum, g_pos=None, g_neg=None):
+    lib = L.load()
+    if g_pos is None:
+        g_pos = torch.empty(B, dtype=torch.float32, device=scores_pos.device)
+    if g_neg is None:
+        g_neg = torch.empty(B * eta * n_sides, dtype=torch.float32, device=scores_pos.device)
+    L.check(lib.emg_loss(loss_id, _chk_vec(scores_pos, torch.float32, "scores_pos", B),
+                         _chk_vec(scores_neg, torch.float32, "scores_neg", B * eta * n_sides), B, eta, n_sides,
+                         margin, alpha, _chk_vec(loss_accum, torch.float64, "loss_accum", 1),
+                         _chk_vec(g_pos, torch.float32, "g_pos", B),
+                         _chk_vec(g_neg, torch.float32, "g_neg", B * eta * n_sides), _stream()), "emg_loss")
+    return g_pos, g_neg
+
+
+def train_backward(model_id, ent, rel, k_int, scale, pos, eta, codes, g_pos, g_neg, contrib_ent, contrib_rel,
+                   dest_ent, dest_rel):
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    B = pos.shape[0]
+    pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
+    pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
+    if ldc != ldc2 or nce < (2 + eta) * B or ncr < B:
+        raise ValueError("contribution buffers have the wrong shape")
+    L.check(lib.emg_train_backward(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
+                                   _chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
+                                   _chk_vec(codes, torch.int32, "codes", B * eta) if eta else None,
+                                   _chk_vec(g_pos, torch.float32, "g_pos", B),
+                                   _chk_vec(g_neg, torch.float32, "g_neg", B * eta) if eta else None,
+                                   pce, pcr, ldc, _chk_vec(dest_ent, torch.int32, "dest_ent", (2 + eta) * B),
+                                   _chk_vec(dest_rel, torch.int32, "dest_rel", B), _stream()), "emg_train_backward")
+
+
+def apply_workspace_bytes(n_contrib, n_rows):
+    n = L.load().emg_apply_workspace_bytes(n_contrib, n_rows)
+    if n < 0:
+        L.check(-1, "emg_apply_workspace_bytes")
+    return int(n)
+
+
+def apply_rows(opt_id, table, k_int, state0, state1, tag, step, contrib, dest, n_contrib, hyper, workspace):
+    """hyper = (lr, momentum, beta1, beta2, eps, lr_t) python floats."""
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
+    p1 = _chk_table(state1, "state1")[0] if state1 is not None else None
+    pc, _, ldc = _chk_table(contrib, "contrib")
+    h = (C.c_float * 6)(*[float(x) for x in hyper])
+    L.check(lib.emg_apply_rows(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc, ldc,
+                               _chk_vec(dest, torch.int32, "dest"), n_contrib, h, workspace.data_ptr(),
+                               workspace.numel() * workspace.element_size(), _stream()), "emg_apply_rows")
+
+
+def lp_regularizer(table, k_int, lam, p, grad_scale_lr, loss_accum):
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    L.check(lib.emg_lp_regularizer(pt, nrows, ld, k_int, lam, p, grad_scale_lr,
+                                   _chk_vec(loss_accum, torch.float64, "loss_accum", 1) if loss_accum is not None else None,
+                                   _stream()), "emg_lp_regularizer")
+
+
+def clip_rows(table, k_int, max_norm=1.0):
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    L.check(lib.emg_clip_rows(pt, nrows, ld, k_int, max_norm, _stream()), "emg_clip_rows")
+
+
+def eval_build_queries(model_id, ent, rel, k_int, scale, test_spo, side_mode, ldq=None):
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    n_q = test_spo.shape[0]
+    n_rows = 2 * n_q if side_mode >= L.EVAL_SPO else n_q
+    ldq = ldq or ((k_int + 3) // 4) * 4
+    Q = torch.zeros((n_rows, ldq), dtype=torch.float32, device=ent.device)
+    pos_int = torch.empty(n_rows, dtype=torch.int32, device=ent.device)
+    L.check(lib.emg_eval_build_queries(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
+                                       _chk_vec(test_spo, torch.int32, "test_spo", 3 * n_q), n_q, side_mode,
+                                       Q.data_ptr(), ldq, pos_int.data_ptr(), _stream()), "emg_eval_build_queries")
+    return Q, pos_int
+
+
+def eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt_gt, cnt_eq, cand=None, n_cand=None, precision=0,
+               ent_bf16=None):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_table(Q, "Q")
+    pe, ne, lde = _chk_table(ent, "ent")
+    if cand is not None:
+        n_cand = cand.numel()
+    elif n_cand is None:
+        n_cand = ne
+    pb, ldb = (None, 0)
+    if ent_bf16 is not None:
+        pb, ldb = ent_bf16.data_ptr(), ent_bf16.stride(0)
+    L.check(lib.emg_eval_count(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), n_rows, pe,
+                               n_cand, lde, _chk_vec(cand, torch.int32, "cand"), k_int, scale, precision, pb, ldb,
+                               _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                               _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_count")
+
+
+def eval_filter_count(model_id, Q, pos_int, ent, ent_offset, k_int, scale, filt_ptr, filt_idx, fcnt_gt, fcnt_eq,
+                      precision=0):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_table(Q, "Q")
+    pe, ne, lde = _chk_table(ent, "ent")
+    L.check(lib.emg_eval_filter_count(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), n_rows, pe,
+                                      ne, lde, ent_offset, k_int, scale, precision,
+                                      _chk_vec(filt_ptr, torch.int64, "filt_ptr", n_rows + 1),
+                                      _chk_vec(filt_idx, torch.int32, "filt_idx"),
+                                      _chk_vec(fcnt_gt, torch.int32, "fcnt_gt", n_rows),
+                                      _chk_vec(fcnt_eq, torch.int32, "fcnt_eq", n_rows), _stream()),
+            "emg_eval_filter_count")
+
+
+def eval_scores_dense(model_id, Q, ent, k_int, scale, cand=None, n_cand=None, precision=0):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_table(Q, "Q")
+    pe, ne, lde = _chk_table(ent, "ent")
+    if cand is not None:
+        n_cand = cand.numel()
+    elif n_cand is None:
+        n_cand = ne
+    S = torch.full((n_rows, n_cand), float("nan"), dtype=torch.float32, device=ent.device)
+    L.check(lib.emg_eval_scores_dense(model_id, pq, ldq, n_rows, pe, n_cand, lde,
+                                      _chk_vec(cand, torch.int32, "cand"), k_int, scale, precision, None, 0,
+                                      S.data_ptr(), S.stride(0), _stream()), "emg_eval_scores_dense")
+    return S
+
+
+def to_bf16(table, k_int, ld_dst=None):
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    ld_dst = ld_dst or ((k_int + 7) // 8) * 8
+    out = torch.empty((nrows, ld_dst), dtype=torch.bfloat16, device=table.device)
+    L.check(lib.emg_to_bf16(pt, nrows, ld, k_int, out.data_ptr(), ld_dst, _stream()), "emg_to_bf16")
+    return out

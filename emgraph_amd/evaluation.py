@@ -1,0 +1,154 @@
+"""Host side of the filtered 1-vs-all ranking path (mirrors emgraph/evaluation/protocol.py and the
+eval half of emgraph/models/EmbeddingModel.py).
+
+What stays on the host (numpy, vectorised — no SQLite, no per-triple Python):
+  * the filter index: a one-off CSR of known positives per (query, side), replacing
+    SQLiteAdapter.get_participating_entities (sqlite_adapter.py:449-508: two SQL queries + a connect per
+    test triple);
+  * turning the device's (gt, eq) counters into ranks (perform_comparision's three strategies,
+    EmbeddingModel.py:2010-2033, and the rank assembly :1966-1986).
+Everything numeric runs in libemgraph_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import device as D
+
+
+def _expand_ranges(lo, hi):
+    """indices of concatenated ranges [lo_i, hi_i) + the owning range id of each index"""
+    lens = (hi - lo).astype(np.int64)
+    total = int(lens.sum())
+    owner = np.repeat(np.arange(len(lo), dtype=np.int64), lens)
+    if total == 0:
+        return np.zeros(0, np.int64), owner
+    starts = np.cumsum(lens) - lens
+    idx = np.arange(total, dtype=np.int64) - np.repeat(starts, lens) + np.repeat(lo.astype(np.int64), lens)
+    return idx, owner
+
+
+def _side_filter_pairs(F_key, F_val, order_key, q_key, q_self):
+    """(row, entity) pairs: entities v with (key == q_key[row]) in the filter, plus the row's own entity
+    ('select <id> union select distinct ...', sqlite_adapter.py:472-495)."""
+    lo = np.searchsorted(order_key, q_key, side="left")
+    hi = np.searchsorted(order_key, q_key, side="right")
+    idx, owner = _expand_ranges(lo, hi)
+    rows = np.concatenate([owner, np.arange(len(q_key), dtype=np.int64)])
+    ents = np.concatenate([F_val[idx], q_self.astype(np.int64)])
+    return rows, ents
+
+
+def build_filter_csr(filter_triples, test_triples, side_mode, n_ent, entities_subset=None):
+    """CSR (filt_ptr int64[n_rows+1], filt_idx int32) of known positives per query ROW, in the row order
+    of emg_eval_build_queries (object-side rows first for 's+o'/'s,o').
+
+    object-side row of (s,p,o):  {o} U {o' : (s,p,o') in F};  subject-side: {s} U {s' : (s',p,o) in F}.
+    With ``entities_subset`` only members of the subset are kept (EmbeddingModel.py:1898-1940 intent).
+    """
+    T = np.asarray(test_triples, dtype=np.int64).reshape(-1, 3)
+    F = np.asarray(filter_triples, dtype=np.int64).reshape(-1, 3)
+    n_q = T.shape[0]
+    n_rel = int(max(F[:, 1].max() if len(F) else 0, T[:, 1].max() if n_q else 0)) + 1
+    rows_all, ents_all = [], []
+    row_base = 0
+    want_obj = side_mode in (L.EVAL_O, L.EVAL_SPO, L.EVAL_S_O)
+    want_sub = side_mode in (L.EVAL_S, L.EVAL_SPO, L.EVAL_S_O)
+    if want_obj:
+        key = F[:, 0] * n_rel + F[:, 1]
+        order = np.argsort(key, kind="stable")
+        r, e = _side_filter_pairs(key, F[order, 2], key[order], T[:, 0] * n_rel + T[:, 1], T[:, 2])
+        rows_all.append(r + row_base)
+        ents_all.append(e)
+        row_base += n_q
+    if want_sub:
+        key = F[:, 2] * n_rel + F[:, 1]
+        order = np.argsort(key, kind="stable")
+        r, e = _side_filter_pairs(key, F[order, 0], key[order], T[:, 2] * n_rel + T[:, 1], T[:, 0])
+        rows_all.append(r + row_base)
+        ents_all.append(e)
+        row_base += n_q
+    n_rows = row_base
+    rows = np.concatenate(rows_all) if rows_all else np.zeros(0, np.int64)
+    ents = np.concatenate(ents_all) if ents_all else np.zeros(0, np.int64)
+    if entities_subset is not None:
+        keep = np.isin(ents, np.asarray(entities_subset, dtype=np.int64))
+        rows, ents = rows[keep], ents[keep]
+    comb = np.unique(rows * np.int64(n_ent) + ents)  # de-duplicate (SQL UNION / DISTINCT), sorted by row
+    rows_u = comb // n_ent
+    ents_u = (comb - rows_u * n_ent).astype(np.int32)
+    ptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(np.bincount(rows_u, minlength=n_rows), out=ptr[1:])
+    return ptr, ents_u
+
+
+def _cmp(gt, eq, strategy):
+    """perform_comparision (EmbeddingModel.py:2018-2033) from the (>, ==) counters."""
+    if strategy == "worst":
+        return gt + eq
+    if strategy == "best":
+        return gt
+    if strategy == "middle":
+        return gt + np.ceil(eq / 2).astype(np.int64)
+    raise AssertionError("Invalid score comparision type!")
+
+
+def ranks_from_counts(gt, eq, fgt, feq, n_q, corrupt_side, strategy):
+    """rank assembly (EmbeddingModel.py:1966-1986).  's,o' -> [n,2] = [subject_rank, object_rank]."""
+    gt, eq, fgt, feq = [np.asarray(a, dtype=np.int64) for a in (gt, eq, fgt, feq)]
+    if corrupt_side in ("s", "o"):
+        return _cmp(gt, eq, strategy) + 1 - _cmp(fgt, feq, strategy)
+    o, s = slice(0, n_q), slice(n_q, 2 * n_q)
+    if corrupt_side == "s,o":
+        rank_s = _cmp(gt[s], eq[s], strategy) + 1 - _cmp(fgt[s], feq[s], strategy)
+        rank_o = _cmp(gt[o], eq[o], strategy) + 1 - _cmp(fgt[o], feq[o], strategy)
+        return np.stack([rank_s, rank_o], axis=1)
+    if corrupt_side == "s+o":
+        return (_cmp(gt[o] + gt[s], eq[o] + eq[s], strategy) + 1
+                - _cmp(fgt[s], feq[s], strategy) - _cmp(fgt[o], feq[o], strategy))
+    raise ValueError("Invalid argument value for corruption side passed for evaluation")
+
+
+def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
+                        filter_triples=None, entities_subset=None, query_chunk=4096, precision=0,
+                        reduce_counts=None, ent_offset=0, n_ent_global=None):
+    """Ranks of ``test_triples`` (int ids) against all entities (or ``entities_subset``).
+
+    ``ent`` may be an entity SLAB holding global rows [ent_offset, ent_offset+rows) — then
+    ``reduce_counts(tensor)`` must sum the int32 counters over the slab owners (RCCL all-reduce) and the
+    rows named by the test triples must be present in ``ent`` via ``query_tables`` (see parallel.py).
+    """
+    if corrupt_side not in L.EVAL_SIDE_IDS:
+        raise ValueError("Invalid argument value for corruption side passed for evaluation")
+    if strategy not in ("worst", "best", "middle"):
+        raise AssertionError("Invalid score comparision type!")
+    side_mode = L.EVAL_SIDE_IDS[corrupt_side]
+    T = np.ascontiguousarray(np.asarray(test_triples, dtype=np.int32).reshape(-1, 3))
+    n = T.shape[0]
+    n_ent = int(ent.shape[0]) if n_ent_global is None else int(n_ent_global)
+    cand = None
+    if entities_subset is not None:
+        cand = torch.from_numpy(np.ascontiguousarray(np.asarray(entities_subset, dtype=np.int32))).to(ent.device)
+    out = []
+    for c0 in range(0, n, query_chunk):
+        Tc = T[c0:c0 + query_chunk]
+        nq = Tc.shape[0]
+        Tt = torch.from_numpy(Tc).to(ent.device)
+        Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
+        n_rows = Q.shape[0]
+        cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
+        D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
+        if filter_triples is not None:
+            ptr, idx = build_filter_csr(filter_triples, Tc, side_mode, n_ent, entities_subset)
+            D.eval_filter_count(model_id, Q, pos_int, ent, ent_offset, k_int, scale,
+                                torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device),
+                                cnt[2], cnt[3], precision=precision)
+        if reduce_counts is not None:
+            reduce_counts(cnt)
+        c = cnt.cpu().numpy()
+        out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
+    if not out:
+        return np.zeros((0, 2) if corrupt_side == "s,o" else (0,), dtype=np.int64)
+    return np.concatenate(out, axis=0)

@@ -1,0 +1,208 @@
+/* emgraph_hip.h — C-ABI of libemgraph_hip.so: the MI355X (gfx950) replacement for
+ * bi-graph/Emgraph's per-batch hot path.
+ *
+ * The reference (pure Python on TensorFlow) has no FFI of its own; the entry points below are
+ * what a ctypes binding inside the reference would call INSTEAD of the TF op groups cited at
+ * each declaration (file:line relative to the reference tree).  INTEGRATION.md shows that stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative EMG_E* code otherwise; the message for the
+ *     calling thread's last failure is emg_last_error().  No C++ exception crosses the ABI.
+ *   - all pointers are DEVICE pointers on the current HIP device unless marked "host"; the caller
+ *     owns every buffer (in our host code they are PyTorch-ROCm tensors); the library allocates
+ *     nothing persistent — scratch comes from caller-provided workspaces sized by *_workspace_bytes.
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and ordered on it.
+ *   - embedding tables are float32 row-major with a row stride `ld` (in floats, ld >= k_int).
+ *     ComplEx/HolE rows are [re(0:k) | im(k:2k)], k_int = 2k (ComplEx.py:224,288-290).
+ *   - triples are int32 [n,3] row-major (s,p,o)  (EmbeddingModel.py:503-505).
+ *   - eta-major negatives: negative row j (0 <= j < eta*B) corrupts positive j mod B
+ *     (protocol.py:598).
+ */
+#ifndef EMGRAPH_HIP_H
+#define EMGRAPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMG_ABI_VERSION 1
+
+#define EMG_OK 0
+#define EMG_EINVAL (-1)   /* bad argument */
+#define EMG_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define EMG_ENOSUP (-3)   /* combination not supported */
+
+/* model ids: TransE.py:208-216 (norm 1 / 2), DistMult.py:201, ComplEx.py:288-298, HolE.py:189 */
+#define EMG_TRANSE_L1 0
+#define EMG_TRANSE_L2 1
+#define EMG_DISTMULT 2
+#define EMG_COMPLEX 3
+#define EMG_HOLE 4
+
+/* corruption side: protocol.py:598-608 ('s,o' is an alias of 's+o' there, :591-593) */
+#define EMG_SIDE_S 0
+#define EMG_SIDE_O 1
+#define EMG_SIDE_SO 2
+
+/* losses: losses/pairwise.py:66-70, nll.py:55-59, absolute_margin.py:66-70,
+ * self_adversarial.py:90-112, nll_multiclass.py:70-81 */
+#define EMG_LOSS_PAIRWISE 0
+#define EMG_LOSS_NLL 1
+#define EMG_LOSS_ABSOLUTE_MARGIN 2
+#define EMG_LOSS_SELF_ADVERSARIAL 3
+#define EMG_LOSS_MULTICLASS_NLL 4
+
+/* optimizers: training/sgd.py:97, momentum.py:63, adagrad.py:42, adam.py:45 (Keras rules) */
+#define EMG_OPT_SGD 0
+#define EMG_OPT_MOMENTUM 1
+#define EMG_OPT_ADAGRAD 2
+#define EMG_OPT_ADAM 3        /* Keras sparse apply == dense-equivalent: every row decays/updates */
+#define EMG_OPT_ADAM_LAZY 4   /* touched rows only (not reference semantics; opt-in) */
+
+/* score flags */
+#define EMG_SCORE_FINAL 0     /* the model's score */
+#define EMG_SCORE_PARTIAL 1   /* k-slice partial: TransE-L2 returns sum(d^2) (no -sqrt), HolE unscaled;
+                                 finish with emg_finalize_scores after summing slices */
+
+int emg_version(void);
+const char* emg_last_error(void);
+/* name of the compiled GPU target ("gfx950") */
+const char* emg_target(void);
+
+/* ---- K1+K2: fused embedding gather + score (replaces EmbeddingModel._lookup_embeddings
+ * :490-533 followed by Model._fn; the predict() path :2132-2133). out[n] f32. */
+int emg_score_triples(int model, const float* ent, int64_t n_ent, int64_t ld_ent,
+                      const float* rel, int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale,
+                      const int32_t* spo, int64_t n, int32_t flags, float* out, void* stream);
+
+/* finish partial scores in place (TransE-L2: -sqrt(x); HolE: scale*x; others unchanged) */
+int emg_finalize_scores(int model, float scale, float* scores, int64_t n, void* stream);
+
+/* ---- K3/K14: corruption draws (replaces the tf.random.uniform + mask logic of
+ * generate_corruptions_for_fit, protocol.py:598-641).
+ * codes[j] = replacement_entity | (keep_subject << 31), j in [0, B*eta).
+ *   side S: keep_subject=0 (subject replaced); O: keep_subject=1; SO: Bernoulli(1/2) per row.
+ *   replacement = idx if entities_list==NULL else entities_list[idx], idx ~ U{0..n_choices-1}
+ *   drawn from Philox4x32-10(key=seed, counter=(j, draw_counter)); or, when inj_repl != NULL,
+ *   idx = inj_repl[j] (and keep_subject = inj_mask[j] for side SO) — the "injected draws" mode
+ *   used to reproduce the reference's golden vectors. */
+int emg_corrupt_codes(int64_t B, int32_t eta, int side, int64_t n_choices,
+                      const int32_t* entities_list, uint64_t seed, uint64_t draw_counter,
+                      const int32_t* inj_mask, const int32_t* inj_repl, int32_t* codes, void* stream);
+
+/* materialise the [B*eta,3] corruption array exactly as generate_corruptions_for_fit returns it
+ * (protocol.py:643-656) from the positives and the codes */
+int emg_corrupt_expand(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes,
+                       int32_t* out_spo, void* stream);
+
+/* ---- K1+K2+K4 for a training batch: scores of the B positives and of their eta*B negatives
+ * given as codes; the [B*eta,3] array and the three gathered [n,k] temporaries of the reference
+ * (EmbeddingModel.py:675-677,788-799) are never materialised.  Rows shared inside a positive
+ * group (p and the kept side) are read once.  scores_neg is eta-major. */
+int emg_train_forward(int model, const float* ent, int64_t n_ent, int64_t ld_ent,
+                      const float* rel, int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale,
+                      const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes, int32_t flags,
+                      float* scores_pos, float* scores_neg, void* stream);
+
+/* ---- K5: loss value + dL/dscore (replaces Loss.apply, losses/loss.py:123-138, and TF autodiff
+ * through it).  scores_neg is [n_sides*eta*B] (side-major, then eta-major); the positive is tiled
+ * per side as EmbeddingModel.py:724-729,786-816.  *loss_accum (device f64) += loss.
+ * g_pos[B] = sum over tiles/sides of dL/dpos, g_neg[n_sides*eta*B] = dL/dneg. */
+int emg_loss(int loss, const float* scores_pos, const float* scores_neg, int64_t B, int32_t eta,
+             int32_t n_sides, float margin, float alpha, double* loss_accum, float* g_pos, float* g_neg,
+             void* stream);
+
+/* ---- K7: adjoint of gather+score.  Writes per-group gradient rows (no atomics):
+ *   contrib_ent[0*B+i] = dL/dE[s_i] from group i,  contrib_ent[1*B+i] = dL/dE[o_i],
+ *   contrib_ent[2*B + j*B + i] = dL/dE[replacement of negative j of positive i]   (j < eta)
+ *   contrib_rel[i] = dL/dR[p_i];   row stride ldc floats (>= k_int).
+ * dest_ent[(2+eta)*B], dest_rel[B] receive the destination row ids of those rows. */
+int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_ent,
+                       const float* rel, int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale,
+                       const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes,
+                       const float* g_pos, const float* g_neg,
+                       float* contrib_ent, float* contrib_rel, int64_t ldc,
+                       int32_t* dest_ent, int32_t* dest_rel, void* stream);
+
+/* ---- K8: deterministic row-sparse optimizer apply.  Sorts (dest, index) (stable radix sort),
+ * sums each destination's contribution rows in index order and updates that table row once.
+ * state0/state1: momentum buffer | adagrad accumulator | adam m, v  (same shape/stride as the table;
+ * NULL when unused).  `tag` int32[n_rows] scratch owned by the caller (persistently, zero-initialised
+ * once) marks rows touched in step `step` (>=1) — needed by EMG_OPT_ADAM's dense pass.
+ * hyper: HOST pointer to 6 floats {lr, momentum, beta1, beta2, eps, lr_t} read at call time
+ * (lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), Adam only). */
+int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows);
+int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
+                   float* state0, float* state1, int32_t* tag, int32_t step,
+                   const float* contrib, int64_t ldc, const int32_t* dest, int64_t n_contrib,
+                   const float* hyper, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- K6: LP regulariser over FULL tables (regularizers/lp.py:107-113): *loss_accum +=
+ * lambda * sum |W|^p, and (if grad_scale_lr != 0) the SGD-style in-place update
+ * W -= grad_scale_lr * lambda * p * |W|^(p-1) * sign(W). */
+int emg_lp_regularizer(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float lambda, int32_t p,
+                       float grad_scale_lr, double* loss_accum, void* stream);
+
+/* ---- K9: optional row-norm clip after a batch (EmbeddingModel.py:1371-1380, clip_by_norm axes=1) */
+int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream);
+
+/* ====================== filtered 1-vs-all ranking (K10-K13) ======================
+ * side_mode: 0 's' | 1 'o' | 2 's+o' | 3 's,o'.  Query rows: for modes 2,3 rows [0,n_q) are the
+ * OBJECT-side queries (s,p,?) and rows [n_q,2n_q) the SUBJECT-side queries (?,p,o) — the block
+ * order of generate_corruptions_for_eval (protocol.py:511-518); modes 0/1 have n_q rows. */
+#define EMG_EVAL_S 0
+#define EMG_EVAL_O 1
+#define EMG_EVAL_SPO 2
+#define EMG_EVAL_S_O 3
+
+/* Build the query matrix Q[n_rows, ldq] and the positive's comparison integer
+ * pos_int[n_rows] = int32(score_pos * 1e5) (EmbeddingModel.py:1865-1866,2010-2014), with the
+ * positive scored through the SAME arithmetic as its corruptions (see DESIGN.md "canonical order").
+ * Query vectors: DistMult q=p*x; ComplEx/HolE the Re/Im-hoisted vectors (SURVEY B-2);
+ * TransE object side q=s+p, subject side q=o-p. */
+int emg_eval_build_queries(int model, const float* ent, int64_t n_ent, int64_t ld_ent,
+                           const float* rel, int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale,
+                           const int32_t* test_spo, int64_t n_q, int side_mode,
+                           float* Q, int64_t ldq, int32_t* pos_int, void* stream);
+
+/* Count, for every query row, the candidates whose comparison integer is > / == the positive's
+ * (perform_comparision, EmbeddingModel.py:2010-2033; worst = gt+eq, best = gt,
+ * middle = gt+ceil(eq/2) are formed by the caller).  Candidates are rows [0,n_cand) of `ent`
+ * (an entity slab) or, if cand != NULL, rows cand[0..n_cand) of it.  cnt_gt/cnt_eq int32[n_rows]
+ * are ACCUMULATED (zero them first; sum over slabs / GPUs).
+ * precision: 0 = fp32 (exact f32-MFMA for DistMult/ComplEx/HolE; f32 VALU for TransE),
+ *            1 = bf16 MFMA (ent_bf16/Q rounded to bf16; rank agreement is statistical). */
+int emg_eval_count(int model, const float* Q, int64_t ldq, const int32_t* pos_int, int64_t n_rows,
+                   const float* ent, int64_t n_cand, int64_t ld_ent, const int32_t* cand,
+                   int32_t k_int, float scale, int precision, const void* ent_bf16, int64_t ld_bf16,
+                   int32_t* cnt_gt, int32_t* cnt_eq, void* stream);
+
+/* Same counts restricted to each query row's filter list (CSR: filt_ptr int64[n_rows+1],
+ * filt_idx int32 GLOBAL entity ids; `ent` points at global row `ent_offset` and holds n_local rows;
+ * entries outside [ent_offset, ent_offset+n_local) are skipped so every slab owner can be handed
+ * the same global list) — replaces the tf.gather(scores, indices_obj/sub) + perform_comparision of
+ * EmbeddingModel.py:1942-1963 and the SQLite lookups feeding it (sqlite_adapter.py:449-508).
+ * fcnt_gt/fcnt_eq are ACCUMULATED. */
+int emg_eval_filter_count(int model, const float* Q, int64_t ldq, const int32_t* pos_int, int64_t n_rows,
+                          const float* ent, int64_t n_local, int64_t ld_ent, int64_t ent_offset,
+                          int32_t k_int, float scale, int precision,
+                          const int64_t* filt_ptr, const int32_t* filt_idx,
+                          int32_t* fcnt_gt, int32_t* fcnt_eq, void* stream);
+
+/* Debug/verification: dense scores S[n_rows, lds>=n_cand] through the SAME kernels as
+ * emg_eval_count (small sizes only). */
+int emg_eval_scores_dense(int model, const float* Q, int64_t ldq, int64_t n_rows,
+                          const float* ent, int64_t n_cand, int64_t ld_ent, const int32_t* cand,
+                          int32_t k_int, float scale, int precision, const void* ent_bf16, int64_t ld_bf16,
+                          float* S, int64_t lds, void* stream);
+
+/* f32 -> bf16 (round-to-nearest-even) copy of a table for precision mode 1 */
+int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int,
+                void* dst_bf16, int64_t ld_dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMGRAPH_HIP_H */

@@ -351,7 +351,8 @@ def loss_grads(name, pos, neg, eta, params=None):
     B = pos.shape[0]
     negr = neg.reshape(eta, B)
     if name == "pairwise":
-        act = ((params.get("margin", DEFAULT_MARGIN) - pos[None, :] + negr) > 0).astype(np.float64)
+        # tf.maximum's gradient goes to x where x >= y (MaximumGrad uses greater_equal)
+        act = ((params.get("margin", DEFAULT_MARGIN) - pos[None, :] + negr) >= 0).astype(np.float64)
         return (-act.sum(0)).astype(F32), act.reshape(-1).astype(F32)
     if name == "nll":
         lo, hi = DEFAULT_CLIP_EXP_LOWER, DEFAULT_CLIP_EXP_UPPER
@@ -361,7 +362,7 @@ def loss_grads(name, pos, neg, eta, params=None):
         gn = inn / (1.0 + np.exp(-np.clip(negr, lo, hi)))
         return gp.astype(F32), gn.reshape(-1).astype(F32)
     if name == "absolute_margin":
-        act = ((params.get("margin", DEFAULT_MARGIN) + negr) > 0).astype(np.float64)
+        act = ((params.get("margin", DEFAULT_MARGIN) + negr) >= 0).astype(np.float64)
         return np.full(B, -float(eta), dtype=F32), act.reshape(-1).astype(F32)
     if name == "self_adversarial":
         m = params.get("margin", DEFAULT_MARGIN_ADVERSARIAL)

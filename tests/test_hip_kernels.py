@@ -1,0 +1,428 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the oracle on seeded inputs.
+Bar: bit-exact for integer/index work (corruptions, ranks, counts); fp32 scores/gradients within
+1e-4 relative (north_star), tolerance written at each assert."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co  # noqa: E402
+from oracle import emgraph_oracle as orc  # noqa: E402
+
+MODELS = ["TransE_L1", "TransE_L2", "DistMult", "ComplEx", "HolE"]
+MID = orc.MODEL_IDS
+F32 = np.float32
+
+
+def dev():
+    from emgraph_amd import device
+    device.require_gpu()
+    return device
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def kint_of(model, k):
+    return 2 * k if model in ("ComplEx", "HolE") else k
+
+
+def scale_of(model, k):
+    return float(F32(2 / k)) if model == "HolE" else 1.0
+
+
+def make_tables(model, k, n_ent, n_rel, seed, scale=0.3, pad=0):
+    rs = np.random.RandomState(seed)
+    ki = kint_of(model, k)
+    E = (rs.randn(n_ent, ki) * scale).astype(F32)
+    R = (rs.randn(n_rel, ki) * scale).astype(F32)
+    return E, R, ki
+
+
+def score_tol(model, E, R, x, k):
+    """|err| <= 1e-4 * (sum of |terms|): relative to the magnitude the reduction actually sums."""
+    es, ep, eo = orc.lookup_embeddings(np.abs(E), np.abs(R), x)
+    if model.startswith("TransE"):
+        mag = np.sum(es + ep + eo, axis=1)
+    elif model == "DistMult":
+        mag = np.sum(es * ep * eo, axis=1)
+    else:
+        sr, si = np.split(es, 2, 1); pr, pi = np.split(ep, 2, 1); orr, oi = np.split(eo, 2, 1)
+        mag = np.sum(pr * sr * orr + pr * si * oi + pi * sr * oi + pi * si * orr, axis=1)
+        if model == "HolE":
+            mag = mag * (2 / k)
+    return 1e-4 * mag + 1e-7
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("k", [3, 10, 50, 100, 200, 260])
+def test_score_triples_vs_oracle(model, k):
+    d = dev()
+    E, R, ki = make_tables(model, k, 211, 7, seed=k)
+    rs = np.random.RandomState(k + 1)
+    n = 333
+    x = np.stack([rs.randint(0, 211, n), rs.randint(0, 7, n), rs.randint(0, 211, n)], 1).astype(np.int32)
+    got = d.score_triples(MID[model], cu(E), cu(R), ki, scale_of(model, k), cu(x)).cpu().numpy()
+    exp = orc.score_triples(model, E, R, x, k=k)
+    assert np.all(np.abs(got - exp) <= score_tol(model, E, R, x, k)), np.abs(got - exp).max()
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_score_triples_golden_fixtures(model, golden):
+    """the reference-generated fixtures (tests/golden/scores.npz) through the HIP path"""
+    d = dev()
+    g = golden("scores")
+    for ci, (k, n) in enumerate(g["cases"]):
+        tag = "%s_c%d" % (model, ci)
+        es, ep, eo = g[tag + "_es"], g[tag + "_ep"], g[tag + "_eo"]
+        n = es.shape[0]
+        E = np.concatenate([es, eo], 0)
+        x = np.stack([np.arange(n), np.arange(n), n + np.arange(n)], 1).astype(np.int32)
+        got = d.score_triples(MID[model], cu(E), cu(ep), es.shape[1], scale_of(model, int(k)), cu(x)).cpu().numpy()
+        tol = score_tol(model, E, ep, x, int(k))
+        assert np.all(np.abs(got - g[tag + "_y"]) <= tol), (tag, np.abs(got - g[tag + "_y"]).max())
+
+
+def test_score_triples_strided_and_odd_layouts():
+    """row stride > k_int, unaligned (odd) strides -> scalar path; huge k -> generic fallback"""
+    d = dev()
+    rs = np.random.RandomState(5)
+    for model, k, ld in [("DistMult", 8, 12), ("ComplEx", 6, 13), ("TransE_L1", 7, 9), ("ComplEx", 700, 1400),
+                         ("DistMult", 1030, 1030)]:
+        ki = kint_of(model, k)
+        Ebuf = (rs.randn(50, ld) * 0.3).astype(F32)
+        Rbuf = (rs.randn(5, ld) * 0.3).astype(F32)
+        x = np.stack([rs.randint(0, 50, 77), rs.randint(0, 5, 77), rs.randint(0, 50, 77)], 1).astype(np.int32)
+        Et, Rt = cu(Ebuf), cu(Rbuf)
+        got = d.score_triples(MID[model], Et[:, :ki], Rt[:, :ki], ki, scale_of(model, k), cu(x)).cpu().numpy()
+        E, R = Ebuf[:, :ki].copy(), Rbuf[:, :ki].copy()
+        exp = orc.score_triples(model, E, R, x, k=k)
+        assert np.all(np.abs(got - exp) <= score_tol(model, E, R, x, k)), (model, k)
+
+
+def test_empty_inputs():
+    d = dev()
+    E, R, ki = make_tables("DistMult", 8, 10, 2, 0)
+    out = d.score_triples(MID["DistMult"], cu(E), cu(R), ki, 1.0, torch.empty((0, 3), dtype=torch.int32, device="cuda"))
+    assert out.numel() == 0
+
+
+# ---------------------------------------------------------------- corruptions (integer: bit-exact)
+def test_corruptions_injected_vs_reference_golden(golden):
+    d = dev()
+    g = golden("corruptions")
+    for ci, (xname, eta, side, mode) in enumerate(g["fit_cases"]):
+        X = g["toy_X_idx"] if xname == "toy" else g["fit_Xbig"]
+        eta = int(eta)
+        tag = "fit_c%d" % ci
+        if mode == "size":
+            n_choices, elist = (8 if xname == "toy" else 50), None
+        elif mode == "list":
+            elist = g["fit_entities_list"]
+            n_choices = len(elist)
+        else:
+            elist = orc.batch_unique_entities(X)
+            n_choices = len(elist)
+        from emgraph_amd import _lib as L
+        codes = d.corrupt_codes(X.shape[0], eta, L.SIDE_IDS[str(side)], n_choices, "cuda",
+                                entities_list=cu(elist) if elist is not None else None,
+                                inj_mask=cu(g[tag + "_mask"]), inj_repl=cu(g[tag + "_repl"]))
+        out = d.corrupt_expand(cu(X), eta, codes).cpu().numpy()
+        np.testing.assert_array_equal(out, g[tag + "_out"], err_msg=str((ci, xname, eta, side, mode)))
+
+
+def test_reference_own_fit_corruption_goldens():
+    """tests/emgraph/evaluation/test_protocol.py:530-605 through the HIP generator (injected draws)"""
+    d = dev()
+    from emgraph_amd import _lib as L
+    Xi = np.array([[0, 0, 1], [2, 0, 3], [4, 0, 5], [1, 1, 6], [0, 1, 7]], np.int32)
+    repl = cu(np.array([1, 3, 3, 0, 3], np.int32))
+    for side, mask, exp in [("o", None, [[0, 0, 1], [2, 0, 3], [4, 0, 3], [1, 1, 0], [0, 1, 3]]),
+                            ("s", None, [[1, 0, 1], [3, 0, 3], [3, 0, 5], [0, 1, 6], [3, 1, 7]]),
+                            ("s,o", [1, 1, 0, 1, 1], [[0, 0, 1], [2, 0, 3], [3, 0, 5], [1, 1, 0], [0, 1, 3]])]:
+        m = cu(np.array(mask, np.int32)) if mask is not None else cu(np.zeros(5, np.int32))
+        codes = d.corrupt_codes(5, 1, L.SIDE_IDS[side], 5, "cuda", inj_mask=m, inj_repl=repl)
+        np.testing.assert_array_equal(d.corrupt_expand(cu(Xi), 1, codes).cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("side", ["s", "o", "s+o"])
+def test_corruptions_philox_bit_exact(side):
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(2)
+    X = np.stack([rs.randint(0, 1000, 4097), rs.randint(0, 9, 4097), rs.randint(0, 1000, 4097)], 1).astype(np.int32)
+    for (eta, n_choices, seed, counter) in [(1, 1000, 0, 0), (5, 14541, 7, 123456789012), (20, 1000000, 2**40 + 3, 5)]:
+        codes = d.corrupt_codes(X.shape[0], eta, L.SIDE_IDS[side], n_choices, "cuda", seed=seed, counter=counter)
+        exp = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side=side, entities_size=n_choices,
+                                                      seed=seed, counter=counter)
+        np.testing.assert_array_equal(d.corrupt_expand(cu(X), eta, codes).cpu().numpy(), exp)
+        np.testing.assert_array_equal(codes.cpu().numpy(),
+                                      co.corrupt_codes(X.shape[0], eta, L.SIDE_IDS[side], n_choices, seed, counter))
+
+
+# ---------------------------------------------------------------- training forward / loss / backward
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("k,eta", [(10, 1), (100, 3), (200, 20), (6, 2)])
+def test_train_forward_vs_oracle(model, k, eta):
+    d = dev()
+    E, R, ki = make_tables(model, k, 300, 11, seed=3 * k + eta)
+    rs = np.random.RandomState(9)
+    B = 130
+    X = np.stack([rs.randint(0, 300, B), rs.randint(0, 11, B), rs.randint(0, 300, B)], 1).astype(np.int32)
+    codes = co.corrupt_codes(B, eta, 2, 300, 11, 22)
+    sp, sn = d.train_forward(MID[model], cu(E), cu(R), ki, scale_of(model, k), cu(X), eta, cu(codes))
+    xneg = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side="s+o", entities_size=300, seed=11, counter=22)
+    exp_p = orc.score_triples(model, E, R, X, k=k)
+    exp_n = orc.score_triples(model, E, R, xneg, k=k)
+    assert np.all(np.abs(sp.cpu().numpy() - exp_p) <= score_tol(model, E, R, X, k))
+    assert np.all(np.abs(sn.cpu().numpy() - exp_n) <= score_tol(model, E, R, xneg, k))
+
+
+@pytest.mark.parametrize("loss", list(orc.REQUIRE_SAME_SIZE))
+@pytest.mark.parametrize("eta,n_sides", [(1, 1), (2, 1), (20, 1), (3, 2)])
+def test_loss_and_grads_vs_oracle(loss, eta, n_sides):
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(17 + eta)
+    B = 301
+    pos = (rs.randn(B) * 3).astype(F32)
+    neg = (rs.randn(n_sides * eta * B) * 3).astype(F32)
+    pos[0], neg[0], neg[-1] = 90.0, -80.0, 76.0  # the +-75 clip
+    params = {"margin": 1.5, "alpha": 0.7} if loss in ("pairwise", "absolute_margin", "self_adversarial") else {}
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    gp, gn = d.loss(L.LOSS_IDS[loss], cu(pos), cu(neg), B, eta, n_sides, params.get("margin", 1.0),
+                    params.get("alpha", 0.5), acc)
+    exp_loss = 0.0
+    exp_gp = np.zeros(B, np.float64)
+    exp_gn = []
+    for sd in range(n_sides):
+        ns = neg[sd * eta * B:(sd + 1) * eta * B]
+        pin = np.tile(pos, eta) if orc.REQUIRE_SAME_SIZE[loss] else pos
+        exp_loss += float(orc.loss_apply(loss, pin, ns, eta, params))
+        a, b = orc.loss_grads(loss, pos, ns, eta, params)
+        exp_gp += a
+        exp_gn.append(b)
+    np.testing.assert_allclose(acc.item(), exp_loss, rtol=2e-5)
+    np.testing.assert_allclose(gp.cpu().numpy(), exp_gp, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gn.cpu().numpy(), np.concatenate(exp_gn), rtol=1e-4, atol=1e-6)
+
+
+def test_losses_golden_fixtures(golden):
+    d = dev()
+    from emgraph_amd import _lib as L
+    g = golden("losses")
+    for ci, (eta, B) in enumerate(g["cases"]):
+        eta, B = int(eta), int(B)
+        pos, neg = g["c%d_pos" % ci], g["c%d_neg" % ci]
+        for name in orc.REQUIRE_SAME_SIZE:
+            margin = 3.0 if name == "self_adversarial" else 1.0
+            acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+            d.loss(L.LOSS_IDS[name], cu(pos), cu(neg), B, eta, 1, margin, 0.5, acc)
+            np.testing.assert_allclose(acc.item(), g["c%d_%s" % (ci, name)], rtol=1e-5, err_msg="%s c%d" % (name, ci))
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("k,eta", [(8, 3), (100, 5), (200, 2), (5, 2)])
+def test_train_backward_vs_oracle(model, k, eta):
+    d = dev()
+    n_ent, n_rel, B = 97, 5, 70
+    E, R, ki = make_tables(model, k, n_ent, n_rel, seed=k)
+    rs = np.random.RandomState(4)
+    X = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    codes = co.corrupt_codes(B, eta, 2, n_ent, 5, 6)
+    xneg = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side="s+o", entities_size=n_ent, seed=5, counter=6)
+    gpos = rs.randn(B).astype(F32)
+    gneg = rs.randn(B * eta).astype(F32)
+    ldc = ((ki + 3) // 4) * 4
+    ce = torch.zeros(((2 + eta) * B, ldc), dtype=torch.float32, device="cuda")
+    cr = torch.zeros((B, ldc), dtype=torch.float32, device="cuda")
+    de = torch.empty((2 + eta) * B, dtype=torch.int32, device="cuda")
+    dr = torch.empty(B, dtype=torch.int32, device="cuda")
+    d.train_backward(MID[model], cu(E), cu(R), ki, scale_of(model, k), cu(X), eta, cu(codes), cu(gpos), cu(gneg),
+                     ce, cr, de, dr)
+    dE = np.zeros((n_ent, ki)); dR = np.zeros((n_rel, ki))
+    np.add.at(dE, de.cpu().numpy(), ce.cpu().numpy()[:, :ki].astype(np.float64))
+    np.add.at(dR, dr.cpu().numpy(), cr.cpu().numpy()[:, :ki].astype(np.float64))
+    eE, eR = orc.score_grads(model, E, R, X, gpos, k=k)
+    a, b = orc.score_grads(model, E, R, xneg, gneg, k=k)
+    eE += a; eR += b
+    # destination ids are integer work: exact
+    np.testing.assert_array_equal(de.cpu().numpy()[:B], X[:, 0])
+    np.testing.assert_array_equal(de.cpu().numpy()[B:2 * B], X[:, 2])
+    np.testing.assert_array_equal(de.cpu().numpy()[2 * B:], codes & 0x7fffffff)
+    np.testing.assert_array_equal(dr.cpu().numpy(), X[:, 1])
+    scale = max(np.abs(eE).max(), 1e-6)
+    np.testing.assert_allclose(dE, eE, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(dR, eR, rtol=1e-4, atol=1e-5 * max(np.abs(eR).max(), 1e-6))
+
+
+@pytest.mark.parametrize("opt", ["sgd", "momentum", "adagrad", "adam", "adam_lazy"])
+def test_apply_rows_vs_oracle(opt):
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(8)
+    n_rows, k, n_c = 50, 12, 400
+    W = rs.randn(n_rows, k).astype(F32)
+    dest = rs.randint(0, 30, n_c).astype(np.int32)  # rows 30..49 untouched, many duplicates
+    contrib = rs.randn(n_c, k).astype(F32)
+    Wt = cu(W)
+    s0 = s1 = None
+    st = orc.opt_init("adam" if opt == "adam_lazy" else opt, W.shape)
+    if opt == "momentum":
+        s0 = torch.zeros_like(Wt)
+    elif opt == "adagrad":
+        s0 = torch.full_like(Wt, 0.1)
+    elif opt in ("adam", "adam_lazy"):
+        s0, s1 = torch.zeros_like(Wt), torch.zeros_like(Wt)
+    tag = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+    ws = torch.empty(d.apply_workspace_bytes(n_c, n_rows), dtype=torch.uint8, device="cuda")
+    Wexp = W.copy()
+    lr, mu, b1, b2, eps = 0.05, 0.9, 0.9, 0.999, 1e-7
+    for step in (1, 2, 3):
+        lr_t = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        d.apply_rows(L.OPT_IDS[opt], Wt, k, s0, s1, tag, step, cu(contrib), cu(dest), n_c,
+                     (lr, mu, b1, b2, eps, lr_t), ws)
+        G = np.zeros((n_rows, k), np.float64)
+        np.add.at(G, dest, contrib.astype(np.float64))
+        touched = np.zeros(n_rows, bool); touched[dest] = True
+        if opt == "adam_lazy":
+            st["t"] += 1
+            m, v = st["m"], st["v"]
+            g = G.astype(F32)
+            m[touched] = F32(b1) * m[touched] + F32(1 - b1) * g[touched]
+            v[touched] = F32(b2) * v[touched] + F32(1 - b2) * g[touched] ** 2
+            Wexp[touched] = Wexp[touched] - F32(lr_t) * m[touched] / (np.sqrt(v[touched]) + F32(eps))
+        else:
+            Wexp = orc.opt_apply(opt, Wexp, G, st, lr=lr, momentum=mu, beta1=b1, beta2=b2, eps=eps,
+                                 touched=None if opt == "adam" else touched)
+        np.testing.assert_allclose(Wt.cpu().numpy(), Wexp, rtol=2e-5, atol=2e-6, err_msg="%s step %d" % (opt, step))
+    if opt in ("sgd", "momentum", "adagrad", "adam_lazy"):
+        np.testing.assert_array_equal(Wt.cpu().numpy()[30:], W[30:])  # untouched rows bit-identical
+
+
+def test_apply_rows_is_deterministic():
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(1)
+    n_rows, k, n_c = 64, 100, 20000
+    W = rs.randn(n_rows, k).astype(F32)
+    dest = rs.randint(0, n_rows, n_c).astype(np.int32)
+    contrib = rs.randn(n_c, k).astype(F32)
+    outs = []
+    for _ in range(3):
+        Wt = cu(W)
+        ws = torch.empty(d.apply_workspace_bytes(n_c, n_rows), dtype=torch.uint8, device="cuda")
+        d.apply_rows(L.OPT_SGD, Wt, k, None, None, None, 1, cu(contrib), cu(dest), n_c, (0.1, 0, 0, 0, 0, 0), ws)
+        outs.append(Wt.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+
+
+def test_lp_regularizer_and_clip(golden):
+    d = dev()
+    g = golden("misc")
+    for p in (1, 2, 3):
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        d.lp_regularizer(cu(g["lp_w1"]), 5, 0.5, p, 0.0, acc)
+        d.lp_regularizer(cu(g["lp_w2"]), 5, 2.0, p, 0.0, acc)
+        np.testing.assert_allclose(acc.item(), g["lp_p%d_list" % p], rtol=1e-5)
+    # reference's own goldens (tests/emgraph/models/test_regularizers.py:7-38)
+    p1 = np.array([[1, -1, 1]], F32); p2 = np.array([[2, -2, 2]], F32)
+    for p, lam, exp in [(1, (1.0, 1.0), 9.0), (1, (2.0, 3.0), 24.0), (2, (1.0, 1.0), 15.0), (2, (2.0, 3.0), 42.0)]:
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        d.lp_regularizer(cu(p1), 3, lam[0], p, 0.0, acc)
+        d.lp_regularizer(cu(p2), 3, lam[1], p, 0.0, acc)
+        assert acc.item() == exp
+    # gradient step of the regulariser: W -= lr*lambda*p*|W|^(p-1)*sign(W)
+    W = g["lp_w1"].copy()
+    Wt = cu(W)
+    d.lp_regularizer(Wt, 5, 0.5, 2, 0.1, None)
+    np.testing.assert_allclose(Wt.cpu().numpy(), W - 0.1 * 0.5 * 2 * W, rtol=1e-6)
+    # clip_by_norm(axes=1)
+    Wt = cu(W * 3)
+    d.clip_rows(Wt, 5, 1.0)
+    nrm = np.linalg.norm(W * 3, axis=1, keepdims=True)
+    np.testing.assert_allclose(Wt.cpu().numpy(), W * 3 / np.maximum(nrm, 1.0), rtol=1e-6)
+
+
+# ---------------------------------------------------------------- 1-vs-all ranking
+EVAL_MODES = {"s": 0, "o": 1, "s+o": 2, "s,o": 3}
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("k,n_ent", [(8, 50), (50, 300), (200, 700), (7, 131)])
+def test_eval_dense_scores_are_the_canonical_chain(model, k, n_ent):
+    """MFMA / VALU count kernels == k-ordered fmaf chain, BITWISE (what makes ranks exact)."""
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k)
+    rs = np.random.RandomState(3)
+    nq = 37
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    sc = scale_of(model, k)
+    Q, pos_int = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    Qe, pe = co.build_queries(MID[model], E, R, ki, sc, T, 3)
+    np.testing.assert_array_equal(Q.cpu().numpy()[:, :ki], Qe)       # query vectors bit-exact
+    np.testing.assert_array_equal(pos_int.cpu().numpy(), pe)         # positives' comparison ints bit-exact
+    S = d.eval_scores_dense(MID[model], Q, cu(E), ki, sc).cpu().numpy()
+    Se = co.scores_dense(MID[model], Qe, E, ki, sc)
+    np.testing.assert_array_equal(S.view(np.int32), Se.view(np.int32))
+
+
+@pytest.mark.parametrize("model", MODELS)
+@pytest.mark.parametrize("strategy", ["worst", "best", "middle"])
+def test_ranks_exact_arithmetic_vs_literal_oracle(model, strategy):
+    """Dyadic embeddings make every fp32 op exact -> any summation order gives the same bits, so the
+    HIP ranks must equal the LITERAL numpy restatement of the reference (incl. ties, filters, sides)."""
+    from emgraph_amd.evaluation import rank_triples_device
+    d = dev()
+    rs = np.random.RandomState(21)
+    k, n_ent, n_rel = 4, 140, 3
+    ki = kint_of(model, k)
+    E = (rs.randint(-4, 5, (n_ent, ki)) / 4.0).astype(F32)
+    R = (rs.randint(-4, 5, (n_rel, ki)) / 4.0).astype(F32)
+    T = np.stack([rs.randint(0, n_ent, 40), rs.randint(0, n_rel, 40), rs.randint(0, n_ent, 40)], 1).astype(np.int32)
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 3000), rs.randint(0, n_rel, 3000),
+                                     rs.randint(0, n_ent, 3000)], 1)]).astype(np.int32)
+    for side in ("s,o", "s+o", "s", "o"):
+        for filt in (None, F):
+            got = rank_triples_device(MID[model], cu(E), cu(R), ki, scale_of(model, k), T, side, strategy,
+                                      filter_triples=filt)
+            exp = orc.get_ranks(model, E, R, T, corrupt_side=side, strategy=strategy, filter_triples=filt, k=k)
+            np.testing.assert_array_equal(got, exp, err_msg=str((model, side, strategy, filt is not None)))
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_ranks_random_embeddings_vs_canonical_oracle(model):
+    """random fp32 embeddings, |E|=5000: counts bit-exact vs the C canonical-order oracle; and ranks
+    within the +-1e-5 score band of the literal numpy oracle."""
+    from emgraph_amd.evaluation import rank_triples_device
+    d = dev()
+    k, n_ent, n_rel, nq = 64, 5000, 6, 50
+    E, R, ki = make_tables(model, k, n_ent, n_rel, seed=77)
+    rs = np.random.RandomState(5)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, n_rel, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    sc = scale_of(model, k)
+    Q, pos_int = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    gt = torch.zeros(2 * nq, dtype=torch.int32, device="cuda"); eq = torch.zeros_like(gt)
+    d.eval_count(MID[model], Q, pos_int, cu(E), ki, sc, gt, eq)
+    Qe, pe = co.build_queries(MID[model], E, R, ki, sc, T, 3)
+    egt, eeq = co.count(MID[model], Qe, pe, E, ki, sc)
+    np.testing.assert_array_equal(gt.cpu().numpy(), egt)
+    np.testing.assert_array_equal(eq.cpu().numpy(), eeq)
+    # candidate subset + slab offsets
+    cand = rs.permutation(n_ent)[:777].astype(np.int32)
+    gt.zero_(); eq.zero_()
+    d.eval_count(MID[model], Q, pos_int, cu(E), ki, sc, gt, eq, cand=cu(cand))
+    egt, eeq = co.count(MID[model], Qe, pe, E, ki, sc, cand=cand)
+    np.testing.assert_array_equal(gt.cpu().numpy(), egt)
+    np.testing.assert_array_equal(eq.cpu().numpy(), eeq)
+    # against the literal oracle: equal unless a candidate's score is within float noise of the positive's
+    got = rank_triples_device(MID[model], cu(E), cu(R), ki, sc, T[:12], "s,o", "worst")
+    exp = orc.get_ranks(model, E, R, T[:12], corrupt_side="s,o", strategy="worst", k=k)
+    assert np.abs(got - exp).max() <= 2

@@ -1,0 +1,160 @@
+"""CPU tests of the host logic (no GPU, no compute calls): the C-ABI library loads and exports every
+declared symbol; filter CSR == the oracle's per-triple SQLite semantics; rank assembly; C oracle ==
+numpy oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import emgraph_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32 = np.float32
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from emgraph_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "emgraph_hip.h")).read()
+    declared = set(re.findall(r"\b(emg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(L.LIB_PATH), "libemgraph_hip.so is not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    handle = L.load()
+    assert handle.emg_version() == L.ABI_VERSION
+    assert handle.emg_target() == b"gfx950"
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "emgraph_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/emg_oracle.c", "").replace("oracle/emgraph_oracle.py", "") \
+                    .replace("oracle/emg_oracle.c", "") or f in ("emg_rank.hip", "emg_common.hpp"), \
+                    "%s mentions the oracle" % f
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), "%s imports the oracle" % f
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    from emgraph_amd import device
+    from emgraph_amd._lib import EmgError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(EmgError):
+        device.require_gpu()
+
+
+@pytest.mark.parametrize("side", ["s", "o", "s+o", "s,o"])
+def test_filter_csr_matches_per_triple_semantics(side):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import build_filter_csr
+    rs = np.random.RandomState(0)
+    n_ent, n_rel = 30, 3
+    F = np.stack([rs.randint(0, n_ent, 600), rs.randint(0, n_rel, 600), rs.randint(0, n_ent, 600)], 1)
+    F = np.concatenate([F, F[:50]])  # duplicates in the filter must not double count (SELECT DISTINCT)
+    T = np.concatenate([F[:10], np.stack([rs.randint(0, n_ent, 15), rs.randint(0, n_rel, 15), rs.randint(0, n_ent, 15)], 1)])
+    ptr, idx = build_filter_csr(F, T, L.EVAL_SIDE_IDS[side], n_ent)
+    n_q = len(T)
+    for qi, x in enumerate(T):
+        objs, subs = orc.participating_entities(F, x)
+        if side == "o":
+            np.testing.assert_array_equal(idx[ptr[qi]:ptr[qi + 1]], objs)
+        elif side == "s":
+            np.testing.assert_array_equal(idx[ptr[qi]:ptr[qi + 1]], subs)
+        else:
+            np.testing.assert_array_equal(idx[ptr[qi]:ptr[qi + 1]], objs)
+            np.testing.assert_array_equal(idx[ptr[n_q + qi]:ptr[n_q + qi + 1]], subs)
+    # with a subset: only members survive
+    sub = np.array([1, 4, 9, 16, 25])
+    ptr2, idx2 = build_filter_csr(F, T, L.EVAL_SIDE_IDS[side], n_ent, entities_subset=sub)
+    assert np.all(np.isin(idx2, sub)) and ptr2[-1] == len(idx2)
+    # empty filter / empty test
+    p0, i0 = build_filter_csr(np.zeros((0, 3), int), T, L.EVAL_SIDE_IDS[side], n_ent)
+    assert p0[-1] == len(i0) == (2 * n_q if side in ("s+o", "s,o") else n_q)  # only the self entries
+    p1, i1 = build_filter_csr(F, np.zeros((0, 3), int), L.EVAL_SIDE_IDS[side], n_ent)
+    assert len(i1) == 0 and p1[-1] == 0
+
+
+def _numpy_counts(model, E, R, T, side_mode, k, filt=None):
+    """(gt, eq, fgt, feq) rows from the LITERAL numpy oracle scores"""
+    rows = []
+    for obj_side in ([True, False] if side_mode >= 2 else [side_mode == 1]):
+        for x in T:
+            C = np.arange(E.shape[0])
+            corr = orc.generate_corruptions_for_eval(x, C, "o" if obj_side else "s")
+            sc = orc.to_cmp_int(orc.score_triples(model, E, R, corr, k=k))
+            p = orc.to_cmp_int(orc.score_triples(model, E, R, x[None], k=k))[0]
+            fg = fe = 0
+            if filt is not None:
+                objs, subs = orc.participating_entities(filt, x)
+                sel = sc[objs if obj_side else subs]
+                fg, fe = int((sel > p).sum()), int((sel == p).sum())
+            rows.append((int((sc > p).sum()), int((sc == p).sum()), fg, fe))
+    return [np.array(c) for c in zip(*rows)]
+
+
+@pytest.mark.parametrize("strategy", ["worst", "best", "middle"])
+@pytest.mark.parametrize("side", ["s", "o", "s+o", "s,o"])
+def test_rank_assembly_matches_oracle(side, strategy):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import ranks_from_counts
+    rs = np.random.RandomState(3)
+    k, n_ent = 3, 25
+    E = (rs.randint(-2, 3, (n_ent, k)) / 2.0).astype(F32)  # many exact ties
+    R = (rs.randint(-2, 3, (2, k)) / 2.0).astype(F32)
+    T = np.stack([rs.randint(0, n_ent, 12), rs.randint(0, 2, 12), rs.randint(0, n_ent, 12)], 1)
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 200), rs.randint(0, 2, 200), rs.randint(0, n_ent, 200)], 1)])
+    for filt in (None, F):
+        gt, eq, fgt, feq = _numpy_counts("DistMult", E, R, T, L.EVAL_SIDE_IDS[side], k, filt)
+        got = ranks_from_counts(gt, eq, fgt, feq, len(T), side, strategy)
+        exp = orc.get_ranks("DistMult", E, R, T, corrupt_side=side, strategy=strategy, filter_triples=filt, k=k)
+        np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("model", ["TransE_L1", "TransE_L2", "DistMult", "ComplEx", "HolE"])
+def test_c_oracle_matches_numpy_oracle(model):
+    """validate the C restatement (canonical order) against the literal numpy restatement"""
+    rs = np.random.RandomState(12)
+    k, n_ent, n_rel = 16, 200, 4
+    ki = 2 * k if model in ("ComplEx", "HolE") else k
+    mid = orc.MODEL_IDS[model]
+    sc = float(F32(2 / k)) if model == "HolE" else 1.0
+    E = (rs.randn(n_ent, ki) * 0.4).astype(F32)
+    R = (rs.randn(n_rel, ki) * 0.4).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 64), rs.randint(0, n_rel, 64), rs.randint(0, n_ent, 64)], 1).astype(np.int32)
+    eta = 4
+    codes = co.corrupt_codes(64, eta, 2, n_ent, 1, 2)
+    xneg = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side="s,o", entities_size=n_ent, seed=1, counter=2)
+    sp, sn = co.train_forward(mid, E, R, ki, sc, X, eta, codes)
+    np.testing.assert_allclose(sp, orc.score_triples(model, E, R, X, k=k), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sn, orc.score_triples(model, E, R, xneg, k=k), rtol=1e-5, atol=1e-6)
+    # canonical 1-vs-all scores == literal scores of the eval corruptions (to fp32 noise)
+    T = X[:5]
+    Q, pos_int = co.build_queries(mid, E, R, ki, sc, T, 3)
+    S = co.scores_dense(mid, Q, E, ki, sc)
+    for qi, x in enumerate(T):
+        corr = orc.generate_corruptions_for_eval(x, np.arange(n_ent), "s,o")
+        lit = orc.score_triples(model, E, R, corr, k=k)
+        np.testing.assert_allclose(S[qi], lit[:n_ent], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(S[5 + qi], lit[n_ent:], rtol=1e-4, atol=2e-5)
+    # on exact (dyadic) data the canonical pipeline reproduces the literal ranks bit for bit
+    from emgraph_amd.evaluation import build_filter_csr, ranks_from_counts
+    Ed = (rs.randint(-4, 5, (n_ent, ki)) / 4.0).astype(F32)
+    Rd = (rs.randint(-4, 5, (n_rel, ki)) / 4.0).astype(F32)
+    Fd = np.concatenate([X, np.stack([rs.randint(0, n_ent, 2000), rs.randint(0, n_rel, 2000), rs.randint(0, n_ent, 2000)], 1)])
+    Q, pos_int = co.build_queries(mid, Ed, Rd, ki, sc, X[:20], 3)
+    gt, eq = co.count(mid, Q, pos_int, Ed, ki, sc)
+    ptr, idx = build_filter_csr(Fd, X[:20], 3, n_ent)
+    fgt, feq = co.filter_count(mid, Q, pos_int, Ed, 0, ki, sc, ptr, idx)
+    for strategy in ("worst", "best", "middle"):
+        got = ranks_from_counts(gt, eq, fgt, feq, 20, "s,o", strategy)
+        exp = orc.get_ranks(model, Ed, Rd, X[:20], corrupt_side="s,o", strategy=strategy, filter_triples=Fd, k=k)
+        np.testing.assert_array_equal(got, exp)
