@@ -423,6 +423,7 @@ extern "C" int emg_train_forward(int model, const float* ent, int64_t n_ent, int
                                  int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale, const int32_t* pos,
                                  int64_t B, int32_t eta, const int32_t* codes, int32_t flags, float* scores_pos,
                                  float* scores_neg, void* stream) {
+    if (B == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && pos && scores_pos, "emg_train_forward: null pointer");
     EMG_REQUIRE(eta == 0 || (codes && scores_neg), "emg_train_forward: eta>0 needs codes and scores_neg");
     GroupParams P{};
@@ -444,6 +445,7 @@ extern "C" int emg_train_backward(int model, const float* ent, int64_t n_ent, in
                                   int64_t B, int32_t eta, const int32_t* codes, const float* g_pos,
                                   const float* g_neg, float* contrib_ent, float* contrib_rel, int64_t ldc,
                                   int32_t* dest_ent, int32_t* dest_rel, void* stream) {
+    if (B == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && pos && g_pos && contrib_ent && contrib_rel && dest_ent && dest_rel,
                 "emg_train_backward: null pointer");
     EMG_REQUIRE(eta == 0 || (codes && g_neg), "emg_train_backward: eta>0 needs codes and g_neg");
