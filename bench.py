@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its own configuration, measured on MI355X.
+
+metric : "positive+negative triples scored/sec at k=200, eta=20; filtered ranks/sec"
+workload (N=1 default) : C3 = ComplEx k=200 (k_int=400) eta=20 on synthetic |E|=1M |R|=1k
+          (BASELINE.json configs[2]; the config the metric's k=200/eta=20 is quoted on and which
+          fits one GPU).  A "step" = one full pass of the hot path over one batch of B positives:
+          Philox corruptions -> fused gather+score of B*(1+eta) triples -> NLL loss + dL/dscore
+          -> fused backward -> deterministic row-sparse SGD apply (the reference forces SGD for
+          |E| > 5e5, EmbeddingModel.py:1267-1274).  value = B*(1+eta)*steps*N / time.
+          The second half of the metric (filtered ranks/sec, config C4) is reported in "eval".
+
+Contract: W untimed warm-up steps, exactly K timed steps bracketed by barrier + synchronize,
+max over ranks, rank 0 prints ONE JSON line.  Inputs are resident in HBM before timing starts.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA == f32 vector peak
+
+WORKLOADS = {
+    # name: model, k, eta, n_ent, n_rel, B, loss, optimizer
+    "C3": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
+               desc="ComplEx k=200 (k_int=400) eta=20, synthetic |E|=1M |R|=1k, B=16384/GPU, NLL, SGD"),
+    "C3p": dict(model="TransE", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
+                desc="TransE-L1 k=200 eta=20 on the |E|=1M table (HBM-roofline target run)"),
+    "C2": dict(model="DistMult", k=200, eta=10, n_ent=14541, n_rel=237, B=2722, loss="nll", optimizer="adam",
+               desc="DistMult k=200 eta=10 NLL, FB15k-237-shaped, B=2722"),
+    "C1": dict(model="TransE", k=100, eta=20, n_ent=38600, n_rel=11, B=1725, loss="pairwise", optimizer="adam",
+               desc="TransE-L1 k=100 eta=20 pairwise, WN11-shaped, B=1725"),
+}
+MODEL_IDS = {"TransE": 0, "TransE_L2": 1, "DistMult": 2, "ComplEx": 3, "HolE": 4}
+
+
+def glorot(rs, rows, cols):
+    lim = math.sqrt(6.0 / (rows + cols))
+    return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
+
+
+def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None):
+    """ALGORITHMIC HBM bytes of one launch (DESIGN.md 'bytes per unit'); int32 ids, fp32 rows."""
+    row = 4 * k_int
+    if stage == "forward":   # spo + codes + (3+eta) rows + (1+eta) scores
+        return B * (12 + 4 * eta + (3 + eta) * row + 4 * (1 + eta))
+    if stage == "backward":  # spo + codes + g + (3+eta) rows read + (3+eta) rows written + dest ids
+        return B * (12 + 4 * eta + 4 * (1 + eta) + (3 + eta) * row + (3 + eta) * row + 4 * (3 + eta))
+    if stage == "apply_ent":  # contribution rows read once + RMW of each touched row (+ sort keys/values)
+        n_c = (2 + eta) * B
+        return n_c * row + 2 * n_unique_ent * row + n_c * 16
+    if stage == "apply_rel":
+        return B * row + 2 * n_unique_rel * row + B * 16
+    return 0
+
+
+def run_train(args, rank, world):
+    import torch
+
+    from emgraph_amd import device as D
+    from emgraph_amd.training import Trainer
+
+    w = WORKLOADS[args.workload]
+    cplx = w["model"] in ("ComplEx", "HolE")
+    k_int = 2 * w["k"] if cplx else w["k"]
+    scale = float(np.float32(2 / w["k"])) if w["model"] == "HolE" else 1.0
+    B, eta = (args.batch or w["B"]), w["eta"]
+    steps, warm = args.steps, args.warmup
+    rs = np.random.RandomState(0)  # init seed 0 (constants.py:52)
+    ent0 = glorot(rs, w["n_ent"], k_int)
+    rel0 = glorot(rs, w["n_rel"], k_int)
+    drs = np.random.RandomState(1234 + rank)
+    n_tr = (steps + warm) * B
+    X = np.stack([drs.randint(0, w["n_ent"], n_tr), drs.randint(0, w["n_rel"], n_tr),
+                  drs.randint(0, w["n_ent"], n_tr)], 1).astype(np.int32)
+    tr = Trainer(MODEL_IDS[w["model"]], k_int, scale, ent0, rel0, eta, loss=w["loss"], optimizer=w["optimizer"],
+                 optimizer_params={"lr": 0.0005}, batches_count=steps + warm, seed=0)
+    tr.set_training_set(X, B)
+    for i in range(warm):
+        tr.step(i * B, B, epoch=1, batch=i + 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    tr.enable_stage_timing()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, warm + steps):
+        tr.step(i * B, B, epoch=1, batch=i + 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = tr.read_loss()
+    assert math.isfinite(loss), "loss is not finite"
+    stage_ms = {k: float(np.mean(v)) for k, v in tr.stage_times_ms().items()}
+    # unique touched rows of the last timed batch (for the apply kernel's algorithmic bytes)
+    n_ce = (2 + eta) * B
+    n_ue = int(torch.unique(tr.dest_ent[:n_ce]).numel())
+    n_ur = int(torch.unique(tr.dest_rel[:B]).numel())
+    stages = {}
+    for name, ms in stage_ms.items():
+        ab = algorithmic_bytes(name, B, eta, k_int, n_ue, n_ur)
+        stages[name] = {"ms": round(ms, 4), "alg_bytes": ab, "GBps": round(ab / (ms * 1e-3) / 1e9, 1) if ab else None}
+    dom = max((s for s in stages if stages[s]["alg_bytes"]), key=lambda s: stages[s]["ms"])
+    ach = stages[dom]["GBps"]
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"]}
+    return dict(dt=dt, B=B, eta=eta, k_int=k_int, stages=stages, roofline=roofline, loss=loss, w=w, tr=tr,
+                ent0=ent0, rel0=rel0, X=X, scale=scale)
+
+
+def run_eval(res, args):
+    """C4: filtered 1-vs-all ranks/sec on the same tables ('s+o', worst), exact f32 MFMA path."""
+    import torch
+
+    from emgraph_amd.evaluation import rank_triples_device
+    w, tr = res["w"], res["tr"]
+    n_test = args.eval_triples
+    rs = np.random.RandomState(99)
+    T = res["X"][rs.choice(len(res["X"]), n_test, replace=False)]
+    F = res["X"]
+    mid = MODEL_IDS[w["model"]]
+    rank_triples_device(mid, tr.ent, tr.rel, res["k_int"], res["scale"], T[:64], "s+o", "worst", filter_triples=F)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ranks = rank_triples_device(mid, tr.ent, tr.rel, res["k_int"], res["scale"], T, "s+o", "worst", filter_triples=F)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_ranks = 2 * n_test  # one rank = one (test triple, side)
+    flops = 2.0 * res["k_int"] * w["n_ent"] * n_ranks
+    cplx = w["model"] in ("ComplEx", "HolE", "DistMult")
+    out = {"metric": "filtered ranks/sec", "value": round(n_ranks / dt, 1), "unit": "ranks/s", "test_triples": n_test,
+           "corrupt_side": "s+o", "precision": "f32 (exact, v_mfma_f32_32x32x2_f32)" if cplx else "f32 VALU",
+           "seconds": round(dt, 4), "mean_rank": float(np.mean(ranks))}
+    if cplx:
+        out["roofline"] = {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
+                           "note": "end-to-end incl. host filter-CSR build; f32-input MFMA peak"}
+    return out
+
+
+def cpu_baseline(res, args):
+    """The oracle's fused C port (OpenMP, all host cores) on a bounded sample of the same workload:
+    forward scoring of B*(1+eta) triples per batch.  A reported baseline, not the target."""
+    from oracle import c_oracle as co
+    w = res["w"]
+    B, eta, k_int = res["B"], res["eta"], res["k_int"]
+    mid = MODEL_IDS[w["model"]]
+    X = res["X"]
+    nb = max(1, min(args.cpu_batches, len(X) // B))
+    co.lib()
+    codes = [co.corrupt_codes(B, eta, 2, w["n_ent"], 0, i) for i in range(nb)]
+    co.train_forward(mid, res["ent0"], res["rel0"], k_int, res["scale"], X[:256], eta, codes[0][:256 * eta])  # warm
+    t0 = time.perf_counter()
+    for i in range(nb):
+        co.train_forward(mid, res["ent0"], res["rel0"], k_int, res["scale"], X[i * B:(i + 1) * B], eta, codes[i])
+    dt = time.perf_counter() - t0
+    return {"value": round(nb * B * (1 + eta) / dt, 1), "unit": "triples scored/s", "cores": co.num_threads(),
+            "kind": "port", "sample": "%d batches of B=%d (%d triples scored), fused C/OpenMP gather+score "
+            "(forward only), same tables" % (nb, B, nb * B * (1 + eta)), "seconds": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--eval-triples", type=int, default=1024)
+    ap.add_argument("--cpu-batches", type=int, default=4)
+    ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    res = run_train(args, rank, world)
+    n = world
+    w = res["w"]
+    triples = res["B"] * (1 + res["eta"]) * args.steps * n
+    line = {
+        "metric": "positive+negative triples scored/sec at k=200, eta=20; filtered ranks/sec",
+        "value": round(triples / res["dt"], 1), "unit": "triples scored/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload + ": " + w["desc"], "step": "corrupt+score(fwd)+loss+bwd+sparse-SGD apply",
+                   "B_per_gpu": res["B"], "eta": res["eta"], "k_int": res["k_int"], "n_ent": w["n_ent"],
+                   "n_rel": w["n_rel"], "parallelism": "replicas" if n > 1 else "single"},
+        "roofline": res["roofline"], "stages": res["stages"], "loss_sum": res["loss"],
+    }
+    if rank == 0:
+        if not args.no_eval:
+            line["eval"] = run_eval(res, args)
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(res, args)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
