@@ -6,3 +6,7 @@ Compute lives in libemgraph_hip.so (hand-written HIP for gfx950) reached through
 (include/emgraph_hip.h); PyTorch-ROCm tensors only hold device memory.  No TensorFlow, no CPU fallback.
 """
 __version__ = "0.1.0"
+
+from .evaluation import (evaluate_performance, hits_at_n_score, mr_score, mrr_score, rank_score)  # noqa: E402,F401
+from .models import ComplEx, DistMult, HolE, TransE  # noqa: E402,F401
+from .utils import restore_model, save_model  # noqa: E402,F401

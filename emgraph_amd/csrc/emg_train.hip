@@ -148,7 +148,8 @@ __device__ __forceinline__ float powi_abs(float a, int p) {
 }
 
 __global__ __launch_bounds__(256) void lp_kernel(float* __restrict__ w, int64_t n_rows, int64_t ld, int k_int,
-                                                 float lambda, int p, float step, double* __restrict__ loss_accum) {
+                                                 float lambda, int p, float step, double* __restrict__ loss_accum,
+                                                 float* __restrict__ contrib, int64_t ldc, int32_t* __restrict__ dest) {
     double acc = 0.0;
     const int64_t total = n_rows * (int64_t)k_int;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -158,10 +159,15 @@ __global__ __launch_bounds__(256) void lp_kernel(float* __restrict__ w, int64_t 
         const float x = *ptr;
         const float a = fabsf(x);
         acc += (double)powi_abs(a, p);
-        if (step != 0.f) {
+        if (step != 0.f || contrib) {
             // d/dx lambda*|x|^p = lambda*p*|x|^(p-1)*sign(x)
             const float g = lambda * (float)p * (p == 1 ? 1.f : powi_abs(a, p - 1)) * sgnf(x);
-            *ptr = x - step * g;
+            if (contrib) {
+                contrib[r * ldc + c] = g;
+                if (c == 0) dest[r] = (int32_t)r;
+            } else {
+                *ptr = x - step * g;
+            }
         }
     }
 #pragma unroll
@@ -251,7 +257,20 @@ extern "C" int emg_lp_regularizer(float* table, int64_t n_rows, int64_t ld, int3
     const int64_t total = n_rows * (int64_t)k_int;
     const unsigned grid = (unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
     hipLaunchKernelGGL(lp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, table, n_rows, ld, (int)k_int, lambda,
-                       (int)p, grad_scale_lr, loss_accum);
+                       (int)p, grad_scale_lr, loss_accum, (float*)nullptr, (int64_t)0, (int32_t*)nullptr);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_lp_grad_rows(const float* table, int64_t n_rows, int64_t ld, int32_t k_int, float lambda, int32_t p,
+                                float* contrib, int64_t ldc, int32_t* dest, double* loss_accum, void* stream) {
+    EMG_REQUIRE(table && contrib && dest && n_rows >= 0 && ld >= k_int && ldc >= k_int && k_int > 0 && p >= 1,
+                "emg_lp_grad_rows: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    const int64_t total = n_rows * (int64_t)k_int;
+    const unsigned grid = (unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(lp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(table), n_rows, ld,
+                       (int)k_int, lambda, (int)p, 0.f, loss_accum, contrib, ldc, dest);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

@@ -164,6 +164,16 @@ def lp_regularizer(table, k_int, lam, p, grad_scale_lr, loss_accum):
                                    _stream()), "emg_lp_regularizer")
 
 
+def lp_grad_rows(table, k_int, lam, p, contrib, dest, loss_accum):
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    pc, nc, ldc = _chk_table(contrib, "contrib")
+    if nc < nrows:
+        raise ValueError("contrib has fewer rows than the table")
+    L.check(lib.emg_lp_grad_rows(pt, nrows, ld, k_int, lam, p, pc, ldc, _chk_vec(dest, torch.int32, "dest", nrows),
+                                 _chk_vec(loss_accum, torch.float64, "loss_accum", 1), _stream()), "emg_lp_grad_rows")
+
+
 def clip_rows(table, k_int, max_norm=1.0):
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")

@@ -1,0 +1,223 @@
+"""Host-side protocol functions — mirrors the hot-path part of emgraph/evaluation/protocol.py
+(same names, argument meaning and error behaviour); the numeric work goes to libemgraph_hip.so.
+
+Not mirrored (out of scope): train_test_split_no_unseen, select_best_model_ranking and the
+param-grid helpers — pure callers of fit()/evaluate_performance() that run unchanged on top of this API.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import device as D
+
+logger = logging.getLogger(__name__)
+
+TOO_MANY_ENTITIES_TH = 50000  # protocol.py:21
+
+_UNSEEN_MSG = (
+    "Input triples include one or more {concept_type} not present in the training set. "
+    "Please filter all concepts in X that do not occur in the training test "
+    "(set filter_unseen=True in evaluate_performance) or retrain the model on a "
+    "training set that includes all the desired concept types."
+)
+
+
+def create_mappings(X):
+    """protocol.py:429-445: ids are ranks in np.unique (sorted) order.  Returns (rel_to_idx, ent_to_idx)."""
+    unique_ent = np.unique(np.concatenate((X[:, 0], X[:, 2])))
+    unique_rel = np.unique(X[:, 1])
+    ent_to_idx = dict(zip(unique_ent, range(len(unique_ent))))
+    rel_to_idx = dict(zip(unique_rel, range(len(unique_rel))))
+    return rel_to_idx, ent_to_idx
+
+
+def create_mappings_and_index(X):
+    """create_mappings + to_idx of the SAME array in one vectorised pass (np.unique(return_inverse));
+    replaces np.vectorize(dict.get) over the training set (protocol.py:682-684, minutes at 10M rows)."""
+    n = X.shape[0]
+    unique_ent, inv_e = np.unique(np.concatenate((X[:, 0], X[:, 2])), return_inverse=True)
+    unique_rel, inv_r = np.unique(X[:, 1], return_inverse=True)
+    X_idx = np.stack([inv_e[:n], inv_r, inv_e[n:]], axis=1).astype(np.int32)
+    ent_to_idx = dict(zip(unique_ent, range(len(unique_ent))))
+    rel_to_idx = dict(zip(unique_rel, range(len(unique_rel))))
+    return rel_to_idx, ent_to_idx, X_idx
+
+
+def _lookup(col, mapping):
+    """vectorised dict lookup; returns (ids, ok_mask)."""
+    if len(mapping) == 0:
+        return np.zeros(len(col), np.int64), np.zeros(len(col), bool)
+    keys = np.array(list(mapping.keys()))
+    vals = np.fromiter(mapping.values(), dtype=np.int64, count=len(mapping))
+    col = np.asarray(col)
+    if keys.dtype.kind != col.dtype.kind and not (keys.dtype.kind in "US" and col.dtype.kind in "US"):
+        got = [mapping.get(v) for v in col.tolist()]
+        ok = np.array([g is not None for g in got], dtype=bool)
+        return np.array([g if g is not None else 0 for g in got], dtype=np.int64), ok
+    order = np.argsort(keys, kind="stable")
+    skeys = keys[order]
+    pos = np.searchsorted(skeys, col)
+    pos_c = np.minimum(pos, len(skeys) - 1)
+    ok = skeys[pos_c] == col
+    return vals[order][pos_c], ok
+
+
+def to_idx(X, ent_to_idx, rel_to_idx):
+    """protocol.py:662-723.  Unseen entity/relation -> ValueError with the reference's message."""
+    X = np.asarray(X)
+    if X.ndim == 1:
+        X = X[np.newaxis, :]
+    s, ok_s = _lookup(X[:, 0], ent_to_idx)
+    p, ok_p = _lookup(X[:, 1], rel_to_idx)
+    o, ok_o = _lookup(X[:, 2], ent_to_idx)
+    if not (ok_s.all() and ok_o.all()):
+        msg = _UNSEEN_MSG.format(concept_type="entities")
+        logger.error(msg)
+        raise ValueError(msg)
+    if not ok_p.all():
+        msg = _UNSEEN_MSG.format(concept_type="relations")
+        logger.error(msg)
+        raise ValueError(msg)
+    return np.dstack([s, p, o]).reshape((-1, 3))
+
+
+def _as_int_seed(rnd):
+    if rnd is None:
+        return 0
+    if isinstance(rnd, (int, np.integer)):
+        return int(rnd)
+    if isinstance(rnd, np.random.RandomState):
+        return int(rnd.randint(0, 2 ** 31 - 1))
+    raise ValueError("rnd must be None, an int seed or a numpy RandomState")
+
+
+def generate_corruptions_for_fit(X, entities_list=None, eta=1, corrupt_side="s,o", entities_size=0, rnd=None,
+                                 draw_counter=0):
+    """protocol.py:531-659 on the GPU: eta-major corruptions of the positives ``X`` (int [n,3]).
+
+    Same arguments as the reference.  The replacement/mask draws come from the on-device Philox4x32-10
+    stream keyed by ``rnd`` (an int seed) and ``draw_counter`` — NOT TensorFlow's stream (which cannot be
+    reproduced without TensorFlow); the distribution is the same: mask ~ U{0,1} (only for 's+o'/'s,o'),
+    replacement ~ U{0..entities_size-1} or a uniform pick from ``entities_list`` / the batch entities.
+    Returns an int32 ndarray [n*eta, 3]."""
+    if corrupt_side == "s,o":
+        corrupt_side = "s+o"
+    if corrupt_side not in ["s+o", "s", "o"]:
+        msg = "Invalid argument value {} for corruption side passed for evaluation.".format(corrupt_side)
+        logger.error(msg)
+        raise ValueError(msg)
+    D.require_gpu()
+    X = np.ascontiguousarray(np.asarray(X), dtype=np.int32).reshape(-1, 3)
+    B = X.shape[0]
+    dev = torch.device("cuda")
+    elist = None
+    if entities_size != 0:
+        n_choices = int(entities_size)
+    else:
+        if entities_list is None:
+            entities_list = batch_entities(X)
+        elist = torch.from_numpy(np.ascontiguousarray(np.asarray(entities_list, dtype=np.int32).reshape(-1))).to(dev)
+        n_choices = int(elist.numel())
+    Xt = torch.from_numpy(X).to(dev)
+    codes = D.corrupt_codes(B, int(eta), L.SIDE_IDS[corrupt_side], n_choices, dev, entities_list=elist,
+                            seed=_as_int_seed(rnd), counter=int(draw_counter))
+    return D.corrupt_expand(Xt, int(eta), codes).cpu().numpy()
+
+
+def batch_entities(X):
+    """protocol.py:621-633: tf.unique(concat(subjects, objects)) — first-appearance order."""
+    cat = np.concatenate([X[:, 0], X[:, 2]])
+    _, first = np.unique(cat, return_index=True)
+    return cat[np.sort(first)].astype(np.int32)
+
+
+def generate_corruptions_for_eval(X, entities_for_corruption, corrupt_side="s,o"):
+    """protocol.py:448-528: the [|C|*sides, 3] corruption array of ONE triple (object block first).
+
+    Index tiling only (no arithmetic).  Kept for API parity; the ranking path never materialises it —
+    the 1-vs-all kernels enumerate the candidates implicitly."""
+    X = np.asarray(X).reshape(1, 3)
+    C = np.asarray(entities_for_corruption).reshape(-1)
+    if corrupt_side == "s,o":
+        corrupt_side = "s+o"
+    if corrupt_side not in ["s+o", "s", "o"]:
+        msg = "Invalid argument value for corruption side passed for evaluation"
+        logger.error(msg)
+        raise ValueError(msg)
+    n = len(C)
+    s, p, o = (np.full(n, X[0, i], dtype=C.dtype) for i in range(3))
+    obj_block = np.stack([s, p, C], axis=1)
+    subj_block = np.stack([C, p, o], axis=1)
+    if corrupt_side == "s+o":
+        return np.concatenate([obj_block, subj_block], axis=0)
+    return obj_block if corrupt_side == "o" else subj_block
+
+
+def check_filter_size(model, corruption_entities):
+    """protocol.py:982-1011."""
+    warn_msg = """You are attempting to use %d distinct entities to generate synthetic negatives in the evaluation
+    protocol. This may be unnecessary and will lead to a 'harder' task. Besides, it will lead to a much slower
+    evaluation procedure. We recommended to set the 'corruption_entities' argument to a reasonably sized set
+    of entities. The size of corruption_entities depends on your domain-specific task."""
+    size = len(model.ent_to_idx) if corruption_entities is None else len(corruption_entities)
+    if size >= TOO_MANY_ENTITIES_TH:
+        warnings.warn(warn_msg % size)
+        logger.warning(warn_msg, size)
+
+
+def filter_unseen_entities(X, model, verbose=False):
+    """protocol.py:1014-1041: drop triples whose subject or object the model has not seen."""
+    ent_seen = np.array(list(model.ent_to_idx.keys()))
+    X = np.asarray(X)
+    keep = np.isin(X[:, 0], ent_seen) & np.isin(X[:, 2], ent_seen)
+    n_removed = int((~keep).sum())
+    if n_removed > 0:
+        msg = "Removing {} triples containing unseen entities. ".format(n_removed)
+        if verbose:
+            logger.info(msg)
+        logger.debug(msg)
+        return X[keep]
+    return X
+
+
+def evaluate_performance(X, model, filter_triples=None, verbose=False, filter_unseen=True, entities_subset=None,
+                         corrupt_side="s,o", ranking_strategy="worst", use_default_protocol=False):
+    """protocol.py:726-979.  Ranks of the positives in ``X`` against their corruptions.
+
+    Returns an int ndarray [n] ('s', 'o', 's+o') or [n,2] = [subject_rank, object_rank] ('s,o')."""
+    if use_default_protocol:
+        logger.warning("DeprecationWarning: use_default_protocol will be removed in future. "
+                       "Please use corrupt_side argument instead.")
+        corrupt_side = "s,o"
+    assert corrupt_side in ["s", "o", "s+o", "s,o"], "Invalid value for corrupt_side."
+    if not isinstance(X, np.ndarray):
+        msg = "X must be either a numpy array or an EmgraphBaseDatasetAdaptor."
+        logger.error(msg)
+        raise ValueError(msg)
+    if filter_unseen:
+        X = filter_unseen_entities(X, model, verbose=verbose)
+    else:
+        logger.warning("If your test set or filter triples contain unseen entities you may get a"
+                       "runtime error. You can filter them by setting filter_unseen=True")
+    X_idx = to_idx(X, ent_to_idx=model.ent_to_idx, rel_to_idx=model.rel_to_idx)
+    F_idx = None
+    if filter_triples is not None:
+        if not isinstance(filter_triples, np.ndarray):
+            raise Exception("Invalid datatype for filter. Expected a numpy array or preset data in the adapter.")
+        if filter_unseen:
+            filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
+        F_idx = to_idx(filter_triples, ent_to_idx=model.ent_to_idx, rel_to_idx=model.rel_to_idx)
+    check_filter_size(model, entities_subset)
+    idx_entities = None
+    if entities_subset is not None:
+        subset = set(entities_subset)
+        idx_entities = np.asarray([idx for uri, idx in model.ent_to_idx.items() if uri in subset])
+    assert ranking_strategy in ["worst", "best", "middle"], "Invalid ranking_strategy!"
+    return np.array(model.get_ranks_idx(X_idx, filter_idx=F_idx, corrupt_side=corrupt_side,
+                                        ranking_strategy=ranking_strategy, corruption_entities=idx_entities,
+                                        verbose=verbose))

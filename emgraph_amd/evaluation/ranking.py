@@ -14,8 +14,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import _lib as L
-from . import device as D
+from .. import _lib as L
+from .. import device as D
 
 
 def _expand_ranges(lo, hi):
@@ -30,58 +30,70 @@ def _expand_ranges(lo, hi):
     return idx, owner
 
 
-def _side_filter_pairs(F_key, F_val, order_key, q_key, q_self):
-    """(row, entity) pairs: entities v with (key == q_key[row]) in the filter, plus the row's own entity
-    ('select <id> union select distinct ...', sqlite_adapter.py:472-495)."""
-    lo = np.searchsorted(order_key, q_key, side="left")
-    hi = np.searchsorted(order_key, q_key, side="right")
-    idx, owner = _expand_ranges(lo, hi)
-    rows = np.concatenate([owner, np.arange(len(q_key), dtype=np.int64)])
-    ents = np.concatenate([F_val[idx], q_self.astype(np.int64)])
-    return rows, ents
+class FilterIndex:
+    """One-off index of the filter triples: (s,p)-sorted objects and (o,p)-sorted subjects.  Built once
+    per evaluate_performance call (two argsorts); each query chunk then costs two searchsorted calls.
+    Replaces the SQLite side-table + its (subject,predicate) / (predicate,object) indexes
+    (sqlite_adapter.py:54-98,234-262) and the two SQL queries + connect per test triple (:449-508)."""
+
+    def __init__(self, filter_triples):
+        F = np.asarray(filter_triples, dtype=np.int64).reshape(-1, 3)
+        self.n_rel = int(F[:, 1].max()) + 1 if len(F) else 1
+        self._sides = {}
+        for name, kcol, vcol in (("obj", 0, 2), ("sub", 2, 0)):
+            key = F[:, kcol] * self.n_rel + F[:, 1]
+            order = np.argsort(key, kind="stable")
+            self._sides[name] = (key[order], F[order, vcol])
+
+    def _pairs(self, name, q_ent, q_rel, q_self):
+        """(row, entity) pairs: filter entities matching the row's (entity, relation) key, plus the row's
+        own entity ('select <id> union select distinct ...', sqlite_adapter.py:472-495)."""
+        skey, sval = self._sides[name]
+        qk = np.where(q_rel < self.n_rel, q_ent * self.n_rel + q_rel, -1)
+        lo = np.searchsorted(skey, qk, side="left")
+        hi = np.searchsorted(skey, qk, side="right")
+        idx, owner = _expand_ranges(lo, hi)
+        rows = np.concatenate([owner, np.arange(len(qk), dtype=np.int64)])
+        ents = np.concatenate([sval[idx], q_self.astype(np.int64)])
+        return rows, ents
+
+    def csr(self, test_triples, side_mode, n_ent, entities_subset=None):
+        """CSR (filt_ptr int64[n_rows+1], filt_idx int32) of known positives per query ROW, in the row
+        order of emg_eval_build_queries (object-side rows first for 's+o'/'s,o').
+
+        object-side row of (s,p,o):  {o} U {o' : (s,p,o') in F};  subject-side: {s} U {s' : (s',p,o) in F}.
+        With ``entities_subset`` only members of the subset are kept (EmbeddingModel.py:1898-1940 intent)."""
+        T = np.asarray(test_triples, dtype=np.int64).reshape(-1, 3)
+        n_q = T.shape[0]
+        rows_all, ents_all = [], []
+        row_base = 0
+        if side_mode in (L.EVAL_O, L.EVAL_SPO, L.EVAL_S_O):
+            r, e = self._pairs("obj", T[:, 0], T[:, 1], T[:, 2])
+            rows_all.append(r + row_base)
+            ents_all.append(e)
+            row_base += n_q
+        if side_mode in (L.EVAL_S, L.EVAL_SPO, L.EVAL_S_O):
+            r, e = self._pairs("sub", T[:, 2], T[:, 1], T[:, 0])
+            rows_all.append(r + row_base)
+            ents_all.append(e)
+            row_base += n_q
+        n_rows = row_base
+        rows = np.concatenate(rows_all) if rows_all else np.zeros(0, np.int64)
+        ents = np.concatenate(ents_all) if ents_all else np.zeros(0, np.int64)
+        if entities_subset is not None:
+            keep = np.isin(ents, np.asarray(entities_subset, dtype=np.int64))
+            rows, ents = rows[keep], ents[keep]
+        comb = np.unique(rows * np.int64(n_ent) + ents)  # de-duplicate (SQL UNION / DISTINCT), sorted by row
+        rows_u = comb // n_ent
+        ents_u = (comb - rows_u * n_ent).astype(np.int32)
+        ptr = np.zeros(n_rows + 1, np.int64)
+        np.cumsum(np.bincount(rows_u, minlength=n_rows), out=ptr[1:])
+        return ptr, ents_u
 
 
 def build_filter_csr(filter_triples, test_triples, side_mode, n_ent, entities_subset=None):
-    """CSR (filt_ptr int64[n_rows+1], filt_idx int32) of known positives per query ROW, in the row order
-    of emg_eval_build_queries (object-side rows first for 's+o'/'s,o').
-
-    object-side row of (s,p,o):  {o} U {o' : (s,p,o') in F};  subject-side: {s} U {s' : (s',p,o) in F}.
-    With ``entities_subset`` only members of the subset are kept (EmbeddingModel.py:1898-1940 intent).
-    """
-    T = np.asarray(test_triples, dtype=np.int64).reshape(-1, 3)
-    F = np.asarray(filter_triples, dtype=np.int64).reshape(-1, 3)
-    n_q = T.shape[0]
-    n_rel = int(max(F[:, 1].max() if len(F) else 0, T[:, 1].max() if n_q else 0)) + 1
-    rows_all, ents_all = [], []
-    row_base = 0
-    want_obj = side_mode in (L.EVAL_O, L.EVAL_SPO, L.EVAL_S_O)
-    want_sub = side_mode in (L.EVAL_S, L.EVAL_SPO, L.EVAL_S_O)
-    if want_obj:
-        key = F[:, 0] * n_rel + F[:, 1]
-        order = np.argsort(key, kind="stable")
-        r, e = _side_filter_pairs(key, F[order, 2], key[order], T[:, 0] * n_rel + T[:, 1], T[:, 2])
-        rows_all.append(r + row_base)
-        ents_all.append(e)
-        row_base += n_q
-    if want_sub:
-        key = F[:, 2] * n_rel + F[:, 1]
-        order = np.argsort(key, kind="stable")
-        r, e = _side_filter_pairs(key, F[order, 0], key[order], T[:, 2] * n_rel + T[:, 1], T[:, 0])
-        rows_all.append(r + row_base)
-        ents_all.append(e)
-        row_base += n_q
-    n_rows = row_base
-    rows = np.concatenate(rows_all) if rows_all else np.zeros(0, np.int64)
-    ents = np.concatenate(ents_all) if ents_all else np.zeros(0, np.int64)
-    if entities_subset is not None:
-        keep = np.isin(ents, np.asarray(entities_subset, dtype=np.int64))
-        rows, ents = rows[keep], ents[keep]
-    comb = np.unique(rows * np.int64(n_ent) + ents)  # de-duplicate (SQL UNION / DISTINCT), sorted by row
-    rows_u = comb // n_ent
-    ents_u = (comb - rows_u * n_ent).astype(np.int32)
-    ptr = np.zeros(n_rows + 1, np.int64)
-    np.cumsum(np.bincount(rows_u, minlength=n_rows), out=ptr[1:])
-    return ptr, ents_u
+    """Convenience: FilterIndex(filter_triples).csr(...)."""
+    return FilterIndex(filter_triples).csr(test_triples, side_mode, n_ent, entities_subset)
 
 
 def _cmp(gt, eq, strategy):
@@ -131,6 +143,9 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     cand = None
     if entities_subset is not None:
         cand = torch.from_numpy(np.ascontiguousarray(np.asarray(entities_subset, dtype=np.int32))).to(ent.device)
+    findex = None
+    if filter_triples is not None:
+        findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
     out = []
     for c0 in range(0, n, query_chunk):
         Tc = T[c0:c0 + query_chunk]
@@ -140,8 +155,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         n_rows = Q.shape[0]
         cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
         D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
-        if filter_triples is not None:
-            ptr, idx = build_filter_csr(filter_triples, Tc, side_mode, n_ent, entities_subset)
+        if findex is not None:
+            ptr, idx = findex.csr(Tc, side_mode, n_ent, entities_subset)
             D.eval_filter_count(model_id, Q, pos_int, ent, ent_offset, k_int, scale,
                                 torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device),
                                 cnt[2], cnt[3], precision=precision)

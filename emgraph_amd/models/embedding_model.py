@@ -1,0 +1,554 @@
+"""EmbeddingModel and the four hot-path models — host-side mirror of emgraph/models/EmbeddingModel.py
+(fit :1113-1492, predict :2101-2186, get_ranks :2046-2099, get_embeddings :455-488) and of
+TransE.py / DistMult.py / ComplEx.py / HolE.py (which only contribute ``_fn`` and ``internal_k``).
+
+Same constructor arguments, defaults (utils/constants.py) and error behaviour; the per-batch work is
+done by libemgraph_hip.so through emgraph_amd.training.Trainer / emgraph_amd.evaluation.ranking.
+
+Deliberate deviations from the reference's *literal* TF2-port behaviour, all in
+favour of its intended (AmpliGraph-1.x) semantics: every batch is trained on exactly once (A-2);
+optimizer state persists across batches (A-3); ranks are computed per test triple (A-1); both
+'corrupt_side' and 'corrupt_sides' keys are honoured (A-5); large-graph host paging is not needed on a
+288 GB GPU, so |E| > ENTITY_THRESHOLD neither pages nor forces SGD.
+"""
+from __future__ import annotations
+
+import abc
+import logging
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import device as D
+from ..evaluation.metrics import hits_at_n_score, mrr_score
+from ..evaluation.protocol import create_mappings_and_index, to_idx
+from ..evaluation.ranking import FilterIndex, rank_triples_device
+from ..training import Trainer, alloc_table
+
+logger = logging.getLogger(__name__)
+
+MODEL_REGISTRY = {}
+
+# utils/constants.py
+DEFAULT_EMBEDDING_SIZE = 100
+DEFAULT_ETA = 2
+DEFAULT_EPOCH = 100
+DEFAULT_BATCH_COUNT = 100
+DEFAULT_SEED = 0
+DEFAULT_OPTIM = "adam"
+DEFAULT_LR = 0.0005
+DEFAULT_LOSS = "nll"
+DEFAULT_REGULARIZER = None
+DEFAULT_INITIALIZER = "glorot_uniform"
+DEFAULT_VERBOSE = False
+DEFAULT_NORM_TRANSE = 1
+DEFAULT_CORRUPTION_ENTITIES = "all"
+DEFAULT_CORRUPT_SIDE_TRAIN = ["s,o"]
+DEFAULT_CORRUPT_SIDE_EVAL = "s,o"
+DEFAULT_NORMALIZE_EMBEDDINGS = False
+DEFAULT_BURN_IN_EARLY_STOPPING = 100
+DEFAULT_CHECK_INTERVAL_EARLY_STOPPING = 10
+DEFAULT_STOP_INTERVAL_EARLY_STOPPING = 3
+DEFAULT_CRITERIA_EARLY_STOPPING = "mrr"
+DEFAULT_RANK_COMPARE_STRATEGY = "worst"
+# initializers/_initializer_constants.py
+DEFAULT_UNIFORM_LOW, DEFAULT_UNIFORM_HIGH = -0.05, 0.05
+DEFAULT_NORMAL_MEAN, DEFAULT_NORMAL_STD = 0, 0.05
+DEFAULT_GLOROT_IS_UNIFORM = False
+
+ENTITY_THRESHOLD = 5e5  # EmbeddingModel.py:37 (kept for API parity; no host paging here)
+
+LOSSES = ("pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll")
+OPTIMIZERS = ("adam", "adagrad", "sgd", "momentum", "adam_lazy")
+INITIALIZERS = ("glorot_uniform", "normal", "uniform", "constant")
+
+
+def set_entity_threshold(threshold):
+    """EmbeddingModel.py:41-49 (API parity)."""
+    global ENTITY_THRESHOLD
+    ENTITY_THRESHOLD = threshold
+
+
+def reset_entity_threshold():
+    """EmbeddingModel.py:52-58 (API parity)."""
+    global ENTITY_THRESHOLD
+    ENTITY_THRESHOLD = 5e5
+
+
+def register_model(name):
+    def deco(cls):
+        MODEL_REGISTRY[name] = cls
+        cls.name = name
+        return cls
+    return deco
+
+
+def _initial_table(kind, params, rnd, rows, cols, concept):
+    """initializers/*.py numpy paths.  glorot_uniform follows the reference's TF path, which ALWAYS
+    returns tf.initializers.GlorotUniform() whatever the 'uniform' flag says (glorot_uniform.py:59-74,
+    SURVEY A-11): U(+-sqrt(6/(rows+cols))).  The draws themselves are parity-unpinned (TF RNG)."""
+    if kind == "glorot_uniform":
+        limit = np.sqrt(6 / (rows + cols))
+        return rnd.uniform(-limit, limit, size=(rows, cols)).astype(np.float32)
+    if kind == "normal":
+        return rnd.normal(params.get("mean", DEFAULT_NORMAL_MEAN), params.get("std", DEFAULT_NORMAL_STD),
+                          size=(rows, cols)).astype(np.float32)
+    if kind == "uniform":
+        return rnd.uniform(params.get("low", DEFAULT_UNIFORM_LOW), params.get("high", DEFAULT_UNIFORM_HIGH),
+                           size=(rows, cols)).astype(np.float32)
+    if kind == "constant":
+        arr = np.asarray(params["entity" if concept == "e" else "relation"], dtype=np.float32)
+        assert arr.shape == (rows, cols), "Invalid shape for {} initializer!".format(
+            "entity" if concept == "e" else "relation")
+        return arr
+    raise ValueError("Unsupported initializer: {}".format(kind))
+
+
+class EmbeddingModel(abc.ABC):  # noqa: B024
+    """Abstract base of the embedding models (EmbeddingModel.py:96-336)."""
+
+    name = "EmbeddingModel"
+
+    def __init__(self, k=DEFAULT_EMBEDDING_SIZE, eta=DEFAULT_ETA, epochs=DEFAULT_EPOCH,
+                 batches_count=DEFAULT_BATCH_COUNT, seed=DEFAULT_SEED, embedding_model_params={},
+                 optimizer=DEFAULT_OPTIM, optimizer_params={"lr": DEFAULT_LR}, loss=DEFAULT_LOSS, loss_params={},
+                 regularizer=DEFAULT_REGULARIZER, regularizer_params={}, initializer=DEFAULT_INITIALIZER,
+                 initializer_params={"uniform": DEFAULT_GLOROT_IS_UNIFORM}, large_graphs=False,
+                 verbose=DEFAULT_VERBOSE):
+        if loss == "bce":  # EmbeddingModel.py:206-210: BCE is ConvE-only
+            raise ValueError("Invalid Model - Loss combination. "
+                             "ConvE model can be used with BCE loss only and vice versa.")
+        self.all_params = {
+            "k": k, "eta": eta, "epochs": epochs, "batches_count": batches_count, "seed": seed,
+            "embedding_model_params": embedding_model_params, "optimizer": optimizer,
+            "optimizer_params": optimizer_params, "loss": loss, "loss_params": loss_params,
+            "regularizer": regularizer, "regularizer_params": regularizer_params, "initializer": initializer,
+            "initializer_params": initializer_params, "verbose": verbose,
+        }
+        self.seed = seed
+        self.loss_params = loss_params
+        self.embedding_model_params = embedding_model_params
+        self.k = k
+        self.internal_k = k
+        self.epochs = epochs
+        self.eta = eta
+        self.regularizer_params = regularizer_params
+        self.batches_count = batches_count
+        self.dealing_with_large_graphs = large_graphs
+        if batches_count == 1:
+            logger.warning("All triples will be processed in the same batch (batches_count=1). "
+                           "When processing large graphs it is recommended to batch the input knowledge graph "
+                           "instead.")
+        if loss not in LOSSES:
+            msg = "Unsupported loss function: {}".format(loss)
+            logger.error(msg)
+            raise ValueError(msg)
+        self.loss = loss
+        if regularizer is not None and regularizer != "LP":
+            msg = "Unsupported regularizer: {}".format(regularizer)
+            logger.error(msg)
+            raise ValueError(msg)
+        self.regularizer = regularizer
+        if optimizer not in OPTIMIZERS:
+            msg = "Unsupported optimizer: {}".format(optimizer)
+            logger.error(msg)
+            raise ValueError(msg)
+        self.optimizer = optimizer
+        self.optimizer_params = optimizer_params
+        self.verbose = verbose
+        if initializer not in INITIALIZERS:
+            msg = "Unsupported initializer: {}".format(initializer)
+            logger.error(msg)
+            raise ValueError(msg)
+        self.initializer = initializer
+        self.initializer_params = initializer_params
+        self.trained_model_params = []
+        self.is_fitted = False
+        self.is_filtered = False
+        self.eval_config = {}
+        self.is_calibrated = False
+        self.calibration_parameters = []
+        self.ent_to_idx = {}
+        self.rel_to_idx = {}
+        self._dev = None  # (ent, rel) device tables of the trained parameters
+
+    # ---- model-specific hooks ----
+    def _model_id(self):
+        raise NotImplementedError
+
+    def _scale(self):
+        return 1.0
+
+    def _fn(self, e_s, e_p, e_o):
+        """Score of already-gathered embedding rows [n, internal_k] — the reference's extension contract
+        (EmbeddingModel.py:316-336; TransE.py:208-216, DistMult.py:201, ComplEx.py:288-298, HolE.py:189).
+        Runs through the same HIP gather+score kernel as everything else (rows are staged as two small
+        tables); fit/predict/evaluation never call it because their gathers are fused into the kernels."""
+        D.require_gpu()
+        dev = torch.device("cuda")
+        rows = [torch.as_tensor(np.asarray(a, dtype=np.float32) if not isinstance(a, torch.Tensor) else a,
+                                dtype=torch.float32, device=dev) for a in (e_s, e_p, e_o)]
+        n, kk = rows[0].shape
+        ent = alloc_table(2 * n, kk, dev)
+        rel = alloc_table(n, kk, dev)
+        ent[:n].copy_(rows[0])
+        ent[n:].copy_(rows[2])
+        rel.copy_(rows[1])
+        ar = torch.arange(n, dtype=torch.int32, device=dev)
+        spo = torch.stack([ar, ar, ar + n], dim=1).contiguous()
+        return D.score_triples(self._model_id(), ent, rel, kk, self._scale(), spo).cpu().numpy()
+
+    # ---- bookkeeping mirrored from the reference ----
+    def get_hyperparameter_dict(self):
+        return self.all_params
+
+    def get_embedding_model_params(self, output_dict):
+        output_dict["model_params"] = self.trained_model_params
+        output_dict["large_graph"] = self.dealing_with_large_graphs
+        output_dict["calibration_parameters"] = self.calibration_parameters
+
+    def restore_model_params(self, in_dict):
+        self.trained_model_params = [np.asarray(p, dtype=np.float32) for p in in_dict["model_params"]]
+        self.calibration_parameters = in_dict.get("calibration_parameters", [])
+        self.dealing_with_large_graphs = in_dict.get("large_graph", False)
+        self._dev = None
+
+    def get_embeddings(self, entities, embedding_type="entity"):
+        """EmbeddingModel.py:455-488."""
+        if not self.is_fitted:
+            msg = "Model has not been fitted."
+            logger.error(msg)
+            raise RuntimeError(msg)
+        if embedding_type == "entity":
+            emb_list, lookup_dict = self.trained_model_params[0], self.ent_to_idx
+        elif embedding_type == "relation":
+            emb_list, lookup_dict = self.trained_model_params[1], self.rel_to_idx
+        else:
+            msg = "Invalid entity type: {}".format(embedding_type)
+            logger.error(msg)
+            raise ValueError(msg)
+        idxs = np.vectorize(lookup_dict.get)(entities)
+        return emb_list[idxs]
+
+    def is_fitted_on(self, X):
+        """EmbeddingModel.py:2188-2210."""
+        if not self.is_fitted:
+            msg = "Model has not been fitted."
+            logger.error(msg)
+            raise RuntimeError(msg)
+        unique_ent = np.unique(np.concatenate((X[:, 0], X[:, 2])))
+        unique_rel = np.unique(X[:, 1])
+        return len(unique_ent) == len(self.ent_to_idx) and len(unique_rel) == len(self.rel_to_idx)
+
+    # ---- training ----
+    def _corrupt_sides(self):
+        p = self.embedding_model_params
+        sides = p.get("corrupt_side", p.get("corrupt_sides", DEFAULT_CORRUPT_SIDE_TRAIN))  # SURVEY A-5
+        if not isinstance(sides, list):
+            sides = [sides]
+        for s in sides:
+            if s not in ("s", "o", "s+o", "s,o"):
+                raise ValueError("Invalid argument value {} for corruption side passed for evaluation.".format(s))
+        return sides
+
+    def _negative_pool(self, X_idx, batch_size):
+        """negative_corruption_entities (EmbeddingModel.py:731-783): 'all' | 'batch' | list of labels | int.
+        Returns (n_choices or None, fixed entities_list tensor or None, per-batch lists or None)."""
+        nce = self.embedding_model_params.get("negative_corruption_entities", DEFAULT_CORRUPTION_ENTITIES)
+        if isinstance(nce, str) and nce == "all":
+            return len(self.ent_to_idx), None, None
+        if isinstance(nce, str) and nce == "batch":
+            from ..evaluation.protocol import batch_entities
+            lists = []
+            for i in range(self.batches_count):
+                xb = X_idx[i * batch_size:(i + 1) * batch_size]
+                lists.append(torch.from_numpy(batch_entities(xb)).cuda() if len(xb) else None)
+            return None, None, lists
+        if isinstance(nce, list):
+            wanted = set(nce)
+            ids = np.asarray([idx for uri, idx in self.ent_to_idx.items() if uri in wanted], dtype=np.int32)
+            return len(ids), torch.from_numpy(ids).cuda(), None
+        if isinstance(nce, (int, np.integer)) and not isinstance(nce, bool):
+            return int(nce), None, None
+        raise ValueError("Invalid negative_corruption_entities: {}".format(nce))
+
+    def fit(self, X, early_stopping=False, early_stopping_params={}, focusE_numeric_edge_values=None,
+            tensorboard_logs_path=None):
+        """Train the model (EmbeddingModel.py:1113-1492).  ``X``: ndarray [n,3] of labels."""
+        D.require_gpu()
+        if focusE_numeric_edge_values is not None:
+            raise NotImplementedError("FocusE numeric edge values are outside the accelerated hot path")
+        if self.embedding_model_params.get("non_linearity", "linear") != "linear":
+            raise NotImplementedError("non_linearity other than 'linear' is outside the accelerated hot path")
+        if not isinstance(X, np.ndarray):
+            msg = "Invalid type for input X. Expected ndarray/EmgraphDataset object, got {}".format(type(X))
+            logger.error(msg)
+            raise ValueError(msg)
+        if X.ndim != 2 or X.shape[1] != 3:
+            msg = "Invalid size for input X. Expected (n,3):  got {}".format(X.shape)
+            logger.error(msg)
+            raise ValueError(msg)
+        self.rel_to_idx, self.ent_to_idx, X_idx = create_mappings_and_index(X)
+        n = X_idx.shape[0]
+        batch_size = int(np.ceil(n / self.batches_count))  # EmbeddingModel.py:1297-1301
+        self.batch_size = batch_size
+        rnd = np.random.RandomState(self.seed)  # refit -> same seed -> same run (EmbeddingModel.py:1286-1290)
+        n_ent, n_rel = len(self.ent_to_idx), len(self.rel_to_idx)
+        ent0 = _initial_table(self.initializer, self.initializer_params, rnd, n_ent, self.internal_k, "e")
+        rel0 = _initial_table(self.initializer, self.initializer_params, rnd, n_rel, self.internal_k, "r")
+        normalize = self.embedding_model_params.get("normalize_ent_emb", DEFAULT_NORMALIZE_EMBEDDINGS)
+        tr = Trainer(self._model_id(), self.internal_k, self._scale(), ent0, rel0, self.eta, loss=self.loss,
+                     loss_params=self.loss_params, optimizer=self.optimizer, optimizer_params=self.optimizer_params,
+                     corrupt_sides=self._corrupt_sides(), batches_count=self.batches_count, seed=self.seed,
+                     regularizer=self.regularizer, regularizer_params=self.regularizer_params,
+                     normalize_ent_emb=normalize)
+        tr.set_training_set(X_idx, batch_size)
+        n_choices, fixed_list, batch_lists = self._negative_pool(X_idx, batch_size)
+        if normalize:  # EmbeddingModel.py:1371-1380: both tables clipped once before the loop
+            D.clip_rows(tr.rel, self.internal_k, 1.0)
+            D.clip_rows(tr.ent, self.internal_k, 1.0)
+        self.early_stopping_params = early_stopping_params
+        es = self._initialize_early_stopping() if early_stopping else None
+        # reported average: sum(losses) / (batch_size * batches_count), batch_size *= eta when the loss
+        # tiles the positives (EmbeddingModel.py:1343-1344,1456)
+        denom = batch_size * self.batches_count
+        if self.loss in ("pairwise", "nll", "absolute_margin"):
+            denom *= self.eta
+        try:
+            from tqdm import tqdm
+            epochs_iter = tqdm(range(1, self.epochs + 1), disable=(not self.verbose), unit="epoch")
+        except ImportError:  # pragma: no cover
+            epochs_iter = range(1, self.epochs + 1)
+        self._trainer = tr
+        for epoch in epochs_iter:
+            for batch in range(1, self.batches_count + 1):
+                start = (batch - 1) * batch_size
+                B = max(0, min(batch_size, n - start))  # last batch may be short / empty (numpy_adapter.py:105-112)
+                if B == 0:
+                    continue
+                if batch_lists is not None:
+                    elist = batch_lists[batch - 1]
+                    tr.step(start, B, epoch, batch, n_choices=elist.numel(), entities_list=elist)
+                else:
+                    tr.step(start, B, epoch, batch, n_choices=n_choices, entities_list=fixed_list)
+            loss_epoch = tr.read_loss()
+            if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)
+                msg = "Loss is {}. Please change the hyperparameters.".format(loss_epoch)
+                logger.error(msg)
+                raise ValueError(msg)
+            if self.verbose:
+                msg = "Average {} Loss: {:10f}".format(self.name, loss_epoch / denom)
+                if es is not None and es["best"] is not None:
+                    msg += " — Best validation ({}): {:5f}".format(es["criteria"], es["best"])
+                logger.debug(msg)
+                if hasattr(epochs_iter, "set_description"):
+                    epochs_iter.set_description(msg)
+            if es is not None and self._perform_early_stopping_test(epoch, es, tr):
+                self.is_fitted = True
+                return
+        self._save_trained_params(tr)
+        self.is_fitted = True
+
+    def _save_trained_params(self, tr):
+        ent, rel = tr.tables_numpy()
+        self.trained_model_params = [ent, rel]
+        self._dev = (tr.ent, tr.rel)
+
+    # ---- early stopping (EmbeddingModel.py:824-1020) ----
+    def _initialize_early_stopping(self):
+        p = self.early_stopping_params
+        try:
+            x_valid = p["x_valid"]
+        except KeyError:
+            msg = "x_valid must be passed for early fitting."
+            logger.error(msg)
+            raise KeyError(msg)
+        if not isinstance(x_valid, np.ndarray):
+            msg = "Invalid type for input X. Expected ndarray/EmgraphDataset object, got {}".format(type(x_valid))
+            logger.error(msg)
+            raise ValueError(msg)
+        if x_valid.ndim <= 1 or np.shape(x_valid)[1] != 3:
+            msg = "Invalid size for input x_valid. Expected (n,3):  got {}".format(np.shape(x_valid))
+            logger.error(msg)
+            raise ValueError(msg)
+        criteria = p.get("criteria", DEFAULT_CRITERIA_EARLY_STOPPING)
+        if criteria not in ["hits10", "hits1", "hits3", "mrr"]:
+            msg = "Unsupported early stopping criteria."
+            logger.error(msg)
+            raise ValueError(msg)
+        ce = p.get("corruption_entities", DEFAULT_CORRUPTION_ENTITIES)
+        subset = None
+        if isinstance(ce, list):
+            wanted = set(ce)
+            subset = np.asarray([idx for uri, idx in self.ent_to_idx.items() if uri in wanted])
+        findex = None
+        if "x_filter" in p:
+            x_filter = p["x_filter"]
+            if x_filter.ndim <= 1 or np.shape(x_filter)[1] != 3:
+                msg = "Invalid size for input x_valid. Expected (n,3):  got {}".format(np.shape(x_filter))
+                logger.error(msg)
+                raise ValueError(msg)
+            findex = FilterIndex(to_idx(x_filter, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx))
+        return {"x_valid": to_idx(x_valid, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx),
+                "criteria": criteria, "subset": subset, "filter": findex,
+                "corrupt_side": p.get("corrupt_side", DEFAULT_CORRUPT_SIDE_EVAL),
+                "best": None, "first": None, "counter": 0, "epoch": None}
+
+    def _perform_early_stopping_test(self, epoch, es, tr):
+        p = self.early_stopping_params
+        if not (epoch >= p.get("burn_in", DEFAULT_BURN_IN_EARLY_STOPPING)
+                and epoch % p.get("check_interval", DEFAULT_CHECK_INTERVAL_EARLY_STOPPING) == 0):
+            return False
+        ranks = rank_triples_device(self._model_id(), tr.ent, tr.rel, self.internal_k, self._scale(), es["x_valid"],
+                                    es["corrupt_side"], DEFAULT_RANK_COMPARE_STRATEGY, filter_triples=es["filter"],
+                                    entities_subset=es["subset"])
+        crit = es["criteria"]
+        cur = mrr_score(ranks) if crit == "mrr" else hits_at_n_score(ranks, int(crit[4:]))
+        if es["best"] is None:
+            es["best"] = es["first"] = cur
+        elif es["best"] >= cur:
+            es["counter"] += 1
+            if es["counter"] == p.get("stop_interval", DEFAULT_STOP_INTERVAL_EARLY_STOPPING):
+                if es["best"] == es["first"]:
+                    self._save_trained_params(tr)
+                if self.verbose:
+                    logger.info("Early stopping at epoch:{}".format(epoch))
+                    logger.info("Best {}: {:10f}".format(crit, es["best"]))
+                self.early_stopping_epoch = epoch
+                return True
+        else:
+            es["best"] = cur
+            es["counter"] = 0
+            self._save_trained_params(tr)
+        return False
+
+    # ---- inference ----
+    def _device_tables(self):
+        if self._dev is None:
+            D.require_gpu()
+            ent, rel = self.trained_model_params
+            self._dev = (alloc_table(ent.shape[0], ent.shape[1], torch.device("cuda"), init=ent),
+                         alloc_table(rel.shape[0], rel.shape[1], torch.device("cuda"), init=rel))
+        return self._dev
+
+    def predict(self, X, from_idx=False, chunk=1 << 22):
+        """Scores of the triples X (EmbeddingModel.py:2101-2186)."""
+        if not self.is_fitted:
+            msg = "Model has not been fitted."
+            logger.error(msg)
+            raise RuntimeError(msg)
+        if self.embedding_model_params.get("non_linearity", "linear") != "linear":
+            raise NotImplementedError("non_linearity other than 'linear' is outside the accelerated hot path")
+        if type(X) is not np.ndarray:
+            X = np.array(X)
+        if X.ndim == 1:
+            X = X[np.newaxis, :]
+        if not from_idx:
+            X = to_idx(X, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx)
+        X = np.ascontiguousarray(X, dtype=np.int32)
+        ent, rel = self._device_tables()
+        out = np.empty(X.shape[0], dtype=np.float32)
+        for c0 in range(0, X.shape[0], chunk):  # SURVEY A-17: chunk instead of one giant gather
+            xt = torch.from_numpy(X[c0:c0 + chunk]).cuda()
+            out[c0:c0 + chunk] = D.score_triples(self._model_id(), ent, rel, self.internal_k, self._scale(),
+                                                 xt).cpu().numpy()
+        return out
+
+    def get_ranks_idx(self, X_idx, filter_idx=None, corrupt_side=DEFAULT_CORRUPT_SIDE_EVAL,
+                      ranking_strategy=DEFAULT_RANK_COMPARE_STRATEGY, corruption_entities=None, verbose=False):
+        """get_ranks (EmbeddingModel.py:2046-2099) on integer ids, intended per-triple semantics."""
+        if not self.is_fitted:
+            msg = "Model has not been fitted."
+            logger.error(msg)
+            raise RuntimeError(msg)
+        ent, rel = self._device_tables()
+        return rank_triples_device(self._model_id(), ent, rel, self.internal_k, self._scale(), X_idx, corrupt_side,
+                                   ranking_strategy, filter_triples=filter_idx, entities_subset=corruption_entities)
+
+
+@register_model("TransE")
+class TransE(EmbeddingModel):
+    """TransE (TransE.py): f = -||e_s + r_p - e_o||_n, n = embedding_model_params['norm'] in {1, 2}."""
+
+    def __init__(self, k=DEFAULT_EMBEDDING_SIZE, eta=DEFAULT_ETA, epochs=DEFAULT_EPOCH,
+                 batches_count=DEFAULT_BATCH_COUNT, seed=DEFAULT_SEED,
+                 embedding_model_params={"norm": DEFAULT_NORM_TRANSE, "normalize_ent_emb": DEFAULT_NORMALIZE_EMBEDDINGS,
+                                         "negative_corruption_entities": DEFAULT_CORRUPTION_ENTITIES,
+                                         "corrupt_sides": DEFAULT_CORRUPT_SIDE_TRAIN},
+                 optimizer=DEFAULT_OPTIM, optimizer_params={"lr": DEFAULT_LR}, loss=DEFAULT_LOSS, loss_params={},
+                 regularizer=DEFAULT_REGULARIZER, regularizer_params={}, initializer=DEFAULT_INITIALIZER,
+                 initializer_params={"uniform": DEFAULT_GLOROT_IS_UNIFORM}, verbose=DEFAULT_VERBOSE,
+                 large_graphs=False):
+        super().__init__(k=k, eta=eta, epochs=epochs, batches_count=batches_count, seed=seed,
+                         embedding_model_params=embedding_model_params, optimizer=optimizer,
+                         optimizer_params=optimizer_params, loss=loss, loss_params=loss_params,
+                         regularizer=regularizer, regularizer_params=regularizer_params, initializer=initializer,
+                         initializer_params=initializer_params, verbose=verbose, large_graphs=large_graphs)
+
+    def _model_id(self):
+        norm = self.embedding_model_params.get("norm", DEFAULT_NORM_TRANSE)
+        if norm == 1:
+            return L.TRANSE_L1
+        if norm == 2:
+            return L.TRANSE_L2
+        raise ValueError("TransE norm {} is not supported by the HIP path (1 or 2)".format(norm))
+
+
+
+@register_model("DistMult")
+class DistMult(EmbeddingModel):
+    """DistMult (DistMult.py): f = <r_p, e_s, e_o>."""
+
+    def __init__(self, k=DEFAULT_EMBEDDING_SIZE, eta=DEFAULT_ETA, epochs=DEFAULT_EPOCH,
+                 batches_count=DEFAULT_BATCH_COUNT, seed=DEFAULT_SEED,
+                 embedding_model_params={"normalize_ent_emb": DEFAULT_NORMALIZE_EMBEDDINGS,
+                                         "negative_corruption_entities": DEFAULT_CORRUPTION_ENTITIES,
+                                         "corrupt_sides": DEFAULT_CORRUPT_SIDE_TRAIN},
+                 optimizer=DEFAULT_OPTIM, optimizer_params={"lr": DEFAULT_LR}, loss=DEFAULT_LOSS, loss_params={},
+                 regularizer=DEFAULT_REGULARIZER, regularizer_params={}, initializer=DEFAULT_INITIALIZER,
+                 initializer_params={"uniform": DEFAULT_GLOROT_IS_UNIFORM}, verbose=DEFAULT_VERBOSE):
+        super().__init__(k=k, eta=eta, epochs=epochs, batches_count=batches_count, seed=seed,
+                         embedding_model_params=embedding_model_params, optimizer=optimizer,
+                         optimizer_params=optimizer_params, loss=loss, loss_params=loss_params,
+                         regularizer=regularizer, regularizer_params=regularizer_params, initializer=initializer,
+                         initializer_params=initializer_params, verbose=verbose)
+
+    def _model_id(self):
+        return L.DISTMULT
+
+
+
+@register_model("ComplEx")
+class ComplEx(EmbeddingModel):
+    """ComplEx (ComplEx.py): f = Re(<r_p, e_s, conj(e_o)>); rows are [re | im], internal_k = 2k (:224)."""
+
+    def __init__(self, k=DEFAULT_EMBEDDING_SIZE, eta=DEFAULT_ETA, epochs=DEFAULT_EPOCH,
+                 batches_count=DEFAULT_BATCH_COUNT, seed=DEFAULT_SEED,
+                 embedding_model_params={"negative_corruption_entities": DEFAULT_CORRUPTION_ENTITIES,
+                                         "corrupt_sides": DEFAULT_CORRUPT_SIDE_TRAIN},
+                 optimizer=DEFAULT_OPTIM, optimizer_params={"lr": DEFAULT_LR}, loss=DEFAULT_LOSS, loss_params={},
+                 regularizer=DEFAULT_REGULARIZER, regularizer_params={}, initializer=DEFAULT_INITIALIZER,
+                 initializer_params={"uniform": DEFAULT_GLOROT_IS_UNIFORM}, verbose=DEFAULT_VERBOSE):
+        super().__init__(k=k, eta=eta, epochs=epochs, batches_count=batches_count, seed=seed,
+                         embedding_model_params=embedding_model_params, optimizer=optimizer,
+                         optimizer_params=optimizer_params, loss=loss, loss_params=loss_params,
+                         regularizer=regularizer, regularizer_params=regularizer_params, initializer=initializer,
+                         initializer_params=initializer_params, verbose=verbose)
+        self.internal_k = self.k * 2
+
+    def _model_id(self):
+        return L.COMPLEX
+
+
+
+@register_model("HolE")
+class HolE(ComplEx):
+    """HolE (HolE.py:189): f = (2/k) * f_ComplEx (Hayashi & Shimbo equivalence; NOT an FFT, SURVEY A-12)."""
+
+    def _model_id(self):
+        return L.HOLE
+
+    def _scale(self):
+        return float(np.float32(2 / self.k))
+

@@ -152,8 +152,9 @@ class Trainer:
                 raise ValueError("Regularizer weight must be a scalar or a list with length equal to number of "
                                  "params passes")
             self.reg = (float(lam[0]), float(lam[1]), int(p))
-            if optimizer != "sgd":
-                raise NotImplementedError("LP regulariser is implemented for optimizer='sgd' in this version")
+        # SGD folds the dense LP gradient into an in-place pass; every other optimizer needs the true
+        # per-element gradient sum, so the LP gradient is appended as one contribution row per table row
+        self.reg_rows = self.reg is not None and optimizer != "sgd"
 
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.X = None
@@ -177,11 +178,13 @@ class Trainer:
         self.scores_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
         self.g_pos = torch.empty(B, dtype=torch.float32, device=dev)
         self.g_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
-        self.contrib_ent = torch.empty(((2 + et) * B, ldc), dtype=torch.float32, device=dev)[:, :k]
-        self.contrib_rel = torch.empty((B, ldc), dtype=torch.float32, device=dev)[:, :k]
-        self.dest_ent = torch.empty((2 + et) * B, dtype=torch.int32, device=dev)
-        self.dest_rel = torch.empty(B, dtype=torch.int32, device=dev)
-        nb = max(D.apply_workspace_bytes((2 + et) * B, self.n_ent), D.apply_workspace_bytes(B, self.n_rel))
+        xe = self.n_ent if self.reg_rows else 0
+        xr = self.n_rel if self.reg_rows else 0
+        self.contrib_ent = torch.empty(((2 + et) * B + xe, ldc), dtype=torch.float32, device=dev)[:, :k]
+        self.contrib_rel = torch.empty((B + xr, ldc), dtype=torch.float32, device=dev)[:, :k]
+        self.dest_ent = torch.empty((2 + et) * B + xe, dtype=torch.int32, device=dev)
+        self.dest_rel = torch.empty(B + xr, dtype=torch.int32, device=dev)
+        nb = max(D.apply_workspace_bytes((2 + et) * B + xe, self.n_ent), D.apply_workspace_bytes(B + xr, self.n_rel))
         self.workspace = torch.empty(nb, dtype=torch.uint8, device=dev)
         self._cap = B
 
@@ -242,17 +245,28 @@ class Trainer:
                                                          et, codes, gp, gn, ce, cr, de, dr))
         lr = self.schedule.lr(batch, epoch) if self.schedule is not None else self.lr
         hyper = self._hyper(lr)
-        if self.reg is not None:
+        n_cr = B
+        if self.reg is not None and not self.reg_rows:
             # dense LP term: value + SGD-style in-place step, both evaluated at the pre-update tables
             # (the sparse contributions above were also computed from the pre-update tables)
             self._timed("regularizer", lambda: (
                 D.lp_regularizer(self.ent, self.k_int, self.reg[0], self.reg[2], lr, self.loss_accum),
                 D.lp_regularizer(self.rel, self.k_int, self.reg[1], self.reg[2], lr, self.loss_accum)))
+        elif self.reg_rows:
+            # LP gradient as one extra contribution row per table row (dense by definition, lp.py:107-113)
+            self._timed("regularizer", lambda: (
+                D.lp_grad_rows(self.ent, self.k_int, self.reg[0], self.reg[2], self.contrib_ent[n_ce:n_ce + self.n_ent],
+                               self.dest_ent[n_ce:n_ce + self.n_ent], self.loss_accum),
+                D.lp_grad_rows(self.rel, self.k_int, self.reg[1], self.reg[2], self.contrib_rel[B:B + self.n_rel],
+                               self.dest_rel[B:B + self.n_rel], self.loss_accum)))
+            ce, de = self.contrib_ent[:n_ce + self.n_ent], self.dest_ent[:n_ce + self.n_ent]
+            cr, dr = self.contrib_rel[:B + self.n_rel], self.dest_rel[:B + self.n_rel]
+            n_ce, n_cr = n_ce + self.n_ent, B + self.n_rel
         self._timed("apply_ent", lambda: D.apply_rows(self.opt_id, self.ent, self.k_int, self.state_ent[0],
                                                       self.state_ent[1], self.tag_ent, self.step_count, ce, de, n_ce,
                                                       hyper, self.workspace))
         self._timed("apply_rel", lambda: D.apply_rows(self.opt_id, self.rel, self.k_int, self.state_rel[0],
-                                                      self.state_rel[1], self.tag_rel, self.step_count, cr, dr, B,
+                                                      self.state_rel[1], self.tag_rel, self.step_count, cr, dr, n_cr,
                                                       hyper, self.workspace))
         if self.normalize:
             # EmbeddingModel.py:1434-1440: tf.clip_by_norm(ent_emb, clip_norm=1, axes=1) after each batch

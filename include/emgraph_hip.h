@@ -145,6 +145,12 @@ int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_
 int emg_lp_regularizer(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float lambda, int32_t p,
                        float grad_scale_lr, double* loss_accum, void* stream);
 
+/* K6, optimizer-agnostic form: the regulariser's gradient as n_rows extra contribution rows
+ * (contrib[r] = lambda*p*|W[r]|^(p-1)*sign(W[r]), dest[r] = r) to be appended to the batch's
+ * contributions before emg_apply_rows; also accumulates the loss term. */
+int emg_lp_grad_rows(const float* table, int64_t n_rows, int64_t ld, int32_t k_int, float lambda, int32_t p,
+                     float* contrib, int64_t ldc, int32_t* dest, double* loss_accum, void* stream);
+
 /* ---- K9: optional row-norm clip after a batch (EmbeddingModel.py:1371-1380, clip_by_norm axes=1) */
 int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream);
 

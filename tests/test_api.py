@@ -1,0 +1,334 @@
+"""GPU tests of the public API (fit / predict / evaluate_performance / save-restore), mirroring the
+reference's own model tests (tests/emgraph/models/test_models.py, tests/emgraph/evaluation/test_protocol.py)
+plus end-to-end parity of fit() against an oracle training loop driven by the same Philox draws."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import emgraph_oracle as orc  # noqa: E402
+
+F32 = np.float32
+TOY = np.array([["a", "y", "b"], ["b", "y", "a"], ["a", "y", "c"], ["c", "y", "a"], ["a", "y", "d"], ["c", "y", "d"],
+                ["b", "y", "c"], ["f", "y", "e"]])
+
+
+def _models():
+    from emgraph_amd.models import ComplEx, DistMult, HolE, TransE
+    return {"TransE": TransE, "DistMult": DistMult, "ComplEx": ComplEx, "HolE": HolE}
+
+
+def synth_graph(n_ent=60, n_rel=4, n=600, seed=0):
+    rs = np.random.RandomState(seed)
+    X = np.stack([rs.randint(0, n_ent, n), rs.randint(0, n_rel, n), rs.randint(0, n_ent, n)], 1)
+    # make sure every entity/relation id occurs so that ids == labels after np.unique mapping
+    X[:n_ent, 0] = np.arange(n_ent)
+    X[:n_rel, 1] = np.arange(n_rel)
+    return X.astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# fit() end to end vs an oracle loop (same batching, same Philox corruptions, same optimizer rule)
+# ------------------------------------------------------------------------------------------------
+def oracle_fit(model, k, X_idx, ent0, rel0, eta, epochs, batches_count, seed, loss, loss_params, opt, lr,
+               sides=("s,o",), reg=None):
+    E, R = ent0.copy(), rel0.copy()
+    n_ent = E.shape[0]
+    stE, stR = orc.opt_init(opt, E.shape), orc.opt_init(opt, R.shape)
+    losses = []
+    for epoch in range(1, epochs + 1):
+        tot = 0.0
+        for b, xb in enumerate(orc.batches(X_idx, batches_count), 1):
+            if len(xb) == 0:
+                continue
+            x_negs = []
+            for sd, side in enumerate(sides):
+                counter = ((epoch - 1) * batches_count + (b - 1)) * len(sides) + sd
+                x_negs.append(orc.generate_corruptions_for_fit_philox(xb, eta=eta, corrupt_side=side,
+                                                                      entities_size=n_ent, seed=seed, counter=counter))
+            val, _, _ = orc.model_loss(model, E, R, xb, eta, loss, loss_params, sides, x_negs,
+                                       regularizer=reg, k=k)
+            tot += float(val)
+            dE, dR = orc.train_grads(model, E, R, xb, eta, loss, loss_params, x_negs, k=k)
+            tE = np.zeros(n_ent, bool)
+            tR = np.zeros(R.shape[0], bool)
+            for xx in [xb] + x_negs:
+                tE[xx[:, 0]] = True
+                tE[xx[:, 2]] = True
+            tR[xb[:, 1]] = True
+            if reg is not None:
+                lam, p = reg["lam"], reg["p"]
+                dE = dE + lam * p * np.abs(E.astype(np.float64)) ** (p - 1) * np.sign(E)
+                dR = dR + lam * p * np.abs(R.astype(np.float64)) ** (p - 1) * np.sign(R)
+                tE[:] = True
+                tR[:] = True
+            E = orc.opt_apply(opt, E, dE, stE, lr=lr, touched=None if opt == "adam" else tE)
+            R = orc.opt_apply(opt, R, dR, stR, lr=lr, touched=None if opt == "adam" else tR)
+        losses.append(tot)
+    return E, R, losses
+
+
+@pytest.mark.parametrize("name,loss,opt", [
+    ("TransE", "pairwise", "adagrad"), ("TransE", "nll", "sgd"), ("DistMult", "nll", "adam"),
+    ("ComplEx", "nll", "momentum"), ("ComplEx", "multiclass_nll", "adam"), ("HolE", "self_adversarial", "adagrad"),
+    ("DistMult", "absolute_margin", "sgd"),
+])
+def test_fit_matches_oracle_training_loop(name, loss, opt):
+    cls = _models()[name]
+    k, eta, epochs, bc, seed, lr = 8, 3, 3, 4, 7, 0.05
+    X = synth_graph()
+    n_ent, n_rel = 60, 4
+    rs = np.random.RandomState(1)
+    ki = 2 * k if name in ("ComplEx", "HolE") else k
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    m = cls(k=k, eta=eta, epochs=epochs, batches_count=bc, seed=seed, loss=loss, optimizer=opt,
+            optimizer_params={"lr": lr}, initializer="constant", initializer_params={"entity": ent0, "relation": rel0})
+    m.fit(X)
+    assert m.ent_to_idx == {i: i for i in range(n_ent)}
+    omodel = "TransE_L1" if name == "TransE" else name
+    E, R, _ = oracle_fit(omodel, k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, loss, None, opt, lr)
+    got_E, got_R = m.trained_model_params
+    # 12 optimizer steps of fp32 arithmetic in a different summation order
+    np.testing.assert_allclose(got_E, E, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(got_R, R, rtol=2e-3, atol=2e-5)
+    # predict() == oracle scores of the fitted parameters (fp32 within 1e-4 relative)
+    Xt = X[:50]
+    np.testing.assert_allclose(m.predict(Xt), orc.score_triples(omodel, got_E, got_R, Xt.astype(np.int32), k=k),
+                               rtol=1e-4, atol=1e-5)
+
+
+def test_fit_with_lp_regulariser_and_two_sides_matches_oracle():
+    from emgraph_amd.models import ComplEx
+    k, eta, epochs, bc, seed, lr = 6, 2, 2, 3, 3, 0.05
+    X = synth_graph(seed=4)
+    rs = np.random.RandomState(2)
+    ent0 = (rs.randn(60, 2 * k) * 0.3).astype(F32)
+    rel0 = (rs.randn(4, 2 * k) * 0.3).astype(F32)
+    for opt in ("sgd", "adagrad"):
+        m = ComplEx(k=k, eta=eta, epochs=epochs, batches_count=bc, seed=seed, loss="nll", optimizer=opt,
+                    optimizer_params={"lr": lr}, regularizer="LP", regularizer_params={"lambda": 0.01, "p": 2},
+                    embedding_model_params={"corrupt_side": ["s", "o"]}, initializer="constant",
+                    initializer_params={"entity": ent0, "relation": rel0})
+        m.fit(X)
+        E, R, _ = oracle_fit("ComplEx", k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, "nll", None, opt, lr,
+                             sides=("s", "o"), reg={"lam": 0.01, "p": 2})
+        np.testing.assert_allclose(m.trained_model_params[0], E, rtol=2e-3, atol=2e-5, err_msg=opt)
+        np.testing.assert_allclose(m.trained_model_params[1], R, rtol=2e-3, atol=2e-5, err_msg=opt)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own toy-graph tests (test_models.py:218-335,338-367,389-409,967-992)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("TransE", dict(batches_count=1, seed=555, epochs=20, k=10, loss="pairwise", loss_params={"margin": 5},
+                    optimizer="adagrad", optimizer_params={"lr": 0.1})),
+    ("DistMult", dict(batches_count=2, seed=555, epochs=20, k=10, loss="pairwise", loss_params={"margin": 5},
+                      optimizer="adagrad", optimizer_params={"lr": 0.1})),
+    ("ComplEx", dict(batches_count=1, seed=555, epochs=20, k=10, loss="pairwise", loss_params={"margin": 1},
+                     regularizer="LP", regularizer_params={"lambda": 0.1, "p": 2}, optimizer="adagrad",
+                     optimizer_params={"lr": 0.1})),
+    ("HolE", dict(batches_count=1, seed=555, epochs=20, k=10, loss="pairwise", loss_params={"margin": 1},
+                  regularizer="LP", regularizer_params={"lambda": 0.1, "p": 2}, optimizer="adagrad",
+                  optimizer_params={"lr": 0.1})),
+])
+def test_fit_predict_toy_graph(name, kw):
+    model = _models()[name](**kw)
+    model.fit(TOY)
+    y_pred = model.predict(np.array([["f", "y", "e"], ["b", "y", "d"]]))
+    assert y_pred.shape == (2,)
+    assert y_pred[0] > y_pred[1]
+
+
+def test_retrain_is_deterministic():
+    from emgraph_amd.models import ComplEx
+    model = ComplEx(batches_count=1, seed=555, epochs=20, k=10, loss="pairwise", loss_params={"margin": 1},
+                    regularizer="LP", regularizer_params={"lambda": 0.1, "p": 2}, optimizer="adagrad",
+                    optimizer_params={"lr": 0.1})
+    model.fit(TOY)
+    y1 = model.predict(np.array([["f", "y", "e"], ["b", "y", "d"]]))
+    model.fit(TOY)
+    y2 = model.predict(np.array([["f", "y", "e"], ["b", "y", "d"]]))
+    np.testing.assert_array_equal(y1, y2)  # bit-identical: no float atomics anywhere in the step
+
+
+def test_missing_entity_raises_value_error():
+    from emgraph_amd.models import ComplEx
+    model = ComplEx(batches_count=1, seed=555, epochs=2, k=5)
+    model.fit(TOY)
+    with pytest.raises(ValueError):
+        model.predict(["a", "y", "zzzzzzzzzzz"])
+    with pytest.raises(ValueError):
+        model.predict(["a", "xxxxxxxxxx", "e"])
+    with pytest.raises(ValueError):
+        model.predict(["zzzzzzzz", "y", "e"])
+
+
+def test_not_fitted_raises_runtime_error():
+    from emgraph_amd.models import TransE
+    with pytest.raises(RuntimeError):
+        TransE(k=5).predict(TOY[:1])
+    with pytest.raises(RuntimeError):
+        TransE(k=5).get_embeddings(["a"])
+
+
+def test_predict_from_idx_equals_labels_and_embeddings_lookup():
+    from emgraph_amd.evaluation import to_idx
+    from emgraph_amd.models import DistMult
+    model = DistMult(batches_count=2, seed=1, epochs=3, k=7)
+    model.fit(TOY)
+    y1 = model.predict(TOY)
+    y2 = model.predict(to_idx(TOY, model.ent_to_idx, model.rel_to_idx), from_idx=True)
+    np.testing.assert_array_equal(y1, y2)
+    emb = model.get_embeddings(np.array(["a", "f"]), "entity")
+    assert emb.shape == (2, 7)
+    np.testing.assert_array_equal(emb[1], model.trained_model_params[0][model.ent_to_idx["f"]])
+    assert model.get_embeddings(np.array(["y"]), "relation").shape == (1, 7)
+    with pytest.raises(ValueError):
+        model.get_embeddings(np.array(["a"]), "bogus")
+    assert model.is_fitted_on(TOY) and not model.is_fitted_on(TOY[:3])
+    # the reference's extension contract _fn(e_s, e_p, e_o) goes through the same HIP kernel
+    E, R = model.trained_model_params
+    xi = to_idx(TOY, model.ent_to_idx, model.rel_to_idx)
+    np.testing.assert_allclose(model._fn(E[xi[:, 0]], R[xi[:, 1]], E[xi[:, 2]]), y1, rtol=1e-6)
+
+
+def test_constructor_errors_match_reference():
+    from emgraph_amd.models import ComplEx, TransE
+    for kw in (dict(loss="nope"), dict(optimizer="nope"), dict(regularizer="nope"), dict(initializer="nope"),
+               dict(loss="bce")):
+        with pytest.raises(ValueError):
+            TransE(**kw)
+    with pytest.raises(ValueError):
+        TransE(k=4, epochs=1, embedding_model_params={"norm": 3}).fit(TOY)
+    assert ComplEx(k=6).internal_k == 12
+    m = TransE(k=3, eta=5)
+    assert m.get_hyperparameter_dict()["eta"] == 5 and m.get_hyperparameter_dict()["optimizer"] == "adam"
+
+
+def test_nan_loss_raises_value_error():
+    from emgraph_amd.models import DistMult
+    ent0 = np.full((6, 4), 1e19, F32)
+    rel0 = np.full((1, 4), 1e19, F32)
+    m = DistMult(k=4, epochs=1, batches_count=1, loss="pairwise", optimizer="sgd", initializer="constant",
+                 initializer_params={"entity": ent0, "relation": rel0})
+    with pytest.raises(ValueError, match="Loss is"):
+        m.fit(TOY)
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluate_performance (test_protocol.py properties; test_models.py:183-215)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fitted_complex():
+    from emgraph_amd.models import ComplEx
+    X = synth_graph(n_ent=200, n_rel=5, n=3000, seed=9)
+    m = ComplEx(k=16, eta=5, epochs=15, batches_count=5, seed=0, optimizer="adam", optimizer_params={"lr": 0.05})
+    m.fit(X[:2700])
+    return m, X[:2700], X[2700:]
+
+
+def test_evaluate_performance_shapes_and_oracle_ranks(fitted_complex):
+    from emgraph_amd.evaluation import evaluate_performance, hits_at_n_score, mr_score, mrr_score
+    m, Xtr, Xte = fitted_complex
+    E, R = m.trained_model_params
+    filt = np.concatenate([Xtr, Xte])
+    for side in ("s,o", "s+o", "s", "o"):
+        ranks = evaluate_performance(Xte, m, filter_triples=filt, corrupt_side=side)
+        assert ranks.shape == ((len(Xte), 2) if side == "s,o" else (len(Xte),))
+        raw = evaluate_performance(Xte, m, corrupt_side=side)
+        assert np.all(ranks <= raw) and np.any(ranks < raw)          # test_models.py:214-215
+        assert raw.min() >= 2 and ranks.min() >= 1                   # SURVEY B-6
+    # literal numpy oracle on the first triples: identical up to float noise around exact ties
+    Xi = Xte[:25].astype(np.int32)
+    got = evaluate_performance(Xte[:25], m, filter_triples=filt, corrupt_side="s,o")
+    exp = orc.get_ranks("ComplEx", E, R, Xi, corrupt_side="s,o", strategy="worst", filter_triples=filt, k=16)
+    assert np.abs(got - exp).max() <= 1 and (got == exp).mean() > 0.9
+    # mr(s) + mr(o) == 2 * mr("s,o")  (test_protocol.py:234,300)
+    rs_ = evaluate_performance(Xte, m, filter_triples=filt, corrupt_side="s")
+    ro_ = evaluate_performance(Xte, m, filter_triples=filt, corrupt_side="o")
+    rso = evaluate_performance(Xte, m, filter_triples=filt, corrupt_side="s,o")
+    np.testing.assert_array_equal(rso[:, 0], rs_)
+    np.testing.assert_array_equal(rso[:, 1], ro_)
+    assert mr_score(rs_) + mr_score(ro_) == pytest.approx(2 * mr_score(rso))
+    assert 0 < mrr_score(rso) <= 1 and 0 <= hits_at_n_score(rso, 10) <= 1
+    for strat in ("best", "middle"):
+        r2 = evaluate_performance(Xte, m, filter_triples=filt, corrupt_side="s,o", ranking_strategy=strat)
+        assert np.all(r2 <= rso)
+
+
+def test_evaluate_performance_entities_subset_and_unseen(fitted_complex):
+    from emgraph_amd.evaluation import evaluate_performance
+    m, Xtr, Xte = fitted_complex
+    subset = list(range(0, 200, 4))
+    ranks = evaluate_performance(Xte, m, filter_triples=np.concatenate([Xtr, Xte]), entities_subset=subset,
+                                 corrupt_side="s,o")
+    assert ranks.max() <= len(subset) + 1  # test_protocol.py:131: ranks bounded by the subset size
+    E, R = m.trained_model_params
+    exp = orc.get_ranks("ComplEx", E, R, Xte[:20].astype(np.int32), corrupt_side="s,o", strategy="worst",
+                        filter_triples=np.concatenate([Xtr, Xte]), corruption_entities=np.array(subset), k=16)
+    assert np.abs(ranks[:20] - exp).max() <= 1
+    # unseen entities are dropped with filter_unseen=True, ValueError otherwise
+    Xu = np.concatenate([Xte[:5], np.array([[100000, 0, 1]])])
+    assert evaluate_performance(Xu, m, corrupt_side="o").shape == (5,)
+    with pytest.raises(ValueError):
+        evaluate_performance(Xu, m, corrupt_side="o", filter_unseen=False)
+    with pytest.raises(AssertionError):
+        evaluate_performance(Xte, m, corrupt_side="bogus")
+    with pytest.raises(AssertionError):
+        evaluate_performance(Xte, m, ranking_strategy="bogus")
+
+
+def test_save_restore_roundtrip(tmp_path, fitted_complex):
+    from emgraph_amd.evaluation import evaluate_performance
+    from emgraph_amd.utils import restore_model, save_model
+    m, Xtr, Xte = fitted_complex
+    path = os.path.join(tmp_path, "model.pkl")
+    save_model(m, path)
+    m2 = restore_model(path)
+    np.testing.assert_array_equal(m.predict(Xte), m2.predict(Xte))
+    np.testing.assert_array_equal(evaluate_performance(Xte[:20], m, corrupt_side="s,o"),
+                                  evaluate_performance(Xte[:20], m2, corrupt_side="s,o"))
+    with pytest.raises(FileNotFoundError):
+        restore_model(os.path.join(tmp_path, "nope.pkl"))
+
+
+def test_early_stopping(fitted_complex):
+    from emgraph_amd.models import DistMult
+    _, Xtr, Xte = fitted_complex
+    m = DistMult(k=8, eta=2, epochs=60, batches_count=3, seed=0, optimizer="adam", optimizer_params={"lr": 0.05})
+    m.fit(Xtr, early_stopping=True, early_stopping_params={"x_valid": Xte[:60], "criteria": "mrr", "burn_in": 5,
+                                                           "check_interval": 5, "stop_interval": 2,
+                                                           "x_filter": np.concatenate([Xtr, Xte])})
+    assert m.is_fitted and len(m.trained_model_params) == 2
+    with pytest.raises(KeyError):
+        DistMult(k=4, epochs=1).fit(Xtr, early_stopping=True, early_stopping_params={})
+    with pytest.raises(ValueError):
+        DistMult(k=4, epochs=1).fit(Xtr, early_stopping=True,
+                                    early_stopping_params={"x_valid": Xte[:10], "criteria": "bogus"})
+
+
+def test_generate_corruptions_for_fit_public_function():
+    from emgraph_amd.evaluation import generate_corruptions_for_fit
+    X = synth_graph(n=100).astype(np.int32)
+    out = generate_corruptions_for_fit(X, eta=3, corrupt_side="s,o", entities_size=60, rnd=5)
+    exp = orc.generate_corruptions_for_fit_philox(X, eta=3, corrupt_side="s,o", entities_size=60, seed=5, counter=0)
+    np.testing.assert_array_equal(out, exp)
+    out = generate_corruptions_for_fit(X, eta=2, corrupt_side="o", entities_size=0, rnd=1)  # batch entities
+    exp = orc.generate_corruptions_for_fit_philox(X, eta=2, corrupt_side="o", entities_size=0, seed=1, counter=0)
+    np.testing.assert_array_equal(out, exp)
+    with pytest.raises(ValueError):
+        generate_corruptions_for_fit(X, corrupt_side="x")
+
+
+def test_negative_corruption_entity_options():
+    from emgraph_amd.models import DistMult
+    X = synth_graph(n=300)
+    for nce in ("batch", [1, 2, 3, 4, 5], 10):
+        m = DistMult(k=4, eta=2, epochs=2, batches_count=3, embedding_model_params={"negative_corruption_entities": nce})
+        m.fit(X)
+        assert np.isfinite(m.trained_model_params[0]).all()
