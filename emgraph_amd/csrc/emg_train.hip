@@ -48,6 +48,8 @@ __device__ __forceinline__ float log_sigmoid(float x) {  // tf.math.log_sigmoid 
     return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tf.maximum(v, 0) propagates NaN (fmaxf would swallow it and hide a diverged model from the NaN check)
+__device__ __forceinline__ float relu_nan(float v) { return (v >= 0.f || v != v) ? v : 0.f; }
 
 template <int LOSS>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp, const float* __restrict__ sn,
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp,
                 for (int j = 0; j < eta; ++j) {
                     const float v = margin - pos + snp[(int64_t)j * B];
                     const float act = v >= 0.f ? 1.f : 0.f;  // TF MaximumGrad: x >= y takes the gradient
-                    loss += fmaxf(v, 0.f);
+                    loss += relu_nan(v);
                     gnp[(int64_t)j * B] = act;
                     gp -= act;
                 }
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp,
             } else if constexpr (LOSS == EMG_LOSS_ABSOLUTE_MARGIN) {  // absolute_margin.py:69
                 for (int j = 0; j < eta; ++j) {
                     const float v = margin + snp[(int64_t)j * B];
-                    loss += fmaxf(v, 0.f) - pos;
+                    loss += relu_nan(v) - pos;
                     gnp[(int64_t)j * B] = v >= 0.f ? 1.f : 0.f;
                     gp -= 1.f;
                 }
