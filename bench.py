@@ -47,18 +47,21 @@ def glorot(rs, rows, cols):
     return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
 
 
-def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None):
+def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None, n_single=0):
     """ALGORITHMIC HBM bytes of one launch (DESIGN.md 'bytes per unit'); int32 ids, fp32 rows."""
     row = 4 * k_int
     if stage == "forward":   # spo + codes + (3+eta) rows + (1+eta) scores
         return B * (12 + 4 * eta + (3 + eta) * row + 4 * (1 + eta))
-    if stage == "backward":  # spo + codes + g + (3+eta) rows read + (3+eta) rows written + dest ids
-        return B * (12 + 4 * eta + 4 * (1 + eta) + (3 + eta) * row + (3 + eta) * row + 4 * (3 + eta))
-    if stage == "apply_ent":  # contribution rows read once + RMW of each touched row (+ sort keys/values)
-        n_c = (2 + eta) * B
-        return n_c * row + 2 * n_unique_ent * row + n_c * 16
+    if stage == "backward":  # spo + codes + g + (3+eta) rows read + (3+eta) rows written
+        return B * (12 + 4 * eta + 4 * (1 + eta) + (3 + eta) * row + (3 + eta) * row)
+    if stage == "fused":     # spo + codes + singleton flags + (3+eta) rows read + (3+eta) rows written
+        # (a singleton row is written in place, any other row to the contribution buffer: one row each)
+        return B * (12 + 4 * eta + (2 + eta) + (3 + eta) * row + (3 + eta) * row)
+    if stage == "apply_ent":  # non-singleton contribution rows read once + RMW of each such destination
+        n_ns = (2 + eta) * B - n_single
+        return n_ns * row + 2 * (n_unique_ent - n_single) * row + (2 + eta) * B * 8
     if stage == "apply_rel":
-        return B * row + 2 * n_unique_rel * row + B * 16
+        return B * row + 2 * n_unique_rel * row + B * 8
     return 0
 
 
@@ -82,10 +85,12 @@ def run_train(args, rank, world):
     X = np.stack([drs.randint(0, w["n_ent"], n_tr), drs.randint(0, w["n_rel"], n_tr),
                   drs.randint(0, w["n_ent"], n_tr)], 1).astype(np.int32)
     tr = Trainer(MODEL_IDS[w["model"]], k_int, scale, ent0, rel0, eta, loss=w["loss"], optimizer=w["optimizer"],
-                 optimizer_params={"lr": 0.0005}, batches_count=steps + warm, seed=0)
+                 optimizer_params={"lr": 0.0005}, batches_count=steps + warm, seed=0, fused=not args.no_fused,
+                 inplace=not args.no_inplace, pipeline=not args.no_pipeline)
     tr.set_training_set(X, B)
+    nxt = lambda i: ((i + 1) * B, B, 1, i + 2) if i + 1 < warm + steps else None  # noqa: E731
     for i in range(warm):
-        tr.step(i * B, B, epoch=1, batch=i + 1)
+        tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -94,7 +99,7 @@ def run_train(args, rank, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(warm, warm + steps):
-        tr.step(i * B, B, epoch=1, batch=i + 1)
+        tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -110,13 +115,16 @@ def run_train(args, rank, world):
     stage_ms = {k: float(np.mean(v)) for k, v in tr.stage_times_ms().items()}
     # unique touched rows of the last timed batch (for the apply kernel's algorithmic bytes)
     n_ce = (2 + eta) * B
-    n_ue = int(torch.unique(tr.dest_ent[:n_ce]).numel())
-    n_ur = int(torch.unique(tr.dest_rel[:B]).numel())
+    sl = tr.slots[0]  # any slot: both hold a full prepared batch of the same shape
+    n_ue = int(torch.unique(sl["dest_ent"][:n_ce]).numel())
+    n_ur = int(torch.unique(sl["dest_rel"][:B]).numel())
+    n_single = int(sl["single"][:n_ce].sum().item()) if tr.inplace else 0
     stages = {}
     for name, ms in stage_ms.items():
-        ab = algorithmic_bytes(name, B, eta, k_int, n_ue, n_ur)
+        ab = algorithmic_bytes(name, B, eta, k_int, n_ue, n_ur, n_single)
         stages[name] = {"ms": round(ms, 4), "alg_bytes": ab, "GBps": round(ab / (ms * 1e-3) / 1e9, 1) if ab else None}
-    dom = max((s for s in stages if stages[s]["alg_bytes"]), key=lambda s: stages[s]["ms"])
+    stages["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur}
+    dom = max((s for s in stages if stages[s].get("alg_bytes")), key=lambda s: stages[s]["ms"])
     ach = stages[dom]["GBps"]
     roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -186,6 +194,9 @@ def main():
     ap.add_argument("--eval-triples", type=int, default=1024)
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="A/B: separate forward / loss / backward kernels")
+    ap.add_argument("--no-inplace", action="store_true", help="A/B: every gradient row through the contribution buffer")
+    ap.add_argument("--no-pipeline", action="store_true", help="A/B: batch preparation on the compute stream")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -207,7 +218,7 @@ def main():
         "value": round(triples / res["dt"], 1), "unit": "triples scored/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload + ": " + w["desc"], "step": "corrupt+score(fwd)+loss+bwd+sparse-SGD apply",
+        "config": {"workload": args.workload + ": " + w["desc"], "step": "corrupt+group | fused score+loss+grad (+in-place singleton SGD) | segmented apply",
                    "B_per_gpu": res["B"], "eta": res["eta"], "k_int": res["k_int"], "n_ent": w["n_ent"],
                    "n_rel": w["n_rel"], "parallelism": "replicas" if n > 1 else "single"},
         "roofline": res["roofline"], "stages": res["stages"], "loss_sum": res["loss"],

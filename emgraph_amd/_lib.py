@@ -65,6 +65,31 @@ SIGNATURES = {
     "emg_to_bf16": (_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
 }
 
+class BackwardArgs(C.Structure):
+    """mirror of `emg_backward_args` (include/emgraph_hip.h)"""
+    _fields_ = [
+        ("model", _i32), ("k_int", _i32), ("scale", _f32), ("eta", _i32),
+        ("ent", _p), ("n_ent", _i64), ("ld_ent", _i64),
+        ("rel", _p), ("n_rel", _i64), ("ld_rel", _i64),
+        ("pos", _p), ("B", _i64), ("codes", _p),
+        ("fused_loss", _i32), ("margin", _f32), ("loss_accum", _p),
+        ("g_pos", _p), ("g_neg", _p),
+        ("bw_scores_pos", _p), ("bw_scores_neg", _p),
+        ("scores_pos_out", _p), ("scores_neg_out", _p),
+        ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
+        ("single_ent", _p), ("opt", _i32), ("step", _i32), ("hyper", _f32 * 6),
+        ("ent_state0", _p), ("ent_state1", _p), ("tag_ent", _p),
+    ]
+
+
+SIGNATURES.update({
+    "emg_build_dest": (_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "emg_train_backward_ex": (_int, [C.POINTER(BackwardArgs), _p]),
+    "emg_group_dest": (_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
+    "emg_apply_grouped": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,
+                                 C.POINTER(_f32), _p, _i64, _p]),
+})
+
 _lib = None
 
 

@@ -1,14 +1,16 @@
 // emg_apply.hip — K8: deterministic row-sparse optimizer apply.
 //
 // The reference hands TF IndexedSlices (row ids + gradient rows) to Keras optimizers
-// (training/sgd.py:97, momentum.py:63, adagrad.py:42, adam.py:45).  Here the backward pass has
-// written one gradient row per (positive group, role) without atomics; this file
-//   1. radix-sorts (destination row, contribution index) — stable, so equal destinations keep
-//      index order and the float sum order is fixed => bit-reproducible training (the reference's
-//      refit-determinism test, tests/emgraph/models/test_models.py:338-367);
-//   2. one wave per segment head sums the segment's rows (16-byte coalesced loads) and performs
-//      the optimizer update of that table row exactly once.
-// HBM-bound streaming: reads every contribution row once, read-modify-writes each touched row once.
+// (training/sgd.py:97, momentum.py:63, adagrad.py:42, adam.py:45).  Here the backward pass writes one
+// gradient row per (positive group, role) without atomics; this file
+//   1. emg_group_dest: stable radix sort of (destination row, contribution index) — equal destinations
+//      keep index order, so the float sum order is fixed => bit-reproducible training (the reference's
+//      refit-determinism test, tests/emgraph/models/test_models.py:338-367) — and a per-contribution
+//      SINGLETON flag (destination hit exactly once in this batch).  Depends only on the batch's
+//      ids, not on the tables, so it can run ahead of / beside the scoring kernels.
+//   2. emg_apply_grouped: one wave per segment head sums the segment's rows (16-byte coalesced loads)
+//      and performs the optimizer update of that table row exactly once.  Singletons can be skipped:
+//      the backward kernel already updated them in place from registers (no contribution round trip).
 #include <string.h>
 #include <cstring>
 
@@ -23,7 +25,8 @@ struct ApplyParams {
     float* state0; float* state1; int32_t* tag; int32_t step;
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
-    float lr, mu, beta1, beta2, eps, lr_t;
+    int32_t skip_single;
+    OptParams opt;
 };
 
 __global__ void iota_kernel(uint32_t* v, int64_t n) {
@@ -31,29 +34,19 @@ __global__ void iota_kernel(uint32_t* v, int64_t n) {
     if (i < n) v[i] = (uint32_t)i;
 }
 
-template <int OPT>
-__device__ __forceinline__ void update_elem(float& w, float g, float* s0, float* s1, const ApplyParams& P) {
-    if constexpr (OPT == EMG_OPT_SGD) {
-        w = w - P.lr * g;
-    } else if constexpr (OPT == EMG_OPT_MOMENTUM) {  // Keras SGD(momentum): v = mu*v - lr*g ; w += v
-        const float v = P.mu * (*s0) - P.lr * g;
-        *s0 = v;
-        w = w + v;
-    } else if constexpr (OPT == EMG_OPT_ADAGRAD) {  // acc += g^2 ; w -= lr*g/(sqrt(acc)+eps)
-        const float a = *s0 + g * g;
-        *s0 = a;
-        w = w - P.lr * g / (sqrtf(a) + P.eps);
-    } else {  // Adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t m/(sqrt(v)+eps)
-        const float m = P.beta1 * (*s0) + (1.f - P.beta1) * g;
-        const float v = P.beta2 * (*s1) + (1.f - P.beta2) * g * g;
-        *s0 = m;
-        *s1 = v;
-        w = w - P.lr_t * m / (sqrtf(v) + P.eps);
-    }
+// flags[original index] = 1 iff its destination occurs exactly once
+__global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
+                                   uint8_t* __restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t key = keys[t];
+    const bool head = (t == 0) || keys[t - 1] != key;
+    const bool last = (t + 1 == n) || keys[t + 1] != key;
+    flags[vals[t]] = (head && last) ? 1 : 0;
 }
 
 // one wave per sorted position; only segment heads work
-template <int OPT, int W>
+template <int W>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -63,6 +56,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     if ((int64_t)key >= P.n_rows) return;  // defensive: never write outside the table
     int64_t end = t + 1;
     while (end < P.n && P.keys[end] == key) ++end;
+    if (P.skip_single && end == t + 1) return;  // already updated in place by the backward kernel
 
     float* wrow = P.table + (int64_t)key * P.ld;
     float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
@@ -85,7 +79,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
         for (int w = 0; w < W; ++w) {
             const int64_t off = (int64_t)c * W + w;
             float wv = wrow[off];
-            update_elem<OPT>(wv, acc[w], s0row ? s0row + off : nullptr, s1row ? s1row + off : nullptr, P);
+            opt_update_elem(P.opt, wv, acc[w], s0row ? s0row + off : nullptr, s1row ? s1row + off : nullptr);
             wrow[off] = wv;
         }
     }
@@ -93,7 +87,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
 }
 
 // Keras Adam's sparse apply is dense-equivalent (every row: m*=b1, v*=b2, w -= lr_t m/(sqrt v + eps));
-// rows touched this step were fully handled by apply_rows_kernel and are skipped via tag.
+// rows touched this step were fully handled elsewhere and are skipped via tag.
 __global__ __launch_bounds__(256) void adam_untouched_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -103,22 +97,50 @@ __global__ __launch_bounds__(256) void adam_untouched_kernel(const ApplyParams P
     float* m = P.state0 + r * P.ld;
     float* v = P.state1 + r * P.ld;
     for (int c = lane; c < P.k_int; c += 64) {
-        const float mm = P.beta1 * m[c];
-        const float vv = P.beta2 * v[c];
+        const float mm = P.opt.beta1 * m[c];
+        const float vv = P.opt.beta2 * v[c];
         m[c] = mm;
         v[c] = vv;
-        w[c] = w[c] - P.lr_t * mm / (sqrtf(vv) + P.eps);
+        w[c] = w[c] - P.opt.lr_t * mm / (sqrtf(vv) + P.opt.eps);
     }
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// force Onesweep (histogram + scan + one pass per 8-bit digit) above 4096 items: the default picks a
+// block sort + ~13 merge launches below 1M items, which is launch-bound at our sizes (3e5 keys)
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 4096>;
+
 static int sort_temp_bytes(int64_t n, size_t* bytes) {
     *bytes = 0;
     if (n <= 0) return EMG_OK;
-    EMG_HIP(rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                      (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32, (hipStream_t)0,
-                                      false));
+    EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
+                                                  (hipStream_t)0, false));
+    return EMG_OK;
+}
+
+// workspace layout: [keys_sorted | vals_in (iota) | vals_sorted | rocprim temp]
+struct WsLayout {
+    size_t kb, temp;
+    uint32_t *keys, *vals_in, *vals;
+    void* tmp;
+};
+
+static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayout* o) {
+    size_t tmp = 0;
+    int rc = sort_temp_bytes(n, &tmp);
+    if (rc != EMG_OK) return rc;
+    o->kb = align256((size_t)n * 4);
+    o->temp = tmp;
+    EMG_REQUIRE((int64_t)(3 * o->kb + align256(tmp)) <= workspace_bytes, "apply workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)(3 * o->kb + align256(tmp)));
+    char* ws = (char*)workspace;
+    o->keys = (uint32_t*)ws;
+    o->vals_in = (uint32_t*)(ws + o->kb);
+    o->vals = (uint32_t*)(ws + 2 * o->kb);
+    o->tmp = ws + 3 * o->kb;
     return EMG_OK;
 }
 
@@ -134,61 +156,59 @@ extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) 
     return (int64_t)(3 * align256((size_t)n_contrib * 4) + align256(tmp) + 256);
 }
 
-extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
-                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
-                              const int32_t* dest, int64_t n_contrib, const float* hyper, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
-    EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_rows: unknown optimizer %d", opt);
-    EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_rows: bad table arguments");
-    EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_rows: too many rows");
-    EMG_REQUIRE(n_contrib == 0 || (contrib && dest && workspace && ldc >= k_int), "emg_apply_rows: bad contribution arguments");
-    EMG_REQUIRE(!(opt == EMG_OPT_MOMENTUM || opt == EMG_OPT_ADAGRAD) || state0, "emg_apply_rows: optimizer needs state0");
-    EMG_REQUIRE(!(opt == EMG_OPT_ADAM || opt == EMG_OPT_ADAM_LAZY) || (state0 && state1),
-                "emg_apply_rows: adam needs state0 and state1");
-    EMG_REQUIRE(opt != EMG_OPT_ADAM || tag, "emg_apply_rows: dense-equivalent adam needs the tag array");
+extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace,
+                              int64_t workspace_bytes, uint8_t* single_flags, void* stream) {
+    EMG_REQUIRE(n >= 0 && n_rows > 0 && n_rows < ((int64_t)1 << 31), "emg_group_dest: bad sizes");
+    if (n == 0) return EMG_OK;
+    EMG_REQUIRE(dest && workspace, "emg_group_dest: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    WsLayout w;
+    int rc = ws_layout(workspace, workspace_bytes, n, &w);
+    if (rc != EMG_OK) return rc;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.vals_in, n);
+    EMG_LAUNCH_CHECK();
+    int end_bit = 1;
+    while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
+    size_t tmp = w.temp;
+    EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(w.tmp, tmp, (const uint32_t*)dest, w.keys, (const uint32_t*)w.vals_in,
+                                                  w.vals, (size_t)n, 0, end_bit, st, false));
+    if (single_flags) {
+        hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
+                           single_flags);
+        EMG_LAUNCH_CHECK();
+    }
+    return EMG_OK;
+}
 
+extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                                 float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                                 int64_t n_contrib, int32_t skip_single, const float* hyper, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
+    EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
+    EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
+    EMG_REQUIRE(n_contrib == 0 || (contrib && workspace && ldc >= k_int), "emg_apply_grouped: bad contribution arguments");
+    EMG_REQUIRE(!(opt == EMG_OPT_MOMENTUM || opt == EMG_OPT_ADAGRAD) || state0, "emg_apply_grouped: optimizer needs state0");
+    EMG_REQUIRE(!(opt == EMG_OPT_ADAM || opt == EMG_OPT_ADAM_LAZY) || (state0 && state1),
+                "emg_apply_grouped: adam needs state0 and state1");
+    EMG_REQUIRE(opt != EMG_OPT_ADAM || tag, "emg_apply_grouped: dense-equivalent adam needs the tag array");
+    hipStream_t st = (hipStream_t)stream;
     ApplyParams P{};
     P.table = table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
     P.state0 = state0; P.state1 = state1; P.tag = tag; P.step = step;
-    P.contrib = contrib; P.ldc = ldc; P.n = n_contrib;
-    P.lr = hyper[0]; P.mu = hyper[1]; P.beta1 = hyper[2]; P.beta2 = hyper[3]; P.eps = hyper[4]; P.lr_t = hyper[5];
-
+    P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
+    P.opt = make_opt_params(opt, hyper);
     if (n_contrib > 0) {
-        size_t tmp = 0;
-        int rc = sort_temp_bytes(n_contrib, &tmp);
+        WsLayout w;
+        int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w);
         if (rc != EMG_OK) return rc;
-        const size_t kb = align256((size_t)n_contrib * 4);
-        EMG_REQUIRE((int64_t)(3 * kb + align256(tmp)) <= workspace_bytes, "emg_apply_rows: workspace too small (%lld < %lld)",
-                    (long long)workspace_bytes, (long long)(3 * kb + align256(tmp)));
-        char* ws = (char*)workspace;
-        uint32_t* keys_out = (uint32_t*)ws;
-        uint32_t* vals_in = (uint32_t*)(ws + kb);
-        uint32_t* vals_out = (uint32_t*)(ws + 2 * kb);
-        void* temp = ws + 3 * kb;
-        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(n_contrib, 256)), dim3(256), 0, st, vals_in, n_contrib);
-        EMG_LAUNCH_CHECK();
-        int end_bit = 1;
-        while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
-        EMG_HIP(rocprim::radix_sort_pairs(temp, tmp, (const uint32_t*)dest, keys_out, (const uint32_t*)vals_in, vals_out,
-                                          (size_t)n_contrib, 0, end_bit, st, false));
-        P.keys = keys_out;
-        P.vals = vals_out;
+        P.keys = w.keys;
+        P.vals = w.vals;
         const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
                          (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
         const dim3 grid((unsigned)cdiv(n_contrib * 64, 256)), block(256);
-#define EMG_LAUNCH_APPLY(O)                                                                   \
-    do {                                                                                      \
-        if (vec) hipLaunchKernelGGL((apply_rows_kernel<O, 4>), grid, block, 0, st, P);        \
-        else hipLaunchKernelGGL((apply_rows_kernel<O, 1>), grid, block, 0, st, P);            \
-    } while (0)
-        switch (opt) {
-            case EMG_OPT_SGD: EMG_LAUNCH_APPLY(EMG_OPT_SGD); break;
-            case EMG_OPT_MOMENTUM: EMG_LAUNCH_APPLY(EMG_OPT_MOMENTUM); break;
-            case EMG_OPT_ADAGRAD: EMG_LAUNCH_APPLY(EMG_OPT_ADAGRAD); break;
-            default: EMG_LAUNCH_APPLY(EMG_OPT_ADAM); break;
-        }
-#undef EMG_LAUNCH_APPLY
+        if (vec) hipLaunchKernelGGL((apply_rows_kernel<4>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((apply_rows_kernel<1>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
     }
     if (opt == EMG_OPT_ADAM) {
@@ -196,4 +216,16 @@ extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld,
         EMG_LAUNCH_CHECK();
     }
     return EMG_OK;
+}
+
+extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                              const int32_t* dest, int64_t n_contrib, const float* hyper, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    EMG_REQUIRE(n_contrib == 0 || dest, "emg_apply_rows: null dest");
+    EMG_REQUIRE(n_rows > 0, "emg_apply_rows: bad table arguments");
+    int rc = emg_group_dest(dest, n_contrib, n_rows, workspace, workspace_bytes, nullptr, stream);
+    if (rc != EMG_OK) return rc;
+    return emg_apply_grouped(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, 0,
+                             hyper, workspace, workspace_bytes, stream);
 }

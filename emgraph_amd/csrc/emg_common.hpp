@@ -125,4 +125,98 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ float sgnf(float d) { return (float)(d > 0.f) - (float)(d < 0.f); }
 
+// ---------------------------------------------------------------------------------------------
+// Optimizer element update (Keras / TF-2.2 rules; training/{sgd,momentum,adagrad,adam}.py).
+// Shared by the segmented apply kernel and by the in-place singleton path of the backward kernel
+// so that both produce bit-identical results.
+// ---------------------------------------------------------------------------------------------
+struct OptParams {
+    int opt;
+    float lr, mu, beta1, beta2, eps, lr_t;
+};
+
+__device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float g) {
+#pragma clang fp contract(off)
+    return w - P.lr * g;
+}
+
+__device__ __forceinline__ void opt_update_elem(const OptParams& P, float& w, float g, float* s0, float* s1) {
+#pragma clang fp contract(off)  // every op rounded separately: identical bits wherever this is inlined
+    if (P.opt == EMG_OPT_SGD) {
+        w = w - P.lr * g;
+    } else if (P.opt == EMG_OPT_MOMENTUM) {  // Keras SGD(momentum): v = mu*v - lr*g ; w += v
+        const float v = P.mu * (*s0) - P.lr * g;
+        *s0 = v;
+        w = w + v;
+    } else if (P.opt == EMG_OPT_ADAGRAD) {  // acc += g^2 ; w -= lr*g/(sqrt(acc)+eps)
+        const float a = *s0 + g * g;
+        *s0 = a;
+        w = w - P.lr * g / (sqrtf(a) + P.eps);
+    } else {  // Adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t m/(sqrt(v)+eps)
+        const float m = P.beta1 * (*s0) + (1.f - P.beta1) * g;
+        const float v = P.beta2 * (*s1) + (1.f - P.beta2) * g * g;
+        *s0 = m;
+        *s1 = v;
+        w = w - P.lr_t * m / (sqrtf(v) + P.eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss pieces shared by loss_kernel (emg_train.hip) and the fused train kernel (emg_score.hip).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clip75(float v) { return fminf(fmaxf(v, -75.0f), 75.0f); }  // losses/utils.py:44-53
+__device__ __forceinline__ float in75(float v) { return (v >= -75.0f && v <= 75.0f) ? 1.f : 0.f; }
+__device__ __forceinline__ float log1pexp_naive(float x) { return logf(1.0f + expf(x)); }  // nll.py:59 literal form
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tf.maximum(v, 0) propagates NaN (fmaxf would swallow it and hide a diverged model from the NaN check)
+__device__ __forceinline__ float relu_nan(float v) { return (v >= 0.f || v != v) ? v : 0.f; }
+
+// The three losses whose dL/dneg_j depends only on (pos_i, neg_j): pairwise.py:69, nll.py:55-59,
+// absolute_margin.py:69.  Returns dL/dneg; adds this pair's loss and dL/dpos share.
+// The positive's share is the same for each of its negatives (the reference tiles the positive eta times,
+// EmbeddingModel.py:724-729), so it is evaluated once per positive (PosTerms) and added once per negative.
+struct PosTerms {
+    float loss, grad;
+};
+
+__device__ __forceinline__ PosTerms local_loss_pos(int loss, float pos) {
+    PosTerms t;
+    t.loss = 0.f;
+    t.grad = 0.f;
+    if (loss == EMG_LOSS_NLL) {
+        const float pc = clip75(pos);
+        t.loss = log1pexp_naive(-pc);
+        t.grad = -in75(pos) * sigmoidf(-pc);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float local_loss_neg(int loss, float pos, const PosTerms& t, float neg, float margin,
+                                                float& loss_acc, float& gpos_acc) {
+    if (loss == EMG_LOSS_PAIRWISE) {
+        const float v = margin - pos + neg;
+        const float act = v >= 0.f ? 1.f : 0.f;  // TF MaximumGrad: x >= y takes the gradient
+        loss_acc += relu_nan(v);
+        gpos_acc -= act;
+        return act;
+    }
+    if (loss == EMG_LOSS_NLL) {
+        const float e = expf(clip75(neg));    // <= e^75 = 3.7e32, finite in f32
+        loss_acc += t.loss + logf(1.0f + e);  // nll.py:59 literal log(1+exp(x))
+        gpos_acc += t.grad;
+        return in75(neg) * (e / (1.0f + e));  // sigmoid(clip(neg))
+    }
+    const float v = margin + neg;  // absolute_margin
+    loss_acc += relu_nan(v) - pos;
+    gpos_acc -= 1.f;
+    return v >= 0.f ? 1.f : 0.f;
+}
+
+static inline OptParams make_opt_params(int opt, const float* hyper) {
+    OptParams o;
+    o.opt = opt == EMG_OPT_ADAM_LAZY ? EMG_OPT_ADAM : opt;
+    o.lr = hyper[0]; o.mu = hyper[1]; o.beta1 = hyper[2]; o.beta2 = hyper[3]; o.eps = hyper[4]; o.lr_t = hyper[5];
+    return o;
+}
+
 }  // namespace emg

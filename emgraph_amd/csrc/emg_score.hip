@@ -1,16 +1,24 @@
-// emg_score.hip — fused embedding gather + score (K1+K2+K4) and its adjoint (K7).
+// emg_score.hip — fused embedding gather + score (K1+K2+K4), its adjoint (K7) and the fused train kernel.
 //
 // Replaces, per training batch, EmbeddingModel._lookup_embeddings (EmbeddingModel.py:490-533, three
 // materialised tf.nn.embedding_lookup gathers), Model._fn (TransE.py:208-216, DistMult.py:201,
-// ComplEx.py:288-298, HolE.py:189), the positive tiling (EmbeddingModel.py:724-729) and the
-// TF-autodiff backward of all of them.
+// ComplEx.py:288-298, HolE.py:189), the positive tiling (EmbeddingModel.py:724-729), Loss.apply for the
+// pair-local losses, and the TF-autodiff backward of all of them.
 //
 // Mapping to CDNA4: one LANE GROUP (16/32/64 lanes of a wave64) owns one positive triple.  The
 // group keeps the s, p, o rows in VGPRs (16-byte global_load_dwordx4 per lane, rows are 16-byte
 // aligned), scores the positive, then streams the eta replacement rows of that positive — the
 // relation row and the kept side are read ONCE per group instead of once per negative:
 // (3+eta) row reads per group instead of 3(1+eta).  k-reductions are __shfl_xor butterflies.
-// HBM-bound by design: algorithmic bytes per group = 12 + (3+eta)*4*k_int + 4*(1+eta)  (DESIGN.md).
+//
+// Backward/fused kernel: for the pair-local losses (pairwise, nll, absolute_margin) dL/dneg_j depends only
+// on (pos_i, neg_j), so score -> loss -> gradient happens in ONE pass over the rows.  A gradient row whose
+// destination is hit exactly once in the batch (the common case for uniform negatives) is applied to the
+// table IN PLACE from the registers that already hold the row: 1 read + 1 write instead of
+// read + contribution write + contribution read + RMW.  Race-free: a singleton destination is, by
+// definition, read by no other group of this batch.  All other rows go to the contribution buffer and
+// are summed in a fixed order by emg_apply_grouped (no float atomics anywhere).
+// HBM-bound by design: algorithmic bytes per group in DESIGN.md §4.
 #include "emg_common.hpp"
 
 namespace emg {
@@ -90,13 +98,10 @@ __device__ __forceinline__ float finalize_score(float sum, float scale, int flag
     return sum;
 }
 
-// inner coefficient from g = dL/dscore and the k-reduced sum
+// inner coefficient from g = dL/dscore and the k-reduced sum (TransE-L2: nrm = sqrt(sum of squares))
 template <int MODEL>
-__device__ __forceinline__ float inner_coef(float g, float sum, float scale) {
-    if constexpr (MODEL == EMG_TRANSE_L2) {
-        const float nrm = sqrtf(sum);
-        return nrm > 0.f ? g / nrm : 0.f;
-    }
+__device__ __forceinline__ float inner_coef(float g, float nrm, float scale) {
+    if constexpr (MODEL == EMG_TRANSE_L2) return nrm > 0.f ? g / nrm : 0.f;
     if constexpr (MODEL == EMG_HOLE) return g * scale;
     return g;
 }
@@ -131,16 +136,29 @@ __device__ __forceinline__ void accum_grads(const Row<MODEL, W, NV>& a, const Ro
     }
 }
 
+// A value that is identical in all lanes of a group.  When the group IS the wave (LPG == 64) tell the
+// compiler so (readfirstlane -> SGPR): branches on it become scalar branches instead of being if-converted
+// into both-sides-plus-select, which doubles the live registers of the role-dependent code.
+template <int LPG>
+__device__ __forceinline__ int uniform_if_wave(int v) {
+    if constexpr (LPG == 64) return __builtin_amdgcn_readfirstlane(v);
+    return v;
+}
+
 struct GroupParams {
     const float* ent; int64_t n_ent; int64_t ld_ent;
     const float* rel; int64_t n_rel; int64_t ld_rel;
     int32_t k_int; int32_t khalf; int32_t nchunks; float scale;
     const int32_t* pos; int64_t B; int32_t eta; const int32_t* codes; int32_t flags;
     float* scores_pos; float* scores_neg;
-    // backward only
-    const float* g_pos; const float* g_neg;
+    // backward / fused
+    const float* g_pos; const float* g_neg;              // external dL/dscore (fused_loss < 0)
+    const float* bw_scores_pos; const float* bw_scores_neg;  // global final scores (TransE-L2 on a k-slice)
+    int32_t fused_loss; float margin; double* loss_accum;
     float* contrib_ent; float* contrib_rel; int64_t ldc;
-    int32_t* dest_ent; int32_t* dest_rel;
+    const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
+    float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
+    OptParams opt;
 };
 
 constexpr int kThreads = 256;
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupPara
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int j = min(j0 + u, P.eta - 1);
-            code[u] = P.codes[(int64_t)j * P.B + g];
+            code[u] = uniform_if_wave<LPG>(P.codes[(int64_t)j * P.B + g]);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -185,13 +203,8 @@ __global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupPara
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const bool keep_s = code[u] < 0;  // bit 31
-            R a, b;
-#pragma unroll
-            for (int e = 0; e < R::N; ++e) {
-                a.x[e] = keep_s ? rs.x[e] : re[u].x[e];
-                b.x[e] = keep_s ? re[u].x[e] : ro.x[e];
-            }
-            part[u] = partial_score<MODEL, W, NV>(a, rp, b);
+            if (keep_s) part[u] = partial_score<MODEL, W, NV>(rs, rp, re[u]);
+            else part[u] = partial_score<MODEL, W, NV>(re[u], rp, ro);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -204,15 +217,74 @@ __global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupPara
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward: gradient rows per group (no atomics; summed per destination by emg_apply_rows)
+// in-place optimizer update of one table row from registers (singleton destinations)
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, int W, int NV, int LPG>
+//   IP == 1: plain SGD (no state; stays lean)   IP == 2: any optimizer (state RMW; elements are fenced with
+//   sched_barrier so the compiler does not interleave eight sqrt/div expansions and blow up the VGPR budget)
+template <int MODEL, int W, int NV, int LPG, int IP>
+__device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row, const Row<MODEL, W, NV>& cur,
+                                               const Row<MODEL, W, NV>& grad, int lg) {
+    // chunk-wise (one 16-byte chunk live at a time) so the singleton path costs almost no extra VGPRs:
+    // occupancy is what keeps enough row loads in flight for this HBM-bound kernel
+    constexpr int E = W * NV;
+    constexpr int HALVES = is_complex<MODEL>::value ? 2 : 1;
+    float* wrow = P.ent_rw + row * P.ld_ent;
+    float* s0row = (IP == 2 && P.ent_state0) ? P.ent_state0 + row * P.ld_ent : nullptr;
+    float* s1row = (IP == 2 && P.ent_state1) ? P.ent_state1 + row * P.ld_ent : nullptr;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int c = lg + it * LPG;
+            if (c < P.nchunks) {
+                const int off = h * P.khalf + c * W;
+                float wv[W], s0v[W], s1v[W];
+                if constexpr (W == 4) {
+                    if (s0row) { const float4 t = *reinterpret_cast<const float4*>(s0row + off); s0v[0] = t.x; s0v[1] = t.y; s0v[2] = t.z; s0v[3] = t.w; }
+                    if (s1row) { const float4 t = *reinterpret_cast<const float4*>(s1row + off); s1v[0] = t.x; s1v[1] = t.y; s1v[2] = t.z; s1v[3] = t.w; }
+                } else {
+                    if (s0row) s0v[0] = s0row[off];
+                    if (s1row) s1v[0] = s1row[off];
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    wv[w] = cur.x[h * E + it * W + w];
+                    if constexpr (IP == 1) {
+                        wv[w] = opt_sgd_elem(P.opt, wv[w], grad.x[h * E + it * W + w]);
+                    } else {
+                        opt_update_elem(P.opt, wv[w], grad.x[h * E + it * W + w], &s0v[w], &s1v[w]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (W == 4) {
+                    *reinterpret_cast<float4*>(wrow + off) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                    if (s0row) *reinterpret_cast<float4*>(s0row + off) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
+                    if (s1row) *reinterpret_cast<float4*>(s1row + off) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
+                } else {
+                    wrow[off] = wv[0];
+                    if (s0row) s0row[off] = s0v[0];
+                    if (s1row) s1row[off] = s1v[0];
+                }
+            }
+        }
+    }
+    if (P.tag_ent && lg == 0) P.tag_ent[row] = P.step;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward / fused: gradient rows per group (no atomics; summed per destination by emg_apply_grouped)
+//   FUSED = true : scores, pair-local loss and dL/dscore are computed here (P.fused_loss)
+//   FUSED = false: dL/dscore comes from P.g_pos / P.g_neg
+// ---------------------------------------------------------------------------------------------
+//   IP    = 0: all rows to the contribution buffer; 1/2: singleton destinations updated in place (see above)
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
 __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupParams P) {
     using R = Row<MODEL, W, NV>;
     const int lg = threadIdx.x % LPG;
     int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPG;
     const bool active = g < P.B;
     if (!active) g = P.B - 1;
+    const int64_t B = P.B;
 
     const int32_t s = P.pos[3 * g + 0], p = P.pos[3 * g + 1], o = P.pos[3 * g + 2];
     R rs, rp, ro, gs, gp, go;
@@ -222,14 +294,25 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
 #pragma unroll
     for (int e = 0; e < R::N; ++e) gs.x[e] = gp.x[e] = go.x[e] = 0.f;
 
-    {
-        float sum = 0.f;
-        if constexpr (MODEL == EMG_TRANSE_L2) sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
-        const float gi = inner_coef<MODEL>(P.g_pos[g], sum, P.scale);
-        accum_grads<MODEL, W, NV>(rs, rp, ro, gi, gs, gp, go);
+    // positive: score (if needed) now, its gradient after the negatives (dL/dpos sums over them)
+    float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
+    if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
+        if (MODEL == EMG_TRANSE_L2 && P.bw_scores_pos) {
+            pos_nrm = -P.bw_scores_pos[g];
+        } else {
+            const float sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
+            pos_score = finalize_score<MODEL>(sum, P.scale, 0);
+            if constexpr (MODEL == EMG_TRANSE_L2) pos_nrm = sqrtf(sum);
+        }
+    }
+    PosTerms pos_terms{0.f, 0.f};
+    if constexpr (FUSED) {
+        if (P.scores_pos && active && lg == 0) P.scores_pos[g] = pos_score;
+        pos_terms = local_loss_pos(P.fused_loss, pos_score);
+    } else {
+        gpos = P.g_pos[g];
     }
 
-    const int64_t B = P.B;
     constexpr int U = 2;
     for (int j0 = 0; j0 < P.eta; j0 += U) {
         int32_t code[U];
@@ -238,8 +321,8 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = min(j0 + u, P.eta - 1);
-            code[u] = P.codes[(int64_t)j * B + g];
-            gj[u] = P.g_neg[(int64_t)j * B + g];
+            code[u] = uniform_if_wave<LPG>(P.codes[(int64_t)j * B + g]);
+            if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)j * B + g];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -251,42 +334,77 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
             const int j = j0 + u;
             if (j >= P.eta) break;
             const bool keep_s = code[u] < 0;
-            R a, b, ta, tb;
-#pragma unroll
-            for (int e = 0; e < R::N; ++e) {
-                a.x[e] = keep_s ? rs.x[e] : re[u].x[e];
-                b.x[e] = keep_s ? re[u].x[e] : ro.x[e];
-                ta.x[e] = 0.f;
-                tb.x[e] = 0.f;
+            const int32_t repl = code[u] & 0x7fffffff;
+            // roles by branch, not by select (no a/b/ta/tb copies: VGPRs are occupancy here).  All lanes of a
+            // group share keep_s, so the __shfl_xor partners inside a branch are always active together.
+            float nrm = 0.f;
+            if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
+                if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
+                    nrm = -P.bw_scores_neg[(int64_t)j * B + g];
+                } else {
+                    float part;
+                    if (keep_s) part = partial_score<MODEL, W, NV>(rs, rp, re[u]);
+                    else part = partial_score<MODEL, W, NV>(re[u], rp, ro);
+                    const float sum = group_sum<LPG>(part);
+                    if constexpr (MODEL == EMG_TRANSE_L2) nrm = sqrtf(sum);
+                    if constexpr (FUSED) {
+                        const float neg = finalize_score<MODEL>(sum, P.scale, 0);
+                        gj[u] = local_loss_neg(P.fused_loss, pos_score, pos_terms, neg, P.margin, loss_acc, gpos);
+                        if (P.scores_neg && active && lg == 0) P.scores_neg[(int64_t)j * B + g] = neg;
+                    }
+                }
             }
-            float sum = 0.f;
-            if constexpr (MODEL == EMG_TRANSE_L2) sum = group_sum<LPG>(partial_score<MODEL, W, NV>(a, rp, b));
-            const float gi = inner_coef<MODEL>(gj[u], sum, P.scale);
-            accum_grads<MODEL, W, NV>(a, rp, b, gi, ta, gp, tb);
+            const float gi = inner_coef<MODEL>(gj[u], nrm, P.scale);
             R row;
 #pragma unroll
-            for (int e = 0; e < R::N; ++e) {
-                gs.x[e] += keep_s ? ta.x[e] : 0.f;
-                go.x[e] += keep_s ? 0.f : tb.x[e];
-                row.x[e] = keep_s ? tb.x[e] : ta.x[e];
-            }
+            for (int e = 0; e < R::N; ++e) row.x[e] = 0.f;
+            if (keep_s) accum_grads<MODEL, W, NV>(rs, rp, re[u], gi, gs, gp, row);   // object replaced
+            else accum_grads<MODEL, W, NV>(re[u], rp, ro, gi, row, gp, go);          // subject replaced
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
-                store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
-                if (lg == 0) P.dest_ent[slot] = code[u] & 0x7fffffff;
+                if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[slot])) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
+                else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }
         }
     }
+    {
+        const float gi = inner_coef<MODEL>(gpos, pos_nrm, P.scale);
+        accum_grads<MODEL, W, NV>(rs, rp, ro, gi, gs, gp, go);
+    }
     if (active) {
-        store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[g])) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
+        else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
+        if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[B + g])) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
+        else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (lg == 0) {
-            P.dest_ent[g] = s;
-            P.dest_ent[B + g] = o;
-            P.dest_rel[g] = p;
+    }
+    if constexpr (FUSED) {
+        // loss: one value per group (lane 0), block-reduced in double, one atomic per block
+        double v = (active && lg == 0) ? (double)loss_acc : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        __shared__ double part[kThreads / 64];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) t += part[w];
+            if (t != 0.0) atomicAdd(P.loss_accum, t);
         }
     }
+}
+
+// destination ids of the contribution rows of a batch (depends only on the batch ids and codes)
+__global__ void build_dest_kernel(const int32_t* __restrict__ pos, int64_t B, int eta, const int32_t* __restrict__ codes,
+                                  int32_t* __restrict__ dest_ent, int32_t* __restrict__ dest_rel) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B) {
+        dest_ent[t] = pos[3 * t + 0];
+        dest_ent[B + t] = pos[3 * t + 2];
+        dest_rel[t] = pos[3 * t + 1];
+    }
+    if (t < (int64_t)eta * B) dest_ent[2 * B + t] = codes[t] & 0x7fffffff;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void train_forward_generic_kernel(const G
 // ---------------------------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------------------------
-enum class Pass { Forward, Backward };
+enum class Pass { Forward, Backward, Fused };
 
 template <int MODEL, int W, int NV, int LPG>
 static void launch_group(Pass pass, const GroupParams& P, hipStream_t st) {
@@ -344,8 +462,14 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st) {
     const unsigned grid = (unsigned)cdiv(P.B, groups_per_block);
     if (pass == Pass::Forward)
         hipLaunchKernelGGL((train_forward_kernel<MODEL, W, NV, LPG>), dim3(grid), dim3(kThreads), 0, st, P);
-    else
-        hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG>), dim3(grid), dim3(kThreads), 0, st, P);
+    else {
+        const int ip = !P.single_ent ? 0 : (P.opt.opt == EMG_OPT_SGD ? 1 : 2);
+        const bool fused = pass == Pass::Fused;
+#define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
+        if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else EMG_BW(true, 2); }
+        else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
+#undef EMG_BW
+    }
 }
 
 // returns false when no register-tiled variant fits
@@ -383,7 +507,11 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) 
     P.khalf = cplx ? P.k_int / 2 : 0;
     const int n = cplx ? P.khalf : P.k_int;
     bool vec = (n % 4 == 0) && (P.ld_ent % 4 == 0) && (P.ld_rel % 4 == 0) && aligned16(P.ent) && aligned16(P.rel);
-    if (pass == Pass::Backward) vec = vec && (P.ldc % 4 == 0) && aligned16(P.contrib_ent) && aligned16(P.contrib_rel);
+    if (pass != Pass::Forward) {
+        vec = vec && (P.ldc % 4 == 0) && aligned16(P.contrib_ent) && aligned16(P.contrib_rel);
+        if (P.single_ent)
+            vec = vec && (!P.ent_state0 || aligned16(P.ent_state0)) && (!P.ent_state1 || aligned16(P.ent_state1));
+    }
     bool ok = false;
     switch (model) {
         case EMG_TRANSE_L1: ok = dispatch_model<EMG_TRANSE_L1>(pass, P, vec, st); break;
@@ -393,8 +521,8 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) 
         case EMG_HOLE: ok = dispatch_model<EMG_HOLE>(pass, P, vec, st); break;
     }
     if (!ok) {
-        if (pass == Pass::Backward)
-            return fail(EMG_ENOSUP, "train_backward: k_int=%d exceeds the register-tiled limit", P.k_int);
+        if (pass != Pass::Forward)
+            return fail(EMG_ENOSUP, "train backward/fused: k_int=%d exceeds the register-tiled limit", P.k_int);
         const unsigned grid = (unsigned)cdiv(P.B, kThreads / 64);
         switch (model) {
             case EMG_TRANSE_L1: hipLaunchKernelGGL(train_forward_generic_kernel<EMG_TRANSE_L1>, dim3(grid), dim3(kThreads), 0, st, P); break;
@@ -440,22 +568,68 @@ extern "C" int emg_score_triples(int model, const float* ent, int64_t n_ent, int
                              out, nullptr, stream);
 }
 
+extern "C" int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes, int32_t* dest_ent,
+                              int32_t* dest_rel, void* stream) {
+    if (B <= 0) return EMG_OK;
+    EMG_REQUIRE(pos && dest_ent && dest_rel && (eta == 0 || codes), "emg_build_dest: null pointer");
+    const int64_t n = B * (int64_t)(eta > 1 ? eta : 1);
+    hipLaunchKernelGGL(build_dest_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pos, B,
+                       (int)eta, codes, dest_ent, dest_rel);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
+    EMG_REQUIRE(a, "emg_train_backward_ex: null args");
+    if (a->B == 0) return EMG_OK;
+    EMG_REQUIRE(a->ent && a->rel && a->pos && a->contrib_ent && a->contrib_rel, "emg_train_backward_ex: null pointer");
+    EMG_REQUIRE(a->eta == 0 || a->codes, "emg_train_backward_ex: eta>0 needs codes");
+    EMG_REQUIRE(a->ldc >= a->k_int, "emg_train_backward_ex: ldc < k_int");
+    const bool fused = a->fused_loss >= 0;
+    if (fused) {
+        EMG_REQUIRE(a->fused_loss == EMG_LOSS_PAIRWISE || a->fused_loss == EMG_LOSS_NLL ||
+                        a->fused_loss == EMG_LOSS_ABSOLUTE_MARGIN,
+                    "emg_train_backward_ex: loss %d is not pair-local, use emg_train_forward + emg_loss", a->fused_loss);
+        EMG_REQUIRE(a->loss_accum, "emg_train_backward_ex: fused loss needs loss_accum");
+        EMG_REQUIRE(!a->bw_scores_pos && !a->bw_scores_neg, "emg_train_backward_ex: fused loss cannot take bw_scores");
+    } else {
+        EMG_REQUIRE(a->g_pos && (a->eta == 0 || a->g_neg), "emg_train_backward_ex: external dL/dscore missing");
+    }
+    GroupParams P{};
+    P.ent = a->ent; P.n_ent = a->n_ent; P.ld_ent = a->ld_ent; P.rel = a->rel; P.n_rel = a->n_rel; P.ld_rel = a->ld_rel;
+    P.k_int = a->k_int; P.scale = a->scale; P.pos = a->pos; P.B = a->B; P.eta = a->eta; P.codes = a->codes;
+    P.g_pos = a->g_pos; P.g_neg = a->g_neg; P.bw_scores_pos = a->bw_scores_pos; P.bw_scores_neg = a->bw_scores_neg;
+    P.fused_loss = a->fused_loss; P.margin = a->margin; P.loss_accum = a->loss_accum;
+    P.scores_pos = a->scores_pos_out; P.scores_neg = a->scores_neg_out;
+    P.contrib_ent = a->contrib_ent; P.contrib_rel = a->contrib_rel; P.ldc = a->ldc;
+    P.single_ent = a->single_ent;
+    if (a->single_ent) {
+        EMG_REQUIRE(a->opt >= EMG_OPT_SGD && a->opt <= EMG_OPT_ADAM_LAZY, "emg_train_backward_ex: unknown optimizer");
+        EMG_REQUIRE(!(a->opt == EMG_OPT_MOMENTUM || a->opt == EMG_OPT_ADAGRAD) || a->ent_state0,
+                    "emg_train_backward_ex: optimizer needs ent_state0");
+        EMG_REQUIRE(!(a->opt == EMG_OPT_ADAM || a->opt == EMG_OPT_ADAM_LAZY) || (a->ent_state0 && a->ent_state1),
+                    "emg_train_backward_ex: adam needs both state tables");
+        P.ent_rw = const_cast<float*>(a->ent);
+        P.ent_state0 = a->ent_state0; P.ent_state1 = a->ent_state1; P.tag_ent = a->tag_ent; P.step = a->step;
+        P.opt = make_opt_params(a->opt, a->hyper);
+    }
+    return run_group_pass(fused ? Pass::Fused : Pass::Backward, a->model, P, (hipStream_t)stream);
+}
+
 extern "C" int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel,
                                   int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale, const int32_t* pos,
                                   int64_t B, int32_t eta, const int32_t* codes, const float* g_pos,
                                   const float* g_neg, float* contrib_ent, float* contrib_rel, int64_t ldc,
                                   int32_t* dest_ent, int32_t* dest_rel, void* stream) {
     if (B == 0) return EMG_OK;
-    EMG_REQUIRE(ent && rel && pos && g_pos && contrib_ent && contrib_rel && dest_ent && dest_rel,
-                "emg_train_backward: null pointer");
-    EMG_REQUIRE(eta == 0 || (codes && g_neg), "emg_train_backward: eta>0 needs codes and g_neg");
-    EMG_REQUIRE(ldc >= k_int, "emg_train_backward: ldc < k_int");
-    GroupParams P{};
-    P.ent = ent; P.n_ent = n_ent; P.ld_ent = ld_ent; P.rel = rel; P.n_rel = n_rel; P.ld_rel = ld_rel;
-    P.k_int = k_int; P.scale = scale; P.pos = pos; P.B = B; P.eta = eta; P.codes = codes;
-    P.g_pos = g_pos; P.g_neg = g_neg; P.contrib_ent = contrib_ent; P.contrib_rel = contrib_rel; P.ldc = ldc;
-    P.dest_ent = dest_ent; P.dest_rel = dest_rel;
-    return run_group_pass(Pass::Backward, model, P, (hipStream_t)stream);
+    EMG_REQUIRE(dest_ent && dest_rel, "emg_train_backward: null pointer");
+    emg_backward_args a{};
+    a.model = model; a.ent = ent; a.n_ent = n_ent; a.ld_ent = ld_ent; a.rel = rel; a.n_rel = n_rel; a.ld_rel = ld_rel;
+    a.k_int = k_int; a.scale = scale; a.pos = pos; a.B = B; a.eta = eta; a.codes = codes; a.fused_loss = -1;
+    a.g_pos = g_pos; a.g_neg = g_neg; a.contrib_ent = contrib_ent; a.contrib_rel = contrib_rel; a.ldc = ldc;
+    int rc = emg_train_backward_ex(&a, stream);
+    if (rc != EMG_OK) return rc;
+    return emg_build_dest(pos, B, eta, codes, dest_ent, dest_rel, stream);
 }
 
 extern "C" int emg_finalize_scores(int model, float scale, float* scores, int64_t n, void* stream) {

@@ -41,15 +41,9 @@ __global__ void corrupt_expand_kernel(const int32_t* __restrict__ pos, int64_t B
 // ---------------------------------------------------------------------------------------------
 // K5 losses.  One thread per positive i; negatives of i are rows (sd*eta + j)*B + i.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float clip75(float v) { return fminf(fmaxf(v, -75.0f), 75.0f); }  // losses/utils.py:44-53
-__device__ __forceinline__ float in75(float v) { return (v >= -75.0f && v <= 75.0f) ? 1.f : 0.f; }
-__device__ __forceinline__ float log1pexp_naive(float x) { return logf(1.0f + expf(x)); }  // nll.py:59 literal form
 __device__ __forceinline__ float log_sigmoid(float x) {  // tf.math.log_sigmoid = -softplus(-x)
     return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-// tf.maximum(v, 0) propagates NaN (fmaxf would swallow it and hide a diverged model from the NaN check)
-__device__ __forceinline__ float relu_nan(float v) { return (v >= 0.f || v != v) ? v : 0.f; }
 
 template <int LOSS>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp, const float* __restrict__ sn,
@@ -64,32 +58,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ sp,
         for (int sd = 0; sd < n_sides; ++sd) {
             const float* snp = sn + (int64_t)sd * eta * B + i;
             float* gnp = g_neg + (int64_t)sd * eta * B + i;
-            if constexpr (LOSS == EMG_LOSS_PAIRWISE) {  // pairwise.py:69
-                for (int j = 0; j < eta; ++j) {
-                    const float v = margin - pos + snp[(int64_t)j * B];
-                    const float act = v >= 0.f ? 1.f : 0.f;  // TF MaximumGrad: x >= y takes the gradient
-                    loss += relu_nan(v);
-                    gnp[(int64_t)j * B] = act;
-                    gp -= act;
-                }
-            } else if constexpr (LOSS == EMG_LOSS_NLL) {  // nll.py:55-59, positives tiled eta times
-                const float pc = clip75(pos);
-                const float lp = log1pexp_naive(-pc);
-                const float gpp = -in75(pos) * sigmoidf(-pc);
-                for (int j = 0; j < eta; ++j) {
-                    const float nv = snp[(int64_t)j * B];
-                    const float nc = clip75(nv);
-                    loss += lp + log1pexp_naive(nc);
-                    gnp[(int64_t)j * B] = in75(nv) * sigmoidf(nc);
-                    gp += gpp;
-                }
-            } else if constexpr (LOSS == EMG_LOSS_ABSOLUTE_MARGIN) {  // absolute_margin.py:69
-                for (int j = 0; j < eta; ++j) {
-                    const float v = margin + snp[(int64_t)j * B];
-                    loss += relu_nan(v) - pos;
-                    gnp[(int64_t)j * B] = v >= 0.f ? 1.f : 0.f;
-                    gp -= 1.f;
-                }
+            if constexpr (LOSS == EMG_LOSS_PAIRWISE || LOSS == EMG_LOSS_NLL || LOSS == EMG_LOSS_ABSOLUTE_MARGIN) {
+                const PosTerms pt = local_loss_pos(LOSS, pos);
+                for (int j = 0; j < eta; ++j)
+                    gnp[(int64_t)j * B] = local_loss_neg(LOSS, pos, pt, snp[(int64_t)j * B], margin, loss, gp);
             } else if constexpr (LOSS == EMG_LOSS_SELF_ADVERSARIAL) {  // self_adversarial.py:98-110
                 loss += -log_sigmoid(margin + pos);
                 gp += -sigmoidf(-(margin + pos));

@@ -136,6 +136,74 @@ def train_backward(model_id, ent, rel, k_int, scale, pos, eta, codes, g_pos, g_n
                                    _chk_vec(dest_rel, torch.int32, "dest_rel", B), _stream()), "emg_train_backward")
 
 
+def build_dest(pos, eta, codes, dest_ent, dest_rel):
+    lib = L.load()
+    B = pos.shape[0]
+    L.check(lib.emg_build_dest(_chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
+                               _chk_vec(codes, torch.int32, "codes", B * eta) if eta else None,
+                               _chk_vec(dest_ent, torch.int32, "dest_ent", (2 + eta) * B),
+                               _chk_vec(dest_rel, torch.int32, "dest_rel", B), _stream()), "emg_build_dest")
+
+
+def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
+                      margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
+                      scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
+                      ent_state0=None, ent_state1=None, tag_ent=None):
+    """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
+    singleton updates (single_ent flags from group_dest)."""
+    lib = L.load()
+    B = pos.shape[0]
+    a = L.BackwardArgs()
+    a.model, a.k_int, a.scale, a.eta = model_id, k_int, scale, eta
+    a.ent, a.n_ent, a.ld_ent = _chk_table(ent, "ent")
+    a.rel, a.n_rel, a.ld_rel = _chk_table(rel, "rel")
+    a.pos, a.B = _chk_vec(pos, torch.int32, "pos", 3 * B), B
+    a.codes = _chk_vec(codes, torch.int32, "codes", B * eta) if eta else None
+    a.fused_loss, a.margin = fused_loss, margin
+    a.loss_accum = _chk_vec(loss_accum, torch.float64, "loss_accum", 1) if loss_accum is not None else None
+    a.g_pos = _chk_vec(g_pos, torch.float32, "g_pos", B)
+    a.g_neg = _chk_vec(g_neg, torch.float32, "g_neg", B * eta) if eta else None
+    a.bw_scores_pos = _chk_vec(bw_scores_pos, torch.float32, "bw_scores_pos", B)
+    a.bw_scores_neg = _chk_vec(bw_scores_neg, torch.float32, "bw_scores_neg", B * eta if bw_scores_neg is not None else None)
+    a.scores_pos_out = _chk_vec(scores_pos_out, torch.float32, "scores_pos_out", B)
+    a.scores_neg_out = _chk_vec(scores_neg_out, torch.float32, "scores_neg_out", B * eta if scores_neg_out is not None else None)
+    pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
+    pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
+    if ldc != ldc2 or nce < (2 + eta) * B or ncr < B:
+        raise ValueError("contribution buffers have the wrong shape")
+    a.contrib_ent, a.contrib_rel, a.ldc = pce, pcr, ldc
+    a.single_ent = _chk_vec(single_ent, torch.uint8, "single_ent", (2 + eta) * B if single_ent is not None else None)
+    a.opt, a.step = opt_id, step
+    if hyper is not None:
+        for i, v in enumerate(hyper):
+            a.hyper[i] = float(v)
+    if ent_state0 is not None:
+        a.ent_state0 = _chk_table(ent_state0, "ent_state0")[0]
+    if ent_state1 is not None:
+        a.ent_state1 = _chk_table(ent_state1, "ent_state1")[0]
+    a.tag_ent = _chk_vec(tag_ent, torch.int32, "tag_ent")
+    L.check(lib.emg_train_backward_ex(C.byref(a), _stream()), "emg_train_backward_ex")
+
+
+def group_dest(dest, n, n_rows, workspace, single_flags=None):
+    lib = L.load()
+    L.check(lib.emg_group_dest(_chk_vec(dest, torch.int32, "dest"), n, n_rows, workspace.data_ptr(),
+                               workspace.numel() * workspace.element_size(),
+                               _chk_vec(single_flags, torch.uint8, "single_flags"), _stream()), "emg_group_dest")
+
+
+def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace):
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
+    p1 = _chk_table(state1, "state1")[0] if state1 is not None else None
+    pc, _, ldc = _chk_table(contrib, "contrib")
+    h = (C.c_float * 6)(*[float(x) for x in hyper])
+    L.check(lib.emg_apply_grouped(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc,
+                                  ldc, n_contrib, int(skip_single), h, workspace.data_ptr(),
+                                  workspace.numel() * workspace.element_size(), _stream()), "emg_apply_grouped")
+
+
 def apply_workspace_bytes(n_contrib, n_rows):
     n = L.load().emg_apply_workspace_bytes(n_contrib, n_rows)
     if n < 0:

@@ -321,17 +321,25 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         except ImportError:  # pragma: no cover
             epochs_iter = range(1, self.epochs + 1)
         self._trainer = tr
+        def batch_args(epoch, batch):
+            """(start, B, epoch, batch, n_choices, entities_list) of a batch, or None past the end"""
+            if batch > self.batches_count:
+                epoch, batch = epoch + 1, 1
+            if epoch > self.epochs:
+                return None
+            start = (batch - 1) * batch_size
+            B = max(0, min(batch_size, n - start))  # last batch may be short / empty (numpy_adapter.py:105-112)
+            if batch_lists is not None:
+                elist = batch_lists[batch - 1]
+                return (start, B, epoch, batch, elist.numel() if elist is not None else 0, elist)
+            return (start, B, epoch, batch, n_choices, fixed_list)
+
         for epoch in epochs_iter:
             for batch in range(1, self.batches_count + 1):
-                start = (batch - 1) * batch_size
-                B = max(0, min(batch_size, n - start))  # last batch may be short / empty (numpy_adapter.py:105-112)
+                start, B, _, _, nc, el = batch_args(epoch, batch)
                 if B == 0:
                     continue
-                if batch_lists is not None:
-                    elist = batch_lists[batch - 1]
-                    tr.step(start, B, epoch, batch, n_choices=elist.numel(), entities_list=elist)
-                else:
-                    tr.step(start, B, epoch, batch, n_choices=n_choices, entities_list=fixed_list)
+                tr.step(start, B, epoch, batch, n_choices=nc, entities_list=el, prefetch=batch_args(epoch, batch + 1))
             loss_epoch = tr.read_loss()
             if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)
                 msg = "Loss is {}. Please change the hyperparameters.".format(loss_epoch)

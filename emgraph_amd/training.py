@@ -96,7 +96,8 @@ class Trainer:
 
     def __init__(self, model_id, k_int, scale, ent_init, rel_init, eta, loss="nll", loss_params=None,
                  optimizer="adam", optimizer_params=None, corrupt_sides=("s,o",), batches_count=1, seed=0,
-                 regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda"):
+                 regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda", fused=True,
+                 inplace=True, pipeline=True):
         D.require_gpu()
         self.device = torch.device(device)
         self.model_id, self.k_int, self.scale, self.eta = model_id, int(k_int), float(scale), int(eta)
@@ -160,6 +161,16 @@ class Trainer:
         self.X = None
         self._cap = 0
         self.stage_events = None  # filled by enable_stage_timing()
+        # execution plan
+        #  fused   : score -> pair-local loss -> gradient in ONE kernel (pairwise / nll / absolute_margin)
+        #  inplace : rows whose destination is hit once in the batch are updated from registers
+        #            (needs the pre-update tables for nothing else: off when a regulariser is set)
+        #  pipeline: codes + destination grouping of batch t+1 run on a side stream while batch t computes
+        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin")
+        self.inplace = inplace and self.reg is None
+        self.pipeline = pipeline
+        self.side = torch.cuda.Stream(device=self.device) if pipeline else None
+        self.slots = []
 
     # ---- data ----
     def set_training_set(self, X_idx, batch_size):
@@ -171,22 +182,36 @@ class Trainer:
     def _alloc_scratch(self, B):
         if B <= self._cap:
             return
+        torch.cuda.synchronize()
         dev, k, et = self.device, self.k_int, self.eta_total
         ldc = _padded_ld(k)
-        self.codes = torch.empty(B * et, dtype=torch.int32, device=dev)
+        xe = self.n_ent if self.reg_rows else 0
+        xr = self.n_rel if self.reg_rows else 0
+        n_ce, n_cr = (2 + et) * B + xe, B + xr
         self.scores_pos = torch.empty(B, dtype=torch.float32, device=dev)
         self.scores_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
         self.g_pos = torch.empty(B, dtype=torch.float32, device=dev)
         self.g_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
-        xe = self.n_ent if self.reg_rows else 0
-        xr = self.n_rel if self.reg_rows else 0
-        self.contrib_ent = torch.empty(((2 + et) * B + xe, ldc), dtype=torch.float32, device=dev)[:, :k]
-        self.contrib_rel = torch.empty((B + xr, ldc), dtype=torch.float32, device=dev)[:, :k]
-        self.dest_ent = torch.empty((2 + et) * B + xe, dtype=torch.int32, device=dev)
-        self.dest_rel = torch.empty(B + xr, dtype=torch.int32, device=dev)
-        nb = max(D.apply_workspace_bytes((2 + et) * B + xe, self.n_ent), D.apply_workspace_bytes(B + xr, self.n_rel))
-        self.workspace = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.contrib_ent = torch.empty((n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
+        self.contrib_rel = torch.empty((n_cr, ldc), dtype=torch.float32, device=dev)[:, :k]
+        self.slots = []
+        for _ in range(2 if self.pipeline else 1):
+            sl = {
+                "codes": torch.empty(B * et, dtype=torch.int32, device=dev),
+                "dest_ent": torch.empty(n_ce, dtype=torch.int32, device=dev),
+                "dest_rel": torch.empty(n_cr, dtype=torch.int32, device=dev),
+                "single": torch.empty(n_ce, dtype=torch.uint8, device=dev),
+                "ws_ent": torch.empty(D.apply_workspace_bytes(n_ce, self.n_ent), dtype=torch.uint8, device=dev),
+                "ws_rel": torch.empty(D.apply_workspace_bytes(n_cr, self.n_rel), dtype=torch.uint8, device=dev),
+                "ready": torch.cuda.Event(), "done": torch.cuda.Event(), "key": None,
+            }
+            if self.reg_rows:  # LP gradient rows come FIRST ([0, n_rows)); their destinations never change
+                sl["dest_ent"][:xe] = torch.arange(self.n_ent, dtype=torch.int32, device=dev)
+                sl["dest_rel"][:xr] = torch.arange(self.n_rel, dtype=torch.int32, device=dev)
+            self.slots.append(sl)
         self._cap = B
+        self._xe, self._xr = xe, xr
+        torch.cuda.synchronize()
 
     # ---- optional per-stage HIP-event timing (bench.py) ----
     def enable_stage_timing(self):
@@ -212,40 +237,87 @@ class Trainer:
         lr_t = lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         return (lr, self.momentum, ADAM_BETA1, ADAM_BETA2, KERAS_EPS, lr_t)
 
-    def step(self, start, B, epoch=1, batch=1, n_choices=None, entities_list=None, inj_mask=None, inj_repl=None):
-        """Train on resident triples [start, start+B).  Draw counter is a pure function of
-        (epoch, batch, side) so a refit with the same seed reproduces the same negatives."""
+    def _prepare(self, sl, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl):
+        """Everything about a batch that does not depend on the tables: corruption codes (Philox, draw counter
+        a pure function of (epoch, batch, side) so a refit reproduces the same negatives), destination ids of
+        the gradient rows, their stable grouping and the singleton flags."""
+        et, eta = self.eta_total, self.eta
+        pos = self.X[start:start + B]
+        n_choices = self.n_ent if n_choices is None else int(n_choices)
+        codes = sl["codes"][:B * et]
+
+        def run():
+            for sd, side in enumerate(self.sides):
+                counter = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides + sd
+                cs = slice(sd * eta * B, (sd + 1) * eta * B)
+                D.corrupt_codes(B, eta, side, n_choices, self.device, entities_list=entities_list, seed=self.seed,
+                                counter=counter, inj_mask=None if inj_mask is None else inj_mask[cs],
+                                inj_repl=None if inj_repl is None else inj_repl[cs], out=codes[cs])
+            n_ce, xe, xr = (2 + et) * B, self._xe, self._xr
+            D.build_dest(pos, et, codes, sl["dest_ent"][xe:xe + n_ce], sl["dest_rel"][xr:xr + B])
+            D.group_dest(sl["dest_ent"][:xe + n_ce], xe + n_ce, self.n_ent, sl["ws_ent"],
+                         sl["single"][:n_ce] if self.inplace else None)
+            D.group_dest(sl["dest_rel"][:xr + B], xr + B, self.n_rel, sl["ws_rel"], None)
+
+        if self.pipeline:
+            self.side.wait_event(sl["done"])  # the compute that last used this slot has finished
+            with torch.cuda.stream(self.side):
+                self._timed("prepare", run)
+                sl["ready"].record(self.side)
+        else:
+            self._timed("prepare", run)
+        sl["key"] = (start, B, epoch, batch)
+
+    def step(self, start, B, epoch=1, batch=1, n_choices=None, entities_list=None, inj_mask=None, inj_repl=None,
+             prefetch=None):
+        """Train on resident triples [start, start+B).  ``prefetch`` = (start, B, epoch, batch[, n_choices,
+        entities_list]) of the NEXT batch lets its preparation overlap this batch's compute."""
         if B <= 0:
             return
         self._alloc_scratch(B)
         self.step_count += 1
+        key = (start, B, epoch, batch)
+        sl = next((s for s in self.slots if s["key"] == key), None)
+        if sl is None:
+            sl = self.slots[0] if not self.pipeline else min(self.slots, key=lambda s: s["key"] is not None)
+            self._prepare(sl, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl)
+        if self.pipeline and prefetch is not None and prefetch[1] > 0:
+            other = next(s for s in self.slots if s is not sl)
+            self._prepare(other, prefetch[0], prefetch[1], prefetch[2], prefetch[3],
+                          prefetch[4] if len(prefetch) > 4 else n_choices,
+                          prefetch[5] if len(prefetch) > 5 else entities_list, None, None)
+        if self.pipeline:
+            torch.cuda.current_stream().wait_event(sl["ready"])
+        self._compute(sl, start, B, epoch, batch)
+        if self.pipeline:
+            sl["done"].record(torch.cuda.current_stream())
+        sl["key"] = None
+
+    def _compute(self, sl, start, B, epoch, batch):
         pos = self.X[start:start + B]
         et, eta = self.eta_total, self.eta
-        n_choices = self.n_ent if n_choices is None else int(n_choices)
-        codes = self.codes[:B * et]
-
-        def gen():
-            for sd, side in enumerate(self.sides):
-                counter = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides + sd
-                sl = slice(sd * eta * B, (sd + 1) * eta * B)
-                D.corrupt_codes(B, eta, side, n_choices, self.device, entities_list=entities_list, seed=self.seed,
-                                counter=counter, inj_mask=None if inj_mask is None else inj_mask[sl],
-                                inj_repl=None if inj_repl is None else inj_repl[sl], out=codes[sl])
-        self._timed("corrupt", gen)
-        sp, sn = self.scores_pos[:B], self.scores_neg[:B * et]
-        self._timed("forward", lambda: D.train_forward(self.model_id, self.ent, self.rel, self.k_int, self.scale, pos,
-                                                       et, codes, scores_pos=sp, scores_neg=sn))
-        gp, gn = self.g_pos[:B], self.g_neg[:B * et]
-        self._timed("loss", lambda: D.loss(self.loss_id, sp, sn, B, eta, self.n_sides, self.margin, self.alpha,
-                                           self.loss_accum, gp, gn))
-        n_ce = (2 + et) * B
-        ce, cr = self.contrib_ent[:n_ce], self.contrib_rel[:B]
-        de, dr = self.dest_ent[:n_ce], self.dest_rel[:B]
-        self._timed("backward", lambda: D.train_backward(self.model_id, self.ent, self.rel, self.k_int, self.scale, pos,
-                                                         et, codes, gp, gn, ce, cr, de, dr))
+        codes = sl["codes"][:B * et]
+        n_ce, n_cr, xe, xr = (2 + et) * B, B, self._xe, self._xr
+        ce, cr = self.contrib_ent[xe:xe + n_ce], self.contrib_rel[xr:xr + B]   # batch rows follow the LP rows
+        single = sl["single"][:n_ce] if self.inplace else None
         lr = self.schedule.lr(batch, epoch) if self.schedule is not None else self.lr
         hyper = self._hyper(lr)
-        n_cr = B
+        inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper,
+                          ent_state0=self.state_ent[0], ent_state1=self.state_ent[1], tag_ent=self.tag_ent)
+        if self.fused:
+            self._timed("fused", lambda: D.train_backward_ex(
+                self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr,
+                fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum, **inplace_kw))
+        else:
+            sp, sn = self.scores_pos[:B], self.scores_neg[:B * et]
+            self._timed("forward", lambda: D.train_forward(self.model_id, self.ent, self.rel, self.k_int, self.scale,
+                                                           pos, et, codes, scores_pos=sp, scores_neg=sn))
+            gp, gn = self.g_pos[:B], self.g_neg[:B * et]
+            self._timed("loss", lambda: D.loss(self.loss_id, sp, sn, B, eta, self.n_sides, self.margin, self.alpha,
+                                               self.loss_accum, gp, gn))
+            self._timed("backward", lambda: D.train_backward_ex(
+                self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
+                g_pos=gp, g_neg=gn, **inplace_kw))
         if self.reg is not None and not self.reg_rows:
             # dense LP term: value + SGD-style in-place step, both evaluated at the pre-update tables
             # (the sparse contributions above were also computed from the pre-update tables)
@@ -253,21 +325,21 @@ class Trainer:
                 D.lp_regularizer(self.ent, self.k_int, self.reg[0], self.reg[2], lr, self.loss_accum),
                 D.lp_regularizer(self.rel, self.k_int, self.reg[1], self.reg[2], lr, self.loss_accum)))
         elif self.reg_rows:
-            # LP gradient as one extra contribution row per table row (dense by definition, lp.py:107-113)
+            # LP gradient as one extra contribution row per table row (dense by definition, lp.py:107-113);
+            # their destinations (iota) are already part of the slot's grouping
             self._timed("regularizer", lambda: (
-                D.lp_grad_rows(self.ent, self.k_int, self.reg[0], self.reg[2], self.contrib_ent[n_ce:n_ce + self.n_ent],
-                               self.dest_ent[n_ce:n_ce + self.n_ent], self.loss_accum),
-                D.lp_grad_rows(self.rel, self.k_int, self.reg[1], self.reg[2], self.contrib_rel[B:B + self.n_rel],
-                               self.dest_rel[B:B + self.n_rel], self.loss_accum)))
-            ce, de = self.contrib_ent[:n_ce + self.n_ent], self.dest_ent[:n_ce + self.n_ent]
-            cr, dr = self.contrib_rel[:B + self.n_rel], self.dest_rel[:B + self.n_rel]
-            n_ce, n_cr = n_ce + self.n_ent, B + self.n_rel
-        self._timed("apply_ent", lambda: D.apply_rows(self.opt_id, self.ent, self.k_int, self.state_ent[0],
-                                                      self.state_ent[1], self.tag_ent, self.step_count, ce, de, n_ce,
-                                                      hyper, self.workspace))
-        self._timed("apply_rel", lambda: D.apply_rows(self.opt_id, self.rel, self.k_int, self.state_rel[0],
-                                                      self.state_rel[1], self.tag_rel, self.step_count, cr, dr, n_cr,
-                                                      hyper, self.workspace))
+                D.lp_grad_rows(self.ent, self.k_int, self.reg[0], self.reg[2], self.contrib_ent[:xe],
+                               sl["dest_ent"][:xe], self.loss_accum),
+                D.lp_grad_rows(self.rel, self.k_int, self.reg[1], self.reg[2], self.contrib_rel[:xr],
+                               sl["dest_rel"][:xr], self.loss_accum)))
+            ce, cr = self.contrib_ent[:xe + n_ce], self.contrib_rel[:xr + B]
+            n_ce, n_cr = xe + n_ce, xr + B
+        self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
+                                                         self.state_ent[1], self.tag_ent, self.step_count, ce, n_ce,
+                                                         self.inplace, hyper, sl["ws_ent"]))
+        self._timed("apply_rel", lambda: D.apply_grouped(self.opt_id, self.rel, self.k_int, self.state_rel[0],
+                                                         self.state_rel[1], self.tag_rel, self.step_count, cr, n_cr,
+                                                         False, hyper, sl["ws_rel"]))
         if self.normalize:
             # EmbeddingModel.py:1434-1440: tf.clip_by_norm(ent_emb, clip_norm=1, axes=1) after each batch
             D.clip_rows(self.ent, self.k_int, 1.0)

@@ -126,6 +126,49 @@ int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_en
                        float* contrib_ent, float* contrib_rel, int64_t ldc,
                        int32_t* dest_ent, int32_t* dest_rel, void* stream);
 
+/* destination ids of the (2+eta)*B entity / B relation contribution rows of a batch (layout above);
+ * depends only on the batch ids and codes, so it can run ahead of the scoring kernels */
+int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes,
+                   int32_t* dest_ent, int32_t* dest_rel, void* stream);
+
+/* ---- K5+K7 fused / extended backward.  One pass over the (3+eta) rows of each positive group:
+ *   fused_loss >= 0 (EMG_LOSS_PAIRWISE | EMG_LOSS_NLL | EMG_LOSS_ABSOLUTE_MARGIN — the losses whose
+ *       dL/dneg_j depends only on (pos_i, neg_j)): scores, loss (accumulated into *loss_accum) and
+ *       dL/dscore are computed in the kernel; scores_*_out optional.
+ *   fused_loss < 0: dL/dscore is read from g_pos / g_neg (any loss; see emg_loss).
+ *   single_ent != NULL: uint8 per entity contribution slot (from emg_group_dest); slots flagged 1 have a
+ *       destination hit exactly once in this batch and are applied to the table IN PLACE (optimizer `opt`,
+ *       hyper = HOST 6 floats as emg_apply_rows) instead of being written to contrib_ent — finish with
+ *       emg_apply_grouped(..., skip_single=1).
+ *   bw_scores_* : optional global final scores, used only by TransE-L2 when `ent`/`rel` are column
+ *       slices (k-sharded multi-GPU) so that the norm is the full one.
+ * Relation gradients always go to contrib_rel. */
+typedef struct emg_backward_args {
+    int32_t model; int32_t k_int; float scale; int32_t eta;
+    const float* ent; int64_t n_ent; int64_t ld_ent;
+    const float* rel; int64_t n_rel; int64_t ld_rel;
+    const int32_t* pos; int64_t B; const int32_t* codes;
+    int32_t fused_loss; float margin; double* loss_accum;
+    const float* g_pos; const float* g_neg;
+    const float* bw_scores_pos; const float* bw_scores_neg;
+    float* scores_pos_out; float* scores_neg_out;
+    float* contrib_ent; float* contrib_rel; int64_t ldc;
+    const uint8_t* single_ent; int32_t opt; int32_t step; float hyper[6];
+    float* ent_state0; float* ent_state1; int32_t* tag_ent;
+} emg_backward_args;
+int emg_train_backward_ex(const emg_backward_args* args, void* stream);
+
+/* ---- K8 in two halves (emg_apply_rows = both):
+ * emg_group_dest: stable sort of (dest, index) into `workspace` (+ optional singleton flags[n]);
+ * emg_apply_grouped: segmented sum + optimizer update using that workspace; skip_single != 0 skips
+ * length-1 segments (already applied in place by emg_train_backward_ex). */
+int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
+                   uint8_t* single_flags, void* stream);
+int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
+                      float* state0, float* state1, int32_t* tag, int32_t step,
+                      const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
+                      const float* hyper, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- K8: deterministic row-sparse optimizer apply.  Sorts (dest, index) (stable radix sort),
  * sums each destination's contribution rows in index order and updates that table row once.
  * state0/state1: momentum buffer | adagrad accumulator | adam m, v  (same shape/stride as the table;

@@ -332,3 +332,41 @@ def test_negative_corruption_entity_options():
         m = DistMult(k=4, eta=2, epochs=2, batches_count=3, embedding_model_params={"negative_corruption_entities": nce})
         m.fit(X)
         assert np.isfinite(m.trained_model_params[0]).all()
+
+
+@pytest.mark.parametrize("opt", ["sgd", "momentum", "adagrad", "adam", "adam_lazy"])
+@pytest.mark.parametrize("model,loss", [("ComplEx", "nll"), ("TransE_L1", "pairwise"), ("TransE_L2", "absolute_margin"),
+                                        ("DistMult", "multiclass_nll")])
+def test_trainer_execution_plans_agree(opt, model, loss):
+    """fused + in-place singleton updates + side-stream pipelining == the plain
+    forward / loss / backward / segmented-apply sequence (same arithmetic, different data movement)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = orc.MODEL_IDS[model]
+    k, n_ent, n_rel, B, eta = 12, 400, 5, 96, 4
+    ki = 2 * k if model in ("ComplEx", "HolE") else k
+    rs = np.random.RandomState(3)
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 4 * B), rs.randint(0, n_rel, 4 * B), rs.randint(0, n_ent, 4 * B)], 1).astype(np.int32)
+    outs = []
+    for plan in (dict(fused=True, inplace=True, pipeline=True), dict(fused=False, inplace=False, pipeline=False),
+                 dict(fused=True, inplace=False, pipeline=False), dict(fused=False, inplace=True, pipeline=True)):
+        tr = Trainer(mid, ki, 1.0, ent0, rel0, eta, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05},
+                     batches_count=4, seed=11, **plan)
+        tr.set_training_set(X, B)
+        for b in range(4):
+            tr.step(b * B, B, 1, b + 1, prefetch=((b + 1) * B, B, 1, b + 2) if b < 3 else None)
+        E, R = tr.tables_numpy()
+        outs.append((E, R, tr.read_loss()))
+    # how many slots were singletons in the last batch (the in-place path must actually be exercised)
+    assert int(tr.slots[0]["single"].sum().item()) + int(tr.slots[1]["single"].sum().item()) > 0
+    for E, R, ls in outs[1:]:
+        # fused and split kernels contract/round the same formulas slightly differently (fp32, few ulp)
+        np.testing.assert_allclose(E, outs[0][0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(R, outs[0][1], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ls, outs[0][2], rtol=1e-5)
+    # in-place vs contribution path differ only in data movement (and in which template instantiation the
+    # compiler contracted into fmas): equal to fp32 rounding
+    np.testing.assert_allclose(outs[1][0], outs[3][0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[0][0], outs[2][0], rtol=1e-5, atol=1e-6)
