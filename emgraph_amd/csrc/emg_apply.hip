@@ -25,16 +25,32 @@ struct ApplyParams {
     float* state0; float* state1; int32_t* tag; int32_t step;
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
+    const uint32_t* heads; const uint32_t* head_count;  // [0]: multi-row segments (front), [1]: singletons (back)
     int32_t skip_single;
+    int32_t win;  // sorted positions per wave
     OptParams opt;
 };
 
-__global__ void iota_kernel(uint32_t* v, int64_t n) {
+__global__ void iota_kernel(uint32_t* v, int64_t n, uint32_t* cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
+    if (i == 0) { cnt[0] = 0u; cnt[1] = 0u; }  // head-list counters (saves a memset launch)
 }
 
-// flags[original index] = 1 iff its destination occurs exactly once
+// wave-aggregated append: ONE atomic per wave per list (a per-lane returning atomic on one counter
+// serialises at ~10 ns each: 3e5 of them cost more than the whole sort)
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// flags[original index] = 1 iff its destination occurs exactly once in the batch
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
                                    uint8_t* __restrict__ flags) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,45 +61,56 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
     flags[vals[t]] = (head && last) ? 1 : 0;
 }
 
-// one wave per sorted position; only segment heads work
+// One wave per WIN (a power of two <= 64) consecutive SORTED positions: the wave finds the segment heads inside its window with
+// one coalesced key load + a ballot (no head list, no atomics — a shared append counter saturates at
+// ~90 atomics/us, slower than the whole sort) and processes them one after the other.  A segment may run
+// past the window's end; its head's wave handles all of it.  Singleton segments are skipped when the
+// backward kernel already applied them in place.
 template <int W>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
-    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (t >= P.n) return;
-    const uint32_t key = P.keys[t];
-    if (t > 0 && P.keys[t - 1] == key) return;
-    if ((int64_t)key >= P.n_rows) return;  // defensive: never write outside the table
-    int64_t end = t + 1;
-    while (end < P.n && P.keys[end] == key) ++end;
-    if (P.skip_single && end == t + 1) return;  // already updated in place by the backward kernel
-
-    float* wrow = P.table + (int64_t)key * P.ld;
-    float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
-    float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t t0 = wave * P.win + lane;
+    const bool in = lane < P.win && t0 < P.n;
+    const uint32_t mykey = in ? P.keys[t0] : 0u;
+    const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
+    const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
+    unsigned long long todo = __ballot(head && !(P.skip_single && last));
     const int nchunks = P.k_int / W;
-    for (int c = lane; c < nchunks; c += 64) {
-        float acc[W];
+    while (todo) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t t = wave * P.win + b;
+        const uint32_t key = __shfl(mykey, b, 64);
+        if ((int64_t)key >= P.n_rows) continue;  // defensive: never write outside the table
+        int64_t end = t + 1;
+        while (end < P.n && P.keys[end] == key) ++end;
+        float* wrow = P.table + (int64_t)key * P.ld;
+        float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+        float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+        for (int c = lane; c < nchunks; c += 64) {
+            float acc[W];
 #pragma unroll
-        for (int w = 0; w < W; ++w) acc[w] = 0.f;
-        for (int64_t u = t; u < end; ++u) {
-            const float* src = P.contrib + (int64_t)P.vals[u] * P.ldc + (int64_t)c * W;
-            if constexpr (W == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-            } else {
-                acc[0] += src[0];
+            for (int w = 0; w < W; ++w) acc[w] = 0.f;
+            for (int64_t u = t; u < end; ++u) {
+                const float* src = P.contrib + (int64_t)P.vals[u] * P.ldc + (int64_t)c * W;
+                if constexpr (W == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                } else {
+                    acc[0] += src[0];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int64_t off = (int64_t)c * W + w;
+                float wv = wrow[off];
+                opt_update_elem(P.opt, wv, acc[w], s0row ? s0row + off : nullptr, s1row ? s1row + off : nullptr);
+                wrow[off] = wv;
             }
         }
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const int64_t off = (int64_t)c * W + w;
-            float wv = wrow[off];
-            opt_update_elem(P.opt, wv, acc[w], s0row ? s0row + off : nullptr, s1row ? s1row + off : nullptr);
-            wrow[off] = wv;
-        }
+        if (P.tag && lane == 0) P.tag[key] = P.step;
     }
-    if (P.tag && lane == 0) P.tag[key] = P.step;
 }
 
 // Keras Adam's sparse apply is dense-equivalent (every row: m*=b1, v*=b2, w -= lr_t m/(sqrt v + eps));
@@ -121,10 +148,10 @@ static int sort_temp_bytes(int64_t n, size_t* bytes) {
     return EMG_OK;
 }
 
-// workspace layout: [keys_sorted | vals_in (iota) | vals_sorted | rocprim temp]
+// workspace layout: [keys_sorted | vals_in (iota) | vals_sorted | heads | 2 counters | rocprim temp]
 struct WsLayout {
     size_t kb, temp;
-    uint32_t *keys, *vals_in, *vals;
+    uint32_t *keys, *vals_in, *vals, *heads, *cnt;
     void* tmp;
 };
 
@@ -134,13 +161,16 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
     if (rc != EMG_OK) return rc;
     o->kb = align256((size_t)n * 4);
     o->temp = tmp;
-    EMG_REQUIRE((int64_t)(3 * o->kb + align256(tmp)) <= workspace_bytes, "apply workspace too small (%lld < %lld)",
-                (long long)workspace_bytes, (long long)(3 * o->kb + align256(tmp)));
+    EMG_REQUIRE((int64_t)(4 * o->kb + 256 + align256(tmp)) <= workspace_bytes,
+                "apply workspace too small (%lld < %lld)", (long long)workspace_bytes,
+                (long long)(4 * o->kb + 256 + align256(tmp)));
     char* ws = (char*)workspace;
     o->keys = (uint32_t*)ws;
     o->vals_in = (uint32_t*)(ws + o->kb);
     o->vals = (uint32_t*)(ws + 2 * o->kb);
-    o->tmp = ws + 3 * o->kb;
+    o->heads = (uint32_t*)(ws + 3 * o->kb);
+    o->cnt = (uint32_t*)(ws + 4 * o->kb);
+    o->tmp = ws + 4 * o->kb + 256;
     return EMG_OK;
 }
 
@@ -153,7 +183,7 @@ extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) 
     if (n_contrib <= 0) return 256;
     size_t tmp = 0;
     if (sort_temp_bytes(n_contrib, &tmp) != EMG_OK) return -1;
-    return (int64_t)(3 * align256((size_t)n_contrib * 4) + align256(tmp) + 256);
+    return (int64_t)(4 * align256((size_t)n_contrib * 4) + 256 + align256(tmp) + 256);
 }
 
 extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace,
@@ -165,7 +195,7 @@ extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, vo
     WsLayout w;
     int rc = ws_layout(workspace, workspace_bytes, n, &w);
     if (rc != EMG_OK) return rc;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.vals_in, n);
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.vals_in, n, w.cnt);
     EMG_LAUNCH_CHECK();
     int end_bit = 1;
     while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
@@ -204,9 +234,15 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         if (rc != EMG_OK) return rc;
         P.keys = w.keys;
         P.vals = w.vals;
+        P.heads = w.heads;
+        P.head_count = w.cnt;
         const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
                          (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
-        const dim3 grid((unsigned)cdiv(n_contrib * 64, 256)), block(256);
+        // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
+        int win = 64;
+        while (win > 1 && n_contrib / win < 16384) win >>= 1;
+        P.win = win;
+        const dim3 grid((unsigned)cdiv(cdiv(n_contrib, win) * 64, 256)), block(256);
         if (vec) hipLaunchKernelGGL((apply_rows_kernel<4>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((apply_rows_kernel<1>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();

@@ -272,11 +272,105 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward / fused: gradient rows per group (no atomics; summed per destination by emg_apply_grouped)
+// backward / fused kernel, register-lean form.
+//
+// Every model here is (bi)linear enough that the loop over a positive's negatives needs only
+//   q_o, q_s : the two HOISTED query rows (object side from (s,p), subject side from (p,o)); a negative's
+//              score is <q, e> (TransE: -||q - e||), its gradient row is gi*q (TransE: +-gi*sgn/diff);
+//   A_o, A_s : two ACCUMULATORS  sum_j gi_j * e_j  (TransE: sum_j t_j) over the object- / subject-corrupted
+//              negatives; the gradients of the kept rows s, p, o are linear in them and are formed once,
+//              after the loop, from s, p, o RE-LOADED at that point (L2-hot) instead of kept live.
+// => 4 persistent rows instead of 6 + no per-negative role copies: ~100 VGPRs with FOUR replacement rows in
+// flight per wave (occupancy x loads in flight is what an HBM-bound gather kernel lives on).
 //   FUSED = true : scores, pair-local loss and dL/dscore are computed here (P.fused_loss)
 //   FUSED = false: dL/dscore comes from P.g_pos / P.g_neg
+//   IP    = 0: all rows to the contribution buffer; 1/2: singleton destinations updated in place
 // ---------------------------------------------------------------------------------------------
-//   IP    = 0: all rows to the contribution buffer; 1/2: singleton destinations updated in place (see above)
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ void make_queries(const Row<MODEL, W, NV>& s, const Row<MODEL, W, NV>& p,
+                                             const Row<MODEL, W, NV>& o, Row<MODEL, W, NV>& qo,
+                                             Row<MODEL, W, NV>& qs) {
+    constexpr int E = W * NV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            qo.x[e] = s.x[e] + p.x[e];  // (s+p) - e
+            qs.x[e] = o.x[e] - p.x[e];  // (e+p) - o = e - (o-p)
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            qo.x[e] = p.x[e] * s.x[e];
+            qs.x[e] = p.x[e] * o.x[e];
+        } else {
+            const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
+            qo.x[e] = pr * sr - pi * si;      qo.x[E + e] = pr * si + pi * sr;    // SURVEY B-2, object side
+            qs.x[e] = pr * orr + pi * oi;     qs.x[E + e] = pr * oi - pi * orr;   // subject side
+        }
+    }
+}
+
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ float neg_partial(const Row<MODEL, W, NV>& q, const Row<MODEL, W, NV>& e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < Row<MODEL, W, NV>::N; ++i) {
+        if constexpr (MODEL == EMG_TRANSE_L1) acc += fabsf(q.x[i] - e.x[i]);
+        else if constexpr (MODEL == EMG_TRANSE_L2) { const float d = q.x[i] - e.x[i]; acc = fmaf(d, d, acc); }
+        else acc = fmaf(q.x[i], e.x[i], acc);
+    }
+    return acc;
+}
+
+// gradient row of the replacement entity + accumulator update.  OBJ: the object was replaced (d = q - e)
+template <int MODEL, int W, int NV, bool OBJ>
+__device__ __forceinline__ void neg_grads(const Row<MODEL, W, NV>& q, const Row<MODEL, W, NV>& e, float gi,
+                                          Row<MODEL, W, NV>& row, Row<MODEL, W, NV>& acc) {
+#pragma unroll
+    for (int i = 0; i < Row<MODEL, W, NV>::N; ++i) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            const float d = OBJ ? q.x[i] - e.x[i] : e.x[i] - q.x[i];
+            const float t = (MODEL == EMG_TRANSE_L1) ? gi * sgnf(d) : gi * d;
+            row.x[i] = OBJ ? t : -t;  // dscore/de = +sgn(d) when e is the object, -sgn(d) when it is the subject
+            acc.x[i] += t;
+        } else {
+            row.x[i] = gi * q.x[i];
+            acc.x[i] = fmaf(gi, e.x[i], acc.x[i]);
+        }
+    }
+}
+
+// gradients of the kept rows from the accumulators (+ the positive's own term, inner coefficient gp_i)
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const Row<MODEL, W, NV>& p,
+                                             const Row<MODEL, W, NV>& o, const Row<MODEL, W, NV>& Ao,
+                                             const Row<MODEL, W, NV>& As, float gp_i, Row<MODEL, W, NV>& gs,
+                                             Row<MODEL, W, NV>& gp, Row<MODEL, W, NV>& go) {
+    constexpr int E = W * NV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            const float d = (s.x[e] + p.x[e]) - o.x[e];
+            const float tp = (MODEL == EMG_TRANSE_L1) ? gp_i * sgnf(d) : gp_i * d;
+            gs.x[e] = -Ao.x[e] - tp;
+            gp.x[e] = -Ao.x[e] - As.x[e] - tp;
+            go.x[e] = As.x[e] + tp;
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            const float bo = fmaf(gp_i, o.x[e], Ao.x[e]);  // effective object row seen by (s,p)
+            const float bs = fmaf(gp_i, s.x[e], As.x[e]);  // effective subject row seen by (p,o)
+            gs.x[e] = p.x[e] * bo;
+            go.x[e] = p.x[e] * bs;
+            gp.x[e] = fmaf(s.x[e], bo, As.x[e] * o.x[e]);
+        } else {
+            const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
+            const float br = fmaf(gp_i, orr, Ao.x[e]), bi = fmaf(gp_i, oi, Ao.x[E + e]);  // b = Ao + gp_i*o
+            const float ar = fmaf(gp_i, sr, As.x[e]), ai = fmaf(gp_i, si, As.x[E + e]);   // a = As + gp_i*s
+            gs.x[e] = pr * br + pi * bi;              gs.x[E + e] = pr * bi - pi * br;     // GA(p, b)
+            go.x[e] = pr * ar - pi * ai;              go.x[E + e] = pr * ai + pi * ar;     // GB(p, a)
+            // GP(s, b) + GP(As, o)
+            gp.x[e] = (sr * br + si * bi) + (As.x[e] * orr + As.x[E + e] * oi);
+            gp.x[E + e] = (sr * bi - si * br) + (As.x[e] * oi - As.x[E + e] * orr);
+        }
+    }
+}
+
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
 __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupParams P) {
     using R = Row<MODEL, W, NV>;
@@ -287,24 +381,29 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
     const int64_t B = P.B;
 
     const int32_t s = P.pos[3 * g + 0], p = P.pos[3 * g + 1], o = P.pos[3 * g + 2];
-    R rs, rp, ro, gs, gp, go;
-    load_row<MODEL, W, NV, LPG>(rs, P.ent + (int64_t)s * P.ld_ent, lg, P.nchunks, P.khalf);
-    load_row<MODEL, W, NV, LPG>(rp, P.rel + (int64_t)p * P.ld_rel, lg, P.nchunks, P.khalf);
-    load_row<MODEL, W, NV, LPG>(ro, P.ent + (int64_t)o * P.ld_ent, lg, P.nchunks, P.khalf);
-#pragma unroll
-    for (int e = 0; e < R::N; ++e) gs.x[e] = gp.x[e] = go.x[e] = 0.f;
-
-    // positive: score (if needed) now, its gradient after the negatives (dL/dpos sums over them)
+    const float* srow = P.ent + (int64_t)s * P.ld_ent;
+    const float* prow = P.rel + (int64_t)p * P.ld_rel;
+    const float* orow = P.ent + (int64_t)o * P.ld_ent;
+    R qo, qs, Ao, As;
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
-    if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
-        if (MODEL == EMG_TRANSE_L2 && P.bw_scores_pos) {
-            pos_nrm = -P.bw_scores_pos[g];
-        } else {
-            const float sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
-            pos_score = finalize_score<MODEL>(sum, P.scale, 0);
-            if constexpr (MODEL == EMG_TRANSE_L2) pos_nrm = sqrtf(sum);
+    {
+        R rs, rp, ro;
+        load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
+        if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
+            if (MODEL == EMG_TRANSE_L2 && P.bw_scores_pos) {
+                pos_nrm = -P.bw_scores_pos[g];
+            } else {
+                const float sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
+                pos_score = finalize_score<MODEL>(sum, P.scale, 0);
+                if constexpr (MODEL == EMG_TRANSE_L2) pos_nrm = sqrtf(sum);
+            }
         }
     }
+#pragma unroll
+    for (int e = 0; e < R::N; ++e) Ao.x[e] = As.x[e] = 0.f;
     PosTerms pos_terms{0.f, 0.f};
     if constexpr (FUSED) {
         if (P.scores_pos && active && lg == 0) P.scores_pos[g] = pos_score;
@@ -313,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
         gpos = P.g_pos[g];
     }
 
-    constexpr int U = 2;
+    constexpr int U = 4;
     for (int j0 = 0; j0 < P.eta; j0 += U) {
         int32_t code[U];
         float gj[U];
@@ -333,18 +432,16 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u;
             if (j >= P.eta) break;
-            const bool keep_s = code[u] < 0;
+            const bool keep_s = code[u] < 0;  // subject kept => the OBJECT was replaced
             const int32_t repl = code[u] & 0x7fffffff;
-            // roles by branch, not by select (no a/b/ta/tb copies: VGPRs are occupancy here).  All lanes of a
-            // group share keep_s, so the __shfl_xor partners inside a branch are always active together.
             float nrm = 0.f;
             if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
                 if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
                     nrm = -P.bw_scores_neg[(int64_t)j * B + g];
                 } else {
                     float part;
-                    if (keep_s) part = partial_score<MODEL, W, NV>(rs, rp, re[u]);
-                    else part = partial_score<MODEL, W, NV>(re[u], rp, ro);
+                    if (keep_s) part = neg_partial<MODEL, W, NV>(qo, re[u]);
+                    else part = neg_partial<MODEL, W, NV>(qs, re[u]);
                     const float sum = group_sum<LPG>(part);
                     if constexpr (MODEL == EMG_TRANSE_L2) nrm = sqrtf(sum);
                     if constexpr (FUSED) {
@@ -356,10 +453,8 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
             }
             const float gi = inner_coef<MODEL>(gj[u], nrm, P.scale);
             R row;
-#pragma unroll
-            for (int e = 0; e < R::N; ++e) row.x[e] = 0.f;
-            if (keep_s) accum_grads<MODEL, W, NV>(rs, rp, re[u], gi, gs, gp, row);   // object replaced
-            else accum_grads<MODEL, W, NV>(re[u], rp, ro, gi, row, gp, go);          // subject replaced
+            if (keep_s) neg_grads<MODEL, W, NV, true>(qo, re[u], gi, row, Ao);
+            else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
                 if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[slot])) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
@@ -367,16 +462,18 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
             }
         }
     }
-    {
-        const float gi = inner_coef<MODEL>(gpos, pos_nrm, P.scale);
-        accum_grads<MODEL, W, NV>(rs, rp, ro, gi, gs, gp, go);
-    }
     if (active) {
+        // kept rows: re-load s, p, o (just read: L2-hot) and form their gradients from the accumulators
+        R rs, rp, ro, gs, gp, go;
+        load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
+        store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
         if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[g])) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
         if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[B + g])) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
-        store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
     }
     if constexpr (FUSED) {
         // loss: one value per group (lane 0), block-reduced in double, one atomic per block

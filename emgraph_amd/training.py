@@ -169,7 +169,7 @@ class Trainer:
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin")
         self.inplace = inplace and self.reg is None
         self.pipeline = pipeline
-        self.side = torch.cuda.Stream(device=self.device) if pipeline else None
+        self.side = torch.cuda.Stream(device=self.device, priority=-1) if pipeline else None  # high priority: its many small kernels must not queue behind the big ones
         self.slots = []
 
     # ---- data ----
