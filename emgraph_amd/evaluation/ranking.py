@@ -124,14 +124,12 @@ def ranks_from_counts(gt, eq, fgt, feq, n_q, corrupt_side, strategy):
 
 
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
-                        filter_triples=None, entities_subset=None, query_chunk=4096, precision=0,
-                        reduce_counts=None, ent_offset=0, n_ent_global=None):
+                        filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None):
     """Ranks of ``test_triples`` (int ids) against all entities (or ``entities_subset``).
 
-    ``ent`` may be an entity SLAB holding global rows [ent_offset, ent_offset+rows) — then
-    ``reduce_counts(tensor)`` must sum the int32 counters over the slab owners (RCCL all-reduce) and the
-    rows named by the test triples must be present in ``ent`` via ``query_tables`` (see parallel.py).
-    """
+    ``shard=(rank, world)`` (multi-GPU, see parallel.py): every rank holds the tables, scores the query tile
+    against ITS contiguous candidate range only and the int32 counters are all-reduced (RCCL) before the
+    ranks are assembled — exact, because counts are integers."""
     if corrupt_side not in L.EVAL_SIDE_IDS:
         raise ValueError("Invalid argument value for corruption side passed for evaluation")
     if strategy not in ("worst", "best", "middle"):
@@ -139,10 +137,22 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     side_mode = L.EVAL_SIDE_IDS[corrupt_side]
     T = np.ascontiguousarray(np.asarray(test_triples, dtype=np.int32).reshape(-1, 3))
     n = T.shape[0]
-    n_ent = int(ent.shape[0]) if n_ent_global is None else int(n_ent_global)
+    n_ent = int(ent.shape[0])
+    rank, world = shard if shard is not None else (0, 1)
+    from .. import parallel
     cand = None
+    slab, e0 = ent, 0
+    subset_local = entities_subset
     if entities_subset is not None:
-        cand = torch.from_numpy(np.ascontiguousarray(np.asarray(entities_subset, dtype=np.int32))).to(ent.device)
+        sub = np.ascontiguousarray(np.asarray(entities_subset, dtype=np.int32))
+        if world > 1:
+            r0, r1 = parallel.entity_range(len(sub), rank, world)
+            sub = sub[r0:r1]
+        subset_local = sub
+        cand = torch.from_numpy(sub).to(ent.device)
+    elif world > 1:
+        e0, e1 = parallel.entity_range(n_ent, rank, world)
+        slab = ent[e0:e1]
     findex = None
     if filter_triples is not None:
         findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
@@ -154,14 +164,21 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
         n_rows = Q.shape[0]
         cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
-        D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
+        if cand is not None:
+            if cand.numel():
+                D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
+        elif slab.shape[0]:
+            D.eval_count(model_id, Q, pos_int, slab, k_int, scale, cnt[0], cnt[1], precision=precision)
         if findex is not None:
-            ptr, idx = findex.csr(Tc, side_mode, n_ent, entities_subset)
-            D.eval_filter_count(model_id, Q, pos_int, ent, ent_offset, k_int, scale,
-                                torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device),
-                                cnt[2], cnt[3], precision=precision)
-        if reduce_counts is not None:
-            reduce_counts(cnt)
+            ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
+            if cand is not None:
+                D.eval_filter_count(model_id, Q, pos_int, ent, 0, k_int, scale, torch.from_numpy(ptr).to(ent.device),
+                                    torch.from_numpy(idx).to(ent.device), cnt[2], cnt[3], precision=precision)
+            elif slab.shape[0]:
+                D.eval_filter_count(model_id, Q, pos_int, slab, e0, k_int, scale, torch.from_numpy(ptr).to(ent.device),
+                                    torch.from_numpy(idx).to(ent.device), cnt[2], cnt[3], precision=precision)
+        if world > 1:
+            parallel.allreduce_sum_(cnt)
         c = cnt.cpu().numpy()
         out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
     if not out:

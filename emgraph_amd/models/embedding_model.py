@@ -21,6 +21,7 @@ import torch
 
 from .. import _lib as L
 from .. import device as D
+from .. import parallel
 from ..evaluation.metrics import hits_at_n_score, mrr_score
 from ..evaluation.protocol import create_mappings_and_index, to_idx
 from ..evaluation.ranking import FilterIndex, rank_triples_device
@@ -298,11 +299,22 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         ent0 = _initial_table(self.initializer, self.initializer_params, rnd, n_ent, self.internal_k, "e")
         rel0 = _initial_table(self.initializer, self.initializer_params, rnd, n_rel, self.internal_k, "r")
         normalize = self.embedding_model_params.get("normalize_ent_emb", DEFAULT_NORMALIZE_EMBEDDINGS)
-        tr = Trainer(self._model_id(), self.internal_k, self._scale(), ent0, rel0, self.eta, loss=self.loss,
+        rank, world = parallel.rank_world()
+        self._sharded = world > 1
+        k_local = self.internal_k
+        if self._sharded:
+            # one process per GPU: this rank trains a COLUMN slab of both tables (parallel.py)
+            if normalize:
+                raise NotImplementedError("normalize_ent_emb needs full rows; not available with k-sharded training")
+            cplx = self.internal_k != self.k
+            ent0 = parallel.shard_columns(ent0, rank, world, cplx)
+            rel0 = parallel.shard_columns(rel0, rank, world, cplx)
+            k_local = ent0.shape[1]
+        tr = Trainer(self._model_id(), k_local, self._scale(), ent0, rel0, self.eta, loss=self.loss,
                      loss_params=self.loss_params, optimizer=self.optimizer, optimizer_params=self.optimizer_params,
                      corrupt_sides=self._corrupt_sides(), batches_count=self.batches_count, seed=self.seed,
                      regularizer=self.regularizer, regularizer_params=self.regularizer_params,
-                     normalize_ent_emb=normalize)
+                     normalize_ent_emb=normalize, sharded=self._sharded)
         tr.set_training_set(X_idx, batch_size)
         n_choices, fixed_list, batch_lists = self._negative_pool(X_idx, batch_size)
         if normalize:  # EmbeddingModel.py:1371-1380: both tables clipped once before the loop
@@ -359,9 +371,26 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         self.is_fitted = True
 
     def _save_trained_params(self, tr):
+        if getattr(self, "_sharded", False):
+            cplx = self.internal_k != self.k
+            ent = parallel.unshard_columns(parallel.gather_slabs(tr.ent), self.k, cplx)
+            rel = parallel.unshard_columns(parallel.gather_slabs(tr.rel), self.k, cplx)
+            self.trained_model_params = [ent, rel]
+            self._dev = None  # full tables are uploaded lazily for predict / evaluation
+            return
         ent, rel = tr.tables_numpy()
         self.trained_model_params = [ent, rel]
         self._dev = (tr.ent, tr.rel)
+
+    def _eval_tables(self, tr):
+        """full-width device tables of the CURRENT training state (early stopping)"""
+        if not getattr(self, "_sharded", False):
+            return tr.ent, tr.rel
+        cplx = self.internal_k != self.k
+        ent = parallel.unshard_columns(parallel.gather_slabs(tr.ent), self.k, cplx)
+        rel = parallel.unshard_columns(parallel.gather_slabs(tr.rel), self.k, cplx)
+        dev = torch.device("cuda")
+        return alloc_table(ent.shape[0], ent.shape[1], dev, init=ent), alloc_table(rel.shape[0], rel.shape[1], dev, init=rel)
 
     # ---- early stopping (EmbeddingModel.py:824-1020) ----
     def _initialize_early_stopping(self):
@@ -408,9 +437,11 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         if not (epoch >= p.get("burn_in", DEFAULT_BURN_IN_EARLY_STOPPING)
                 and epoch % p.get("check_interval", DEFAULT_CHECK_INTERVAL_EARLY_STOPPING) == 0):
             return False
-        ranks = rank_triples_device(self._model_id(), tr.ent, tr.rel, self.internal_k, self._scale(), es["x_valid"],
+        ent_f, rel_f = self._eval_tables(tr)
+        ranks = rank_triples_device(self._model_id(), ent_f, rel_f, self.internal_k, self._scale(), es["x_valid"],
                                     es["corrupt_side"], DEFAULT_RANK_COMPARE_STRATEGY, filter_triples=es["filter"],
-                                    entities_subset=es["subset"])
+                                    entities_subset=es["subset"],
+                                    shard=parallel.rank_world() if parallel.is_active() else None)
         crit = es["criteria"]
         cur = mrr_score(ranks) if crit == "mrr" else hits_at_n_score(ranks, int(crit[4:]))
         if es["best"] is None:
@@ -472,7 +503,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             raise RuntimeError(msg)
         ent, rel = self._device_tables()
         return rank_triples_device(self._model_id(), ent, rel, self.internal_k, self._scale(), X_idx, corrupt_side,
-                                   ranking_strategy, filter_triples=filter_idx, entities_subset=corruption_entities)
+                                   ranking_strategy, filter_triples=filter_idx, entities_subset=corruption_entities,
+                                   shard=parallel.rank_world() if parallel.is_active() else None)
 
 
 @register_model("TransE")

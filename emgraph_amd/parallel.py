@@ -1,0 +1,144 @@
+"""Multi-GPU execution of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no distributed code at all.  Two shardings, chosen by where the path has a
+real exchange step and by what xGMI can carry (7 links x ~153 GB/s per GPU  <<  8 TB/s HBM):
+
+TRAINING — embedding-DIMENSION (k) sharding.  Rank r owns a column slab of BOTH tables (and of the optimizer
+  state).  Every score is a sum over k, so each rank computes a PARTIAL score of every triple of the global
+  batch from its slab; the only collective of a step is one all-reduce(sum) of [(1+eta)*B] fp32 partial
+  scores (TransE-L2 reduces sums of squares, finished by -sqrt afterwards).  Loss and dL/dscore are then
+  evaluated redundantly (they are O(B*eta) scalars) and each rank back-propagates into its own columns:
+  NO gradient exchange, optimizer state sharded for free.
+  Why not batch-sharding + gradient all-reduce (what a port of a data-parallel trainer would do): at eta=20
+  almost every scored triple produces its own k-float gradient row, so the gradient volume equals the
+  gather volume; moving it over xGMI (~1 TB/s aggregate) costs ~8x the HBM-bound compute it belongs to.
+  A dense all-reduce of the |E|=1M table is 1.6 GB per step (~8 ms at RCCL bus bandwidth vs 0.6 ms of compute).
+  Negatives are Philox draws keyed by (seed, epoch, batch, row): identical on every rank, no broadcast.
+
+EVALUATION — candidate-RANGE sharding.  Every rank holds the (small: 1.6 GB at |E|=1M) table; rank r scores the
+  query tile against entities [e0_r, e1_r) only and the int32 (>, ==) counters are all-reduced — 8 bytes per
+  query row.  Ranks are exact because counts are integers.
+
+Everything here is plumbing (slab arithmetic + collectives); the kernels are the same single-GPU ones.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def is_active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+# ------------------------------------------------------------------------------------------------
+# column (k) slabs
+# ------------------------------------------------------------------------------------------------
+def column_slabs(k, world):
+    """Split k embedding dimensions into ``world`` contiguous slabs, as even as possible.
+    Returns [(start, stop)] per rank.  For complex models the SAME slab is taken from the real and from the
+    imaginary half (a rank needs matching re/im columns)."""
+    base, rem = divmod(int(k), int(world))
+    out, s = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+def padded_width(n):
+    """slab width rounded up to a multiple of 4 floats (16-byte rows for dwordx4 loads); the padding columns
+    are zero and stay zero (their score terms and gradients are exactly 0 for every model)."""
+    return ((int(n) + 3) // 4) * 4
+
+
+def shard_columns(table, rank, world, is_complex):
+    """[rows, k_int] -> this rank's [rows, k_int_local] slab (numpy or torch).  Complex layout stays
+    [re_slab | pad | im_slab | pad] so that the kernels see an ordinary (smaller) ComplEx table."""
+    k_int = table.shape[1]
+    k = k_int // 2 if is_complex else k_int
+    a, b = column_slabs(k, world)[rank]
+    w = padded_width(b - a)
+    zeros = (lambda r, c: np.zeros((r, c), dtype=table.dtype)) if isinstance(table, np.ndarray) else \
+        (lambda r, c: torch.zeros((r, c), dtype=table.dtype, device=table.device))
+    cat = np.concatenate if isinstance(table, np.ndarray) else torch.cat
+    parts = []
+    for h in range(2 if is_complex else 1):
+        parts.append(table[:, h * k + a:h * k + b])
+        if w > b - a:
+            parts.append(zeros(table.shape[0], w - (b - a)))
+    return cat(parts, 1)
+
+
+def unshard_columns(slabs, k, is_complex):
+    """inverse of shard_columns given every rank's slab (list ordered by rank) -> [rows, k_int] numpy"""
+    world = len(slabs)
+    rows = slabs[0].shape[0]
+    k_int = 2 * k if is_complex else k
+    out = np.zeros((rows, k_int), dtype=np.float32)
+    for r, (a, b) in enumerate(column_slabs(k, world)):
+        w = padded_width(b - a)
+        sl = np.asarray(slabs[r])
+        for h in range(2 if is_complex else 1):
+            out[:, h * k + a:h * k + b] = sl[:, h * w:h * w + (b - a)]
+    return out
+
+
+def local_k_int(k, rank, world, is_complex):
+    a, b = column_slabs(k, world)[rank]
+    return padded_width(b - a) * (2 if is_complex else 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# collectives
+# ------------------------------------------------------------------------------------------------
+def allreduce_sum_(t, group=None):
+    """in-place all-reduce(sum); no-op without a process group"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            # test harness only (two ranks sharing one GPU): stage through the host
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def gather_slabs(local, group=None):
+    """all_gather of equally-shaped... slabs may differ in width across ranks -> gather via object-free path:
+    pad to the maximum width, all_gather, trim.  Returns a list of numpy arrays ordered by rank."""
+    r, world = rank_world()
+    if world == 1:
+        return [local.detach().cpu().numpy()]
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # test harness only
+        local = local.detach().cpu()
+    width = torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device)
+    widths = [torch.zeros_like(width) for _ in range(world)]
+    dist.all_gather(widths, width, group=group)
+    wmax = int(max(int(w.item()) for w in widths))
+    buf = torch.zeros((local.shape[0], wmax), dtype=local.dtype, device=local.device)
+    buf[:, :local.shape[1]] = local
+    buf = buf.contiguous()
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [o[:, :int(w.item())].cpu().numpy() for o, w in zip(outs, widths)]
+
+
+# ------------------------------------------------------------------------------------------------
+# candidate (entity) ranges for evaluation
+# ------------------------------------------------------------------------------------------------
+def entity_range(n, rank, world):
+    """contiguous candidate range [e0, e1) of this rank"""
+    base, rem = divmod(int(n), int(world))
+    e0 = rank * base + min(rank, rem)
+    return e0, e0 + base + (1 if rank < rem else 0)

@@ -21,6 +21,7 @@ import torch
 
 from . import _lib as L
 from . import device as D
+from . import parallel
 
 DEFAULT_LR = 0.0005            # training/_optimizer_constants.py:9
 DEFAULT_MOMENTUM = 0.9         # :11
@@ -97,7 +98,9 @@ class Trainer:
     def __init__(self, model_id, k_int, scale, ent_init, rel_init, eta, loss="nll", loss_params=None,
                  optimizer="adam", optimizer_params=None, corrupt_sides=("s,o",), batches_count=1, seed=0,
                  regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda", fused=True,
-                 inplace=True, pipeline=True):
+                 inplace=True, pipeline=True, sharded=False):
+        """``sharded=True``: ent_init / rel_init are this rank's COLUMN slabs (emgraph_amd.parallel.shard_columns)
+        and k_int is the local width; every step all-reduces the partial scores (see parallel.py)."""
         D.require_gpu()
         self.device = torch.device(device)
         self.model_id, self.k_int, self.scale, self.eta = model_id, int(k_int), float(scale), int(eta)
@@ -158,6 +161,7 @@ class Trainer:
         self.reg_rows = self.reg is not None and optimizer != "sgd"
 
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.reg_accum = torch.zeros(1, dtype=torch.float64, device=self.device)  # LP term (column-local when sharded)
         self.X = None
         self._cap = 0
         self.stage_events = None  # filled by enable_stage_timing()
@@ -166,7 +170,8 @@ class Trainer:
         #  inplace : rows whose destination is hit once in the batch are updated from registers
         #            (needs the pre-update tables for nothing else: off when a regulariser is set)
         #  pipeline: codes + destination grouping of batch t+1 run on a side stream while batch t computes
-        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin")
+        self.sharded = bool(sharded)
+        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded
         self.inplace = inplace and self.reg is None
         self.pipeline = pipeline
         self.side = torch.cuda.Stream(device=self.device, priority=-1) if pipeline else None  # high priority: its many small kernels must not queue behind the big ones
@@ -188,8 +193,7 @@ class Trainer:
         xe = self.n_ent if self.reg_rows else 0
         xr = self.n_rel if self.reg_rows else 0
         n_ce, n_cr = (2 + et) * B + xe, B + xr
-        self.scores_pos = torch.empty(B, dtype=torch.float32, device=dev)
-        self.scores_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
+        self.scores_all = torch.empty(B * (1 + et), dtype=torch.float32, device=dev)  # [pos | neg], one all-reduce
         self.g_pos = torch.empty(B, dtype=torch.float32, device=dev)
         self.g_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
         self.contrib_ent = torch.empty((n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
@@ -309,29 +313,38 @@ class Trainer:
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr,
                 fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum, **inplace_kw))
         else:
-            sp, sn = self.scores_pos[:B], self.scores_neg[:B * et]
+            sall = self.scores_all[:B * (1 + et)]
+            sp, sn = sall[:B], sall[B:]
+            flags = L.SCORE_PARTIAL if self.sharded else L.SCORE_FINAL
             self._timed("forward", lambda: D.train_forward(self.model_id, self.ent, self.rel, self.k_int, self.scale,
-                                                           pos, et, codes, scores_pos=sp, scores_neg=sn))
+                                                           pos, et, codes, flags=flags, scores_pos=sp, scores_neg=sn))
+            bw = {}
+            if self.sharded:
+                # the ONE collective of a training step: sum the k-slab partial scores over the ranks
+                self._timed("allreduce", lambda: (parallel.allreduce_sum_(sall),
+                                                  D.finalize_scores(self.model_id, self.scale, sall)))
+                if self.model_id == L.TRANSE_L2:  # its gradient needs the full norm, not the slab's
+                    bw = dict(bw_scores_pos=sp, bw_scores_neg=sn)
             gp, gn = self.g_pos[:B], self.g_neg[:B * et]
             self._timed("loss", lambda: D.loss(self.loss_id, sp, sn, B, eta, self.n_sides, self.margin, self.alpha,
                                                self.loss_accum, gp, gn))
             self._timed("backward", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
-                g_pos=gp, g_neg=gn, **inplace_kw))
+                g_pos=gp, g_neg=gn, **bw, **inplace_kw))
         if self.reg is not None and not self.reg_rows:
             # dense LP term: value + SGD-style in-place step, both evaluated at the pre-update tables
             # (the sparse contributions above were also computed from the pre-update tables)
             self._timed("regularizer", lambda: (
-                D.lp_regularizer(self.ent, self.k_int, self.reg[0], self.reg[2], lr, self.loss_accum),
-                D.lp_regularizer(self.rel, self.k_int, self.reg[1], self.reg[2], lr, self.loss_accum)))
+                D.lp_regularizer(self.ent, self.k_int, self.reg[0], self.reg[2], lr, self.reg_accum),
+                D.lp_regularizer(self.rel, self.k_int, self.reg[1], self.reg[2], lr, self.reg_accum)))
         elif self.reg_rows:
             # LP gradient as one extra contribution row per table row (dense by definition, lp.py:107-113);
             # their destinations (iota) are already part of the slot's grouping
             self._timed("regularizer", lambda: (
                 D.lp_grad_rows(self.ent, self.k_int, self.reg[0], self.reg[2], self.contrib_ent[:xe],
-                               sl["dest_ent"][:xe], self.loss_accum),
+                               sl["dest_ent"][:xe], self.reg_accum),
                 D.lp_grad_rows(self.rel, self.k_int, self.reg[1], self.reg[2], self.contrib_rel[:xr],
-                               sl["dest_rel"][:xr], self.loss_accum)))
+                               sl["dest_rel"][:xr], self.reg_accum)))
             ce, cr = self.contrib_ent[:xe + n_ce], self.contrib_rel[:xr + B]
             n_ce, n_cr = xe + n_ce, xr + B
         self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
@@ -345,9 +358,13 @@ class Trainer:
             D.clip_rows(self.ent, self.k_int, 1.0)
 
     def read_loss(self, reset=True):
-        v = float(self.loss_accum.item())
+        """data loss (identical on every rank) + LP term (summed over the column slabs when sharded)"""
+        if self.sharded:
+            parallel.allreduce_sum_(self.reg_accum)
+        v = float(self.loss_accum.item()) + float(self.reg_accum.item())
         if reset:
             self.loss_accum.zero_()
+            self.reg_accum.zero_()
         return v
 
     def tables_numpy(self):

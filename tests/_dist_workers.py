@@ -1,0 +1,131 @@
+"""Worker bodies for the multi-process tests (spawned with torch.multiprocessing; rendezvous on 127.0.0.1)."""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32 = np.float32
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def run(fn, rank, world, port, out_dir, *args):
+    """wrapper: exceptions of a rank end up in a file the parent asserts on"""
+    import torch.distributed as dist
+    try:
+        _init(rank, world, port)
+        fn(rank, world, out_dir, *args)
+        open(os.path.join(out_dir, "ok_%d" % rank), "w").write("ok")
+    except Exception:  # noqa: BLE001
+        open(os.path.join(out_dir, "fail_%d" % rank), "w").write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------- CPU (gloo) workers
+def _oracle_partial(model, E, R, x, k):
+    """what one rank's forward kernel produces with EMG_SCORE_PARTIAL on its column slab"""
+    from oracle import emgraph_oracle as orc
+    es, ep, eo = orc.lookup_embeddings(E, R, x)
+    if model == "TransE_L2":
+        d = (es + ep) - eo
+        return np.sum(d * d, axis=1, dtype=F32)
+    if model == "HolE":
+        return orc.fn_complex(es, ep, eo)  # unscaled
+    return orc.score_fn(model, es, ep, eo, k=k)
+
+
+def kshard_scores_worker(rank, world, out_dir):
+    """k-slab partial scores + all-reduce + finish == full scores (every model, uneven slabs)"""
+    import torch
+
+    from emgraph_amd import parallel
+    from oracle import emgraph_oracle as orc
+    rs = np.random.RandomState(0)
+    for model, k in (("TransE_L1", 10), ("TransE_L2", 7), ("DistMult", 9), ("ComplEx", 5), ("HolE", 6)):
+        cplx = model in ("ComplEx", "HolE")
+        ki = 2 * k if cplx else k
+        E = (rs.randn(40, ki) * 0.4).astype(F32)
+        R = (rs.randn(3, ki) * 0.4).astype(F32)
+        x = np.stack([rs.randint(0, 40, 64), rs.randint(0, 3, 64), rs.randint(0, 40, 64)], 1)
+        El = parallel.shard_columns(E, rank, world, cplx)
+        Rl = parallel.shard_columns(R, rank, world, cplx)
+        assert El.shape[1] == parallel.local_k_int(k, rank, world, cplx) and El.shape[1] % 4 == 0
+        part = torch.from_numpy(_oracle_partial(model, El, Rl, x, k))
+        parallel.allreduce_sum_(part)
+        tot = part.numpy()
+        if model == "TransE_L2":
+            tot = -np.sqrt(tot)
+        elif model == "HolE":
+            tot = F32(2 / k) * tot
+        np.testing.assert_allclose(tot, orc.score_triples(model, E, R, x, k=k), rtol=1e-5, atol=1e-6, err_msg=model)
+        # gather + unshard is the inverse of shard
+        back = parallel.unshard_columns(parallel.gather_slabs(torch.from_numpy(El)), k, cplx)
+        np.testing.assert_array_equal(back, E)
+
+
+def eval_counts_worker(rank, world, out_dir):
+    """candidate-range sharding: per-range counts (C oracle) + all-reduce == unsharded counts -> same ranks"""
+    import torch
+
+    from emgraph_amd import parallel
+    from emgraph_amd.evaluation import build_filter_csr, ranks_from_counts
+    from oracle import c_oracle as co
+    rs = np.random.RandomState(1)
+    k, n_ent, n_rel, nq = 8, 101, 3, 9
+    E = (rs.randn(n_ent, 2 * k) * 0.4).astype(F32)
+    R = (rs.randn(n_rel, 2 * k) * 0.4).astype(F32)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, n_rel, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 500), rs.randint(0, n_rel, 500), rs.randint(0, n_ent, 500)], 1)])
+    Q, pos_int = co.build_queries(3, E, R, 2 * k, 1.0, T, 3)
+    ptr, idx = build_filter_csr(F, T, 3, n_ent)
+    e0, e1 = parallel.entity_range(n_ent, rank, world)
+    ranges = [parallel.entity_range(n_ent, r, world) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_ent and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    gt, eq = co.count(3, Q, pos_int, E[e0:e1], 2 * k, 1.0)
+    fgt, feq = co.filter_count(3, Q, pos_int, E[e0:e1], e0, 2 * k, 1.0, ptr, idx)
+    cnt = torch.from_numpy(np.stack([gt, eq, fgt, feq]))
+    parallel.allreduce_sum_(cnt)
+    c = cnt.numpy()
+    fgt0, feq0 = co.filter_count(3, Q, pos_int, E, 0, 2 * k, 1.0, ptr, idx)
+    gt0, eq0 = co.count(3, Q, pos_int, E, 2 * k, 1.0)
+    np.testing.assert_array_equal(c, np.stack([gt0, eq0, fgt0, feq0]))
+    np.testing.assert_array_equal(ranks_from_counts(c[0], c[1], c[2], c[3], nq, "s,o", "worst"),
+                                  ranks_from_counts(gt0, eq0, fgt0, feq0, nq, "s,o", "worst"))
+
+
+# --------------------------------------------------------------------------------- GPU worker (2 ranks, one GPU)
+def sharded_fit_worker(rank, world, out_dir, name, loss, opt):
+    """the REAL k-sharded training + range-sharded evaluation path (HIP kernels), two ranks sharing cuda:0"""
+    import torch
+
+    from emgraph_amd.evaluation import evaluate_performance
+    from emgraph_amd import models
+    torch.cuda.set_device(0)
+    rs = np.random.RandomState(5)
+    n_ent, n_rel = 80, 4
+    X = np.stack([rs.randint(0, n_ent, 900), rs.randint(0, n_rel, 900), rs.randint(0, n_ent, 900)], 1)
+    X[:n_ent, 0] = np.arange(n_ent)
+    X[:n_rel, 1] = np.arange(n_rel)
+    kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    if name == "TransE_L2":
+        m = models.TransE(embedding_model_params={"norm": 2}, **kw)
+    else:
+        m = getattr(models, name)(**kw)
+    m.fit(X[:800])
+    ranks = evaluate_performance(X[800:], m, filter_triples=X, corrupt_side="s,o")
+    ranks_sub = evaluate_performance(X[800:840], m, filter_triples=X, corrupt_side="s+o", entities_subset=list(range(0, 80, 3)))
+    np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
+             ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:]))

@@ -1,0 +1,102 @@
+"""Multi-process tests of the N>1 path.
+
+CPU (gloo, world_size 2): the slab / range arithmetic and the collectives of emgraph_amd.parallel, with the
+oracle standing in for the kernels (test-only), must reproduce the unsharded result.
+GPU: the real k-sharded training + range-sharded evaluation (HIP kernels) with two ranks sharing cuda:0
+over gloo must match a single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+from tests import _dist_workers as W  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(fn, world, tmp_path, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=W.run, args=(fn, r, world, port, str(tmp_path)) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join()
+            raise AssertionError("distributed worker hung")
+    for r in range(world):
+        fail = os.path.join(tmp_path, "fail_%d" % r)
+        assert not os.path.exists(fail), open(fail).read()
+        assert os.path.exists(os.path.join(tmp_path, "ok_%d" % r)), "rank %d did not finish" % r
+
+
+def test_slab_and_range_arithmetic():
+    from emgraph_amd import parallel
+    for k, world in ((200, 8), (100, 3), (7, 4), (5, 8)):
+        sl = parallel.column_slabs(k, world)
+        assert sl[0][0] == 0 and sl[-1][1] == k and all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in sl) - min(b - a for a, b in sl) <= 1
+    rs = np.random.RandomState(0)
+    for cplx in (False, True):
+        T = rs.randn(6, 20).astype(np.float32)
+        k = 10 if cplx else 20
+        slabs = [parallel.shard_columns(T, r, 3, cplx) for r in range(3)]
+        assert all(s.shape[1] % 4 == 0 for s in slabs)
+        np.testing.assert_array_equal(parallel.unshard_columns(slabs, k, cplx), T)
+        ts = [parallel.shard_columns(torch.from_numpy(T), r, 3, cplx).numpy() for r in range(3)]
+        for a, b in zip(slabs, ts):
+            np.testing.assert_array_equal(a, b)
+    for n, world in ((1000000, 8), (10, 3), (2, 4)):
+        rr = [parallel.entity_range(n, r, world) for r in range(world)]
+        assert rr[0][0] == 0 and rr[-1][1] == n and all(rr[i][1] == rr[i + 1][0] for i in range(world - 1))
+
+
+def test_kshard_partial_scores_allreduce_gloo(tmp_path):
+    _spawn(W.kshard_scores_worker, 2, tmp_path)
+
+
+def test_range_sharded_eval_counts_allreduce_gloo(tmp_path):
+    _spawn(W.eval_counts_worker, 2, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "adam"), ("TransE_L2", "pairwise", "sgd"),
+                                           ("HolE", "multiclass_nll", "adagrad"), ("DistMult", "nll", "momentum")])
+def test_sharded_fit_and_eval_two_ranks_match_single_process(tmp_path, name, loss, opt):
+    from emgraph_amd import models
+    from emgraph_amd.evaluation import evaluate_performance
+    _spawn(W.sharded_fit_worker, 2, tmp_path, name, loss, opt)
+    res = [np.load(os.path.join(tmp_path, "res_%d.npz" % r)) for r in range(2)]
+    for key in ("E", "R", "ranks", "ranks_sub", "pred"):
+        np.testing.assert_array_equal(res[0][key], res[1][key])  # both ranks end with the same full model
+    # single-process reference run (same data / seed as the worker)
+    rs = np.random.RandomState(5)
+    n_ent, n_rel = 80, 4
+    X = np.stack([rs.randint(0, n_ent, 900), rs.randint(0, n_rel, 900), rs.randint(0, n_ent, 900)], 1)
+    X[:n_ent, 0] = np.arange(n_ent)
+    X[:n_rel, 1] = np.arange(n_rel)
+    kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    m = models.TransE(embedding_model_params={"norm": 2}, **kw) if name == "TransE_L2" else getattr(models, name)(**kw)
+    m.fit(X[:800])
+    # k-slab partial sums change the fp32 summation order only
+    np.testing.assert_allclose(res[0]["E"], m.trained_model_params[0], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(res[0]["R"], m.trained_model_params[1], rtol=1e-3, atol=1e-5)
+    # range-sharded evaluation of the SAME parameters is exact (integer counters): restore rank 0's tables
+    m.trained_model_params = [res[0]["E"], res[0]["R"]]
+    m._dev = None
+    np.testing.assert_array_equal(evaluate_performance(X[800:], m, filter_triples=X, corrupt_side="s,o"), res[0]["ranks"])
+    np.testing.assert_array_equal(evaluate_performance(X[800:840], m, filter_triples=X, corrupt_side="s+o",
+                                                       entities_subset=list(range(0, 80, 3))), res[0]["ranks_sub"])
