@@ -65,6 +65,20 @@ def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None
     return 0
 
 
+def pmc_traffic(stage, args, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md).  Only valid for the configuration it was collected on; else null."""
+    if stage != "fused" or args.workload != "C3" or args.batch or world != 1 or args.no_inplace or args.no_fused:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
+        return k[0]["hbm_bytes_per_launch"] if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def run_train(args, rank, world):
     import torch
 
@@ -137,7 +151,7 @@ def run_train(args, rank, world):
     dom = max((s for s in stages if stages[s].get("alg_bytes")), key=lambda s: stages[s]["ms"])
     ach = stages[dom]["GBps"]
     roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args, world),
                 "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"]}
     return dict(dt=dt, B=B, B0=B0, eta=eta, k_int=k_full, k_local=k_int, stages=stages, roofline=roofline, loss=loss,
                 w=w, tr=tr, ent0=ent0, rel0=rel0, X=X, scale=scale)
