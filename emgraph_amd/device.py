@@ -317,3 +317,66 @@ def to_bf16(table, k_int, ld_dst=None):
     out = torch.empty((nrows, ld_dst), dtype=torch.bfloat16, device=table.device)
     L.check(lib.emg_to_bf16(pt, nrows, ld, k_int, out.data_ptr(), ld_dst, _stream()), "emg_to_bf16")
     return out
+
+
+# ---- bf16 MFMA evaluation path (throughput mode) -------------------------------------------------
+def bf16_pad(k_int):
+    """row width (elements) of the bf16 operands: zero-padded to a multiple of the kernel's k-tile (32)"""
+    return ((k_int + 31) // 32) * 32
+
+
+def _chk_bf16(t, name):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError("%s must be a 2-D bfloat16 CUDA tensor with unit column stride" % name)
+    return t.data_ptr(), t.shape[0], t.stride(0)
+
+
+def eval_pos_int_bf16(model_id, ent_bf16, k_int, scale, test_spo, side_mode, q_bf16):
+    lib = L.load()
+    pe, ne, lde = _chk_bf16(ent_bf16, "ent_bf16")
+    pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")
+    n_q = test_spo.shape[0]
+    pos_int = torch.empty(n_rows, dtype=torch.int32, device=q_bf16.device)
+    self_ent = torch.empty(n_rows, dtype=torch.int32, device=q_bf16.device)
+    L.check(lib.emg_eval_pos_int_bf16(model_id, pe, lde, k_int, scale, _chk_vec(test_spo, torch.int32, "test_spo", 3 * n_q),
+                                      n_q, side_mode, pq, ldq, pos_int.data_ptr(), self_ent.data_ptr(), _stream()),
+            "emg_eval_pos_int_bf16")
+    return pos_int, self_ent
+
+
+def eval_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, k_int, scale, cnt_gt, cnt_eq, cand=None, ent_offset=0):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")
+    pe, ne, lde = _chk_bf16(ent_bf16, "ent_bf16")
+    n_cand = cand.numel() if cand is not None else ne
+    L.check(lib.emg_eval_count_bf16(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
+                                    _chk_vec(self_ent, torch.int32, "self_ent", n_rows), n_rows, pe, n_cand, lde,
+                                    _chk_vec(cand, torch.int32, "cand"), ent_offset, bf16_pad(k_int), scale,
+                                    _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                    _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_count_bf16")
+
+
+def eval_filter_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, ent_offset, k_int, scale, filt_ptr, filt_idx,
+                           fcnt_gt, fcnt_eq):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")
+    pe, ne, lde = _chk_bf16(ent_bf16, "ent_bf16")
+    L.check(lib.emg_eval_filter_count_bf16(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
+                                           _chk_vec(self_ent, torch.int32, "self_ent", n_rows), n_rows, pe, ne, lde,
+                                           ent_offset, k_int, scale, _chk_vec(filt_ptr, torch.int64, "filt_ptr", n_rows + 1),
+                                           _chk_vec(filt_idx, torch.int32, "filt_idx"),
+                                           _chk_vec(fcnt_gt, torch.int32, "fcnt_gt", n_rows),
+                                           _chk_vec(fcnt_eq, torch.int32, "fcnt_eq", n_rows), _stream()),
+            "emg_eval_filter_count_bf16")
+
+
+def eval_scores_dense_bf16(model_id, q_bf16, ent_bf16, k_int, scale, cand=None):
+    lib = L.load()
+    pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")
+    pe, ne, lde = _chk_bf16(ent_bf16, "ent_bf16")
+    n_cand = cand.numel() if cand is not None else ne
+    S = torch.full((n_rows, n_cand), float("nan"), dtype=torch.float32, device=q_bf16.device)
+    L.check(lib.emg_eval_scores_dense_bf16(model_id, pq, ldq, n_rows, pe, n_cand, lde,
+                                           _chk_vec(cand, torch.int32, "cand"), bf16_pad(k_int), scale, S.data_ptr(),
+                                           S.stride(0), _stream()), "emg_eval_scores_dense_bf16")
+    return S

@@ -124,12 +124,20 @@ def ranks_from_counts(gt, eq, fgt, feq, n_q, corrupt_side, strategy):
 
 
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
-                        filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None):
+                        filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None,
+                        ent_bf16=None):
     """Ranks of ``test_triples`` (int ids) against all entities (or ``entities_subset``).
 
     ``shard=(rank, world)`` (multi-GPU, see parallel.py): every rank holds the tables, scores the query tile
     against ITS contiguous candidate range only and the int32 counters are all-reduced (RCCL) before the
-    ranks are assembled — exact, because counts are integers."""
+    ranks are assembled — exact, because counts are integers.
+
+    ``precision=1``: bf16 MFMA throughput mode for DistMult/ComplEx/HolE (ranks agree with the exact f32 path
+    statistically, not bit for bit); ``ent_bf16`` optionally passes a cached bf16 copy of the table."""
+    if precision not in (0, 1):
+        raise ValueError("precision must be 0 (exact f32) or 1 (bf16 MFMA)")
+    if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):
+        raise ValueError("the bf16 MFMA mode needs a contraction model (DistMult, ComplEx, HolE)")
     if corrupt_side not in L.EVAL_SIDE_IDS:
         raise ValueError("Invalid argument value for corruption side passed for evaluation")
     if strategy not in ("worst", "best", "middle"):
@@ -164,6 +172,39 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
         n_rows = Q.shape[0]
         cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
+        if precision == 1:
+            # bf16 MFMA throughput mode (statistical rank agreement; see emg_rank_bf16.hip)
+            kp = D.bf16_pad(k_int)
+            if ent_bf16 is None:
+                ent_bf16 = D.to_bf16(ent, k_int, ld_dst=kp)
+            Qb = D.to_bf16(Q, k_int, ld_dst=kp)
+            pos_int, self_ent = D.eval_pos_int_bf16(model_id, ent_bf16, k_int, scale, Tt, side_mode, Qb)
+            fp_ = fi_ = None
+            if findex is not None:
+                ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
+                fp_, fi_ = torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device)
+            if cand is not None:
+                if cand.numel():
+                    D.eval_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, k_int, scale, cnt[0], cnt[1], cand=cand)
+                    if fp_ is not None:
+                        D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, 0, k_int, scale, fp_, fi_,
+                                                 cnt[2], cnt[3])
+            elif slab.shape[0]:
+                eb = ent_bf16[e0:e0 + slab.shape[0]]
+                D.eval_count_bf16(model_id, Qb, pos_int, self_ent, eb, k_int, scale, cnt[0], cnt[1], ent_offset=e0)
+                if fp_ is not None:
+                    D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, eb, e0, k_int, scale, fp_, fi_, cnt[2], cnt[3])
+            if world > 1:
+                parallel.allreduce_sum_(cnt)
+            c = cnt.cpu().numpy().astype(np.int64)
+            # the true entity was excluded by index: add it back as exactly one tie (where it is a candidate)
+            selfs = self_ent.cpu().numpy()
+            self_in = np.ones(n_rows, np.int64) if entities_subset is None else np.isin(selfs, np.asarray(entities_subset)).astype(np.int64)
+            c[1] += self_in
+            if findex is not None:
+                c[3] += self_in
+            out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
+            continue
         if cand is not None:
             if cand.numel():
                 D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)

@@ -251,6 +251,28 @@ int emg_eval_scores_dense(int model, const float* Q, int64_t ldq, int64_t n_rows
 int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int,
                 void* dst_bf16, int64_t ld_dst, void* stream);
 
+/* ---- bf16 MFMA variant of the 1-vs-all path (DistMult / ComplEx / HolE only; v_mfma_f32_32x32x16_bf16).
+ * Throughput mode, NOT a parity mode: operands are the bf16 (RNE) copies made by emg_to_bf16, rows zero-padded
+ * to k_pad = multiple of 32 elements (ld multiple of 8).  The true entity of each row (self_ent, written by
+ * emg_eval_pos_int_bf16) is excluded from the counts BY INDEX; the caller adds it back as one tie, and the
+ * filter lists' self entries are skipped likewise, so the filtered rank's self-cancellation stays exact.
+ * ent_offset: global id of row 0 of `ent_bf16` (slabs); cand: optional row indices. */
+int emg_eval_pos_int_bf16(int model, const void* ent_bf16, int64_t ld_ent, int32_t k_int, float scale,
+                          const int32_t* test_spo, int64_t n_q, int side_mode, const void* q_bf16, int64_t ldq,
+                          int32_t* pos_int, int32_t* self_ent, void* stream);
+int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, const int32_t* pos_int, const int32_t* self_ent,
+                        int64_t n_rows, const void* ent_bf16, int64_t n_cand, int64_t ld_ent, const int32_t* cand,
+                        int64_t ent_offset, int32_t k_pad, float scale, int32_t* cnt_gt, int32_t* cnt_eq,
+                        void* stream);
+int emg_eval_filter_count_bf16(int model, const void* q_bf16, int64_t ldq, const int32_t* pos_int,
+                               const int32_t* self_ent, int64_t n_rows, const void* ent_bf16, int64_t n_local,
+                               int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
+                               const int64_t* filt_ptr, const int32_t* filt_idx, int32_t* fcnt_gt,
+                               int32_t* fcnt_eq, void* stream);
+int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64_t n_rows, const void* ent_bf16,
+                               int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
+                               float* S, int64_t lds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,3 +426,72 @@ def test_ranks_random_embeddings_vs_canonical_oracle(model):
     got = rank_triples_device(MID[model], cu(E), cu(R), ki, sc, T[:12], "s,o", "worst")
     exp = orc.get_ranks(model, E, R, T[:12], corrupt_side="s,o", strategy="worst", k=k)
     assert np.abs(got - exp).max() <= 2
+
+
+# ---------------------------------------------------------------- bf16 MFMA throughput mode
+@pytest.mark.parametrize("model", ["DistMult", "ComplEx", "HolE"])
+@pytest.mark.parametrize("k,n_ent", [(8, 200), (100, 700), (37, 300)])
+def test_bf16_dense_scores_match_rounded_operands(model, k, n_ent):
+    """bf16 MFMA kernel == fp32-accumulated product of the bf16-ROUNDED operands (fragment layout, LDS
+    swizzle and tile edges are all exercised; asymmetric random data catches transposes)"""
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k + 1)
+    rs = np.random.RandomState(8)
+    nq = 70
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    sc = scale_of(model, k)
+    Q, _ = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    kp = d.bf16_pad(ki)
+    Eb = d.to_bf16(cu(E), ki, ld_dst=kp)
+    Qb = d.to_bf16(Q, ki, ld_dst=kp)
+    np.testing.assert_array_equal(Eb.float().cpu().numpy()[:, :ki], torch.from_numpy(E).to(torch.bfloat16).float().numpy())
+    assert float(Eb.float().abs()[:, ki:].sum()) == 0.0  # zero padding up to the k-tile
+    S = d.eval_scores_dense_bf16(MID[model], Qb, Eb, ki, sc).cpu().numpy()
+    ref = Qb.double().cpu().numpy() @ Eb.double().cpu().numpy().T
+    if model == "HolE":
+        ref = ref * sc
+    mag = np.abs(Qb.double().cpu().numpy()) @ np.abs(Eb.double().cpu().numpy()).T + 1e-12
+    assert np.max(np.abs(S - ref) / mag) < 1e-5
+    cand = rs.permutation(n_ent)[:77].astype(np.int32)
+    S2 = d.eval_scores_dense_bf16(MID[model], Qb, Eb, ki, sc, cand=cu(cand)).cpu().numpy()
+    np.testing.assert_array_equal(S2, S[:, cand])
+
+
+@pytest.mark.parametrize("model", ["DistMult", "ComplEx", "HolE"])
+def test_bf16_ranks_exact_on_bf16_representable_data(model):
+    """values that bf16 holds exactly -> the bf16 path must reproduce the literal oracle's ranks, incl. the
+    index-based self exclusion, filters, subsets, ties and all strategies"""
+    from emgraph_amd.evaluation import rank_triples_device
+    rs = np.random.RandomState(31)
+    k, n_ent, n_rel = 4, 150, 3
+    ki = kint_of(model, k)
+    E = (rs.randint(-4, 5, (n_ent, ki)) / 4.0).astype(F32)
+    R = (rs.randint(-4, 5, (n_rel, ki)) / 4.0).astype(F32)
+    T = np.stack([rs.randint(0, n_ent, 30), rs.randint(0, n_rel, 30), rs.randint(0, n_ent, 30)], 1).astype(np.int32)
+    Fl = np.concatenate([T, np.stack([rs.randint(0, n_ent, 2000), rs.randint(0, n_rel, 2000),
+                                      rs.randint(0, n_ent, 2000)], 1)]).astype(np.int32)
+    sub = np.arange(0, n_ent, 3)
+    for side in ("s,o", "s+o", "o"):
+        for strategy in ("worst", "best", "middle"):
+            for filt, subset in ((None, None), (Fl, None), (Fl, sub)):
+                got = rank_triples_device(MID[model], cu(E), cu(R), ki, scale_of(model, k), T, side, strategy,
+                                          filter_triples=filt, entities_subset=subset, precision=1)
+                exp = orc.get_ranks(model, E, R, T, corrupt_side=side, strategy=strategy, filter_triples=filt,
+                                    corruption_entities=subset, k=k)
+                np.testing.assert_array_equal(got, exp, err_msg=str((side, strategy, filt is not None, subset is not None)))
+
+
+def test_bf16_rank_agreement_with_exact_path():
+    """random trained-scale embeddings: bf16 ranks track the exact f32 ranks (statistical contract)"""
+    from emgraph_amd.evaluation import rank_triples_device
+    k, n_ent, n_rel, nq = 100, 20000, 5, 200
+    E, R, ki = make_tables("ComplEx", k, n_ent, n_rel, seed=3, scale=0.1)
+    rs = np.random.RandomState(4)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, n_rel, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    exact = rank_triples_device(MID["ComplEx"], cu(E), cu(R), ki, 1.0, T, "s,o", "worst", filter_triples=T)
+    fast = rank_triples_device(MID["ComplEx"], cu(E), cu(R), ki, 1.0, T, "s,o", "worst", filter_triples=T, precision=1)
+    rel_err = np.abs(fast - exact) / n_ent
+    assert np.median(rel_err) < 0.005 and rel_err.max() < 0.05, (np.median(rel_err), rel_err.max())
+    assert abs((1.0 / fast).mean() - (1.0 / exact).mean()) < 0.01  # MRR agrees
+    with pytest.raises(ValueError):
+        rank_triples_device(MID["TransE_L1"], cu(E[:, :k]), cu(R[:, :k]), k, 1.0, T, precision=1)
