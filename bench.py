@@ -200,7 +200,7 @@ def run_eval(res, args):
         # bf16 MFMA throughput mode (statistical rank agreement, see emg_rank_bf16.hip); the bf16 copy of the
         # table is made once per evaluation run, like the filter index
         from emgraph_amd import device as D
-        eb = D.to_bf16(ent, res["k_int"], ld_dst=D.bf16_pad(res["k_int"]))
+        eb = D.to_bf16(ent, res["k_int"], ld_dst=D.bf16_ld(res["k_int"]))
         kw = dict(filter_triples=F, shard=shard, precision=1, ent_bf16=eb)
         rank_triples_device(mid, ent, rel, res["k_int"], res["scale"], T[:64], "s+o", "worst", **kw)
         torch.cuda.synchronize()

@@ -321,8 +321,13 @@ def to_bf16(table, k_int, ld_dst=None):
 
 # ---- bf16 MFMA evaluation path (throughput mode) -------------------------------------------------
 def bf16_pad(k_int):
-    """row width (elements) of the bf16 operands: zero-padded to a multiple of the kernel's k-tile (32)"""
+    """contraction length the bf16 kernels multiply over: k_int rounded up to a whole MFMA k-pair (32)"""
     return ((k_int + 31) // 32) * 32
+
+
+def bf16_ld(k_int):
+    """row stride (elements) of the bf16 operands: zero-padded to the kernel's 64-element k-slice"""
+    return ((k_int + 63) // 64) * 64
 
 
 def _chk_bf16(t, name):

@@ -174,7 +174,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
         if precision == 1:
             # bf16 MFMA throughput mode (statistical rank agreement; see emg_rank_bf16.hip)
-            kp = D.bf16_pad(k_int)
+            kp = D.bf16_ld(k_int)
             if ent_bf16 is None:
                 ent_bf16 = D.to_bf16(ent, k_int, ld_dst=kp)
             Qb = D.to_bf16(Q, k_int, ld_dst=kp)
@@ -196,13 +196,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
                     D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, eb, e0, k_int, scale, fp_, fi_, cnt[2], cnt[3])
             if world > 1:
                 parallel.allreduce_sum_(cnt)
+            # the true entity ties with itself by construction (pos_int comes from the same MFMA arithmetic)
             c = cnt.cpu().numpy().astype(np.int64)
-            # the true entity was excluded by index: add it back as exactly one tie (where it is a candidate)
-            selfs = self_ent.cpu().numpy()
-            self_in = np.ones(n_rows, np.int64) if entities_subset is None else np.isin(selfs, np.asarray(entities_subset)).astype(np.int64)
-            c[1] += self_in
-            if findex is not None:
-                c[3] += self_in
             out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
             continue
         if cand is not None:

@@ -252,10 +252,12 @@ int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int,
                 void* dst_bf16, int64_t ld_dst, void* stream);
 
 /* ---- bf16 MFMA variant of the 1-vs-all path (DistMult / ComplEx / HolE only; v_mfma_f32_32x32x16_bf16).
- * Throughput mode, NOT a parity mode: operands are the bf16 (RNE) copies made by emg_to_bf16, rows zero-padded
- * to k_pad = multiple of 32 elements (ld multiple of 8).  The true entity of each row (self_ent, written by
- * emg_eval_pos_int_bf16) is excluded from the counts BY INDEX; the caller adds it back as one tie, and the
- * filter lists' self entries are skipped likewise, so the filtered rank's self-cancellation stays exact.
+ * Throughput mode, NOT a parity mode: operands are the bf16 (RNE) copies made by emg_to_bf16; the kernels
+ * multiply over k_pad = round_up(k_int, 32) elements and rows are stored zero-padded with
+ * ld >= round_up(k_pad, 64).  emg_eval_pos_int_bf16 writes the true entity of each row (self_ent) and the
+ * positive's comparison integer computed by the SAME MFMA arithmetic as the count pass, so the true entity
+ * counts as exactly one tie (as in the f32 path); emg_eval_filter_count_bf16 counts a filter list's self entry
+ * as that same tie by index, so the filtered rank's self-cancellation stays exact.
  * ent_offset: global id of row 0 of `ent_bf16` (slabs); cand: optional row indices. */
 int emg_eval_pos_int_bf16(int model, const void* ent_bf16, int64_t ld_ent, int32_t k_int, float scale,
                           const int32_t* test_spo, int64_t n_q, int side_mode, const void* q_bf16, int64_t ldq,

@@ -441,7 +441,7 @@ def test_bf16_dense_scores_match_rounded_operands(model, k, n_ent):
     T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
     sc = scale_of(model, k)
     Q, _ = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
-    kp = d.bf16_pad(ki)
+    kp = d.bf16_ld(ki)
     Eb = d.to_bf16(cu(E), ki, ld_dst=kp)
     Qb = d.to_bf16(Q, ki, ld_dst=kp)
     np.testing.assert_array_equal(Eb.float().cpu().numpy()[:, :ki], torch.from_numpy(E).to(torch.bfloat16).float().numpy())
