@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemgraph_hip.so")
+LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
 ABI_VERSION = 1

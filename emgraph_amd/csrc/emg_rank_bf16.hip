@@ -20,17 +20,22 @@
 // Row storage contract: ld >= round_up(k_pad, 64) elements (k_pad itself is a multiple of 32; a trailing
 // half slice is loaded but not multiplied).
 #include "emg_common.hpp"
+#include <type_traits>
 
 namespace emg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct CountBf16Params {
     const uint16_t* Q; int64_t ldq; const int32_t* pos_int; const int32_t* self_ent; int64_t n_rows;
     const uint16_t* ent; int64_t n_cand; int64_t ld_ent; const int32_t* cand; int64_t ent_offset;
     int32_t k_pad; float scale; int32_t model;
+    int32_t k16;  // ceil(k_int / 16): MFMA k-steps that hold real data (v3)
+    int32_t qs;  // v2: LDS query-row stride in bytes (odd multiple of 64)
+    float cmul;  // score -> comparison integer: int(acc * cmul), cmul = 1e5 (* 2/k for HolE), one rounding
     int32_t* cnt_gt; int32_t* cnt_eq;
     float* S; int64_t lds;
     int32_t* pos_out;
@@ -171,9 +176,7 @@ __global__ __launch_bounds__(256, 2) void count_mfma_bf16_kernel(const CountBf16
                     const bool cok = full || tile * HBN_ + wc * 64 + tb * 32 + l31 < P.n_cand;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = acc[ta][tb][r];
-                        if (hole) v = v * P.scale;
-                        const int ci = (int)(v * 100000.0f);
+                        const int ci = (int)(acc[ta][tb][r] * P.cmul);
                         const int p = pos_s[wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
                         const unsigned inc = (ci > p ? 1u : 0u) + (ci == p ? 0x10000u : 0u);
                         cnt[ta][r] += cok ? inc : 0u;
@@ -190,12 +193,11 @@ __global__ __launch_bounds__(256, 2) void count_mfma_bf16_kernel(const CountBf16
                     for (int r = 0; r < 16; ++r) {
                         const int rl = wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                         const int64_t qr = qb * HBM_ + rl;
-                        float v = acc[ta][tb][r];
-                        if (hole) v = v * P.scale;
+                        const float v = acc[ta][tb][r];
                         if constexpr (MODE == BF_DENSE) {
-                            if (ecol < P.n_cand && qr < P.n_rows) P.S[qr * P.lds + ecol] = v;
+                            if (ecol < P.n_cand && qr < P.n_rows) P.S[qr * P.lds + ecol] = hole ? v * P.scale : v;
                         } else {
-                            if (cl == rl && qr < P.n_rows) P.pos_out[qr] = (int)(v * 100000.0f);
+                            if (cl == rl && qr < P.n_rows) P.pos_out[qr] = (int)(v * P.cmul);
                         }
                     }
                 }
@@ -219,6 +221,527 @@ __global__ __launch_bounds__(256, 2) void count_mfma_bf16_kernel(const CountBf16
                 }
             }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// v2 count kernel: query-stationary, LDS-DMA streamed entities.
+//
+// One workgroup = 8 waves (2 x 4, each 64 query rows x 64 entities) owns 128 query rows for its whole life:
+// their bf16 rows (<= 128 x 832 B) are copied into LDS ONCE, so the k-loop streams ONLY the entity table.
+// Entity slices (256 rows x 32 k = 16 KB) arrive by global_load_lds_dwordx4 into a 3-slot LDS ring, issued two
+// k-steps ahead; the loop has ONE raw s_barrier per k-step and a counted `s_waitcnt vmcnt(2)` (never 0 in
+// steady state), and the stream runs straight across tile boundaries.  LDS-DMA writes lane-linearly, so the
+// bank swizzle is applied on the SOURCE side (which 16-byte k-chunk a lane fetches) and again on the read.
+// All LDS lives in one dynamic array (a second __shared__ object makes hipcc drain vmcnt before every ds_read).
+//
+// Epilogue: compare against per-row float thresholds instead of converting every score: with c = cmul > 0,
+// int(fl(v*c)) > p  <=>  fl(v*c) >= G(p)  <=>  v >= g*, where g* is the smallest float whose rounded product
+// reaches G (fl(v*c) is monotone in v) — found once per row per block.  Same for >=.  Results are IDENTICAL to
+// the v1 kernel's integer compare for every non-NaN score (tests/test_hip_kernels.py compares the two).
+constexpr int V2_BM = 128, V2_BN = 256, V2_NS = 3, V2_STAGE = V2_BN * 64;  // bytes per ring slot (32 bf16 per row)
+constexpr int V2_KPAD_MAX = 416;
+
+__device__ __forceinline__ void glds16(const uint16_t* gsrc, unsigned lds_base) {
+    // wave-uniform LDS base (M0) + lane*16 <- 16 bytes from each lane's own global address
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)lds_base, 16, 0, 0);
+}
+
+// thresholds in the ACCUMULATOR domain (see header): smallest v with fl(v*c) >= T
+__device__ __forceinline__ float acc_threshold(float T, float c) {
+#pragma clang fp contract(off)
+    float a = T / c;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) { const float d = nextafterf(a, -INFINITY); if (d * c >= T) a = d; }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) { if (!(a * c >= T)) a = nextafterf(a, INFINITY); }
+    return a;
+}
+__device__ __forceinline__ float gt_threshold(int p) {   // int(x) > p  <=>  x >= G
+    const float pf = (float)p;
+    return (p >= 0 && p < (1 << 24)) ? (float)(p + 1) : nextafterf(pf, INFINITY);
+}
+__device__ __forceinline__ float ge_threshold(int p) {   // int(x) >= p  <=>  x >= E
+    const float pf = (float)p;
+    return (p > 0 || p < -(1 << 24)) ? pf : nextafterf((float)(p - 1), INFINITY);
+}
+
+__global__ __launch_bounds__(512, 1) void count_mfma_bf16_v2_kernel(const CountBf16Params P) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ring | Q rows | thresholds | counts
+    const int qs = P.qs;                                                     // LDS query row stride, bytes
+    unsigned char* Qs = smem + V2_NS * V2_STAGE;
+    float* thr_s = reinterpret_cast<float*>(Qs + V2_BM * qs);  // [0,128): gt thresholds, [128,256): ge thresholds
+    unsigned* cnt_s = reinterpret_cast<unsigned*>(thr_s + 2 * V2_BM);
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot_id = id >> 3;
+    const int64_t qb = slot_id % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot_id / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int xq = (l31 >> 2) & 3;
+
+    // ---- one-time: per-row thresholds -> LDS, query rows -> LDS (swizzled) ------------------------------
+    if (tid < 2 * V2_BM) {
+        const int row = tid & (V2_BM - 1);
+        const int64_t qr = qb * V2_BM + row;
+        float t = INFINITY;  // rows past the end count nothing
+        if (qr < P.n_rows) {
+            const int p = P.pos_int[qr];
+            t = acc_threshold(tid < V2_BM ? gt_threshold(p) : ge_threshold(p), P.cmul);
+        }
+        thr_s[tid] = t;
+    } else if (tid < 3 * V2_BM) {
+        cnt_s[tid - 2 * V2_BM] = 0u;
+    }
+    {
+        const int nslots = P.k_pad >> 3;
+        for (int i = tid; i < V2_BM * nslots; i += 512) {
+            const int row = i / nslots, slot = i - row * nslots;
+            const int64_t qr = min(qb * V2_BM + row, P.n_rows - 1);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(P.Q + qr * P.ldq + 8 * slot);
+            *reinterpret_cast<u32x4*>(Qs + row * qs + ((slot ^ ((row >> 2) & 3)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    unsigned cnt[16];  // per accumulator register: four packed 8-bit counters (<= 2 x tiles_per_chunk = 32 each)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cnt[r] = 0u;
+
+    // ---- LDS-DMA producer state: this lane's two 16-byte pieces of every ring slot -----------------------
+    const int KS = P.k_pad >> 5;  // k-steps per tile
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int ntile = (int)(min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles) - tile0);
+    const int S = ntile * KS;
+    int prow[2], pslot[2];
+    const uint16_t* gp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        prow[j] = (2 * wave + j) * 16 + (lane >> 2);
+        pslot[j] = (lane & 3) ^ ((prow[j] >> 2) & 3);
+    }
+    // Tiles are visited in a per-block ROTATED order: the workgroups that share this entity chunk (same XCD,
+    // consecutive qb) would otherwise stream identical addresses in lockstep and all wait on the same HBM lines.
+    const int rot = (int)(qb % ntile);
+    int itile = rot;  // producer's tile (chunk-local)
+    int ik = 0, islot = 0;
+    auto point = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t el = min((tile0 + itile) * V2_BN + prow[j], P.n_cand - 1);
+            gp[j] = P.ent + el * P.ld_ent + 8 * pslot[j];
+        }
+    };
+    const unsigned ring0 = (unsigned)(uintptr_t)smem + (unsigned)(2 * wave) * 1024u;
+    auto issue = [&]() {
+        const unsigned base = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)islot * V2_STAGE);
+        glds16(gp[0] + ik * 32, base);
+        glds16(gp[1] + ik * 32, base + 1024u);
+        islot = islot == V2_NS - 1 ? 0 : islot + 1;
+        if (++ik == KS) { ik = 0; itile = itile + 1 == ntile ? 0 : itile + 1; point(); }
+    };
+    point();
+    issue();
+    if (S > 1) issue();
+    if (S > 2) issue();
+
+    // ---- consumer addressing ----------------------------------------------------------------------------
+    int aoff[2], boff[2], sl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        aoff[t] = (wr * 64 + t * 32 + l31) * qs;
+        boff[t] = (wc * 64 + t * 32 + l31) * 64;
+        sl[t] = ((2 * t + lhi) ^ xq) << 4;  // t = MFMA k-half of the 32-wide step
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    int kk = 0, cslot = 0;
+    int ctile = rot;  // consumer's tile (chunk-local)
+
+    // Fragments for step s+1 are read while the MFMAs of step s execute: two register sets swap roles every
+    // step, which is why the loop body is written out twice.  Schedule of one step (s):
+    //   vmcnt: my pieces of stage s+1 landed -> s_barrier: everyone's landed AND every wave has finished reading
+    //   stage s (its fragments sit in registers) -> refill that slot with stage s+3  |  ds_read the fragments of
+    //   stage s+1 and the next query k-slice (they land under the MFMAs)  |  8 MFMAs(s)  |  (epilogue of a tile)
+    bf16x8 A0[2][2], A1[2][2], B0[2][2], B1[2][2];
+    auto load_frags = [&](bf16x8 (&af)[2][2], bf16x8 (&bf)[2][2], int k_idx, int slot) {
+        const unsigned char* Bst = smem + slot * V2_STAGE;
+        const unsigned char* Ak = Qs + k_idx * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf[ks][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bst + boff[t] + sl[ks]));
+                af[ks][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ak + aoff[t] + sl[ks]));
+            }
+    };
+    // stage 0
+    if (S > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(A0, B0, 0, 0);
+
+    auto step = [&](int s, bf16x8 (&acur)[2][2], bf16x8 (&bcur)[2][2], bf16x8 (&anxt)[2][2], bf16x8 (&bnxt)[2][2]) {
+        const int knext = kk + 1 == KS ? 0 : kk + 1;
+        cslot = cslot == V2_NS - 1 ? 0 : cslot + 1;
+        // (the last step runs the same sequence on a stale slot: no branch around the ds_reads, so hipcc can
+        // count them — a join would force lgkmcnt(0) in front of the MFMAs)
+        // compiler-visible lgkmcnt(0): the CURRENT fragments (read a whole MFMA group ago) are retired here, so
+        // hipcc does not put an lgkmcnt(0) between the reads below and the MFMAs that do not depend on them
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (s + 2 < S) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 3 < S) issue();
+        load_frags(anxt, bnxt, knext, cslot);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks][ta], bcur[ks][tb], acc[ta][tb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        kk = knext;
+        if (knext == 0) {  // the tile's last k-step: compare-and-count, then clear the accumulators
+            auto epilogue = [&](auto FULL) {
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    float thrG[16], thrE[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r0 = wr * 64 + ta * 32 + 8 * j + 4 * lhi;  // rows of accumulator regs 4j..4j+3
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V2_BM + r0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { thrG[4 * j + i] = g4[i]; thrE[4 * j + i] = e4[i]; }
+                    }
+                    const unsigned one = ta ? 0x10000u : 1u;  // packed 8-bit fields: gt0 | eq0<<8 | gt1<<16 | eq1<<24
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) {
+                        if constexpr (FULL.value) {
+                            unsigned long long tie = 0ull;  // lanes holding a score equal to the positive's (rare)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[ta][tb][r];
+                                const unsigned long long mg = __builtin_amdgcn_fcmpf(v, thrG[r], 3);  // v >= thr
+                                const unsigned long long me = __builtin_amdgcn_fcmpf(v, thrE[r], 3);
+                                cnt[r] += (v >= thrG[r]) ? one : 0u;
+                                tie |= mg ^ me;
+                            }
+                            if (tie) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float v = acc[ta][tb][r];
+                                    cnt[r] += (v >= thrE[r] && !(v >= thrG[r])) ? (one << 8) : 0u;
+                                }
+                            }
+                        } else {
+                            const bool cok = (tile0 + ctile) * V2_BN + wc * 64 + tb * 32 + l31 < P.n_cand;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[ta][tb][r];
+                                const bool gt = v >= thrG[r], ge = v >= thrE[r];
+                                cnt[r] += (cok && gt) ? one : 0u;
+                                cnt[r] += (cok && ge && !gt) ? (one << 8) : 0u;
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
+                    }
+                }
+            };
+            if ((tile0 + ctile + 1) * V2_BN <= P.n_cand) epilogue(std::true_type{});  // block-uniform
+            else epilogue(std::false_type{});
+            ctile = ctile + 1 == ntile ? 0 : ctile + 1;
+        }
+    };
+    for (int s = 0; s < S; s += 2) {
+        step(s, A0, B0, A1, B1);
+        if (s + 1 >= S) break;
+        step(s + 1, A1, B1, A0, B0);
+    }
+
+    // ---- block reduction: lanes -> rows (shuffles), 4 column-waves -> LDS, one global atomic per row ------
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned pk = cnt[r] >> (16 * ta);
+            unsigned c = (pk & 0xffu) | ((pk & 0xff00u) << 8);  // gt | eq<<16, wide enough for the lane sum
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (l31 == 0 && c) atomicAdd(&cnt_s[wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi], c);
+        }
+    __syncthreads();
+    if (tid < V2_BM) {
+        const int64_t qr = qb * V2_BM + tid;
+        const unsigned c = cnt_s[tid];
+        if (qr < P.n_rows) {
+            if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+            if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// v3 count kernel: query fragments in REGISTERS, LDS holds nothing but a deep LDS-DMA ring of entity slices.
+//
+// Measured on v2: one 16 KB LDS-DMA fill takes ~1.1-1.3 us issue->landed under load, so with the two fills
+// v2's ring can keep in flight a CU streams ~25 GB/s and the MFMAs wait (33 % MFMA busy).  v3 removes the
+// query tile from LDS: wave w keeps the A fragments of ITS 32 query rows for the whole k range in VGPRs
+// (NQ x 4 registers, NQ = ceil(k_int/16) MFMA k-steps; the k-loop is fully unrolled so the indices are
+// static, and a trailing all-padding k-step is never multiplied).  A workgroup is 8 waves = 256 query rows
+// (twice v2's reuse of every streamed entity byte) against 128-entity tiles, and all of LDS is a ring of
+// 128 KB of entity slices (128 entities x 16*SQ k): all but two of them in flight.
+// Per slice and wave: 4*SQ ds_read_b128 (every wave reads the whole slice), 4*SQ MFMA 32x32x16 (32 x 128
+// outputs), ONE raw s_barrier, SQ/2 global_load_lds_dwordx4, a constant counted `s_waitcnt vmcnt`: the loop
+// body is branch-free (past the end the producer keeps issuing wrapped, never-read fills so the count stays
+// constant), which lets hipcc count the ds_reads instead of draining them.  B fragments are double-buffered
+// by k-step: each is read under the previous k-step's MFMAs.  Epilogue and thresholds as in v2; each wave
+// owns its rows, so the block reduction is a lane shuffle and one global atomic per row.
+#ifndef V3_ABLATE
+#define V3_ABLATE 0  // timing experiments only (wrong results): 1 no DMA wait, 2 no barrier, 4 no DMA issue
+#endif
+constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
+
+template <int NQ, int SQ>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4)
+__global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
+    constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
+    constexpr int SPR = SQ * 2;                 // 16-byte slots per slice row
+    constexpr int RPB = 256 / RB;               // rows per 256-byte LDS bank row
+    constexpr int STAGE = V3_BN * RB;           // 8 KB / 16 KB
+    constexpr int NS = V3_RING / STAGE;         // 16 / 8 slots
+    constexpr int G = STAGE / 8192;             // LDS-DMA instructions per wave and slice
+    constexpr int D = (NQ + SQ - 1) / SQ;       // slices per tile
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ring | thresholds
+    float* thr_s = reinterpret_cast<float*>(smem + V3_RING);                // [0,256): gt, [256,512): ge
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot_id = id >> 3;
+    const int64_t qb = slot_id % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot_id / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int64_t n_cand = P.n_cand, ld_ent = P.ld_ent;
+    const uint16_t* const ent = P.ent;
+
+    // ---- one-time: thresholds -> LDS, this wave's query fragments -> registers ---------------------------
+    {
+        const int row = tid & (V3_BM - 1);
+        const int64_t qr = qb * V3_BM + row;
+        float t = INFINITY;  // rows past the end count nothing
+        if (qr < P.n_rows) {
+            const int p = P.pos_int[qr];
+            t = acc_threshold(tid < V3_BM ? gt_threshold(p) : ge_threshold(p), P.cmul);
+        }
+        thr_s[tid] = t;
+    }
+    bf16x8 A[NQ];
+    {
+        const int64_t qr = min(qb * V3_BM + wave * 32 + l31, P.n_rows - 1);
+        const uint16_t* qp = P.Q + qr * P.ldq + 8 * lhi;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) A[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + q * 16));
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): from here on only LDS-DMA is in the VMEM queue
+    __syncthreads();
+
+    // per PAIR of accumulator registers (= two query rows of this lane) four packed 8-bit counters:
+    // gt(r even) | eq(r even) << 8 | gt(r odd) << 16 | eq(r odd) << 24; each <= 4 x tiles_per_chunk (<= 32) = 128
+    unsigned cnt[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cnt[r] = 0u;
+
+    // ---- LDS-DMA producer: this lane's 16-byte pieces of every slice -------------------------------------
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int ntile = (int)(min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles) - tile0);
+    int prow[G], pslot[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const int pos = (G * wave + j) * 64 + lane;  // 16-byte position inside the slice
+        prow[j] = pos / SPR;
+        pslot[j] = (pos % SPR) ^ ((prow[j] / RPB) & (SPR - 1));
+    }
+    // Tiles are visited in a per-block ROTATED order (see v2).
+    const int rot = (int)(qb % ntile);
+    int itile = rot, islot = 0;
+    const uint16_t* gp[G];
+    auto point = [&]() {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int64_t el = min((tile0 + itile) * V3_BN + prow[j], n_cand - 1);
+            gp[j] = ent + el * ld_ent + 8 * pslot[j];
+        }
+    };
+    const unsigned ring0 = (unsigned)(uintptr_t)smem + (unsigned)(G * wave) * 1024u;
+    auto issue = [&](int d) {  // d: slice of the tile (static at every call site)
+        const unsigned base = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)islot * STAGE);
+#pragma unroll
+        for (int j = 0; j < G; ++j) glds16(gp[j] + d * (16 * SQ), base + 1024u * j);
+        islot = (islot + 1) & (NS - 1);
+        if (d == D - 1) { itile = itile + 1 == ntile ? 0 : itile + 1; point(); }
+    };
+    point();
+    // slices 0 .. NS-2 (the stream simply wraps around the chunk; fills past the last real slice are never read)
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t % D);
+
+    // ---- consumer ---------------------------------------------------------------------------------------
+    const int xq = (l31 / RPB) & (SPR - 1);
+    const unsigned char* const bptr = smem + l31 * RB;
+    int sl[SQ];
+#pragma unroll
+    for (int t = 0; t < SQ; ++t) sl[t] = ((2 * t + lhi) ^ xq) << 4;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    bf16x8 X[4], Y[4];
+    int cslot = 0;
+    auto load_step = [&](bf16x8 (&dst)[4], int slot, int ks) {
+        const unsigned char* st = bptr + slot * STAGE + sl[ks];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+            dst[tb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(st + tb * (32 * RB)));
+    };
+    auto mma_step = [&](const bf16x8& a, bf16x8 (&bq)[4]) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[tb], acc[tb], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (G * (NS - 2)));  // slice 0 landed (mine) ...
+    __builtin_amdgcn_s_barrier();                          // ... and everyone's
+    load_step(X, 0, 0);
+
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int ctile = rot + ti >= ntile ? rot + ti - ntile : rot + ti;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int d = q / SQ, ks = q % SQ;                         // static
+            const bool last_of_slice = ks == SQ - 1 || q == NQ - 1;    // static
+            bf16x8 (&cur)[4] = (q & 1) ? Y : X;
+            bf16x8 (&nxt)[4] = (q & 1) ? X : Y;
+            if (!last_of_slice) {
+                load_step(nxt, cslot, ks + 1);
+            } else {
+                // next slice: mine landed when at most the G(NS-3) younger fills are still flying; the barrier
+                // makes it everyone's, and says every wave is done with the PREVIOUS slice -> refill that slot
+#if !(V3_ABLATE & 1)
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (G * (NS - 3)));
+#endif
+#if !(V3_ABLATE & 2)
+                __builtin_amdgcn_s_barrier();
+#endif
+                cslot = (cslot + 1) & (NS - 1);
+                load_step(nxt, cslot, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#if !(V3_ABLATE & 4)
+                issue((d + NS - 1) % D);  // after the reads: the DMA issue is slow and would delay them
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(A[q], cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NQ & 1) {  // an odd k-step count leaves the next tile's first fragments in Y: swap roles back
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) X[tb] = Y[tb];
+        }
+        // ---- tile epilogue: compare-and-count, clear -----------------------------------------------------
+        auto epilogue = [&](auto FULL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = wave * 32 + 8 * j + 4 * lhi;  // query rows of accumulator registers 4j..4j+3
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V3_BM + r0);
+                if constexpr (FULL.value) {
+                    unsigned long long tie = 0ull;  // lanes holding a score equal to the positive's (rare)
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = acc[tb][4 * j + i];
+                            cnt[2 * j + (i >> 1)] += (v >= g4[i]) ? (1u << (16 * (i & 1))) : 0u;
+                            tie |= __builtin_amdgcn_fcmpf(v, g4[i], 3) ^ __builtin_amdgcn_fcmpf(v, e4[i], 3);
+                        }
+                    if (tie) {
+#pragma unroll
+                        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = acc[tb][4 * j + i];
+                                cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        const bool cok = (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = acc[tb][4 * j + i];
+                            const bool gt = v >= g4[i], ge = v >= e4[i];
+                            cnt[2 * j + (i >> 1)] += (cok && gt) ? (1u << (16 * (i & 1))) : 0u;
+                            cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tb][r] = 0.f;
+        };
+        if ((tile0 + ctile + 1) * V3_BN <= n_cand) epilogue(std::true_type{});  // block-uniform
+        else epilogue(std::false_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
+
+    // ---- rows are private to the wave: lane shuffle, one global atomic per row and counter ----------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned pk = cnt[r >> 1] >> (16 * (r & 1));
+        unsigned c = (pk & 0xffu) | ((pk & 0xff00u) << 8);  // gt | eq << 16: room for the 32-lane sum
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (l31 == 0) {
+            const int64_t qr = qb * V3_BM + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (qr < P.n_rows) {
+                if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+                if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+            }
+        }
+    }
+}
+
+template <int NQ, int SQ>
+static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
+    const size_t lds_bytes = (size_t)V3_RING + 2 * V3_BM * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v3_kernel<NQ, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
+    return EMG_OK;
 }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
@@ -249,6 +772,7 @@ __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const
     if (r >= n_rows) return;
     const int p = pos_int[r];
     const int self = self_ent[r];
+    const float cmul = (model == EMG_HOLE ? scale : 1.0f) * 100000.0f;
     const uint16_t* q = Q + r * ldq;
     int gt = 0, eq = 0;
     for (int64_t u = fptr[r] + lane; u < fptr[r + 1]; u += 64) {
@@ -259,8 +783,7 @@ __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const
         const uint16_t* er = ent + e * ld_ent;
         float acc = 0.f;
         for (int k = 0; k < k_int; ++k) acc = fmaf(bf16_to_f32(q[k]), bf16_to_f32(er[k]), acc);
-        if (model == EMG_HOLE) acc *= scale;
-        const int ci = (int)(acc * 100000.0f);
+        const int ci = (int)(acc * cmul);
         gt += ci > p;
         eq += ci == p;
     }
@@ -278,11 +801,14 @@ __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const
 static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
     EMG_REQUIRE(P.model >= EMG_DISTMULT && P.model <= EMG_HOLE, "bf16 eval: model %d is not a contraction (TransE stays f32 VALU)", P.model);
     const int64_t ld_min = (P.k_pad + HBK_ - 1) / HBK_ * HBK_;
-    EMG_REQUIRE(P.k_pad > 0 && P.k_pad % 32 == 0 && P.ldq >= ld_min && P.ld_ent >= ld_min,
-                "bf16 eval: k_pad must be a multiple of 32 and rows stored with ld >= round_up(k_pad, %d) (k_pad=%d ldq=%lld ld=%lld)",
+    EMG_REQUIRE(P.k_pad > 0 && P.k_pad % 16 == 0 && P.ldq >= ld_min && P.ld_ent >= ld_min,
+                "bf16 eval: k_pad must be a multiple of 16 and rows stored zero-padded with ld >= round_up(k_pad, %d) (k_pad=%d ldq=%lld ld=%lld)",
                 HBK_, P.k_pad, (long long)P.ldq, (long long)P.ld_ent);
+    P.k16 = P.k_pad / 16;               // MFMA k-steps holding real data
+    P.k_pad = (P.k_pad + 31) / 32 * 32;  // the v1/v2 kernels multiply whole 32-wide steps (the tail is zero padding)
     EMG_REQUIRE(P.ldq % 8 == 0 && P.ld_ent % 8 == 0 && aligned16(P.Q) && aligned16(P.ent), "bf16 eval: rows must be 16-byte aligned");
     if (P.n_rows == 0 || P.n_cand == 0) return EMG_OK;
+    P.cmul = (P.model == EMG_HOLE ? P.scale : 1.0f) * 100000.0f;
     P.n_qb = cdiv(P.n_rows, HBM_);
     P.n_tiles = cdiv(P.n_cand, HBN_);
     P.tiles_per_chunk = mode == BF_DENSE ? 4 : 32;
@@ -291,7 +817,37 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
     EMG_REQUIRE(blocks < ((int64_t)1 << 31), "bf16 eval: grid too large");
     if (mode == BF_DENSE) hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_DENSE>, dim3((unsigned)blocks), dim3(256), 0, st, P);
     else if (mode == BF_DIAG) hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_DIAG>, dim3((unsigned)blocks), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_COUNT>, dim3((unsigned)blocks), dim3(256), 0, st, P);
+    else if (P.cand == nullptr && P.cmul > 0.f && P.cmul < INFINITY && P.n_rows > V2_BM &&
+             (P.k16 == 25 || P.k16 == 13 || P.k16 == 8)) {
+        // register-stationary query fragments + deep LDS-DMA ring (see its header); common k only
+        P.n_qb = cdiv(P.n_rows, V3_BM);
+        P.n_tiles = cdiv(P.n_cand, V3_BN);
+        P.tiles_per_chunk = 32;  // <= 32: the epilogue's packed counters are 8 bits wide
+        P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
+        const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
+        EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
+        int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
+        if (P.k16 == 25) rc = launch_v3<25, 4>(P, nblk, st);
+        else if (P.k16 == 13) rc = launch_v3<13, 4>(P, nblk, st);
+        else rc = launch_v3<8, 4>(P, nblk, st);
+        if (rc != EMG_OK) return rc;
+    } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
+        // query-stationary LDS-DMA kernel (see its header); anything else takes the v1 tile kernel above
+        const int m = P.k_pad / 32;
+        P.qs = (m & 1) ? 64 * m : 64 * (m + 1);
+        P.n_tiles = cdiv(P.n_cand, V2_BN);
+        P.tiles_per_chunk = 16;
+        P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
+        const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
+        EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
+        const size_t lds_bytes = (size_t)V2_NS * V2_STAGE + (size_t)V2_BM * P.qs + 3 * V2_BM * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(count_mfma_bf16_v2_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
+    } else hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_COUNT>, dim3((unsigned)blocks), dim3(256), 0, st, P);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

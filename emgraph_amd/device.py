@@ -321,8 +321,8 @@ def to_bf16(table, k_int, ld_dst=None):
 
 # ---- bf16 MFMA evaluation path (throughput mode) -------------------------------------------------
 def bf16_pad(k_int):
-    """contraction length the bf16 kernels multiply over: k_int rounded up to a whole MFMA k-pair (32)"""
-    return ((k_int + 31) // 32) * 32
+    """contraction length handed to the bf16 kernels: k_int rounded up to a whole MFMA k-step (16)"""
+    return ((k_int + 15) // 16) * 16
 
 
 def bf16_ld(k_int):

@@ -123,9 +123,34 @@ def ranks_from_counts(gt, eq, fgt, feq, n_q, corrupt_side, strategy):
     raise ValueError("Invalid argument value for corruption side passed for evaluation")
 
 
+def _ev_start(stats):
+    if stats is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _ev_stop(stats, e0):
+    if stats is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    stats.setdefault("_events", []).append((e0, e1))
+
+
+def _ev_collect(stats):
+    if stats is None:
+        return
+    torch.cuda.synchronize()
+    evs = stats.pop("_events", [])
+    stats["count_ms"] = stats.get("count_ms", 0.0) + sum(a.elapsed_time(b) for a, b in evs)
+    stats["count_launches"] = stats.get("count_launches", 0) + len(evs)
+
+
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
                         filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None,
-                        ent_bf16=None):
+                        ent_bf16=None, stats=None):
     """Ranks of ``test_triples`` (int ids) against all entities (or ``entities_subset``).
 
     ``shard=(rank, world)`` (multi-GPU, see parallel.py): every rank holds the tables, scores the query tile
@@ -133,7 +158,10 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     ranks are assembled — exact, because counts are integers.
 
     ``precision=1``: bf16 MFMA throughput mode for DistMult/ComplEx/HolE (ranks agree with the exact f32 path
-    statistically, not bit for bit); ``ent_bf16`` optionally passes a cached bf16 copy of the table."""
+    statistically, not bit for bit); ``ent_bf16`` optionally passes a cached bf16 copy of the table.
+
+    ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
+    (HIP events on the launch stream) and ``count_launches``."""
     if precision not in (0, 1):
         raise ValueError("precision must be 0 (exact f32) or 1 (bf16 MFMA)")
     if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):
@@ -185,13 +213,17 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
                 fp_, fi_ = torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device)
             if cand is not None:
                 if cand.numel():
+                    ev = _ev_start(stats)
                     D.eval_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, k_int, scale, cnt[0], cnt[1], cand=cand)
+                    _ev_stop(stats, ev)
                     if fp_ is not None:
                         D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, 0, k_int, scale, fp_, fi_,
                                                  cnt[2], cnt[3])
             elif slab.shape[0]:
                 eb = ent_bf16[e0:e0 + slab.shape[0]]
+                ev = _ev_start(stats)
                 D.eval_count_bf16(model_id, Qb, pos_int, self_ent, eb, k_int, scale, cnt[0], cnt[1], ent_offset=e0)
+                _ev_stop(stats, ev)
                 if fp_ is not None:
                     D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, eb, e0, k_int, scale, fp_, fi_, cnt[2], cnt[3])
             if world > 1:
@@ -202,9 +234,13 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             continue
         if cand is not None:
             if cand.numel():
+                ev = _ev_start(stats)
                 D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
+                _ev_stop(stats, ev)
         elif slab.shape[0]:
+            ev = _ev_start(stats)
             D.eval_count(model_id, Q, pos_int, slab, k_int, scale, cnt[0], cnt[1], precision=precision)
+            _ev_stop(stats, ev)
         if findex is not None:
             ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
             if cand is not None:
@@ -217,6 +253,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             parallel.allreduce_sum_(cnt)
         c = cnt.cpu().numpy()
         out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
+    _ev_collect(stats)
     if not out:
         return np.zeros((0, 2) if corrupt_side == "s,o" else (0,), dtype=np.int64)
     return np.concatenate(out, axis=0)

@@ -253,8 +253,8 @@ int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int,
 
 /* ---- bf16 MFMA variant of the 1-vs-all path (DistMult / ComplEx / HolE only; v_mfma_f32_32x32x16_bf16).
  * Throughput mode, NOT a parity mode: operands are the bf16 (RNE) copies made by emg_to_bf16; the kernels
- * multiply over k_pad = round_up(k_int, 32) elements and rows are stored zero-padded with
- * ld >= round_up(k_pad, 64).  emg_eval_pos_int_bf16 writes the true entity of each row (self_ent) and the
+ * multiply over k_pad = round_up(k_int, 16) elements (one MFMA k-step) and rows are stored zero-padded
+ * with ld >= round_up(k_pad, 64).  emg_eval_pos_int_bf16 writes the true entity of each row (self_ent) and the
  * positive's comparison integer computed by the SAME MFMA arithmetic as the count pass, so the true entity
  * counts as exactly one tie (as in the f32 path); emg_eval_filter_count_bf16 counts a filter list's self entry
  * as that same tie by index, so the filtered rank's self-cancellation stays exact.

@@ -481,6 +481,44 @@ def test_bf16_ranks_exact_on_bf16_representable_data(model):
                 np.testing.assert_array_equal(got, exp, err_msg=str((side, strategy, filt is not None, subset is not None)))
 
 
+@pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 5000, 300), ("HolE", 200, 3001, 130),
+                                              ("DistMult", 32, 700, 40), ("DistMult", 64, 1024, 128),
+                                              ("ComplEx", 96, 2049, 257), ("DistMult", 7, 100, 5),
+                                              ("ComplEx", 100, 4000, 200), ("ComplEx", 64, 1500, 100),
+                                              ("ComplEx", 200, 9000, 40)])
+def test_bf16_stationary_kernel_equals_tile_kernel(model, k, n_ent, nq):
+    """the query-stationary LDS-DMA count kernels (v2: query tile in LDS; v3: query fragments in registers, for
+    k_pad in {128, 224, 416} and > 128 rows; float thresholds, streamed ring) must produce EXACTLY the
+    counters of the v1 tile kernel (integer compare): same MFMA k-order, so (gt, eq) agree bit for bit.
+    A candidate list forces the v1 kernel; duplicated rows plant exact ties with the positive."""
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k + n_ent, scale=0.2)
+    rs = np.random.RandomState(k)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 3):      # exact ties: other entities carry the true object's / subject's row
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+        E[rs.randint(0, n_ent, 1)] = E[T[j, 0]]
+    sc = scale_of(model, k)
+    Q, _ = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    ld = d.bf16_ld(ki)
+    Eb, Qb = d.to_bf16(cu(E), ki, ld_dst=ld), d.to_bf16(Q, ki, ld_dst=ld)
+    pos_int, self_ent = d.eval_pos_int_bf16(MID[model], Eb, ki, sc, cu(T), 3, Qb)
+    n_rows = Qb.shape[0]
+    got = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    exp = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb, ki, sc, got[0], got[1])
+    d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb, ki, sc, exp[0], exp[1],
+                      cand=torch.arange(n_ent, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy())
+    assert int(exp[1].min()) >= 1 and int(exp[1].max()) >= 2   # every row ties with itself; planted ties are seen
+    # slab form (ent_offset) and repeated launches accumulate
+    d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb[: n_ent // 2], ki, sc, got[0], got[1])
+    d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb[: n_ent // 2], ki, sc, exp[0], exp[1],
+                      cand=torch.arange(n_ent // 2, dtype=torch.int32, device="cuda"))
+    np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy())
+
+
 def test_bf16_rank_agreement_with_exact_path():
     """random trained-scale embeddings: bf16 ranks track the exact f32 ranks (statistical contract)"""
     from emgraph_amd.evaluation import rank_triples_device
