@@ -198,7 +198,7 @@ def run_eval(res, args):
     if cplx:
         kflops = flops / world  # each rank's count kernels cover its candidate range
         kt = st["count_ms"] * 1e-3
-        out["roofline"] = {"bound": "mfma", "kernel": "count_mfma_kernel", "achieved": round(kflops / kt / 1e12, 2),
+        out["roofline"] = {"bound": "mfma", "kernel": "count_mfma_pipe_kernel", "achieved": round(kflops / kt / 1e12, 2),
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(kflops / kt / 1e12 / MFMA_F32_PEAK_TF, 4),
                            "launches": st["count_launches"], "kernel_ms": round(st["count_ms"], 3),
                            "end_to_end_TFLOPs": round(flops / dt / 1e12, 2),
@@ -258,7 +258,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--eval-triples", type=int, default=1024)
+    ap.add_argument("--eval-triples", type=int, default=4096)
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="A/B: separate forward / loss / backward kernels")

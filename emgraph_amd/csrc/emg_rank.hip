@@ -21,6 +21,8 @@
 
 namespace emg {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int cmp_int(float score) { return (int)__fmul_rn(score, 100000.0f); }  // EmbeddingModel.py:2010-2014
@@ -427,6 +429,150 @@ __global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, in
     dst[t] = out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined form of count_mfma_kernel for 16-byte-aligned rows (k_int % 4 == 0): same MFMA chain (so the same
+// bits), but (1) the next k-slice's global loads are issued before the MFMAs of the current one and stay in
+// registers across the tile boundary, (2) rows past the end are CLAMPED instead of predicated (their results
+// are masked in the epilogue), (3) LDS is k-major [16][130]: a lane group reads 32 consecutive floats, and
+// the stride 130 (= 2 mod 8) makes the transposing dwordx4 -> 4 x ds_write_b32 stores conflict-free too
+// (the row-major stride-17 layout of the kernel above has 2-way write conflicts: 25 % of its LDS cycles).
+// ---------------------------------------------------------------------------------------------
+constexpr int LDK = 130;
+
+template <bool DENSE>
+__global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountParams P) {
+    __shared__ float As[BK * LDK];
+    __shared__ float Bs[BK * LDK];
+    __shared__ int pos_s[BM];
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot = id >> 3;
+    const int64_t qb = slot % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lrow = tid >> 2, kq = tid & 3;  // loader: rows lrow, lrow+64 ; floats [4kq,4kq+4) of the 16-wide slice
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    if (tid < BM) {
+        const int64_t qr = qb * BM + tid;
+        pos_s[tid] = (!DENSE && qr < P.n_rows) ? P.pos_int[qr] : 0x7fffffff;
+    }
+    const float* arow[2];
+    const float* brow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) arow[r] = P.Q + min(qb * BM + lrow + 64 * r, P.n_rows - 1) * P.ldq + 4 * kq;
+    auto point_b = [&](int64_t tile) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t el = min(tile * BN + lrow + 64 * r, P.n_cand - 1);
+            brow[r] = P.ent + (P.cand ? (int64_t)P.cand[el] : el) * P.ld_ent + 4 * kq;
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 av[2], bv[2];
+    auto fetch = [&](int k0) {  // k_int % 4 == 0: a 4-float piece is either whole or past the end
+        const bool in = k0 + 4 * kq < P.k_int;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            av[r] = in ? *reinterpret_cast<const f32x4*>(arow[r] + k0) : zero4;
+            bv[r] = in ? *reinterpret_cast<const f32x4*>(brow[r] + k0) : zero4;
+        }
+    };
+
+    unsigned cnt[2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cnt[a][r] = 0u;
+
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int64_t tile1 = min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles);
+    point_b(tile0);
+    fetch(0);
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        float16v acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        for (int k0 = 0; k0 < P.k_int; k0 += BK) {
+            __syncthreads();  // previous slice's LDS reads done
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    As[(4 * kq + c) * LDK + lrow + 64 * r] = av[r][c];
+                    Bs[(4 * kq + c) * LDK + lrow + 64 * r] = bv[r][c];
+                }
+            __syncthreads();
+            // next slice (or the next tile's first one) flies while this one is multiplied
+            if (k0 + BK < P.k_int) fetch(k0 + BK);
+            else if (tile + 1 < tile1) { point_b(tile + 1); fetch(0); }
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int k = 2 * kk + lhi;  // A[i][k=lane>>5], B[k=lane>>5][j]
+                float a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = As[k * LDK + wr * 64 + t * 32 + l31];
+                    b[t] = Bs[k * LDK + wc * 64 + t * 32 + l31];
+                }
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+        // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int64_t ecol = tile * BN + wc * 64 + tb * 32 + l31;
+                const bool cok = ecol < P.n_cand;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float v = acc[ta][tb][r];
+                    if (P.model == EMG_HOLE) v = __fmul_rn(v, P.scale);
+                    if constexpr (DENSE) {
+                        const int64_t qr = qb * BM + rl;
+                        if (cok && qr < P.n_rows) P.S[qr * P.lds + ecol] = v;
+                    } else {
+                        const int ci = cmp_int(v);
+                        const int p = pos_s[rl];
+                        cnt[ta][r] += (unsigned)(cok && ci > p) + ((unsigned)(cok && ci == p) << 16);
+                    }
+                }
+            }
+    }
+    if constexpr (!DENSE) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned c = cnt[ta][r];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+                if (l31 == 0) {
+                    const int rl = wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int64_t qr = qb * BM + rl;
+                    if (qr < P.n_rows) {
+                        if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+                        if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+                    }
+                }
+            }
+    }
+}
+
 static int launch_count(bool dense, int model, CountParams& P, int precision, hipStream_t st) {
     EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "unknown model id %d", model);
     if (precision != 0) return fail(EMG_ENOSUP, "eval precision mode %d is not built in this version", precision);
@@ -435,7 +581,9 @@ static int launch_count(bool dense, int model, CountParams& P, int precision, hi
     const int bm = transe ? TQ : BM, bn = transe ? TE : BN;
     P.n_qb = cdiv(P.n_rows, bm);
     P.n_tiles = cdiv(P.n_cand, bn);
-    P.tiles_per_chunk = dense ? 4 : (transe ? 64 : 32);  // packed 16-bit per-lane counters stay < 65536
+    // packed 16-bit per-lane counters stay < 65536; an f32 chunk of 16 tiles (2048 rows, 3.3 MB at k_int=400)
+    // stays in the XCD's 4 MB L2 next to the query tiles that stream past it (32 tiles = 6.5 MB thrashed: 27 % misses)
+    P.tiles_per_chunk = dense ? 4 : (transe ? 64 : 16);
     P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
     const int64_t blocks = 8 * P.n_qb * cdiv(P.n_cb, 8);
     EMG_REQUIRE(blocks < ((int64_t)1 << 31), "emg_eval_count: grid too large");
@@ -451,8 +599,8 @@ static int launch_count(bool dense, int model, CountParams& P, int precision, hi
     } else {
         const bool vec = (P.k_int % 4 == 0) && (P.ldq % 4 == 0) && (P.ld_ent % 4 == 0) && aligned16(P.Q) && aligned16(P.ent);
         if (vec) {
-            if (dense) hipLaunchKernelGGL((count_mfma_kernel<true, true>), grid, block, 0, st, P);
-            else hipLaunchKernelGGL((count_mfma_kernel<true, false>), grid, block, 0, st, P);
+            if (dense) hipLaunchKernelGGL((count_mfma_pipe_kernel<true>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_mfma_pipe_kernel<false>), grid, block, 0, st, P);
         } else {
             if (dense) hipLaunchKernelGGL((count_mfma_kernel<false, true>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((count_mfma_kernel<false, false>), grid, block, 0, st, P);

@@ -25,9 +25,30 @@ def main():
     ap.add_argument("--k", type=int, default=400)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--v1", action="store_true", help="also time the v1 tile kernel")
+    ap.add_argument("--f32", action="store_true", help="time the exact f32 MFMA count kernel instead")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
+    if a.f32:
+        ld4 = (a.k + 3) // 4 * 4
+        E = torch.zeros((a.ent, ld4), dtype=torch.float32, device=dev)
+        E[:, :a.k] = torch.randn((a.ent, a.k), generator=g, device=dev) * 0.1
+        Q = torch.zeros((a.rows, ld4), dtype=torch.float32, device=dev)
+        Q[:, :a.k] = torch.randn((a.rows, a.k), generator=g, device=dev) * 0.1
+        pos = torch.randint(-200000, 200000, (a.rows,), generator=g, device=dev, dtype=torch.int32)
+        cnt = torch.zeros((2, a.rows), dtype=torch.int32, device=dev)
+        best = 1e9
+        for _ in range(a.reps):
+            cnt.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            D.eval_count(L.COMPLEX, Q, pos, E, a.k, 1.0, cnt[0], cnt[1])
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        print("f32 exact count: %.3f ms  %.1f TFLOP/s  (checksum %d)" % (best, 2.0 * a.rows * a.ent * a.k / best * 1e-9,
+                                                                         int(cnt.sum().item())))
+        return
     ld = D.bf16_ld(a.k)
     E = torch.zeros((a.ent, ld), dtype=torch.bfloat16, device=dev)
     E[:, :a.k] = (torch.randn((a.ent, a.k), generator=g, device=dev) * 0.1).to(torch.bfloat16)
