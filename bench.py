@@ -113,7 +113,7 @@ def run_train(args, rank, world):
                  optimizer_params={"lr": 0.0005}, batches_count=steps + warm, seed=0, fused=not args.no_fused,
                  inplace=not args.no_inplace, pipeline=not args.no_pipeline, sharded=world > 1)
     tr.set_training_set(X, B)
-    nxt = lambda i: ((i + 1) * B, B, 1, i + 2) if i + 1 < warm + steps else None  # noqa: E731
+    nxt = lambda i: [((j) * B, B, 1, j + 1) for j in (i + 1, i + 2, i + 3) if j < warm + steps]  # noqa: E731  (batches ahead)
     for i in range(warm):
         tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
     torch.cuda.synchronize()

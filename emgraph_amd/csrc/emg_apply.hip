@@ -70,43 +70,75 @@ template <int W>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t t0 = wave * P.win + lane;
+    const int64_t w0 = wave * P.win;
+    const int64_t t0 = w0 + lane;
     const bool in = lane < P.win && t0 < P.n;
     const uint32_t mykey = in ? P.keys[t0] : 0u;
+    const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
+    const unsigned long long heads = __ballot(head);
     unsigned long long todo = __ballot(head && !(P.skip_single && last));
+    const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     while (todo) {
         const int b = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int64_t t = wave * P.win + b;
+        const int64_t t = w0 + b;
         const uint32_t key = __shfl(mykey, b, 64);
         if ((int64_t)key >= P.n_rows) continue;  // defensive: never write outside the table
-        int64_t end = t + 1;
-        while (end < P.n && P.keys[end] == key) ++end;
+        // segment end: the next head inside the window (ballot, no memory traffic), else scan on past the window
+        const unsigned long long after = heads & ~((2ull << b) - 1ull);
+        int64_t end = after ? w0 + (__ffsll((long long)after) - 1) : wend;
+        if (!after) while (end < P.n && P.keys[end] == key) ++end;
+        auto contrib_index = [&](int64_t u) -> int64_t {  // wave-uniform u
+            return u < wend ? (int64_t)__shfl(myval, (int)(u - w0), 64) : (int64_t)P.vals[u];
+        };
         float* wrow = P.table + (int64_t)key * P.ld;
         float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
         float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
-        for (int c = lane; c < nchunks; c += 64) {
-            float acc[W];
-#pragma unroll
-            for (int w = 0; w < W; ++w) acc[w] = 0.f;
-            for (int64_t u = t; u < end; ++u) {
-                const float* src = P.contrib + (int64_t)P.vals[u] * P.ldc + (int64_t)c * W;
-                if constexpr (W == 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(src);
-                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-                } else {
-                    acc[0] += src[0];
+        if constexpr (W == 4) {
+            // two row chunks per lane (columns 4*lane.. and 4*(lane+64)..) x two contributions per trip: up to four
+            // independent 16-byte loads in flight, added in contribution order (bit-reproducible sums)
+            for (int c0 = 0; c0 < nchunks; c0 += 128) {
+                const int ca = c0 + lane, cb = c0 + 64 + lane;
+                const bool oa = ca < nchunks, ob = cb < nchunks;
+                float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA, wA = accA, wB = accA;
+                if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
+                if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
+                for (int64_t u = t; u < end; u += 2) {
+                    const bool two = u + 1 < end;
+                    const float* r0 = P.contrib + contrib_index(u) * P.ldc;
+                    const float* r1 = two ? P.contrib + contrib_index(u + 1) * P.ldc : r0;
+                    float4 v0a = accA, v0b = accA, v1a = accA, v1b = accA;
+                    if (oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
+                    if (ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
+                    if (oa && two) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
+                    if (ob && two) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
+                    if (oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
+                    if (ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
+                    if (oa && two) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
+                    if (ob && two) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
                 }
-            }
+                auto finish = [&](int c, float4 wv, const float4& g) {
+                    const int64_t off = 4 * (int64_t)c;
+                    float w[4] = {wv.x, wv.y, wv.z, wv.w};
+                    const float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const int64_t off = (int64_t)c * W + w;
-                float wv = wrow[off];
-                opt_update_elem(P.opt, wv, acc[w], s0row ? s0row + off : nullptr, s1row ? s1row + off : nullptr);
-                wrow[off] = wv;
+                    for (int j = 0; j < 4; ++j)
+                        opt_update_elem(P.opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+                    *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
+                };
+                if (oa) finish(ca, wA, accA);
+                if (ob) finish(cb, wB, accB);
+            }
+        } else {
+            for (int c = lane; c < nchunks; c += 64) {
+                float acc = 0.f;
+                for (int64_t u = t; u < end; ++u) acc += P.contrib[contrib_index(u) * P.ldc + c];
+                float wv = wrow[c];
+                opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
+                wrow[c] = wv;
             }
         }
         if (P.tag && lane == 0) P.tag[key] = P.step;

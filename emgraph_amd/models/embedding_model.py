@@ -335,8 +335,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         self._trainer = tr
         def batch_args(epoch, batch):
             """(start, B, epoch, batch, n_choices, entities_list) of a batch, or None past the end"""
-            if batch > self.batches_count:
-                epoch, batch = epoch + 1, 1
+            epoch, batch = epoch + (batch - 1) // self.batches_count, (batch - 1) % self.batches_count + 1
             if epoch > self.epochs:
                 return None
             start = (batch - 1) * batch_size
@@ -351,7 +350,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                 start, B, _, _, nc, el = batch_args(epoch, batch)
                 if B == 0:
                     continue
-                tr.step(start, B, epoch, batch, n_choices=nc, entities_list=el, prefetch=batch_args(epoch, batch + 1))
+                tr.step(start, B, epoch, batch, n_choices=nc, entities_list=el,
+                        prefetch=[batch_args(epoch, batch + j) for j in (1, 2, 3)])
             loss_epoch = tr.read_loss()
             if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)
                 msg = "Loss is {}. Please change the hyperparameters.".format(loss_epoch)
