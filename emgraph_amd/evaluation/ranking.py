@@ -192,7 +192,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     findex = None
     if filter_triples is not None:
         findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
-    out = []
+    pending = []  # (counters on the device, nq) per chunk: every launch is asynchronous, ONE D2H at the end
     for c0 in range(0, n, query_chunk):
         Tc = T[c0:c0 + query_chunk]
         nq = Tc.shape[0]
@@ -200,58 +200,41 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
         n_rows = Q.shape[0]
         cnt = torch.zeros((4, n_rows), dtype=torch.int32, device=ent.device)
+        have_cands = cand.numel() > 0 if cand is not None else slab.shape[0] > 0
         if precision == 1:
             # bf16 MFMA throughput mode (statistical rank agreement; see emg_rank_bf16.hip)
             kp = D.bf16_ld(k_int)
             if ent_bf16 is None:
                 ent_bf16 = D.to_bf16(ent, k_int, ld_dst=kp)
             Qb = D.to_bf16(Q, k_int, ld_dst=kp)
+            # the true entity ties with itself by construction: pos_int comes from the same MFMA arithmetic
             pos_int, self_ent = D.eval_pos_int_bf16(model_id, ent_bf16, k_int, scale, Tt, side_mode, Qb)
-            fp_ = fi_ = None
-            if findex is not None:
-                ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
-                fp_, fi_ = torch.from_numpy(ptr).to(ent.device), torch.from_numpy(idx).to(ent.device)
-            if cand is not None:
-                if cand.numel():
-                    ev = _ev_start(stats)
-                    D.eval_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, k_int, scale, cnt[0], cnt[1], cand=cand)
-                    _ev_stop(stats, ev)
-                    if fp_ is not None:
-                        D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, ent_bf16, 0, k_int, scale, fp_, fi_,
-                                                 cnt[2], cnt[3])
-            elif slab.shape[0]:
-                eb = ent_bf16[e0:e0 + slab.shape[0]]
-                ev = _ev_start(stats)
-                D.eval_count_bf16(model_id, Qb, pos_int, self_ent, eb, k_int, scale, cnt[0], cnt[1], ent_offset=e0)
-                _ev_stop(stats, ev)
-                if fp_ is not None:
-                    D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, eb, e0, k_int, scale, fp_, fi_, cnt[2], cnt[3])
-            if world > 1:
-                parallel.allreduce_sum_(cnt)
-            # the true entity ties with itself by construction (pos_int comes from the same MFMA arithmetic)
-            c = cnt.cpu().numpy().astype(np.int64)
-            out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
-            continue
-        if cand is not None:
-            if cand.numel():
-                ev = _ev_start(stats)
-                D.eval_count(model_id, Q, pos_int, ent, k_int, scale, cnt[0], cnt[1], cand=cand, precision=precision)
-                _ev_stop(stats, ev)
-        elif slab.shape[0]:
+            tab, off = (ent_bf16, 0) if cand is not None else (ent_bf16[e0:e0 + slab.shape[0]], e0)
+            count = lambda: D.eval_count_bf16(model_id, Qb, pos_int, self_ent, tab, k_int, scale, cnt[0], cnt[1],  # noqa: E731
+                                              cand=cand, ent_offset=off)
+            fcount = lambda fp_, fi_: D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, tab, off, k_int,  # noqa: E731
+                                                               scale, fp_, fi_, cnt[2], cnt[3])
+        else:
+            tab, off = (ent, 0) if cand is not None else (slab, e0)
+            count = lambda: D.eval_count(model_id, Q, pos_int, tab, k_int, scale, cnt[0], cnt[1], cand=cand,  # noqa: E731
+                                         precision=precision)
+            fcount = lambda fp_, fi_: D.eval_filter_count(model_id, Q, pos_int, tab, off, k_int, scale, fp_, fi_,  # noqa: E731
+                                                          cnt[2], cnt[3], precision=precision)
+        if have_cands:
             ev = _ev_start(stats)
-            D.eval_count(model_id, Q, pos_int, slab, k_int, scale, cnt[0], cnt[1], precision=precision)
+            count()  # the big kernel goes first: the host-side filter CSR below is built underneath it
             _ev_stop(stats, ev)
         if findex is not None:
             ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
-            if cand is not None:
-                D.eval_filter_count(model_id, Q, pos_int, ent, 0, k_int, scale, torch.from_numpy(ptr).to(ent.device),
-                                    torch.from_numpy(idx).to(ent.device), cnt[2], cnt[3], precision=precision)
-            elif slab.shape[0]:
-                D.eval_filter_count(model_id, Q, pos_int, slab, e0, k_int, scale, torch.from_numpy(ptr).to(ent.device),
-                                    torch.from_numpy(idx).to(ent.device), cnt[2], cnt[3], precision=precision)
+            if have_cands:
+                fcount(torch.from_numpy(ptr).to(ent.device, non_blocking=True),
+                       torch.from_numpy(idx).to(ent.device, non_blocking=True))
         if world > 1:
             parallel.allreduce_sum_(cnt)
-        c = cnt.cpu().numpy()
+        pending.append((cnt, nq))
+    out = []
+    for cnt, nq in pending:
+        c = cnt.cpu().numpy().astype(np.int64)
         out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
     _ev_collect(stats)
     if not out:
