@@ -90,6 +90,22 @@ SIGNATURES.update({
                                  C.POINTER(_f32), _p, _i64, _p]),
 })
 
+class PrepareArgs(C.Structure):
+    """mirror of `emg_prepare_args` (include/emgraph_hip.h)"""
+    _fields_ = [
+        ("pos", _p), ("B", _i64), ("eta", _i32), ("n_sides", _i32), ("sides", _i32 * 4),
+        ("n_choices", _i64), ("entities_list", _p), ("seed", _u64), ("draw_counter0", _u64),
+        ("inj_mask", _p), ("inj_repl", _p),
+        ("codes", _p),
+        ("dest_ent", _p), ("n_extra_ent", _i64), ("n_ent", _i64),
+        ("dest_rel", _p), ("n_extra_rel", _i64), ("n_rel", _i64),
+        ("ws_ent", _p), ("ws_ent_bytes", _i64), ("ws_rel", _p), ("ws_rel_bytes", _i64),
+        ("single_flags", _p),
+    ]
+
+
+SIGNATURES.update({"emg_prepare_batch": (_int, [C.POINTER(PrepareArgs), _p])})
+
 SIGNATURES.update({
     "emg_eval_pos_int_bf16": (_int, [_int, _p, _i64, _i32, _f32, _p, _i64, _int, _p, _i64, _p, _p, _p]),
     "emg_eval_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _p, _p, _p]),

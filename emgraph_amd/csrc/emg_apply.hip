@@ -206,6 +206,92 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
     return EMG_OK;
 }
 
+// Small grouping problems (the relation table: n <= 16384 contributions, keys < 65536) are sorted by ONE
+// workgroup: 16-bit keys and 16-bit positions through rocprim::block_radix_sort (stable), instead of the
+// device-wide sort's histogram + one launch per digit.
+constexpr int BS_THREADS = 1024, BS_ITEMS = 16, BS_MAX = BS_THREADS * BS_ITEMS;
+
+__global__ __launch_bounds__(BS_THREADS) void block_group_kernel(const int32_t* __restrict__ dest, int n, int end_bit,
+                                                                 uint32_t* __restrict__ keys_out,
+                                                                 uint32_t* __restrict__ vals_out) {
+    using sort_t = rocprim::block_radix_sort<uint16_t, BS_THREADS, BS_ITEMS, uint16_t>;
+    __shared__ typename sort_t::storage_type storage;
+    uint16_t k[BS_ITEMS], v[BS_ITEMS];
+    const int base = threadIdx.x * BS_ITEMS;  // blocked arrangement: thread t holds positions [16t, 16t+16)
+#pragma unroll
+    for (int i = 0; i < BS_ITEMS; ++i) {
+        const int idx = base + i;
+        k[i] = idx < n ? (uint16_t)dest[idx] : (uint16_t)0xffffu;  // padding sorts to the back (real keys < 2^end_bit)
+        v[i] = (uint16_t)idx;
+    }
+    sort_t().sort(k, v, storage, 0, end_bit < 16 ? end_bit + 1 : 16);  // +1 bit: keeps the 0xffff padding behind
+#pragma unroll
+    for (int i = 0; i < BS_ITEMS; ++i) {
+        const int idx = base + i;
+        if (idx < n) { keys_out[idx] = k[i]; vals_out[idx] = v[i]; }
+    }
+}
+
+// stable grouping of n destination ids: sorted keys + original positions into the workspace
+static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
+                           uint8_t* single_flags, hipStream_t st) {
+    WsLayout w;
+    int rc = ws_layout(workspace, workspace_bytes, n, &w);
+    if (rc != EMG_OK) return rc;
+    int end_bit = 1;
+    while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
+    if (n <= BS_MAX && end_bit <= 15) {
+        hipLaunchKernelGGL(block_group_kernel, dim3(1), dim3(BS_THREADS), 0, st, dest, (int)n, end_bit, w.keys, w.vals);
+        EMG_LAUNCH_CHECK();
+    } else {
+        size_t tmp = w.temp;
+        // values = original positions, generated on the fly (no iota array)
+        EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(w.tmp, tmp, (const uint32_t*)dest, w.keys,
+                                                      rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
+                                                      end_bit, st, false));
+    }
+    if (single_flags) {
+        hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
+                           single_flags);
+        EMG_LAUNCH_CHECK();
+    }
+    return EMG_OK;
+}
+
+// corruption codes (Philox / injected) + the destination ids they imply, for every corruption side, ONE launch
+struct PrepParams {
+    const int32_t* pos; int64_t B; int32_t eta; int32_t n_sides; int32_t sides[4];
+    uint64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t counter0;
+    const int32_t* inj_mask; const int32_t* inj_repl;
+    int32_t* codes; int32_t* dest_ent; int32_t* dest_rel;
+};
+
+__global__ void prepare_ids_kernel(const PrepParams P) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_side = (int64_t)P.eta * P.B;
+    if (j < P.B) {
+        P.dest_ent[j] = P.pos[3 * j + 0];
+        P.dest_ent[P.B + j] = P.pos[3 * j + 2];
+        P.dest_rel[j] = P.pos[3 * j + 1];
+    }
+    if (j >= per_side * P.n_sides) return;
+    const int sd = (int)(j / per_side);
+    const int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
+    const int side = P.sides[sd];
+    uint32_t keep, idx;
+    if (P.inj_repl) {
+        idx = (uint32_t)P.inj_repl[j];
+        keep = P.inj_mask ? (uint32_t)(P.inj_mask[j] != 0) : 0u;
+    } else {
+        corruption_draw(P.seed, P.counter0 + (uint64_t)sd, (uint64_t)jj, P.n_choices, &keep, &idx);
+    }
+    if (side == EMG_SIDE_O) keep = 1u;
+    else if (side == EMG_SIDE_S) keep = 0u;
+    const uint32_t repl = P.entities_list ? (uint32_t)P.entities_list[idx] : idx;
+    P.codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
+    P.dest_ent[2 * P.B + j] = (int32_t)(repl & 0x7fffffffu);
+}
+
 }  // namespace emg
 
 using namespace emg;
@@ -223,23 +309,33 @@ extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, vo
     EMG_REQUIRE(n >= 0 && n_rows > 0 && n_rows < ((int64_t)1 << 31), "emg_group_dest: bad sizes");
     if (n == 0) return EMG_OK;
     EMG_REQUIRE(dest && workspace, "emg_group_dest: null pointer");
+    return group_dest_impl(dest, n, n_rows, workspace, workspace_bytes, single_flags, (hipStream_t)stream);
+}
+
+extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
+    EMG_REQUIRE(a, "emg_prepare_batch: null args");
+    EMG_REQUIRE(a->B >= 0 && a->eta >= 1 && a->n_sides >= 1 && a->n_sides <= 4, "emg_prepare_batch: bad sizes");
+    if (a->B == 0) return EMG_OK;
+    EMG_REQUIRE(a->pos && a->codes && a->dest_ent && a->dest_rel && a->ws_ent && a->ws_rel, "emg_prepare_batch: null pointer");
+    EMG_REQUIRE(a->inj_repl || a->n_choices > 0, "emg_prepare_batch: n_choices must be positive");
+    EMG_REQUIRE(a->n_extra_ent >= 0 && a->n_extra_rel >= 0 && a->n_ent > 0 && a->n_rel > 0, "emg_prepare_batch: bad table sizes");
     hipStream_t st = (hipStream_t)stream;
-    WsLayout w;
-    int rc = ws_layout(workspace, workspace_bytes, n, &w);
-    if (rc != EMG_OK) return rc;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.vals_in, n, w.cnt);
-    EMG_LAUNCH_CHECK();
-    int end_bit = 1;
-    while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
-    size_t tmp = w.temp;
-    EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(w.tmp, tmp, (const uint32_t*)dest, w.keys, (const uint32_t*)w.vals_in,
-                                                  w.vals, (size_t)n, 0, end_bit, st, false));
-    if (single_flags) {
-        hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                           single_flags);
-        EMG_LAUNCH_CHECK();
+    PrepParams P{};
+    P.pos = a->pos; P.B = a->B; P.eta = a->eta; P.n_sides = a->n_sides;
+    for (int i = 0; i < a->n_sides; ++i) {
+        EMG_REQUIRE(a->sides[i] >= EMG_SIDE_S && a->sides[i] <= EMG_SIDE_SO, "emg_prepare_batch: bad side %d", a->sides[i]);
+        P.sides[i] = a->sides[i];
     }
-    return EMG_OK;
+    P.n_choices = (uint64_t)a->n_choices; P.entities_list = a->entities_list; P.seed = a->seed; P.counter0 = a->draw_counter0;
+    P.inj_mask = a->inj_mask; P.inj_repl = a->inj_repl; P.codes = a->codes;
+    P.dest_ent = a->dest_ent + a->n_extra_ent; P.dest_rel = a->dest_rel + a->n_extra_rel;
+    const int64_t n_neg = a->B * (int64_t)a->eta * a->n_sides;
+    hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)cdiv(n_neg > a->B ? n_neg : a->B, 256)), dim3(256), 0, st, P);
+    EMG_LAUNCH_CHECK();
+    const int64_t n_ce = a->n_extra_ent + 2 * a->B + n_neg, n_cr = a->n_extra_rel + a->B;
+    int rc = group_dest_impl(a->dest_ent, n_ce, a->n_ent, a->ws_ent, a->ws_ent_bytes, a->single_flags, st);
+    if (rc != EMG_OK) return rc;
+    return group_dest_impl(a->dest_rel, n_cr, a->n_rel, a->ws_rel, a->ws_rel_bytes, nullptr, st);
 }
 
 extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,

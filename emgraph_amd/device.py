@@ -192,6 +192,33 @@ def group_dest(dest, n, n_rows, workspace, single_flags=None):
                                _chk_vec(single_flags, torch.uint8, "single_flags"), _stream()), "emg_group_dest")
 
 
+def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, n_rel, ws_ent, ws_rel,
+                  entities_list=None, seed=0, counter0=0, inj_mask=None, inj_repl=None, n_extra_ent=0, n_extra_rel=0,
+                  single_flags=None):
+    """codes of all corruption sides + destination ids + stable grouping (+ singleton flags) in ONE library call"""
+    lib = L.load()
+    B = pos.shape[0]
+    n_neg = B * eta * len(sides)
+    a = L.PrepareArgs()
+    a.pos = _chk_vec(pos, torch.int32, "pos", 3 * B)
+    a.B, a.eta, a.n_sides = B, eta, len(sides)
+    for i, sd in enumerate(sides):
+        a.sides[i] = sd
+    a.n_choices = n_choices
+    a.entities_list = _chk_vec(entities_list, torch.int32, "entities_list")
+    a.seed, a.draw_counter0 = seed & 0xFFFFFFFFFFFFFFFF, counter0 & 0xFFFFFFFFFFFFFFFF
+    a.inj_mask = _chk_vec(inj_mask, torch.int32, "inj_mask", n_neg if inj_mask is not None else None)
+    a.inj_repl = _chk_vec(inj_repl, torch.int32, "inj_repl", n_neg if inj_repl is not None else None)
+    a.codes = _chk_vec(codes, torch.int32, "codes", n_neg)
+    a.dest_ent = _chk_vec(dest_ent, torch.int32, "dest_ent", n_extra_ent + 2 * B + n_neg)
+    a.dest_rel = _chk_vec(dest_rel, torch.int32, "dest_rel", n_extra_rel + B)
+    a.n_extra_ent, a.n_ent, a.n_extra_rel, a.n_rel = n_extra_ent, n_ent, n_extra_rel, n_rel
+    a.ws_ent, a.ws_ent_bytes = ws_ent.data_ptr(), ws_ent.numel() * ws_ent.element_size()
+    a.ws_rel, a.ws_rel_bytes = ws_rel.data_ptr(), ws_rel.numel() * ws_rel.element_size()
+    a.single_flags = _chk_vec(single_flags, torch.uint8, "single_flags")
+    L.check(lib.emg_prepare_batch(C.byref(a), _stream()), "emg_prepare_batch")
+
+
 def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace):
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")

@@ -265,17 +265,14 @@ class Trainer:
         codes = sl["codes"][:B * et]
 
         def run():
-            for sd, side in enumerate(self.sides):
-                counter = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides + sd
-                cs = slice(sd * eta * B, (sd + 1) * eta * B)
-                D.corrupt_codes(B, eta, side, n_choices, self.device, entities_list=entities_list, seed=self.seed,
-                                counter=counter, inj_mask=None if inj_mask is None else inj_mask[cs],
-                                inj_repl=None if inj_repl is None else inj_repl[cs], out=codes[cs])
-            n_ce, xe, xr = (2 + et) * B, self._xe, self._xr
-            D.build_dest(pos, et, codes, sl["dest_ent"][xe:xe + n_ce], sl["dest_rel"][xr:xr + B])
-            D.group_dest(sl["dest_ent"][:xe + n_ce], xe + n_ce, self.n_ent, sl["ws_ent"],
-                         sl["single"][:n_ce] if self.inplace else None)
-            D.group_dest(sl["dest_rel"][:xr + B], xr + B, self.n_rel, sl["ws_rel"], None)
+            # draw counter of side sd = ((epoch-1)*batches_count + (batch-1))*n_sides + sd
+            counter0 = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides
+            xe, xr = self._xe, self._xr
+            n_ce = (2 + et) * B
+            D.prepare_batch(pos, eta, self.sides, n_choices, codes, sl["dest_ent"][:xe + n_ce], sl["dest_rel"][:xr + B],
+                            self.n_ent, self.n_rel, sl["ws_ent"], sl["ws_rel"], entities_list=entities_list,
+                            seed=self.seed, counter0=counter0, inj_mask=inj_mask, inj_repl=inj_repl, n_extra_ent=xe,
+                            n_extra_rel=xr, single_flags=sl["single"][:n_ce] if self.inplace else None)
 
         if self.pipeline:
             side = self.sides_st[self._side_rr]

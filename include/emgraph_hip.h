@@ -131,6 +131,24 @@ int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_en
 int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes,
                    int32_t* dest_ent, int32_t* dest_rel, void* stream);
 
+/* ---- everything about a training batch that does not depend on the tables, in one call (what the step
+ * pipeline runs ahead on a side stream): the corruption codes of every corruption side (as emg_corrupt_codes,
+ * side sd drawing with counter draw_counter0 + sd, codes side-major then eta-major), the destination ids of
+ * all gradient rows (as emg_build_dest) and their stable grouping + singleton flags (as emg_group_dest) for
+ * the entity and the relation table.  dest_ent / dest_rel start with n_extra_* caller-filled entries (the LP
+ * regulariser's dense rows) followed by the batch's; the grouping covers both. */
+typedef struct emg_prepare_args {
+    const int32_t* pos; int64_t B; int32_t eta; int32_t n_sides; int32_t sides[4];
+    int64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t draw_counter0;
+    const int32_t* inj_mask; const int32_t* inj_repl;       /* optional injected draws [n_sides*eta*B] */
+    int32_t* codes;                                          /* out [n_sides*eta*B] */
+    int32_t* dest_ent; int64_t n_extra_ent; int64_t n_ent;   /* out [n_extra_ent + (2+n_sides*eta)*B] */
+    int32_t* dest_rel; int64_t n_extra_rel; int64_t n_rel;   /* out [n_extra_rel + B] */
+    void* ws_ent; int64_t ws_ent_bytes; void* ws_rel; int64_t ws_rel_bytes;  /* emg_apply_workspace_bytes */
+    uint8_t* single_flags;                                   /* optional out, per entity contribution row */
+} emg_prepare_args;
+int emg_prepare_batch(const emg_prepare_args* args, void* stream);
+
 /* ---- K5+K7 fused / extended backward.  One pass over the (3+eta) rows of each positive group:
  *   fused_loss >= 0 (EMG_LOSS_PAIRWISE | EMG_LOSS_NLL | EMG_LOSS_ABSOLUTE_MARGIN — the losses whose
  *       dL/dneg_j depends only on (pos_i, neg_j)): scores, loss (accumulated into *loss_accum) and

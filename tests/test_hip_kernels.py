@@ -481,6 +481,59 @@ def test_bf16_ranks_exact_on_bf16_representable_data(model):
                 np.testing.assert_array_equal(got, exp, err_msg=str((side, strategy, filt is not None, subset is not None)))
 
 
+@pytest.mark.parametrize("B,eta,sides,n_ent,n_rel,xe", [(1000, 5, (2,), 50000, 37, 0), (16384, 3, (0, 1), 300000, 1000, 0),
+                                                         (257, 2, (2,), 90, 70000, 90), (40, 1, (1,), 12, 3, 0)])
+def test_prepare_batch_equals_separate_calls(B, eta, sides, n_ent, n_rel, xe):
+    """emg_prepare_batch == emg_corrupt_codes (per side) + emg_build_dest + emg_group_dest: identical codes,
+    destination ids, sorted keys, ORIGINAL positions (stable) and singleton flags; covers the one-workgroup
+    16-bit sort (<= 16384 rows, ids < 32768) and the device-wide sort, and caller-filled leading rows."""
+    d = dev()
+    rs = np.random.RandomState(B + eta)
+    pos = cu(np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32))
+    et = eta * len(sides)
+    n_ce, n_cr = xe + (2 + et) * B, B
+    mk = lambda n, rows: torch.zeros(d.apply_workspace_bytes(n, rows), dtype=torch.uint8, device="cuda")  # noqa: E731
+    # reference: the separate entry points
+    codes_ref = torch.empty(B * et, dtype=torch.int32, device="cuda")
+    for sd, side in enumerate(sides):
+        d.corrupt_codes(B, eta, side, n_ent, "cuda", seed=7, counter=11 + sd, out=codes_ref[sd * eta * B:(sd + 1) * eta * B])
+    de_ref = torch.empty(n_ce, dtype=torch.int32, device="cuda")
+    dr_ref = torch.empty(n_cr, dtype=torch.int32, device="cuda")
+    de_ref[:xe] = torch.arange(xe, dtype=torch.int32, device="cuda")
+    d.build_dest(pos, et, codes_ref, de_ref[xe:], dr_ref)
+    we_ref, wr_ref = mk(n_ce, n_ent), mk(n_cr, n_rel)
+    single_ref = torch.zeros(n_ce, dtype=torch.uint8, device="cuda")
+    d.group_dest(de_ref, n_ce, n_ent, we_ref, single_ref)
+    d.group_dest(dr_ref, n_cr, n_rel, wr_ref, None)
+    # one call
+    codes = torch.empty_like(codes_ref)
+    de, dr = torch.empty_like(de_ref), torch.empty_like(dr_ref)
+    de[:xe] = torch.arange(xe, dtype=torch.int32, device="cuda")
+    we, wr = mk(n_ce, n_ent), mk(n_cr, n_rel)
+    single = torch.zeros(n_ce, dtype=torch.uint8, device="cuda")
+    d.prepare_batch(pos, eta, list(sides), n_ent, codes, de, dr, n_ent, n_rel, we, wr, seed=7, counter0=11,
+                    n_extra_ent=xe, single_flags=single)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(codes.cpu().numpy(), codes_ref.cpu().numpy())
+    np.testing.assert_array_equal(de.cpu().numpy(), de_ref.cpu().numpy())
+    np.testing.assert_array_equal(dr.cpu().numpy(), dr_ref.cpu().numpy())
+    np.testing.assert_array_equal(single.cpu().numpy(), single_ref.cpu().numpy())
+
+    def grouped(ws, n):  # workspace layout: keys | (unused) | vals, each 256-byte aligned
+        kb = (4 * n + 255) // 256 * 256
+        raw = ws.cpu().numpy()
+        return raw[:4 * n].view(np.uint32), raw[2 * kb:2 * kb + 4 * n].view(np.uint32)
+    for ws, ws_ref, dest, n in ((we, we_ref, de, n_ce), (wr, wr_ref, dr, n_cr)):
+        keys, vals = grouped(ws, n)
+        kref, vref = grouped(ws_ref, n)
+        dn = dest.cpu().numpy()
+        order = np.argsort(dn, kind="stable")
+        np.testing.assert_array_equal(keys, dn[order].astype(np.uint32))
+        np.testing.assert_array_equal(vals, order.astype(np.uint32))
+        np.testing.assert_array_equal(keys, kref)
+        np.testing.assert_array_equal(vals, vref)
+
+
 @pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 5000, 300), ("HolE", 200, 3001, 130),
                                               ("DistMult", 32, 700, 40), ("DistMult", 64, 1024, 128),
                                               ("ComplEx", 96, 2049, 257), ("DistMult", 7, 100, 5),
