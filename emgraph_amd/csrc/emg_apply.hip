@@ -90,7 +90,15 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
         // segment end: the next head inside the window (ballot, no memory traffic), else scan on past the window
         const unsigned long long after = heads & ~((2ull << b) - 1ull);
         int64_t end = after ? w0 + (__ffsll((long long)after) - 1) : wend;
-        if (!after) while (end < P.n && P.keys[end] == key) ++end;
+        if (!after) {  // 64 keys per trip: a serial scan costs one dependent load per row of a long segment
+            for (;;) {
+                const int64_t q = end + lane;
+                const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
+                if (same == ~0ull) { end += 64; continue; }
+                end += __ffsll((long long)~same) - 1;
+                break;
+            }
+        }
         auto contrib_index = [&](int64_t u) -> int64_t {  // wave-uniform u
             return u < wend ? (int64_t)__shfl(myval, (int)(u - w0), 64) : (int64_t)P.vals[u];
         };
@@ -106,7 +114,23 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
                 float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA, wA = accA, wB = accA;
                 if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
                 if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
-                for (int64_t u = t; u < end; u += 2) {
+                int64_t u = t;
+                // long segments (a relation row collects hundreds of contributions): eight rows in flight per trip
+                for (; u + 8 <= end; u += 8) {
+                    float4 va[8], vb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float* rj = P.contrib + contrib_index(u + j) * P.ldc;
+                        va[j] = oa ? *reinterpret_cast<const float4*>(rj + 4 * ca) : accA;
+                        vb[j] = ob ? *reinterpret_cast<const float4*>(rj + 4 * cb) : accA;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {  // added in contribution order
+                        if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
+                        if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
+                    }
+                }
+                for (; u < end; u += 2) {
                     const bool two = u + 1 < end;
                     const float* r0 = P.contrib + contrib_index(u) * P.ldc;
                     const float* r1 = two ? P.contrib + contrib_index(u + 1) * P.ldc : r0;
