@@ -17,6 +17,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "emg_common.hpp"
+#include <mutex>
 
 namespace emg {
 
@@ -195,12 +196,25 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                               rocprim::default_config, 4096>;
 
+// the size query walks rocPRIM's host-side config selection (device lookup included): remember the last few
+// answers — a training run asks for the same two sizes four times per step
 static int sort_temp_bytes(int64_t n, size_t* bytes) {
     *bytes = 0;
     if (n <= 0) return EMG_OK;
+    static std::mutex mu;
+    static int64_t cached_n[8] = {0};
+    static size_t cached_b[8] = {0};
+    static int next = 0;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (int i = 0; i < 8; ++i)
+            if (cached_n[i] == n) { *bytes = cached_b[i]; return EMG_OK; }
+    }
     EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
                                                   (hipStream_t)0, false));
+    std::lock_guard<std::mutex> g(mu);
+    cached_n[next] = n; cached_b[next] = *bytes; next = (next + 1) & 7;
     return EMG_OK;
 }
 
