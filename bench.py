@@ -94,6 +94,10 @@ def run_train(args, rank, world):
     # weak scaling: the per-GPU batch is fixed, the GLOBAL batch grows with N.  With k-sharding every rank
     # walks all B_global groups but only its 1/N column slab of each row => per-GPU bytes stay constant.
     B0, eta = (args.batch or w["B"]), w["eta"]
+    real_world = world
+    sim = max(1, args.simulate_ranks)   # profiling aid: ONE GPU runs rank 0's share of an N-rank job (no collective)
+    if sim > 1:
+        world, rank = sim, 0
     B = B0 * world
     steps, warm = args.steps, args.warmup
     rs = np.random.RandomState(0)  # init seed 0 (constants.py:52)
@@ -117,7 +121,7 @@ def run_train(args, rank, world):
     for i in range(warm):
         tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
     torch.cuda.synchronize()
-    if world > 1:
+    if real_world > 1:
         import torch.distributed as dist
         dist.barrier()
     tr.enable_stage_timing()
@@ -127,11 +131,11 @@ def run_train(args, rank, world):
         tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
     t_issue = time.perf_counter() - t0  # host time to enqueue the timed steps (host-bound if ~= dt)
     torch.cuda.synchronize()
-    if world > 1:
+    if real_world > 1:
         import torch.distributed as dist
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if real_world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,6 +299,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--eval-triples", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work timed for cpu_baseline")
+    ap.add_argument("--simulate-ranks", type=int, default=1,
+                    help="profiling aid: run rank 0's share (column slab, N-fold batch) of an N-rank job on one GPU; "
+                         "the all-reduce is a no-op, results are not a valid bench line")
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="A/B: separate forward / loss / backward kernels")
