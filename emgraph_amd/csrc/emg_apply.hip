@@ -170,6 +170,146 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     }
 }
 
+// Variant of apply_rows_kernel for SKINNY rows (<= 16 sixteen-byte chunks: a column slab of an 8-GPU job, TransE
+// k <= 64): LPS lanes work on one segment (16-byte chunk c of the row on lane c % LPS), so a wave processes 64/LPS segments
+// at once — with all 64 lanes on one segment a 200-byte row keeps 13 lanes busy (0.81 -> 0.55 ms on the 8-rank
+// share).  Wider rows stay on apply_rows_kernel: its contribution indices come from v_readlane (wave-uniform),
+// here they need a ds_bpermute per row, which costs more than the idle lanes once a row fills >= 25 lanes.
+template <int W, int LPS>
+__global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P) {
+    constexpr int NSUB = 64 / LPS;
+    constexpr unsigned long long SUBMASK = LPS == 64 ? ~0ull : ((1ull << (LPS & 63)) - 1ull);
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPS, sl = lane % LPS;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t w0 = wave * P.win;
+    const int64_t t0 = w0 + lane;
+    const bool in = lane < P.win && t0 < P.n;
+    const uint32_t mykey = in ? P.keys[t0] : 0u;
+    const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
+    const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
+    const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long todo = __ballot(head && !(P.skip_single && last));
+    const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
+    const int nchunks = P.k_int / W;
+    const int ntodo = __popcll(todo);
+    for (int it = 0; it * NSUB < ntodo; ++it) {
+        // this round's heads: ranks it*NSUB .. it*NSUB+NSUB-1 among the todo bits; subgroup `sub` takes the sub-th
+        unsigned long long m = todo;
+        for (int j = 0; j < it * NSUB + sub && m; ++j) m &= m - 1;
+        const bool has0 = m != 0ull;
+        const int b = has0 ? __ffsll((long long)m) - 1 : 0;
+        const int64_t t = w0 + b;
+        const uint32_t key = __shfl(mykey, b, 64);
+        const bool has = has0 && (int64_t)key < P.n_rows;  // defensive: never write outside the table
+        // segment end: the next head inside the window (ballot, no memory traffic), else scan on past the window
+        const unsigned long long after = heads & ~((2ull << b) - 1ull);
+        int64_t end = after ? w0 + (__ffsll((long long)after) - 1) : wend;
+        bool open = has && !after;
+        while (__ballot(open)) {  // LPS keys per trip (a serial scan costs one dependent load per row of a long segment)
+            const int64_t q = end + sl;
+            const unsigned long long same = __ballot(open && q < P.n && P.keys[q] == key);
+            const unsigned long long mine = (same >> (sub * LPS)) & SUBMASK;
+            if (open) {
+                if (mine == SUBMASK) {
+                    end += LPS;
+                } else {
+                    end += __ffsll((long long)~mine) - 1;
+                    open = false;
+                }
+            }
+        }
+        if (!has) end = t;  // nothing to do for this subgroup in this round
+        auto contrib_index = [&](int64_t u) -> int64_t {  // u is uniform inside a subgroup
+            const uint32_t inwin = __shfl(myval, (int)(u < wend ? u - w0 : 0), 64);
+            return u < wend ? (int64_t)inwin : (int64_t)P.vals[u];
+        };
+        float* wrow = P.table + (int64_t)key * P.ld;
+        float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+        float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+        if constexpr (W == 4) {
+            // two row chunks per lane x two contributions per trip (eight for long segments): independent 16-byte
+            // loads in flight, added in contribution order (bit-reproducible sums).  The trip counts depend on the
+            // subgroup's segment: the shuffles inside contrib_index need every lane, so all subgroups run the
+            // longest trip count and idle ones repeat their last row into a discarded sum.
+            for (int c0 = 0; c0 < nchunks; c0 += 2 * LPS) {
+                const int ca = c0 + sl, cb = c0 + LPS + sl;
+                const bool oa = has && ca < nchunks, ob = has && cb < nchunks;
+                float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA, wA = accA, wB = accA;
+                if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
+                if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
+                int64_t u = t;
+                while (__ballot(u + 8 <= end)) {  // (wave-uniform loop: see above)
+                    const bool act = u + 8 <= end;
+                    float4 va[8], vb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t ci = contrib_index(act ? u + j : t);
+                        const float* rj = P.contrib + ci * P.ldc;
+                        va[j] = (act && oa) ? *reinterpret_cast<const float4*>(rj + 4 * ca) : accA;
+                        vb[j] = (act && ob) ? *reinterpret_cast<const float4*>(rj + 4 * cb) : accA;
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {  // added in contribution order
+                            if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
+                            if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
+                        }
+                        u += 8;
+                    }
+                }
+                while (__ballot(u < end)) {
+                    const bool act = u < end, two = u + 1 < end;
+                    const int64_t i0 = contrib_index(act ? u : t), i1 = contrib_index(two ? u + 1 : t);
+                    const float* r0 = P.contrib + i0 * P.ldc;
+                    const float* r1 = P.contrib + i1 * P.ldc;
+                    float4 v0a = accA, v0b = accA, v1a = accA, v1b = accA;
+                    if (act && oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
+                    if (act && ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
+                    if (two && oa) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
+                    if (two && ob) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
+                    if (act && oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
+                    if (act && ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
+                    if (two && oa) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
+                    if (two && ob) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
+                    if (act) u += 2;
+                }
+                auto finish = [&](int c, float4 wv, const float4& g) {
+                    const int64_t off = 4 * (int64_t)c;
+                    float w[4] = {wv.x, wv.y, wv.z, wv.w};
+                    const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        opt_update_elem(P.opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+                    *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
+                };
+                if (oa) finish(ca, wA, accA);
+                if (ob) finish(cb, wB, accB);
+            }
+        } else {
+            for (int c0 = 0; c0 < nchunks; c0 += LPS) {
+                const int c = c0 + sl;
+                const bool oc = has && c < nchunks;
+                float acc = 0.f;
+                int64_t u = t;
+                while (__ballot(u < end)) {
+                    const bool act = u < end;
+                    const int64_t ci = contrib_index(act ? u : t);
+                    if (act && oc) acc += P.contrib[ci * P.ldc + c];
+                    if (act) ++u;
+                }
+                if (oc) {
+                    float wv = wrow[c];
+                    opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
+                    wrow[c] = wv;
+                }
+            }
+        }
+        if (P.tag && sl == 0 && has) P.tag[key] = P.step;
+    }
+}
+
 // Keras Adam's sparse apply is dense-equivalent (every row: m*=b1, v*=b2, w -= lr_t m/(sqrt v + eps));
 // rows touched this step were fully handled elsewhere and are skipped via tag.
 __global__ __launch_bounds__(256) void adam_untouched_kernel(const ApplyParams P) {
@@ -409,7 +549,11 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         while (win > 1 && n_contrib / win < 16384) win >>= 1;
         P.win = win;
         const dim3 grid((unsigned)cdiv(cdiv(n_contrib, win) * 64, 256)), block(256);
-        if (vec) hipLaunchKernelGGL((apply_rows_kernel<4>), grid, block, 0, st, P);
+        const int nch = vec ? k_int / 4 : k_int;
+        if (nch <= 16) {  // skinny rows: four segments per wave
+            if (vec) hipLaunchKernelGGL((apply_rows_sub_kernel<4, 16>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((apply_rows_sub_kernel<1, 16>), grid, block, 0, st, P);
+        } else if (vec) hipLaunchKernelGGL((apply_rows_kernel<4>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((apply_rows_kernel<1>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
     }

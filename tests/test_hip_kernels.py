@@ -306,6 +306,35 @@ def test_apply_rows_vs_oracle(opt):
         np.testing.assert_array_equal(Wt.cpu().numpy()[30:], W[30:])  # untouched rows bit-identical
 
 
+@pytest.mark.parametrize("k,n_rows,n_c,hot", [(12, 40, 3000, 0), (50, 300, 5000, 0), (100, 64, 20000, 0), (200, 500, 9000, 0),
+                                              (400, 200, 6000, 0), (7, 33, 2000, 0), (30, 50, 700, 0), (52, 2000, 40000, 500)])
+def test_apply_rows_sums_in_contribution_order(k, n_rows, n_c, hot):
+    """bit-exact: every destination row gets w - lr * (fp32 sum of its contributions IN INDEX ORDER).  Covers the
+    16 / 32 / 64 lanes-per-segment variants, the scalar (k % 4 != 0) kernels, segments longer than a wave's window
+    (one hot destination collecting `hot` rows) and untouched rows."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(k + n_c)
+    W = rs.randn(n_rows, k).astype(F32)
+    dest = rs.randint(0, n_rows - 3, n_c).astype(np.int32)          # the last three rows stay untouched
+    if hot:
+        dest[rs.choice(n_c, hot, replace=False)] = 5
+    contrib = rs.randn(n_c, k).astype(F32)
+    Wt = cu(W)
+    ws = torch.empty(d.apply_workspace_bytes(n_c, n_rows), dtype=torch.uint8, device="cuda")
+    lr = F32(0.05)
+    d.apply_rows(L.OPT_SGD, Wt, k, None, None, None, 1, cu(contrib), cu(dest), n_c, (float(lr), 0, 0, 0, 0, 0), ws)
+    exp = W.copy()
+    order = np.argsort(dest, kind="stable")
+    bounds = np.flatnonzero(np.diff(dest[order])) + 1
+    for seg in np.split(order, bounds):
+        g = np.zeros(k, F32)
+        for i in seg:                                               # sequential fp32 adds, index order
+            g = g + contrib[i]
+        exp[dest[seg[0]]] = W[dest[seg[0]]] - lr * g
+    np.testing.assert_array_equal(Wt.cpu().numpy(), exp)
+
+
 def test_apply_rows_is_deterministic():
     d = dev()
     from emgraph_amd import _lib as L
