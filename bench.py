@@ -68,12 +68,12 @@ def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None
 
 def pmc_traffic(stage, args, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
+    (profiles/r1_d_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
     doubled per MI355X_MICROARCH.md).  Only valid for the configuration it was collected on; else null."""
     if stage != "fused" or args.workload != "C3" or args.batch or world != 1 or args.no_inplace or args.no_fused:
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_d_pmc_traffic.json")))
         k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
         return k[0]["hbm_bytes_per_launch"] if k else None
     except (OSError, ValueError, KeyError):
