@@ -127,5 +127,22 @@ def sharded_fit_worker(rank, world, out_dir, name, loss, opt):
     m.fit(X[:800])
     ranks = evaluate_performance(X[800:], m, filter_triples=X, corrupt_side="s,o")
     ranks_sub = evaluate_performance(X[800:840], m, filter_triples=X, corrupt_side="s+o", entities_subset=list(range(0, 80, 3)))
+    extra = {}
+    if name in ("ComplEx", "DistMult", "HolE"):
+        # bf16 MFMA mode, range-sharded: integer counters, so the 2-rank result must equal the 1-rank one exactly
+        from emgraph_amd import _lib as L
+        from emgraph_amd.evaluation import rank_triples_device
+        E, R = m.trained_model_params
+        k_int = E.shape[1]
+        sc = 2.0 / 10 if name == "HolE" else 1.0
+        Xi = X[800:].astype(np.int32)
+        from emgraph_amd.training import alloc_table
+        dev0 = torch.device("cuda")
+        ent, rel = alloc_table(E.shape[0], k_int, dev0, init=E), alloc_table(R.shape[0], k_int, dev0, init=R)
+        mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "HolE": L.HOLE}[name]
+        extra["ranks_bf16"] = rank_triples_device(mid, ent, rel, k_int, sc, Xi, "s,o", "worst", filter_triples=X.astype(np.int32),
+                                                  precision=1, shard=(rank, world))
+        extra["ranks_bf16_single"] = rank_triples_device(mid, ent, rel, k_int, sc, Xi, "s,o", "worst",
+                                                         filter_triples=X.astype(np.int32), precision=1)
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
-             ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:]))
+             ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:]), **extra)
