@@ -97,6 +97,7 @@ def alloc_table(rows, k_int, device, init=None, fill=None):
 # Two, not more: main + apply_rel stream + 2 side streams = 4 = the HIP runtime's hardware queues per device;
 # a fifth stream is multiplexed onto them and the step got SLOWER (measured 0.47 -> 0.67 ms at 3, 0.73 at 4).
 LOOKAHEAD = int(os.environ.get("EMG_LOOKAHEAD", "2"))
+AUX_MIN_ROWS = 100_000  # entity contribution rows per batch above which apply_rel gets its own stream
 
 
 class Trainer:
@@ -372,7 +373,9 @@ class Trainer:
         apply_rel = lambda: D.apply_grouped(self.opt_id, self.rel, self.k_int, self.state_rel[0],  # noqa: E731
                                             self.state_rel[1], self.tag_rel, self.step_count, cr, n_cr,
                                             False, hyper, sl["ws_rel"])
-        if self.aux is not None:
+        # (small batches stay on one stream: the fork/join costs ~60 us of host time, more than the overlap buys)
+        use_aux = self.aux is not None and n_ce >= AUX_MIN_ROWS
+        if use_aux:
             # the relation table's apply (few, long segments: latency-bound, ~0.06 ms at 0.5 TB/s) is independent
             # of the entity table's: it runs on a second stream underneath it
             main = torch.cuda.current_stream()
@@ -384,7 +387,7 @@ class Trainer:
         self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
                                                          self.state_ent[1], self.tag_ent, self.step_count, ce, n_ce,
                                                          self.inplace, hyper, sl["ws_ent"]))
-        if self.aux is not None:
+        if use_aux:
             torch.cuda.current_stream().wait_event(self.aux_join)
         else:
             self._timed("apply_rel", apply_rel)
