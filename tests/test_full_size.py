@@ -1,0 +1,209 @@
+"""GPU tests at BASELINE.json's FULL sizes (|E| = 1M, k = 200, eta = 20, B = 16384), through size-independent
+properties — the oracle cannot run these sizes in seconds, so each test checks an invariant the domain offers:
+consistency between two independent code paths, linearity of integer counters over entity ranges, a checksum of
+checksums, idempotence, determinism, monotonicity of the comparison strategies.  fp32 tolerances are written at
+each assert; everything integer is exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+N_ENT, N_REL, K, ETA, B = 1_000_000, 1000, 200, 20, 16384
+K_INT = 2 * K
+
+
+def dev():
+    from emgraph_amd import device
+    device.require_gpu()
+    return device
+
+
+@pytest.fixture(scope="module")
+def world():
+    """trained-scale ComplEx tables of the C3/C4 shape + one batch of positives, all on the device"""
+    from emgraph_amd.training import alloc_table
+    dev()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ent = alloc_table(N_ENT, K_INT, torch.device("cuda"))
+    rel = alloc_table(N_REL, K_INT, torch.device("cuda"))
+    ent[:, :K_INT] = torch.randn((N_ENT, K_INT), generator=g, device="cuda") * 0.1
+    rel[:, :K_INT] = torch.randn((N_REL, K_INT), generator=g, device="cuda") * 0.1
+    rs = np.random.RandomState(5)
+    pos = np.stack([rs.randint(0, N_ENT, B), rs.randint(0, N_REL, B), rs.randint(0, N_ENT, B)], 1).astype(np.int32)
+    return ent, rel, torch.from_numpy(pos).cuda(), pos
+
+
+def complex_score_f64(ent, rel, spo):
+    """plain torch float64 restatement of ComplEx._fn (ComplEx.py:288-298) on gathered rows"""
+    s, p, o = (ent[spo[:, 0].long(), :K_INT].double(), rel[spo[:, 1].long(), :K_INT].double(),
+               ent[spo[:, 2].long(), :K_INT].double())
+    sr, si, pr, pi, or_, oi = s[:, :K], s[:, K:], p[:, :K], p[:, K:], o[:, :K], o[:, K:]
+    val = (pr * sr * or_ + pr * si * oi + pi * sr * oi - pi * si * or_).sum(1)
+    mag = (pr.abs() * sr.abs() * or_.abs() + pr.abs() * si.abs() * oi.abs() + pi.abs() * sr.abs() * oi.abs()
+           + pi.abs() * si.abs() * or_.abs()).sum(1)
+    return val, mag
+
+
+def test_corruptions_full_size_properties(world):
+    """344k draws: range, side balance, uniformity, determinism, counter sensitivity, expand semantics"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    _, _, pos_t, pos = world
+    codes = d.corrupt_codes(B, ETA, L.SIDE_SO, N_ENT, "cuda", seed=3, counter=17)
+    again = d.corrupt_codes(B, ETA, L.SIDE_SO, N_ENT, "cuda", seed=3, counter=17)
+    other = d.corrupt_codes(B, ETA, L.SIDE_SO, N_ENT, "cuda", seed=3, counter=18)
+    c = codes.cpu().numpy()
+    np.testing.assert_array_equal(c, again.cpu().numpy())                       # counter-based: a pure function
+    assert (c != other.cpu().numpy()).mean() > 0.99
+    repl, keep = c & 0x7FFFFFFF, (c < 0)
+    assert repl.min() >= 0 and repl.max() < N_ENT
+    n = c.size
+    assert abs(keep.mean() - 0.5) < 4 * 0.5 / np.sqrt(n)                          # Bernoulli(1/2), 4 sigma
+    hist = np.bincount(repl // (N_ENT // 100), minlength=100)[:100]
+    assert np.abs(hist - n / 100).max() < 5 * np.sqrt(n / 100)                    # uniform over 100 buckets, 5 sigma
+    x = d.corrupt_expand(pos_t, ETA, codes).cpu().numpy()
+    tiled = np.tile(pos, (ETA, 1))                                                # eta-major: row j <-> positive j mod B
+    np.testing.assert_array_equal(x[:, 1], tiled[:, 1])
+    np.testing.assert_array_equal(x[keep, 0], tiled[keep, 0])                     # kept subject
+    np.testing.assert_array_equal(x[~keep, 2], tiled[~keep, 2])                   # kept object
+    np.testing.assert_array_equal(np.where(keep, x[:, 2], x[:, 0]), repl)
+    for side, kept_col in ((L.SIDE_S, 2), (L.SIDE_O, 0)):
+        cs = d.corrupt_codes(B, ETA, side, N_ENT, "cuda", seed=3, counter=17)
+        xs = d.corrupt_expand(pos_t, ETA, cs).cpu().numpy()
+        np.testing.assert_array_equal(xs[:, kept_col], tiled[:, kept_col])
+
+
+def test_scores_full_size_two_paths_and_f64(world):
+    """group-fused forward == arbitrary-triple scoring of the expanded corruptions (bitwise), and both within
+    1e-4 * sum|terms| of a float64 torch restatement"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    ent, rel, pos_t, _ = world
+    codes = d.corrupt_codes(B, ETA, L.SIDE_SO, N_ENT, "cuda", seed=0, counter=1)
+    sp, sn = d.train_forward(L.COMPLEX, ent, rel, K_INT, 1.0, pos_t, ETA, codes)
+    xneg = d.corrupt_expand(pos_t, ETA, codes)
+    sn2 = d.score_triples(L.COMPLEX, ent, rel, K_INT, 1.0, xneg)
+    sp2 = d.score_triples(L.COMPLEX, ent, rel, K_INT, 1.0, pos_t)
+    assert torch.equal(sn, sn2) and torch.equal(sp, sp2)
+    ref, mag = complex_score_f64(ent, rel, xneg)
+    assert float(((sn.double() - ref).abs() / (mag + 1e-12)).max()) < 1e-4
+    assert float(sn.double().sum() - ref.sum()) == pytest.approx(0.0, abs=1e-4 * float(mag.sum()) / np.sqrt(len(mag)))
+
+
+def _trainer(ent, rel, **kw):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    E = ent[:, :K_INT].cpu().numpy()
+    R = rel[:, :K_INT].cpu().numpy()
+    return Trainer(L.COMPLEX, K_INT, 1.0, E, R, ETA, loss="nll", optimizer="sgd", optimizer_params={"lr": 0.05},
+                   batches_count=4, seed=0, **kw)
+
+
+def test_training_step_full_size_invariants(world):
+    """one C3 step: (1) rows outside {s, o, replacements} are bit-identical, (2) the fused + in-place + pipelined plan
+    and the plain forward / loss / backward / sort-apply plan agree, (3) repeating the run is bit-identical,
+    (4) checksum: sum(delta table) == -lr * sum(all gradient rows) accumulated independently in float64"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    ent, rel, pos_t, pos = world
+    X = np.concatenate([pos, pos[::-1]])  # two batches resident, train on the first
+    outs = []
+    for kw in (dict(), dict(), dict(fused=False, inplace=False, pipeline=False)):
+        tr = _trainer(ent, rel, **kw)
+        tr.set_training_set(X, B)
+        tr.step(0, B, epoch=1, batch=1)
+        torch.cuda.synchronize()
+        outs.append((tr.ent[:, :K_INT].clone(), tr.rel[:, :K_INT].clone(), tr.read_loss()))
+        del tr
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    # plans agree: same gradients, different fp32 summation order inside a row's segment -> 1e-5 relative
+    assert float((outs[0][0] - outs[2][0]).abs().max()) <= 1e-5 * float(outs[2][0].abs().max())
+    assert outs[0][2] == pytest.approx(outs[2][2], rel=1e-6)
+    E0, E1 = ent[:, :K_INT], outs[0][0]
+    codes = d.corrupt_codes(B, ETA, L.SIDE_SO, N_ENT, "cuda", seed=0, counter=0)  # epoch 1, batch 1, side 0
+    touched = torch.zeros(N_ENT, dtype=torch.bool, device="cuda")
+    touched[pos_t[:, 0].long()] = True
+    touched[pos_t[:, 2].long()] = True
+    touched[(codes & 0x7FFFFFFF).long()] = True
+    assert torch.equal(E1[~touched], E0[~touched])                                 # untouched rows: bit-identical
+    assert float((E1[touched] - E0[touched]).abs().sum()) > 0
+    # checksum of checksums: independent gradient rows (external dL/dscore path, no in-place, no apply)
+    sp, sn = d.train_forward(L.COMPLEX, ent, rel, K_INT, 1.0, pos_t, ETA, codes)
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    gp = torch.empty(B, dtype=torch.float32, device="cuda")
+    gn = torch.empty(B * ETA, dtype=torch.float32, device="cuda")
+    d.loss(L.LOSS_NLL, sp, sn, B, ETA, 1, 1.0, 0.5, acc, gp, gn)
+    ce = torch.empty(((2 + ETA) * B, K_INT), dtype=torch.float32, device="cuda")
+    cr = torch.empty((B, K_INT), dtype=torch.float32, device="cuda")
+    d.train_backward_ex(L.COMPLEX, ent, rel, K_INT, 1.0, pos_t, ETA, codes, ce, cr, fused_loss=-1, g_pos=gp, g_neg=gn)
+    lr = 0.05
+    d_ent = float((E1.double() - E0.double()).sum())
+    d_rel = float((outs[0][1].double() - rel[:, :K_INT].double()).sum())
+    g_ent, g_rel = float(ce.double().sum()), float(cr.double().sum())
+    scale_e, scale_r = float(ce.double().abs().sum()), float(cr.double().abs().sum())
+    assert abs(d_ent + lr * g_ent) < 1e-6 * lr * scale_e
+    assert abs(d_rel + lr * g_rel) < 1e-6 * lr * scale_r
+    assert float(acc.item()) == pytest.approx(outs[0][2], rel=1e-6)               # the loss value itself
+
+
+def test_zero_learning_rate_step_is_idempotent(world):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    ent, rel, _, pos = world
+    tr = Trainer(L.COMPLEX, K_INT, 1.0, ent[:, :K_INT].cpu().numpy(), rel[:, :K_INT].cpu().numpy(), ETA, loss="nll",
+                 optimizer="sgd", optimizer_params={"lr": 0.0}, batches_count=1, seed=0)
+    tr.set_training_set(pos, B)
+    tr.step(0, B, epoch=1, batch=1)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.ent[:, :K_INT], ent[:, :K_INT]) and torch.equal(tr.rel[:, :K_INT], rel[:, :K_INT])
+
+
+def test_ranking_full_size_invariants(world):
+    """1-vs-all over 1M entities: counters are linear over entity ranges, agree with an independent torch
+    reduction of the kernel's own dense scores, dense scores agree with float64, filtered <= raw,
+    best <= middle <= worst; the bf16 mode keeps the self tie and tracks the exact ranks"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex, rank_triples_device
+    d = dev()
+    ent, rel, pos_t, pos = world
+    T = pos[:96]
+    Tt = pos_t[:96]
+    Q, pos_int = d.eval_build_queries(L.COMPLEX, ent, rel, K_INT, 1.0, Tt, L.EVAL_SPO)
+    n_rows = Q.shape[0]
+    full = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    d.eval_count(L.COMPLEX, Q, pos_int, ent, K_INT, 1.0, full[0], full[1])
+    parts = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    for a, b in ((0, 333_333), (333_333, 333_400), (333_400, N_ENT)):           # ragged ranges, counters accumulate
+        d.eval_count(L.COMPLEX, Q, pos_int, ent[a:b], K_INT, 1.0, parts[0], parts[1])
+    assert torch.equal(full, parts)
+    assert int(full[1].min()) >= 1                                                # every positive ties with itself
+    # independent reduction of the kernel's dense scores for a slice of the rows
+    S = d.eval_scores_dense(L.COMPLEX, Q[:32], ent, K_INT, 1.0)                  # [32, 1M]
+    ci = (S * 100000.0).to(torch.int32)                                           # truncation toward zero, as the reference
+    p = pos_int[:32, None]
+    assert torch.equal((ci > p).sum(1).to(torch.int32), full[0, :32])
+    assert torch.equal((ci == p).sum(1).to(torch.int32), full[1, :32])
+    ref = Q[:32, :K_INT].double() @ ent[:, :K_INT].double().T
+    mag = Q[:32, :K_INT].double().abs() @ ent[:, :K_INT].double().abs().T
+    assert float(((S.double() - ref).abs() / (mag + 1e-12)).max()) < 1e-4
+    del S, ci, ref, mag
+    # public ranking: filtered <= raw, strategies ordered, 's,o' columns are the 's' and 'o' runs
+    F = FilterIndex(np.concatenate([pos, pos[:, [2, 1, 0]]]))
+    raw = rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "s,o", "worst")
+    flt = {s: rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "s,o", s, filter_triples=F)
+           for s in ("worst", "middle", "best")}
+    assert np.all(flt["worst"] <= raw) and raw.min() >= 1 and raw.max() <= N_ENT + 1
+    assert np.all(flt["best"] <= flt["middle"]) and np.all(flt["middle"] <= flt["worst"])
+    np.testing.assert_array_equal(flt["worst"][:, 0], rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "s", "worst",
+                                                                          filter_triples=F))
+    np.testing.assert_array_equal(flt["worst"][:, 1], rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "o", "worst",
+                                                                          filter_triples=F))
+    # query-chunking must not matter
+    np.testing.assert_array_equal(raw, rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "s,o", "worst", query_chunk=40))
+    # bf16 throughput mode (register-stationary kernel: 192 rows > 128): statistical agreement, exact self tie
+    fast = rank_triples_device(L.COMPLEX, ent, rel, K_INT, 1.0, T, "s,o", "worst", filter_triples=F, precision=1)
+    rel_err = np.abs(fast - flt["worst"]) / N_ENT
+    assert np.median(rel_err) < 2e-3 and rel_err.max() < 2e-2, (np.median(rel_err), rel_err.max())
+    assert fast.min() >= 1
