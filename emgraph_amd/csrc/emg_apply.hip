@@ -26,30 +26,10 @@ struct ApplyParams {
     float* state0; float* state1; int32_t* tag; int32_t step;
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
-    const uint32_t* heads; const uint32_t* head_count;  // [0]: multi-row segments (front), [1]: singletons (back)
     int32_t skip_single;
     int32_t win;  // sorted positions per wave
     OptParams opt;
 };
-
-__global__ void iota_kernel(uint32_t* v, int64_t n, uint32_t* cnt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
-    if (i == 0) { cnt[0] = 0u; cnt[1] = 0u; }  // head-list counters (saves a memset launch)
-}
-
-// wave-aggregated append: ONE atomic per wave per list (a per-lane returning atomic on one counter
-// serialises at ~10 ns each: 3e5 of them cost more than the whole sort)
-__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0u;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
 
 // flags[original index] = 1 iff its destination occurs exactly once in the batch
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
@@ -358,10 +338,10 @@ static int sort_temp_bytes(int64_t n, size_t* bytes) {
     return EMG_OK;
 }
 
-// workspace layout: [keys_sorted | vals_in (iota) | vals_sorted | heads | 2 counters | rocprim temp]
+// workspace layout: [keys_sorted | (unused) | vals_sorted | (unused) | 256 B | rocprim temp]  (sizes kept: ABI)
 struct WsLayout {
     size_t kb, temp;
-    uint32_t *keys, *vals_in, *vals, *heads, *cnt;
+    uint32_t *keys, *vals;
     void* tmp;
 };
 
@@ -376,10 +356,7 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
                 (long long)(4 * o->kb + 256 + align256(tmp)));
     char* ws = (char*)workspace;
     o->keys = (uint32_t*)ws;
-    o->vals_in = (uint32_t*)(ws + o->kb);
     o->vals = (uint32_t*)(ws + 2 * o->kb);
-    o->heads = (uint32_t*)(ws + 3 * o->kb);
-    o->cnt = (uint32_t*)(ws + 4 * o->kb);
     o->tmp = ws + 4 * o->kb + 256;
     return EMG_OK;
 }
@@ -540,8 +517,6 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         if (rc != EMG_OK) return rc;
         P.keys = w.keys;
         P.vals = w.vals;
-        P.heads = w.heads;
-        P.head_count = w.cnt;
         const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
                          (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
         // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
