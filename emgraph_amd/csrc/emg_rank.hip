@@ -438,11 +438,17 @@ __global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, in
 // (the row-major stride-17 layout of the kernel above has 2-way write conflicts: 25 % of its LDS cycles).
 // ---------------------------------------------------------------------------------------------
 constexpr int LDK = 130;
+#ifndef PIPE_NTB
+#define PIPE_NTB 4
+#endif
 
-template <bool DENSE>
+template <bool DENSE, int NTB>  // NTB: 32-column MFMA tiles per wave along the entities (wave tile 64 x 32*NTB)
 __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountParams P) {
+    constexpr int BNW = 2 * 32 * NTB;       // entities per workgroup tile (two waves across)
+    constexpr int LDB = BNW + 2;            // = 2 mod 8: conflict-free transposing stores (see header)
+    constexpr int NBR = BNW / 64;           // entity rows each loader thread stages per slice
     __shared__ float As[BK * LDK];
-    __shared__ float Bs[BK * LDK];
+    __shared__ float Bs[BK * LDB];
     __shared__ int pos_s[BM];
 
     const int64_t id = blockIdx.x;
@@ -461,25 +467,24 @@ __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountPara
         pos_s[tid] = (!DENSE && qr < P.n_rows) ? P.pos_int[qr] : 0x7fffffff;
     }
     const float* arow[2];
-    const float* brow[2];
+    const float* brow[NBR];
 #pragma unroll
     for (int r = 0; r < 2; ++r) arow[r] = P.Q + min(qb * BM + lrow + 64 * r, P.n_rows - 1) * P.ldq + 4 * kq;
     auto point_b = [&](int64_t tile) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t el = min(tile * BN + lrow + 64 * r, P.n_cand - 1);
+        for (int r = 0; r < NBR; ++r) {
+            const int64_t el = min(tile * BNW + lrow + 64 * r, P.n_cand - 1);
             brow[r] = P.ent + (P.cand ? (int64_t)P.cand[el] : el) * P.ld_ent + 4 * kq;
         }
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 av[2], bv[2];
+    f32x4 av[2], bv[NBR];
     auto fetch = [&](int k0) {  // k_int % 4 == 0: a 4-float piece is either whole or past the end
         const bool in = k0 + 4 * kq < P.k_int;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            av[r] = in ? *reinterpret_cast<const f32x4*>(arow[r] + k0) : zero4;
-            bv[r] = in ? *reinterpret_cast<const f32x4*>(brow[r] + k0) : zero4;
-        }
+        for (int r = 0; r < 2; ++r) av[r] = in ? *reinterpret_cast<const f32x4*>(arow[r] + k0) : zero4;
+#pragma unroll
+        for (int r = 0; r < NBR; ++r) bv[r] = in ? *reinterpret_cast<const f32x4*>(brow[r] + k0) : zero4;
     };
 
     unsigned cnt[2][16];
@@ -493,23 +498,23 @@ __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountPara
     point_b(tile0);
     fetch(0);
     for (int64_t tile = tile0; tile < tile1; ++tile) {
-        float16v acc[2][2];
+        float16v acc[2][NTB];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NTB; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
         for (int k0 = 0; k0 < P.k_int; k0 += BK) {
             __syncthreads();  // previous slice's LDS reads done
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    As[(4 * kq + c) * LDK + lrow + 64 * r] = av[r][c];
-                    Bs[(4 * kq + c) * LDK + lrow + 64 * r] = bv[r][c];
-                }
+                for (int r = 0; r < 2; ++r) As[(4 * kq + c) * LDK + lrow + 64 * r] = av[r][c];
+#pragma unroll
+                for (int r = 0; r < NBR; ++r) Bs[(4 * kq + c) * LDB + lrow + 64 * r] = bv[r][c];
+            }
             __syncthreads();
             // next slice (or the next tile's first one) flies while this one is multiplied
             if (k0 + BK < P.k_int) fetch(k0 + BK);
@@ -517,16 +522,15 @@ __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountPara
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 const int k = 2 * kk + lhi;  // A[i][k=lane>>5], B[k=lane>>5][j]
-                float a[2], b[2];
+                float a[2], b[NTB];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = As[k * LDK + wr * 64 + t * 32 + l31];
-                    b[t] = Bs[k * LDK + wc * 64 + t * 32 + l31];
-                }
+                for (int t = 0; t < 2; ++t) a[t] = As[k * LDK + wr * 64 + t * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) b[t] = Bs[k * LDB + wc * (32 * NTB) + t * 32 + l31];
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int tb = 0; tb < 2; ++tb)
+                    for (int tb = 0; tb < NTB; ++tb)
                         acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
             }
         }
@@ -534,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountPara
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const int64_t ecol = tile * BN + wc * 64 + tb * 32 + l31;
+            for (int tb = 0; tb < NTB; ++tb) {
+                const int64_t ecol = tile * BNW + wc * (32 * NTB) + tb * 32 + l31;
                 const bool cok = ecol < P.n_cand;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -598,9 +602,15 @@ static int launch_count(bool dense, int model, CountParams& P, int precision, hi
         }
     } else {
         const bool vec = (P.k_int % 4 == 0) && (P.ldq % 4 == 0) && (P.ld_ent % 4 == 0) && aligned16(P.Q) && aligned16(P.ent);
-        if (vec) {
-            if (dense) hipLaunchKernelGGL((count_mfma_pipe_kernel<true>), grid, block, 0, st, P);
-            else hipLaunchKernelGGL((count_mfma_pipe_kernel<false>), grid, block, 0, st, P);
+        if (vec && !dense && PIPE_NTB == 4) {  // 128 x 256 workgroup tiles
+            P.n_tiles = cdiv(P.n_cand, 256);
+            P.tiles_per_chunk = 8;
+            P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
+            const int64_t blocks4 = 8 * P.n_qb * cdiv(P.n_cb, 8);
+            hipLaunchKernelGGL((count_mfma_pipe_kernel<false, 4>), dim3((unsigned)blocks4), block, 0, st, P);
+        } else if (vec) {
+            if (dense) hipLaunchKernelGGL((count_mfma_pipe_kernel<true, 2>), grid, block, 0, st, P);
+            else hipLaunchKernelGGL((count_mfma_pipe_kernel<false, 2>), grid, block, 0, st, P);
         } else {
             if (dense) hipLaunchKernelGGL((count_mfma_kernel<false, true>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((count_mfma_kernel<false, false>), grid, block, 0, st, P);
