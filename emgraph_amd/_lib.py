@@ -108,7 +108,7 @@ SIGNATURES.update({"emg_prepare_batch": (_int, [C.POINTER(PrepareArgs), _p])})
 
 SIGNATURES.update({
     "emg_eval_pos_int_bf16": (_int, [_int, _p, _i64, _i32, _f32, _p, _i64, _int, _p, _i64, _p, _p, _p]),
-    "emg_eval_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _p, _p, _p]),
+    "emg_eval_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _f32, _p, _p, _i32, _p]),
     "emg_eval_filter_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p,
                                           _p, _p, _p]),
     "emg_eval_scores_dense_bf16": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _p, _i64, _p]),

@@ -33,6 +33,7 @@ struct CountBf16Params {
     const uint16_t* Q; int64_t ldq; const int32_t* pos_int; const int32_t* self_ent; int64_t n_rows;
     const uint16_t* ent; int64_t n_cand; int64_t ld_ent; const int32_t* cand; int64_t ent_offset;
     int32_t k_pad; float scale; int32_t model;
+    int32_t need;  // 0: both counters; 1: cnt_gt receives #(>=) only; 2: cnt_gt receives #(>) only (cnt_eq untouched)
     int32_t k16;  // ceil(k_int / 16): MFMA k-steps that hold real data (v3)
     int32_t qs;  // v2: LDS query-row stride in bytes (odd multiple of 64)
     float cmul;  // score -> comparison integer: int(acc * cmul), cmul = 1e5 (* 2/k for HolE), one rounding
@@ -518,7 +519,9 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v2_kernel(const CountB
 #endif
 constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
 
-template <int NQ, int SQ>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4)
+// ONE: only one comparison per score (P.need = 1: count `>=`, the 'worst' strategy's only input; 2: count `>`,
+// 'best'): half the epilogue's VALU work.  Both counters are produced only when the caller needs ties ('middle').
+template <int NQ, int SQ, bool ONE>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4)
 __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
     constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
     constexpr int SPR = SQ * 2;                 // 16-byte slots per slice row
@@ -548,7 +551,8 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
         float t = INFINITY;  // rows past the end count nothing
         if (qr < P.n_rows) {
             const int p = P.pos_int[qr];
-            t = acc_threshold(tid < V3_BM ? gt_threshold(p) : ge_threshold(p), P.cmul);
+            const bool want_gt = ONE ? P.need == 2 : tid < V3_BM;
+            t = acc_threshold(want_gt ? gt_threshold(p) : ge_threshold(p), P.cmul);
         }
         thr_s[tid] = t;
     }
@@ -672,7 +676,15 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                 const int r0 = wave * 32 + 8 * j + 4 * lhi;  // query rows of accumulator registers 4j..4j+3
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V3_BM + r0);
-                if constexpr (FULL.value) {
+                if constexpr (ONE) {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        const bool cok = FULL.value || (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            cnt[2 * j + (i >> 1)] += (cok && acc[tb][4 * j + i] >= g4[i]) ? (1u << (16 * (i & 1))) : 0u;
+                    }
+                } else if constexpr (FULL.value) {
                     unsigned long long tie = 0ull;  // lanes holding a score equal to the positive's (rare)
 #pragma unroll
                     for (int tb = 0; tb < 4; ++tb)
@@ -732,15 +744,15 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     }
 }
 
-template <int NQ, int SQ>
+template <int NQ, int SQ, bool ONE>
 static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
     const size_t lds_bytes = (size_t)V3_RING + 2 * V3_BM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v3_kernel<NQ, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
+    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, ONE>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
     return EMG_OK;
 }
 
@@ -827,9 +839,10 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
         EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
         int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
-        if (P.k16 == 25) rc = launch_v3<25, 4>(P, nblk, st);
-        else if (P.k16 == 13) rc = launch_v3<13, 4>(P, nblk, st);
-        else rc = launch_v3<8, 4>(P, nblk, st);
+        const bool one = P.need != 0;
+        if (P.k16 == 25) rc = one ? launch_v3<25, 4, true>(P, nblk, st) : launch_v3<25, 4, false>(P, nblk, st);
+        else if (P.k16 == 13) rc = one ? launch_v3<13, 4, true>(P, nblk, st) : launch_v3<13, 4, false>(P, nblk, st);
+        else rc = one ? launch_v3<8, 4, true>(P, nblk, st) : launch_v3<8, 4, false>(P, nblk, st);
         if (rc != EMG_OK) return rc;
     } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
         // query-stationary LDS-DMA kernel (see its header); anything else takes the v1 tile kernel above
@@ -878,13 +891,16 @@ extern "C" int emg_eval_pos_int_bf16(int model, const void* ent_bf16, int64_t ld
 extern "C" int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, const int32_t* pos_int,
                                    const int32_t* self_ent, int64_t n_rows, const void* ent_bf16, int64_t n_cand,
                                    int64_t ld_ent, const int32_t* cand, int64_t ent_offset, int32_t k_pad, float scale,
-                                   int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
+                                   int32_t* cnt_gt, int32_t* cnt_eq, int32_t need, void* stream) {
     EMG_REQUIRE((n_rows == 0 || n_cand == 0) || (q_bf16 && pos_int && ent_bf16 && cnt_gt && cnt_eq),
                 "emg_eval_count_bf16: null pointer");
+    EMG_REQUIRE(need >= 0 && need <= 2, "emg_eval_count_bf16: need must be 0 (both), 1 (>=) or 2 (>)");
     CountBf16Params P{};
     P.Q = (const uint16_t*)q_bf16; P.ldq = ldq; P.pos_int = pos_int; P.self_ent = self_ent; P.n_rows = n_rows;
     P.ent = (const uint16_t*)ent_bf16; P.n_cand = n_cand; P.ld_ent = ld_ent; P.cand = cand; P.ent_offset = ent_offset;
-    P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
+    P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq; P.need = need;
+    // the tile kernels always produce both counters: for need = 1 their ties are added into cnt_gt as well
+    if (need == 1) P.cnt_eq = cnt_gt;
     return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
 }
 

@@ -376,7 +376,9 @@ def eval_pos_int_bf16(model_id, ent_bf16, k_int, scale, test_spo, side_mode, q_b
     return pos_int, self_ent
 
 
-def eval_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, k_int, scale, cnt_gt, cnt_eq, cand=None, ent_offset=0):
+def eval_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, k_int, scale, cnt_gt, cnt_eq, cand=None, ent_offset=0,
+                    need=0):
+    """need: 0 both counters; 1 cnt_gt += #(>=) only ('worst'); 2 cnt_gt += #(>) only ('best'); cnt_eq unspecified then"""
     lib = L.load()
     pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")
     pe, ne, lde = _chk_bf16(ent_bf16, "ent_bf16")
@@ -385,7 +387,8 @@ def eval_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, k_int, scale,
                                     _chk_vec(self_ent, torch.int32, "self_ent", n_rows), n_rows, pe, n_cand, lde,
                                     _chk_vec(cand, torch.int32, "cand"), ent_offset, bf16_pad(k_int), scale,
                                     _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
-                                    _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_count_bf16")
+                                    _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), int(need), _stream()),
+            "emg_eval_count_bf16")
 
 
 def eval_filter_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, ent_offset, k_int, scale, filt_ptr, filt_idx,

@@ -210,8 +210,10 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             # the true entity ties with itself by construction: pos_int comes from the same MFMA arithmetic
             pos_int, self_ent = D.eval_pos_int_bf16(model_id, ent_bf16, k_int, scale, Tt, side_mode, Qb)
             tab, off = (ent_bf16, 0) if cand is not None else (ent_bf16[e0:e0 + slab.shape[0]], e0)
+            # 'worst' reads only #(>=), 'best' only #(>): one comparison per score in the kernel's epilogue
+            need = {"worst": 1, "best": 2, "middle": 0}[strategy]
             count = lambda: D.eval_count_bf16(model_id, Qb, pos_int, self_ent, tab, k_int, scale, cnt[0], cnt[1],  # noqa: E731
-                                              cand=cand, ent_offset=off)
+                                              cand=cand, ent_offset=off, need=need)
             fcount = lambda fp_, fi_: D.eval_filter_count_bf16(model_id, Qb, pos_int, self_ent, tab, off, k_int,  # noqa: E731
                                                                scale, fp_, fi_, cnt[2], cnt[3])
         else:
@@ -231,10 +233,12 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
                        torch.from_numpy(idx).to(ent.device, non_blocking=True))
         if world > 1:
             parallel.allreduce_sum_(cnt)
-        pending.append((cnt, nq))
+        pending.append((cnt, nq, precision == 1 and strategy != "middle"))
     out = []
-    for cnt, nq in pending:
+    for cnt, nq, single in pending:
         c = cnt.cpu().numpy().astype(np.int64)
+        if single:
+            c[1] = 0  # single-counter mode: c[0] already is what the strategy reads (see `need` above)
         out.append(ranks_from_counts(c[0], c[1], c[2], c[3], nq, corrupt_side, strategy))
     _ev_collect(stats)
     if not out:

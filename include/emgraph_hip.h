@@ -283,7 +283,10 @@ int emg_eval_pos_int_bf16(int model, const void* ent_bf16, int64_t ld_ent, int32
 int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, const int32_t* pos_int, const int32_t* self_ent,
                         int64_t n_rows, const void* ent_bf16, int64_t n_cand, int64_t ld_ent, const int32_t* cand,
                         int64_t ent_offset, int32_t k_pad, float scale, int32_t* cnt_gt, int32_t* cnt_eq,
-                        void* stream);
+                        int32_t need, void* stream);
+/* need: 0 = both counters (cnt_gt += #(>), cnt_eq += #(==));  1 = cnt_gt += #(>=) — all the 'worst' strategy
+ * (the reference's default) reads;  2 = cnt_gt += #(>) — all 'best' reads.  With need != 0 the register-stationary
+ * kernel does one comparison per score instead of two and the content of cnt_eq is unspecified. */
 int emg_eval_filter_count_bf16(int model, const void* q_bf16, int64_t ldq, const int32_t* pos_int,
                                const int32_t* self_ent, int64_t n_rows, const void* ent_bf16, int64_t n_local,
                                int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,

@@ -594,6 +594,13 @@ def test_bf16_stationary_kernel_equals_tile_kernel(model, k, n_ent, nq):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy())
     assert int(exp[1].min()) >= 1 and int(exp[1].max()) >= 2   # every row ties with itself; planted ties are seen
+    # single-counter modes: need=1 -> #(>=) = gt + eq, need=2 -> #(>) = gt, for the stationary AND the tile kernels
+    both = exp.clone()
+    for need, want in ((1, both[0] + both[1]), (2, both[0])):
+        for cand in (None, torch.arange(n_ent, dtype=torch.int32, device="cuda")):
+            one = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+            d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb, ki, sc, one[0], one[1], cand=cand, need=need)
+            np.testing.assert_array_equal(one[0].cpu().numpy(), want.cpu().numpy(), err_msg="need=%d" % need)
     # slab form (ent_offset) and repeated launches accumulate
     d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb[: n_ent // 2], ki, sc, got[0], got[1])
     d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb[: n_ent // 2], ki, sc, exp[0], exp[1],

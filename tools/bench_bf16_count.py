@@ -58,14 +58,14 @@ def main():
     selfe = torch.zeros(a.rows, dtype=torch.int32, device=dev)
     flop = 2.0 * a.rows * a.ent * a.k
 
-    def run(cand):
+    def run(cand, need=0):
         cnt = torch.zeros((2, a.rows), dtype=torch.int32, device=dev)
         best = 1e9
         for _ in range(a.reps):
             cnt.zero_()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            D.eval_count_bf16(L.COMPLEX, Q, pos, selfe, E, a.k, 1.0, cnt[0], cnt[1], cand=cand)
+            D.eval_count_bf16(L.COMPLEX, Q, pos, selfe, E, a.k, 1.0, cnt[0], cnt[1], cand=cand, need=need)
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
@@ -73,6 +73,9 @@ def main():
 
     ms2, c2 = run(None)
     print("v2 query-stationary: %.3f ms  %.1f TFLOP/s" % (ms2, flop / ms2 * 1e-9))
+    ms3, c3 = run(None, need=1)
+    print("  one comparison ('worst'): %.3f ms  %.1f TFLOP/s  (#(>=) equals gt+eq: %s)"
+          % (ms3, flop / ms3 * 1e-9, bool(np.array_equal(c3[0], c2[0] + c2[1]))))
     if a.v1:
         ms1, c1 = run(torch.arange(a.ent, dtype=torch.int32, device=dev))
         print("v1 tile kernel     : %.3f ms  %.1f TFLOP/s" % (ms1, flop / ms1 * 1e-9))
