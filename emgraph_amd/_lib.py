@@ -114,6 +114,31 @@ SIGNATURES.update({
     "emg_eval_scores_dense_bf16": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _p, _i64, _p]),
 })
 
+class StepArgs(C.Structure):
+    """mirror of `emg_step_args` (include/emgraph_hip.h)"""
+    _fields_ = [
+        ("model", _i32), ("k_int", _i32), ("scale", _f32), ("eta", _i32), ("n_sides", _i32), ("sides", _i32 * 4),
+        ("ent", _p), ("n_ent", _i64), ("ld_ent", _i64), ("rel", _p), ("n_rel", _i64), ("ld_rel", _i64),
+        ("ent_state0", _p), ("ent_state1", _p), ("rel_state0", _p), ("rel_state1", _p),
+        ("tag_ent", _p), ("tag_rel", _p),
+        ("opt", _i32), ("step", _i32), ("hyper", _f32 * 6),
+        ("pos", _p), ("B", _i64),
+        ("n_choices", _i64), ("entities_list", _p), ("seed", _u64), ("draw_counter0", _u64),
+        ("inj_mask", _p), ("inj_repl", _p),
+        ("loss", _i32), ("margin", _f32), ("alpha", _f32), ("loss_accum", _p),
+        ("inplace", _i32),
+        ("workspace", _p), ("workspace_bytes", _i64),
+    ]
+
+
+SIGNATURES.update({
+    "emg_corrupt_fit": (_int, [_p, _i64, _i32, _int, _i64, _p, _i64, _u64, _u64, _p, _p]),
+    "emg_rank_1vsall": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _int, _p, _i64, _p, _p, _int,
+                               _int, _p, _p]),
+    "emg_train_step_workspace_bytes": (_i64, [_i64, _i32, _i32, _i64, _i64]),
+    "emg_train_step": (_int, [C.POINTER(StepArgs), _p]),
+})
+
 _lib = None
 
 

@@ -415,3 +415,72 @@ def eval_scores_dense_bf16(model_id, q_bf16, ent_bf16, k_int, scale, cand=None):
                                            _chk_vec(cand, torch.int32, "cand"), bf16_pad(k_int), scale, S.data_ptr(),
                                            S.stride(0), _stream()), "emg_eval_scores_dense_bf16")
     return S
+
+
+# ---- one-call forms (emg_api.hip): the C-ABI a maintainer binds from the reference; this package's own training /
+# ---- evaluation loops use the fine-grained calls above so that they can overlap stages on several streams
+def corrupt_fit(pos, eta, side, entities_size=0, entities_list=None, seed=0, counter=0):
+    lib = L.load()
+    B = pos.shape[0]
+    out = torch.empty((B * eta, 3), dtype=torch.int32, device=pos.device)
+    n_list = entities_list.numel() if entities_list is not None else 0
+    L.check(lib.emg_corrupt_fit(_chk_vec(pos, torch.int32, "pos", 3 * B), B, eta, side, entities_size,
+                                _chk_vec(entities_list, torch.int32, "entities_list"), n_list,
+                                seed & 0xFFFFFFFFFFFFFFFF, counter & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), _stream()),
+            "emg_corrupt_fit")
+    return out
+
+
+def rank_1vsall(model_id, ent, rel, k_int, scale, test_spo, side_mode, strategy=0, cand=None, filt_ptr=None,
+                filt_idx=None, precision_mode=0):
+    """ranks int32 [n_q] (or [n_q, 2] = [subject, object] for side_mode 's,o'), everything on the current stream"""
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    n_q = test_spo.shape[0]
+    out = torch.empty((n_q, 2) if side_mode == L.EVAL_S_O else (n_q,), dtype=torch.int32, device=ent.device)
+    n_rows = 2 * n_q if side_mode >= L.EVAL_SPO else n_q
+    L.check(lib.emg_rank_1vsall(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
+                                _chk_vec(test_spo, torch.int32, "test_spo", 3 * n_q), n_q, side_mode,
+                                _chk_vec(cand, torch.int32, "cand"), cand.numel() if cand is not None else 0,
+                                _chk_vec(filt_ptr, torch.int64, "filt_ptr", n_rows + 1 if filt_ptr is not None else None),
+                                _chk_vec(filt_idx, torch.int32, "filt_idx"), strategy, precision_mode, out.data_ptr(),
+                                _stream()), "emg_rank_1vsall")
+    return out
+
+
+def train_step_workspace_bytes(B, eta_total, k_int, n_ent, n_rel):
+    n = L.load().emg_train_step_workspace_bytes(B, eta_total, k_int, n_ent, n_rel)
+    if n < 0:
+        L.check(-1, "emg_train_step_workspace_bytes")
+    return int(n)
+
+
+def train_step(model_id, ent, rel, k_int, scale, pos, eta, sides, loss_id, loss_accum, opt_id, step, hyper, workspace,
+               margin=1.0, alpha=0.5, states=(None, None, None, None), tags=(None, None), n_choices=0,
+               entities_list=None, seed=0, counter0=0, inj_mask=None, inj_repl=None, inplace=True):
+    lib = L.load()
+    a = L.StepArgs()
+    a.model, a.k_int, a.scale, a.eta, a.n_sides = model_id, k_int, scale, eta, len(sides)
+    for i, sd in enumerate(sides):
+        a.sides[i] = sd
+    a.ent, a.n_ent, a.ld_ent = _chk_table(ent, "ent")
+    a.rel, a.n_rel, a.ld_rel = _chk_table(rel, "rel")
+    a.ent_state0, a.ent_state1, a.rel_state0, a.rel_state1 = [(_chk_table(t, "state")[0] if t is not None else None)
+                                                              for t in states]
+    a.tag_ent, a.tag_rel = [_chk_vec(t, torch.int32, "tag") for t in tags]
+    a.opt, a.step = opt_id, step
+    for i, h in enumerate(hyper):
+        a.hyper[i] = float(h)
+    B = pos.shape[0]
+    a.pos, a.B = _chk_vec(pos, torch.int32, "pos", 3 * B), B
+    a.n_choices = n_choices
+    a.entities_list = _chk_vec(entities_list, torch.int32, "entities_list")
+    a.seed, a.draw_counter0 = seed & 0xFFFFFFFFFFFFFFFF, counter0 & 0xFFFFFFFFFFFFFFFF
+    a.inj_mask = _chk_vec(inj_mask, torch.int32, "inj_mask")
+    a.inj_repl = _chk_vec(inj_repl, torch.int32, "inj_repl")
+    a.loss, a.margin, a.alpha = loss_id, margin, alpha
+    a.loss_accum = _chk_vec(loss_accum, torch.float64, "loss_accum", 1)
+    a.inplace = 1 if inplace else 0
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    L.check(lib.emg_train_step(C.byref(a), _stream()), "emg_train_step")

@@ -296,6 +296,49 @@ int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);
 
+/* ====================== one-call forms (compositions of the entry points above, one stream) ==============
+ * The C-ABI sketched in SURVEY.md 8b.  A maintainer binding the library from the reference calls these once per
+ * batch / per test set; the finer-grained entry points exist so that a host can overlap stages on several
+ * streams (as emgraph_amd/training.py does). */
+
+/* generate_corruptions_for_fit (protocol.py:531-659) in one call: out_spo int32 [B*eta, 3], eta-major.
+ * entities_size > 0: replacements are ids drawn from [0, entities_size) (:616-619); otherwise they are drawn
+ * from entities_list[0..n_list) (:620-641).  Draws: Philox4x32-10 keyed by (seed; row, counter). */
+int emg_corrupt_fit(const int32_t* pos, int64_t B, int32_t eta, int side, int64_t entities_size,
+                    const int32_t* entities_list, int64_t n_list, uint64_t seed, uint64_t counter,
+                    int32_t* out_spo, void* stream);
+
+/* Filtered ranks of n_q test triples against all entities (cand == NULL) or the rows cand[0..n_cand):
+ * emg_eval_build_queries -> emg_eval_count[_bf16] -> emg_eval_filter_count[_bf16] -> rank assembly
+ * (EmbeddingModel.py:1845-2033).  filt_ptr/filt_idx: optional CSR over the n_rows query rows in the row order
+ * documented above (object-side rows first), GLOBAL entity ids, each list containing the row's true entity.
+ * strategy: 0 worst | 1 best | 2 middle.  precision_mode: 0 exact f32 | 1 bf16 MFMA (statistical agreement).
+ * rank_out int32: [n_q] for side_mode 0,1,2; [n_q,2] = [subject_rank, object_rank] for side_mode 3. */
+int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel,
+                    int64_t ld_rel, int32_t k_int, float scale, const int32_t* test_spo, int64_t n_q, int side_mode,
+                    const int32_t* cand, int64_t n_cand, const int64_t* filt_ptr, const int32_t* filt_idx,
+                    int strategy, int precision_mode, int32_t* rank_out, void* stream);
+
+/* One training batch: corruptions of every side -> scores -> loss (accumulated into *loss_accum) -> gradients ->
+ * row-sparse optimizer update of both tables (EmbeddingModel.py:614-822 + training/*.py), without the LP
+ * regulariser.  `workspace` (device, emg_train_step_workspace_bytes) holds all per-batch scratch.
+ * inplace != 0: rows whose destination occurs once in the batch are updated by the gradient kernel itself. */
+typedef struct emg_step_args {
+    int32_t model; int32_t k_int; float scale; int32_t eta; int32_t n_sides; int32_t sides[4];
+    float* ent; int64_t n_ent; int64_t ld_ent; float* rel; int64_t n_rel; int64_t ld_rel;
+    float* ent_state0; float* ent_state1; float* rel_state0; float* rel_state1;   /* optimizer state, NULL if unused */
+    int32_t* tag_ent; int32_t* tag_rel;                                           /* int32[n_rows], zeroed once */
+    int32_t opt; int32_t step; float hyper[6];                                    /* as emg_apply_rows */
+    const int32_t* pos; int64_t B;                                                /* device int32 [B,3] */
+    int64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t draw_counter0;
+    const int32_t* inj_mask; const int32_t* inj_repl;                             /* optional injected draws */
+    int32_t loss; float margin; float alpha; double* loss_accum;
+    int32_t inplace;
+    void* workspace; int64_t workspace_bytes;
+} emg_step_args;
+int64_t emg_train_step_workspace_bytes(int64_t B, int32_t eta_total, int32_t k_int, int64_t n_ent, int64_t n_rel);
+int emg_train_step(const emg_step_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

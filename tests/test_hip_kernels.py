@@ -622,3 +622,86 @@ def test_bf16_rank_agreement_with_exact_path():
     assert abs((1.0 / fast).mean() - (1.0 / exact).mean()) < 0.01  # MRR agrees
     with pytest.raises(ValueError):
         rank_triples_device(MID["TransE_L1"], cu(E[:, :k]), cu(R[:, :k]), k, 1.0, T, precision=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# one-call forms (emg_api.hip) == the fine-grained path
+# ------------------------------------------------------------------------------------------------
+def test_corrupt_fit_one_call_matches_oracle():
+    d = dev()
+    rs = np.random.RandomState(2)
+    X = np.stack([rs.randint(0, 50, 37), rs.randint(0, 3, 37), rs.randint(0, 50, 37)], 1).astype(np.int32)
+    for side, name in ((0, "s"), (1, "o"), (2, "s,o")):
+        got = d.corrupt_fit(cu(X), 4, side, entities_size=50, seed=9, counter=5).cpu().numpy()
+        exp = orc.generate_corruptions_for_fit_philox(X, eta=4, corrupt_side=name, entities_size=50, seed=9, counter=5)
+        np.testing.assert_array_equal(got, exp)
+    elist = np.array([3, 7, 11, 40], np.int32)
+    got = d.corrupt_fit(cu(X), 2, 2, entities_list=cu(elist), seed=1, counter=0).cpu().numpy()
+    exp = orc.generate_corruptions_for_fit_philox(X, entities_list=elist, eta=2, corrupt_side="s,o", seed=1, counter=0)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("model", ["TransE_L1", "DistMult", "ComplEx", "HolE"])
+def test_rank_1vsall_one_call_matches_python_path(model):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex, rank_triples_device
+    d = dev()
+    k, n_ent, n_rel, nq = 24, 700, 5, 60
+    E, R, ki = make_tables(model, k, n_ent, n_rel, seed=4)
+    rs = np.random.RandomState(6)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, n_rel, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    Fl = np.concatenate([T, np.stack([rs.randint(0, n_ent, 4000), rs.randint(0, n_rel, 4000), rs.randint(0, n_ent, 4000)], 1)]).astype(np.int32)
+    F = FilterIndex(Fl)
+    sub = np.arange(0, n_ent, 3).astype(np.int32)
+    sc = scale_of(model, k)
+    for side, sm in (("s", L.EVAL_S), ("o", L.EVAL_O), ("s+o", L.EVAL_SPO), ("s,o", L.EVAL_S_O)):
+        for si, strategy in enumerate(("worst", "best", "middle")):
+            for subset in (None, sub):
+                ptr, idx = F.csr(T, sm, n_ent, subset)
+                exp = rank_triples_device(MID[model], cu(E), cu(R), ki, sc, T, side, strategy, filter_triples=F,
+                                          entities_subset=subset)
+                got = d.rank_1vsall(MID[model], cu(E), cu(R), ki, sc, cu(T), sm, strategy=si,
+                                    cand=None if subset is None else cu(subset), filt_ptr=cu(ptr), filt_idx=cu(idx))
+                np.testing.assert_array_equal(got.cpu().numpy(), exp, err_msg=str((side, strategy, subset is not None)))
+        raw = d.rank_1vsall(MID[model], cu(E), cu(R), ki, sc, cu(T), sm).cpu().numpy()
+        np.testing.assert_array_equal(raw, rank_triples_device(MID[model], cu(E), cu(R), ki, sc, T, side, "worst"))
+    if model != "TransE_L1":  # bf16 mode through the same call
+        ptr, idx = F.csr(T, L.EVAL_S_O, n_ent, None)
+        got = d.rank_1vsall(MID[model], cu(E), cu(R), ki, sc, cu(T), L.EVAL_S_O, filt_ptr=cu(ptr), filt_idx=cu(idx), precision_mode=1)
+        exp = rank_triples_device(MID[model], cu(E), cu(R), ki, sc, T, "s,o", "worst", filter_triples=F, precision=1)
+        np.testing.assert_array_equal(got.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("model,loss,opt,sides", [("ComplEx", "nll", "adam", ("s,o",)), ("TransE_L2", "pairwise", "sgd", ("s", "o")),
+                                                  ("DistMult", "self_adversarial", "adagrad", ("s,o",)),
+                                                  ("HolE", "multiclass_nll", "momentum", ("s,o",))])
+def test_train_step_one_call_matches_trainer(model, loss, opt, sides):
+    """emg_train_step (prepare + score/loss/grad + both applies in one library call) leaves bit-identical tables,
+    optimizer state and loss as Trainer's unpipelined step over three batches"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    d = dev()
+    k, n_ent, n_rel, B, eta = 20, 300, 6, 128, 3
+    E, R, ki = make_tables(model, k, n_ent, n_rel, seed=12)
+    rs = np.random.RandomState(3)
+    X = np.stack([rs.randint(0, n_ent, 3 * B), rs.randint(0, n_rel, 3 * B), rs.randint(0, n_ent, 3 * B)], 1).astype(np.int32)
+    sc = scale_of(model, k)
+    tr = Trainer(MID[model], ki, sc, E, R, eta, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05},
+                 corrupt_sides=sides, batches_count=3, seed=5, pipeline=False)
+    tr.set_training_set(X, B)
+    tr2 = Trainer(MID[model], ki, sc, E, R, eta, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05},
+                  corrupt_sides=sides, batches_count=3, seed=5, pipeline=False)   # only as a holder of tables / state
+    ws = torch.empty(d.train_step_workspace_bytes(B, eta * len(sides), ki, n_ent, n_rel), dtype=torch.uint8, device="cuda")
+    Xt = cu(X)
+    for b in range(3):
+        tr.step(b * B, B, epoch=1, batch=b + 1)
+        tr2.step_count += 1
+        d.train_step(MID[model], tr2.ent, tr2.rel, ki, sc, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum,
+                     tr2.opt_id, tr2.step_count, tr2._hyper(tr2.lr), ws, margin=tr2.margin, alpha=tr2.alpha,
+                     states=(tr2.state_ent[0], tr2.state_ent[1], tr2.state_rel[0], tr2.state_rel[1]),
+                     tags=(tr2.tag_ent, tr2.tag_rel), n_choices=n_ent, seed=5, counter0=b * len(sides), inplace=tr.inplace)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.ent, tr2.ent) and torch.equal(tr.rel, tr2.rel)
+    for a_, b_ in zip(tr.state_ent + tr.state_rel, tr2.state_ent + tr2.state_rel):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+    assert tr.read_loss() == tr2.read_loss()
