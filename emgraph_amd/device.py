@@ -20,8 +20,37 @@ def require_gpu():
     L.load()
 
 
+_forced = None  # (torch stream object, c_void_p handle) while inside `on_stream`
+
+
 def _stream():
+    if _forced is not None:
+        return _forced[1]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class on_stream:
+    """Route the library calls made inside the block to ``stream`` WITHOUT touching torch's current stream:
+    `torch.cuda.current_stream()` / `with torch.cuda.stream(...)` cost ~8 us each and a training step makes a
+    dozen of them.  Only for calls whose outputs are preallocated (torch allocations still follow torch's stream)."""
+
+    def __init__(self, stream):
+        self._new = (stream, C.c_void_p(stream.cuda_stream))
+
+    def __enter__(self):
+        global _forced
+        self._prev, _forced = _forced, self._new
+        return self._new[0]
+
+    def __exit__(self, *exc):
+        global _forced
+        _forced = self._prev
+        return False
+
+
+def active_stream():
+    """the stream library calls currently go to (torch stream object)"""
+    return _forced[0] if _forced is not None else torch.cuda.current_stream()
 
 
 def _chk_table(t, name):

@@ -243,9 +243,10 @@ class Trainer:
         if self.stage_events is None or len(self.stage_events.get(name, ())) >= self._stage_max:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        st = D.active_stream()
+        e0.record(st)
         r = fn()
-        e1.record()
+        e1.record(st)
         self.stage_events.setdefault(name, []).append((e0, e1))
         return r
 
@@ -282,7 +283,7 @@ class Trainer:
             side = self.sides_st[self._side_rr]
             self._side_rr = (self._side_rr + 1) % len(self.sides_st)
             side.wait_event(sl["done"])  # the compute that last used this slot has finished
-            with torch.cuda.stream(side):
+            with D.on_stream(side):
                 self._timed("prepare", run)
                 sl["ready"].record(side)
         else:
@@ -316,14 +317,16 @@ class Trainer:
                     break
                 self._prepare(free, pf[0], pf[1], pf[2], pf[3], pf[4] if len(pf) > 4 else n_choices,
                               pf[5] if len(pf) > 5 else entities_list, None, None)
+        main = torch.cuda.current_stream()  # looked up once per step; every call below is routed explicitly
         if self.pipeline:
-            torch.cuda.current_stream().wait_event(sl["ready"])
-        self._compute(sl, start, B, epoch, batch)
+            main.wait_event(sl["ready"])
+        with D.on_stream(main):
+            self._compute(sl, start, B, epoch, batch, main)
         if self.pipeline:
-            sl["done"].record(torch.cuda.current_stream())
+            sl["done"].record(main)
         sl["key"] = None
 
-    def _compute(self, sl, start, B, epoch, batch):
+    def _compute(self, sl, start, B, epoch, batch, main):
         pos = self.X[start:start + B]
         et, eta = self.eta_total, self.eta
         codes = sl["codes"][:B * et]
@@ -381,17 +384,16 @@ class Trainer:
         if use_aux:
             # the relation table's apply (few, long segments: latency-bound, ~0.06 ms at 0.5 TB/s) is independent
             # of the entity table's: it runs on a second stream underneath it
-            main = torch.cuda.current_stream()
             self.aux_fork.record(main)
             self.aux.wait_event(self.aux_fork)
-            with torch.cuda.stream(self.aux):
+            with D.on_stream(self.aux):
                 self._timed("apply_rel", apply_rel)
                 self.aux_join.record(self.aux)
         self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
                                                          self.state_ent[1], self.tag_ent, self.step_count, ce, n_ce,
                                                          self.inplace, hyper, sl["ws_ent"]))
         if use_aux:
-            torch.cuda.current_stream().wait_event(self.aux_join)
+            main.wait_event(self.aux_join)
         else:
             self._timed("apply_rel", apply_rel)
         if self.normalize:
