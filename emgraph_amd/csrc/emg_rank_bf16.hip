@@ -20,6 +20,7 @@
 // Row storage contract: ld >= round_up(k_pad, 64) elements (k_pad itself is a multiple of 32; a trailing
 // half slice is loaded but not multiplied).
 #include "emg_common.hpp"
+#include <atomic>
 #include <type_traits>
 
 namespace emg {
@@ -744,14 +745,25 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     }
 }
 
+// The opt-in to > 64 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device (bit d of `done`)
+// so that a process driving several GPUs sets it on each, and so that two host threads may race here harmlessly
+// (hipFuncSetAttribute is idempotent; the flag is only ever set after a successful call).
+static int allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    EMG_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return EMG_OK;
+    EMG_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+    return EMG_OK;
+}
+
 template <int NQ, int SQ, bool ONE>
 static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
     const size_t lds_bytes = (size_t)V3_RING + 2 * V3_BM * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> devices_done{0};  // one flag per template instance and device
+    int rc = allow_full_lds((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, ONE>, devices_done);
+    if (rc != EMG_OK) return rc;
     hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, ONE>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
     return EMG_OK;
 }
@@ -854,11 +866,9 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
         EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
         const size_t lds_bytes = (size_t)V2_NS * V2_STAGE + (size_t)V2_BM * P.qs + 3 * V2_BM * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            EMG_HIP(hipFuncSetAttribute((const void*)count_mfma_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> devices_done{0};
+        int rc2 = allow_full_lds((const void*)count_mfma_bf16_v2_kernel, devices_done);
+        if (rc2 != EMG_OK) return rc2;
         hipLaunchKernelGGL(count_mfma_bf16_v2_kernel, dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
     } else hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_COUNT>, dim3((unsigned)blocks), dim3(256), 0, st, P);
     EMG_LAUNCH_CHECK();

@@ -58,6 +58,7 @@ DEFAULT_UNIFORM_LOW, DEFAULT_UNIFORM_HIGH = -0.05, 0.05
 DEFAULT_NORMAL_MEAN, DEFAULT_NORMAL_STD = 0, 0.05
 DEFAULT_GLOROT_IS_UNIFORM = False
 
+MAX_TRAIN_K = 512  # widest row the register-tiled gradient kernels hold (csrc/emg_score.hip::dispatch_model)
 ENTITY_THRESHOLD = 5e5  # EmbeddingModel.py:37 (kept for API parity; no host paging here)
 
 LOSSES = ("pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll")
@@ -290,6 +291,10 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             msg = "Invalid size for input X. Expected (n,3):  got {}".format(X.shape)
             logger.error(msg)
             raise ValueError(msg)
+        if self.k > MAX_TRAIN_K:
+            # the gradient kernels keep a whole row in registers (emg_score.hip: 128 sixteen-byte chunks per lane
+            # group); scoring / ranking have no such limit.  Fail here, not with EMG_ENOSUP inside the first step.
+            raise ValueError("k={} is not supported for training by the HIP path (k <= {})".format(self.k, MAX_TRAIN_K))
         self.rel_to_idx, self.ent_to_idx, X_idx = create_mappings_and_index(X)
         n = X_idx.shape[0]
         batch_size = int(np.ceil(n / self.batches_count))  # EmbeddingModel.py:1297-1301
@@ -304,6 +309,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         k_local = self.internal_k
         if self._sharded:
             # one process per GPU: this rank trains a COLUMN slab of both tables (parallel.py)
+            if world > self.k:
+                raise ValueError("k-sharded training needs k >= number of ranks (k={}, ranks={})".format(self.k, world))
             if normalize:
                 raise NotImplementedError("normalize_ent_emb needs full rows; not available with k-sharded training")
             cplx = self.internal_k != self.k
@@ -367,10 +374,15 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             if es is not None and self._perform_early_stopping_test(epoch, es, tr):
                 self.is_fitted = True
                 return
-        self._save_trained_params(tr)
+        self._save_trained_params(tr, live=True)
         self.is_fitted = True
 
-    def _save_trained_params(self, tr):
+    def _save_trained_params(self, tr, live=False):
+        """Snapshot the tables into ``trained_model_params`` (EmbeddingModel.py:385-401).  ``live=True`` only for
+        the final save at the end of fit(): inference may then read the trainer's tables directly.  A snapshot
+        taken by early stopping must NOT alias them — training continues in place for ``stop_interval`` more
+        checks, and predict()/get_ranks() have to use the best snapshot (the reference always infers from
+        trained_model_params, :403-453) — so the device copy is dropped and re-uploaded lazily."""
         if getattr(self, "_sharded", False):
             cplx = self.internal_k != self.k
             ent = parallel.unshard_columns(parallel.gather_slabs(tr.ent), self.k, cplx)
@@ -380,7 +392,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             return
         ent, rel = tr.tables_numpy()
         self.trained_model_params = [ent, rel]
-        self._dev = (tr.ent, tr.rel)
+        self._dev = (tr.ent, tr.rel) if live else None
 
     def _eval_tables(self, tr):
         """full-width device tables of the CURRENT training state (early stopping)"""

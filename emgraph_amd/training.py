@@ -35,46 +35,34 @@ ADAM_BETA1, ADAM_BETA2, KERAS_EPS = 0.9, 0.999, 1e-7   # tf.optimizers defaults 
 ADAGRAD_INIT_ACC = 0.1
 
 
-class SGDSchedule:
-    """Learning-rate schedule of training/sgd.py:127-185 (`update_feed_dict`), restated as host logic.
-    The reference's TF2 port never calls it (SURVEY A-4); values pinned by
-    tests/emgraph/models/test_optimizers.py:21,41-43,72-79."""
+def sgd_learning_rate(params, batches_count, epoch, batch):
+    """Learning rate of plain SGD for (epoch, batch), both 1-based: a pure function of the optimizer parameters.
 
-    def __init__(self, params, batches_count):
-        self.batches_count = batches_count
-        self.start_lr = params.get("lr", DEFAULT_LR)
-        self.current_lr = self.start_lr
-        self.decay_cycle_rate = params.get("decay_cycle", DEFAULT_DECAY_CYCLE)
-        self.end_lr = params.get("end_lr", DEFAULT_END_LR)
-        self.is_cosine_decay = params.get("cosine_decay", DEFAULT_SINE)
-        self.next_cycle_epoch = self.decay_cycle_rate + 1
-        self.decay_cycle_expand_factor = params.get("expand_factor", DEFAULT_DECAY_CYCLE_MULTIPLE)
-        self.decay_lr_rate = params.get("decay_lr_rate", DEFAULT_LR_DECAY_FACTOR)
-        self.curr_cycle_length = self.decay_cycle_rate
-        self.curr_start = 0
-
-    def lr(self, batch_num, epoch_num):
-        if self.is_cosine_decay:
-            current_cycle_num = ((epoch_num - 1 - self.curr_start) * self.batches_count + (batch_num - 1)) / (
-                self.curr_cycle_length * self.batches_count)
-            self.current_lr = self.end_lr + (self.start_lr - self.end_lr) * 0.5 * (
-                1 + math.cos(math.pi * current_cycle_num))
-            if epoch_num % (self.next_cycle_epoch - 1) == 0 and batch_num == self.batches_count:
-                self.curr_cycle_length = self.curr_cycle_length * self.decay_cycle_expand_factor
-                self.next_cycle_epoch = self.next_cycle_epoch + self.curr_cycle_length
-                self.curr_start = epoch_num
-                self.start_lr = self.start_lr / self.decay_lr_rate
-            if self.current_lr < self.end_lr:
-                self.current_lr = self.end_lr
-        elif self.decay_cycle_rate > 0:
-            if epoch_num % self.next_cycle_epoch == 0 and batch_num == 1:
-                if self.current_lr > self.end_lr:
-                    self.next_cycle_epoch = (self.decay_cycle_rate
-                                             + ((self.next_cycle_epoch - 1) * self.decay_cycle_expand_factor) + 1)
-                    self.current_lr = self.current_lr / self.decay_lr_rate
-                    if self.current_lr < self.end_lr:
-                        self.current_lr = self.end_lr
-        return self.current_lr
+    Semantics of the reference's schedule (training/sgd.py:127-185; its TF2 port never calls it, SURVEY A-4),
+    values pinned by tests/emgraph/models/test_optimizers.py:21,41-43,72-79:
+      * neither 'decay_cycle' nor 'cosine_decay': constant 'lr';
+      * 'cosine_decay': warm restarts.  Cycle i (i = 0, 1, ...) lasts decay_cycle * expand_factor**i epochs and
+        anneals from lr / decay_lr_rate**i down to 'end_lr' along half a cosine, batch by batch;
+      * fixed decay ('decay_cycle' > 0): the rate is divided by 'decay_lr_rate' at the first batch of epoch
+        b_1 = decay_cycle + 1, b_(j+1) = decay_cycle + (b_j - 1) * expand_factor + 1, never below 'end_lr'
+        (once 'end_lr' is reached the schedule stops)."""
+    lr0 = params.get("lr", DEFAULT_LR)
+    cycle = params.get("decay_cycle", DEFAULT_DECAY_CYCLE)
+    end_lr = params.get("end_lr", DEFAULT_END_LR)
+    expand = params.get("expand_factor", DEFAULT_DECAY_CYCLE_MULTIPLE)
+    shrink = params.get("decay_lr_rate", DEFAULT_LR_DECAY_FACTOR)
+    if cycle <= 0:
+        return lr0
+    if params.get("cosine_decay", DEFAULT_SINE):
+        first, length, top = 0, cycle, lr0          # the cycle holding `epoch` covers epochs (first, first + length]
+        while epoch > first + length:
+            first, length, top = first + length, length * expand, top / shrink
+        done = ((epoch - 1 - first) * batches_count + (batch - 1)) / (length * batches_count)
+        return max(end_lr, end_lr + (top - end_lr) * 0.5 * (1 + math.cos(math.pi * done)))
+    lr, boundary = lr0, cycle + 1
+    while boundary <= epoch and lr > end_lr:
+        lr, boundary = max(end_lr, lr / shrink), cycle + (boundary - 1) * expand + 1
+    return lr
 
 
 def _padded_ld(k_int):
@@ -133,7 +121,7 @@ class Trainer:
         self.opt_id = L.OPT_IDS[optimizer]
         self.lr = float(op.get("lr", DEFAULT_LR))
         self.momentum = float(op.get("momentum", DEFAULT_MOMENTUM))
-        self.schedule = SGDSchedule(op, self.batches_count) if optimizer == "sgd" else None
+        self.sgd_params = dict(op) if optimizer == "sgd" else None
         self.state_ent = [None, None]
         self.state_rel = [None, None]
         if optimizer == "momentum":
@@ -186,9 +174,11 @@ class Trainer:
         # alternately: a preparation chain is latency-bound (each small launch waits for a CU slot), so two
         # chains in flight double the rate at which prepared batches arrive
         self.lookahead = LOOKAHEAD if pipeline else 0
+        if self.lookahead <= 0:  # EMG_LOOKAHEAD=0: nothing to prepare ahead on, run the plain single-stream plan
+            self.pipeline, self.lookahead = False, 0
         self.sides_st = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(self.lookahead)]
         self._side_rr = 0
-        self.aux = torch.cuda.Stream(device=self.device) if pipeline else None  # apply_rel under apply_ent
+        self.aux = torch.cuda.Stream(device=self.device) if self.pipeline else None  # apply_rel under apply_ent
         self.aux_fork, self.aux_join = torch.cuda.Event(), torch.cuda.Event()
         self.slots = []
 
@@ -283,6 +273,8 @@ class Trainer:
             side = self.sides_st[self._side_rr]
             self._side_rr = (self._side_rr + 1) % len(self.sides_st)
             side.wait_event(sl["done"])  # the compute that last used this slot has finished
+            if sl["key"] is not None:    # evicting a prepared-but-never-consumed slot (caller's prefetch list did
+                side.wait_event(sl["ready"])  # not match its steps): its chain may still run on the other side stream
             with D.on_stream(side):
                 self._timed("prepare", run)
                 sl["ready"].record(side)
@@ -333,7 +325,8 @@ class Trainer:
         n_ce, n_cr, xe, xr = (2 + et) * B, B, self._xe, self._xr
         ce, cr = self.contrib_ent[xe:xe + n_ce], self.contrib_rel[xr:xr + B]   # batch rows follow the LP rows
         single = sl["single"][:n_ce] if self.inplace else None
-        lr = self.schedule.lr(batch, epoch) if self.schedule is not None else self.lr
+        lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
+              else self.lr)
         hyper = self._hyper(lr)
         inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper,
                           ent_state0=self.state_ent[0], ent_state1=self.state_ent[1], tag_ent=self.tag_ent)
@@ -402,9 +395,10 @@ class Trainer:
 
     def read_loss(self, reset=True):
         """data loss (identical on every rank) + LP term (summed over the column slabs when sharded)"""
-        if self.sharded:
-            parallel.allreduce_sum_(self.reg_accum)
-        v = float(self.loss_accum.item()) + float(self.reg_accum.item())
+        reg = self.reg_accum
+        if self.sharded:  # sum a COPY over the ranks: the accumulator itself stays rank-local (reset=False calls)
+            reg = parallel.allreduce_sum_(self.reg_accum.clone())
+        v = float(self.loss_accum.item()) + float(reg.item())
         if reset:
             self.loss_accum.zero_()
             self.reg_accum.zero_()

@@ -239,8 +239,9 @@ int emg_eval_build_queries(int model, const float* ent, int64_t n_ent, int64_t l
  * middle = gt+ceil(eq/2) are formed by the caller).  Candidates are rows [0,n_cand) of `ent`
  * (an entity slab) or, if cand != NULL, rows cand[0..n_cand) of it.  cnt_gt/cnt_eq int32[n_rows]
  * are ACCUMULATED (zero them first; sum over slabs / GPUs).
- * precision: 0 = fp32 (exact f32-MFMA for DistMult/ComplEx/HolE; f32 VALU for TransE),
- *            1 = bf16 MFMA (ent_bf16/Q rounded to bf16; rank agreement is statistical). */
+ * precision: must be 0 = fp32 (exact f32-MFMA for DistMult/ComplEx/HolE; f32 VALU for TransE); any other value
+ *            returns EMG_ENOSUP.  ent_bf16 / ld_bf16 are ignored (reserved): the bf16 MFMA throughput mode has its
+ *            own entry points below (emg_eval_count_bf16 ...) because its operands are the bf16 copies. */
 int emg_eval_count(int model, const float* Q, int64_t ldq, const int32_t* pos_int, int64_t n_rows,
                    const float* ent, int64_t n_cand, int64_t ld_ent, const int32_t* cand,
                    int32_t k_int, float scale, int precision, const void* ent_bf16, int64_t ld_bf16,
@@ -320,7 +321,7 @@ int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, 
                     int strategy, int precision_mode, int32_t* rank_out, void* stream);
 
 /* One training batch: corruptions of every side -> scores -> loss (accumulated into *loss_accum) -> gradients ->
- * row-sparse optimizer update of both tables (EmbeddingModel.py:614-822 + training/*.py), without the LP
+ * row-sparse optimizer update of both tables (EmbeddingModel.py:614-822 + training/{sgd,momentum,adagrad,adam}.py), without the LP
  * regulariser.  `workspace` (device, emg_train_step_workspace_bytes) holds all per-batch scratch.
  * inplace != 0: rows whose destination occurs once in the batch are updated by the gradient kernel itself. */
 typedef struct emg_step_args {

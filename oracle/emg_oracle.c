@@ -14,7 +14,7 @@
  *        perform_comparision             emgraph/models/EmbeddingModel.py:1989-2033
  *        filter correction               emgraph/models/EmbeddingModel.py:1894-1986
  *      It is itself validated against the literal numpy restatement (oracle/emgraph_oracle.py,
- *      pinned on the reference's goldens) in tests/test_oracle_c.py.
+ *      pinned on the reference's goldens) in tests/test_host_logic.py::test_c_oracle_matches_numpy_oracle.
  *  (2) the timed CPU baseline ("port"): fused gather+score of a training batch
  *      (EmbeddingModel.py:675-677,788-799; TransE.py:208-216, DistMult.py:201, ComplEx.py:288-298,
  *      HolE.py:189) with OpenMP over triples.

@@ -147,7 +147,7 @@ def philox_corruption_draws(seed, counter, n_rows, n_choices):
     """Draws for ``n_rows`` corruption rows: (keep_subject_mask in {0,1}, replacement index
     in [0, n_choices)).  Row j uses Philox counter (j_lo, j_hi, counter_lo, counter_hi), key
     (seed_lo, seed_hi); mask = out0 & 1; index = mulhi64((out2<<32)|out1, n_choices).
-    Mirrored bit-for-bit by emgraph_amd/csrc (emg_philox.h)."""
+    Mirrored bit-for-bit by emgraph_amd/csrc/emg_common.hpp::philox4x32_10 / corruption_draw and by oracle/emg_oracle.c."""
     j = np.arange(n_rows, dtype=np.uint64)
     seed = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
     counter = np.uint64(counter & 0xFFFFFFFFFFFFFFFF)

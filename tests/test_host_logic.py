@@ -162,30 +162,21 @@ def test_c_oracle_matches_numpy_oracle(model):
 
 def test_sgd_lr_schedule_reference_goldens():
     """tests/emgraph/models/test_optimizers.py:21,41-43,72-79 (values of update_feed_dict)"""
-    from emgraph_amd.training import SGDSchedule
-    s = SGDSchedule({"lr": 0.001}, 10)
-    for epoch in range(1, 11):
-        for batch in range(1, 11):
-            lr = s.lr(batch, epoch)
-    assert lr == 0.001
-    s = SGDSchedule({"lr": 0.001, "decay_lr_rate": 2, "cosine_decay": False, "decay_cycle": 10}, 10)
-    for epoch in range(1, 11):
-        for batch in range(1, 11):
-            lr = s.lr(batch, epoch)
-    assert lr == 0.001
-    assert s.lr(1, 11) == 0.0005
-    s = SGDSchedule({"lr": 0.001, "end_lr": 0.00001, "decay_lr_rate": 2, "expand_factor": 2, "cosine_decay": True,
-                     "decay_cycle": 10}, 10)
-    for epoch in range(1, 31):
-        for batch in range(1, 11):
-            lr = s.lr(batch, epoch)
-            if epoch == 11 and batch == 1:
-                assert lr == 0.0005
-            if epoch == 6 and batch == 1:
-                assert lr == 0.000505
-            if epoch == 21 and batch == 1:
-                assert lr == 0.000255
-    assert s.lr(1, 31) == 0.00025
+    from emgraph_amd.training import sgd_learning_rate as lr_at
+    assert all(lr_at({"lr": 0.001}, 10, e, b) == 0.001 for e in range(1, 11) for b in range(1, 11))
+    fixed = {"lr": 0.001, "decay_lr_rate": 2, "cosine_decay": False, "decay_cycle": 10}
+    assert all(lr_at(fixed, 10, e, b) == 0.001 for e in range(1, 11) for b in range(1, 11))
+    assert lr_at(fixed, 10, 11, 1) == 0.0005 and lr_at(fixed, 10, 20, 10) == 0.0005 and lr_at(fixed, 10, 21, 1) == 0.00025
+    assert lr_at(dict(fixed, end_lr=0.0004), 10, 300, 1) == 0.0004      # never below end_lr; the schedule then stops
+    cos = {"lr": 0.001, "end_lr": 0.00001, "decay_lr_rate": 2, "expand_factor": 2, "cosine_decay": True,
+           "decay_cycle": 10}
+    assert lr_at(cos, 10, 1, 1) == 0.001
+    assert lr_at(cos, 10, 6, 1) == 0.000505         # half-way through the first 10-epoch cycle
+    assert lr_at(cos, 10, 11, 1) == 0.0005          # restart at half the rate, cycle length doubled
+    assert lr_at(cos, 10, 21, 1) == 0.000255
+    assert lr_at(cos, 10, 31, 1) == 0.00025         # second restart after 10 + 20 epochs
+    rates = [lr_at(cos, 10, e, b) for e in range(1, 31) for b in range(1, 11)]
+    assert all(x >= 0.00001 for x in rates) and rates[:100] == sorted(rates[:100], reverse=True)
 
 
 def test_mappings_and_to_idx_match_oracle():
