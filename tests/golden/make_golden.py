@@ -181,9 +181,110 @@ def gen_misc():
     return out
 
 
+def gen_ranks():
+    """The rank path, executed from the reference:
+      * EmbeddingModel.perform_comparision (EmbeddingModel.py:1989-2033) — the method is called on a model object
+        with eval_config['ranking_strategy'] set, for all three strategies, on score vectors with planted ties,
+        zeros, negative scores and values inside one comparison quantum (int32(score * 1e5) truncates toward 0);
+      * SQLiteAdapter.get_participating_entities (datasets/sqlite_adapter.py:449-508) — a real sqlite3 database
+        built by the adapter's own set_data path (numpy_adapter.py:229-247: use_mappings + set_data(.., 'filter',
+        mapped_status)), queried per test triple;
+      * and, assembled from those two plus the reference's own _fn and generate_corruptions_for_eval, the filtered
+        ranks of a small random model following EmbeddingModel.py:1856-1986 line by line (that method itself needs
+        tf.data and cannot run under the shim; every numeric piece below is the reference's)."""
+    from emgraph.datasets import SQLiteAdapter
+    out = {}
+    m = TransE(k=3)
+    rs = np.random.RandomState(5000)
+    cases = []
+    explicit = [
+        # (corruption scores, positive score): the docstring example of EmbeddingModel.py:2017-2031
+        (np.array([0.5, 0.5, 0.3, 0.6, 0.5, 0.5], F32), F32(0.5)),
+        # one quantum is 1e-5: everything in (-1e-5, 1e-5) truncates to 0 and TIES with a zero positive
+        (np.array([0.0, 4e-6, -4e-6, 9.9e-6, -9.9e-6, 1e-5, -1e-5, 1.1e-5, -1.1e-5], F32), F32(0.0)),
+        (np.array([0.0, 4e-6, -4e-6, 9.9e-6, -9.9e-6, 1e-5, -1e-5, 1.1e-5, -1.1e-5], F32), F32(-3e-6)),
+        # truncation toward zero of negative scores: -1.234567 -> -123456, not -123457
+        (np.array([-1.234567, -1.234561, -1.234571, -1.23457, -1.23456, -1.2345], F32), F32(-1.234565)),
+        (np.array([2.5, 2.5, 2.5, 2.5], F32), F32(2.5)),                       # all ties (even count)
+        (np.array([2.5, 2.5, 2.5], F32), F32(2.5)),                            # all ties (odd count: ceil)
+        (np.array([-7.25], F32), F32(3.0)),
+        (np.array([1e3, -1e3, 123.456, 123.4561, 123.45599], F32), F32(123.456)),
+    ]
+    for corr, pos in explicit:
+        cases.append((corr, pos))
+    for n in (1, 2, 17, 64, 301):
+        corr = (rs.randn(n) * 0.01).astype(F32)
+        pos = F32(rs.randn() * 0.01)
+        corr[rs.randint(0, n, max(1, n // 5))] = pos          # exact ties
+        if n > 4:
+            corr[:2] = pos + F32(3e-6)                            # same quantum or not, depending on pos
+        cases.append((corr, pos))
+    out["cmp_n"] = np.array(len(cases))
+    for ci, (corr, pos) in enumerate(cases):
+        out["cmp_c%d_corr" % ci], out["cmp_c%d_pos" % ci] = corr, np.array(pos, F32)
+        for strat in ("worst", "best", "middle"):
+            m.eval_config = {"ranking_strategy": strat}
+            out["cmp_c%d_%s" % (ci, strat)] = np.array(int(m.perform_comparision(corr, pos)), np.int64)
+
+    # ---- SQLite filter lookups
+    n_ent, n_rel = 40, 3
+    F = np.stack([rs.randint(0, n_ent, 400), rs.randint(0, n_rel, 400), rs.randint(0, n_ent, 400)], 1).astype(np.int32)
+    F = np.concatenate([F, F[:25]])                               # duplicate rows: SQL DISTINCT / UNION
+    T = np.concatenate([F[rs.choice(400, 12, replace=False)],     # test triples present in the filter ...
+                        np.stack([rs.randint(0, n_ent, 6), rs.randint(0, n_rel, 6), rs.randint(0, n_ent, 6)], 1),
+                        np.array([[39, 2, 39], [0, 0, 0]])]).astype(np.int32)   # ... absent from it, and s == o
+    ent_to_idx = {i: i for i in range(n_ent)}
+    rel_to_idx = {i: i for i in range(n_rel)}
+    ad = SQLiteAdapter()
+    ad.use_mappings(rel_to_idx, ent_to_idx)
+    ad.set_data(F, "filter", True)                                # mapped_status=True (numpy_adapter.py:245-247)
+    objs, subs = [], []
+    for x in T:
+        po, ps = ad.get_participating_entities(x)
+        objs.append(np.sort(np.asarray(po).reshape(-1)).astype(np.int64))
+        subs.append(np.sort(np.asarray(ps).reshape(-1)).astype(np.int64))
+    ad.cleanup()
+    out["flt_filter"], out["flt_test"], out["flt_n_ent"] = F, T, np.array(n_ent)
+    out["flt_obj_ptr"] = np.cumsum([0] + [len(a) for a in objs]).astype(np.int64)
+    out["flt_obj_idx"] = np.concatenate(objs)
+    out["flt_sub_ptr"] = np.cumsum([0] + [len(a) for a in subs]).astype(np.int64)
+    out["flt_sub_idx"] = np.concatenate(subs)
+
+    # ---- filtered ranks of a small dyadic model (every fp32 op exact: any summation order gives these bits)
+    k = 4
+    all_ent = np.arange(n_ent, dtype=np.int64)
+    for name, cls, kint in (("TransE", TransE, k), ("DistMult", DistMult, k), ("ComplEx", ComplEx, 2 * k), ("HolE", HolE, 2 * k)):
+        E = (rs.randint(-4, 5, (n_ent, kint)) / 4.0).astype(F32)
+        R = (rs.randint(-4, 5, (n_rel, kint)) / 4.0).astype(F32)
+        mdl = cls(k=k)
+        out["rk_%s_E" % name], out["rk_%s_R" % name] = E, R
+        fn = lambda x: np.asarray(mdl._fn(E[x[:, 0]], R[x[:, 1]], E[x[:, 2]]), F32)   # noqa: E731 (:1861-1866 lookup + _fn)
+        for strat in ("worst", "best", "middle"):
+            mdl.eval_config = {"ranking_strategy": strat}
+            cmpf = mdl.perform_comparision
+            ranks_so, ranks_spo, ranks_raw = [], [], []
+            for ti, x in enumerate(T):
+                corr = np.asarray(generate_corruptions_for_eval(x[None, :].astype(np.int64), all_ent, "s,o"))  # :1856
+                sc = fn(corr.astype(np.int64))
+                sp = fn(x[None, :].astype(np.int64))[0]
+                obj_sc, sub_sc = sc[:n_ent], sc[n_ent:]                                   # :1883-1892
+                io = out["flt_obj_idx"][out["flt_obj_ptr"][ti]:out["flt_obj_ptr"][ti + 1]]
+                isub = out["flt_sub_idx"][out["flt_sub_ptr"][ti]:out["flt_sub_ptr"][ti + 1]]
+                f_o, f_s = int(cmpf(obj_sc[io], sp)), int(cmpf(sub_sc[isub], sp))        # :1942-1963
+                r_s = int(cmpf(sub_sc, sp)) + 1 - f_s                                     # :1967-1979
+                r_o = int(cmpf(obj_sc, sp)) + 1 - f_o
+                ranks_so.append((r_s, r_o))
+                ranks_spo.append(int(cmpf(sc, sp)) + 1 - f_s - f_o)                       # :1981-1986
+                ranks_raw.append((int(cmpf(sub_sc, sp)) + 1, int(cmpf(obj_sc, sp)) + 1))
+            out["rk_%s_%s_s,o" % (name, strat)] = np.array(ranks_so, np.int64)
+            out["rk_%s_%s_s+o" % (name, strat)] = np.array(ranks_spo, np.int64)
+            out["rk_%s_%s_raw" % (name, strat)] = np.array(ranks_raw, np.int64)
+    return out
+
+
 def main():
     for name, fn in (("scores", gen_scores), ("losses", gen_losses), ("corruptions", gen_corruptions),
-                     ("misc", gen_misc)):
+                     ("misc", gen_misc), ("ranks", gen_ranks)):
         data = fn()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)
