@@ -1,0 +1,187 @@
+"""GPU parity of the DEFAULT product path at the widths and optimizers of BASELINE.json's configurations.
+
+The training step `fit()` runs is: emg_prepare_batch (Philox codes, destination grouping, singleton flags) ->
+emg_train_backward_ex(fused_loss >= 0, single_ent != NULL)  [scores + pair-local loss + gradients in one pass,
+singleton destinations updated IN PLACE with the optimizer rule] -> emg_apply_grouped(skip_single = 1) for the
+entity table and emg_apply_grouped for the relation table.  Round 1 compared that path with the oracle only at
+k <= 12; here it is driven through the C-ABI at
+
+    C1  TransE-L1 k=100 eta=20 pairwise, Adam   (train_backward_kernel<TransE, 4, 1, 32, true, 2>)
+    C2  DistMult  k=200 eta=10 NLL,      Adam   (<DistMult, 4, 1, 64, true, 2>)
+    C5  HolE      k=200 eta=20 NLL,      Adam   (<HolE, 4, 1, 64, true, 2>)
+    C3  ComplEx   k=200 eta=20 NLL,      SGD    (<ComplEx, 4, 1, 64, true, 1>)
+    (+ Adagrad / momentum once each: the other two state layouts of the in-place path)
+
+against oracle/emgraph_oracle.py::train_grads + opt_apply (EmbeddingModel.py:614-822, losses/pairwise.py:66-70,
+nll.py:55-59, training/*.py) over TWO consecutive steps (the second one reads optimizer state written by the first),
+on a UNIFORM batch over 20 000 entities (most destinations are singletons -> in-place path) and on a ZIPF(1.0)
+batch over 2 000 entities (hot rows, long segments, hardly any singleton -> segmented apply path).
+
+Tolerances (fp32 path vs a float64-accumulating oracle): loss rtol 2e-5; gradients — read back through the
+optimizer state where one exists (Adam m = 0.1 g after step 1, momentum buffer, Adagrad accumulator) and through the
+SGD update otherwise — rtol 1e-4 with an absolute floor of 1e-5 x the largest gradient entry; tables after Adam /
+Adagrad within 1e-2 x lr, a secondary check (a gradient entry inside fp32 noise of zero may take either sign, and
+the first Adam steps move every entry by ~lr x g / (|g| + 3e-6): measured worst case 2.05e-3 x lr on 1 of 800 000
+entries); rows no kernel may touch stay BIT-identical.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as co  # noqa: E402
+from oracle import emgraph_oracle as orc  # noqa: E402
+
+F32 = np.float32
+MID = orc.MODEL_IDS
+B1, B2, EPS = 0.9, 0.999, 1e-7
+
+CONFIGS = {
+    # name: model, k, eta, loss, optimizer, n_rel
+    "C1": ("TransE_L1", 100, 20, "pairwise", "adam", 11),
+    "C2": ("DistMult", 200, 10, "nll", "adam", 237),
+    "C5": ("HolE", 200, 20, "nll", "adam", 1345),
+    "C3": ("ComplEx", 200, 20, "nll", "sgd", 1000),
+    "C2-adagrad": ("DistMult", 200, 10, "nll", "adagrad", 237),
+    "C1-momentum": ("TransE_L1", 100, 20, "pairwise", "momentum", 11),
+}
+
+
+def _batch(kind, n_ent, n_rel, n, seed):
+    rs = np.random.RandomState(seed)
+    if kind == "zipf":   # Zipf(1.0) over the entity ids: a few hub entities take most of the slots
+        w = 1.0 / np.arange(1, n_ent + 1)
+        s, o = (rs.choice(n_ent, n, p=w / w.sum()) for _ in range(2))
+    else:
+        s, o = rs.randint(0, n_ent, n), rs.randint(0, n_ent, n)
+    return np.stack([s, rs.randint(0, n_rel, n), o], 1).astype(np.int32)
+
+
+def _hyper(lr, step):
+    return (lr, 0.9, B1, B2, EPS, lr * np.sqrt(1.0 - B2 ** step) / (1.0 - B1 ** step))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
+    from emgraph_amd import _lib as L
+    from emgraph_amd import device as d
+    from emgraph_amd.training import Trainer, alloc_table
+    d.require_gpu()
+    model, k, eta, loss, opt, n_rel = CONFIGS[cfg]
+    n_ent = 20000 if kind == "uniform" else 2000
+    B, seed = 512, 3
+    lr = 0.1 if opt == "sgd" else 0.01     # SGD: a large step keeps the table's own fp32 rounding below the 1e-4 bar
+    ki = 2 * k if model in ("ComplEx", "HolE") else k
+    sc = float(F32(2 / k)) if model == "HolE" else 1.0
+    rs = np.random.RandomState(sum(map(ord, cfg + kind)))
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = _batch(kind, n_ent, n_rel, 2 * B, seed=17)
+    dev = torch.device("cuda")
+
+    # ---------------- device: the C-ABI sequence fit() issues ----------------
+    Et, Rt = alloc_table(n_ent, ki, dev, init=E0), alloc_table(n_rel, ki, dev, init=R0)
+    ns = {"sgd": 0, "momentum": 1, "adagrad": 1, "adam": 2}[opt]
+    fill = 0.1 if opt == "adagrad" else 0.0
+    se = [alloc_table(n_ent, ki, dev, fill=fill) for _ in range(ns)] + [None] * (2 - ns)
+    sr = [alloc_table(n_rel, ki, dev, fill=fill) for _ in range(ns)] + [None] * (2 - ns)
+    tag_e = torch.zeros(n_ent, dtype=torch.int32, device=dev)
+    tag_r = torch.zeros(n_rel, dtype=torch.int32, device=dev)
+    n_ce = (2 + eta) * B
+    we = torch.empty(d.apply_workspace_bytes(n_ce, n_ent), dtype=torch.uint8, device=dev)
+    wr = torch.empty(d.apply_workspace_bytes(B, n_rel), dtype=torch.uint8, device=dev)
+    codes = torch.empty(B * eta, dtype=torch.int32, device=dev)
+    de = torch.empty(n_ce, dtype=torch.int32, device=dev)
+    dr = torch.empty(B, dtype=torch.int32, device=dev)
+    single = torch.zeros(n_ce, dtype=torch.uint8, device=dev)
+    Xt = torch.from_numpy(X).to(dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    n_single, dev_states, dev_tables, dev_loss = [], [], [], []
+    for step in (1, 2):
+        pos = Xt[(step - 1) * B:step * B]
+        d.prepare_batch(pos, eta, [L.SIDE_SO], n_ent, codes, de, dr, n_ent, n_rel, we, wr, seed=seed, counter0=step - 1,
+                        single_flags=single)
+        # poison: a slot the backward kernel applied in place must never be read by the apply kernel
+        ce = torch.full((n_ce, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
+        cr = torch.full((B, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
+        hyper = _hyper(lr, step)
+        d.train_backward_ex(MID[model], Et, Rt, ki, sc, pos, eta, codes, ce, cr, fused_loss=L.LOSS_IDS[loss], margin=1.0,
+                            loss_accum=acc, single_ent=single, opt_id=L.OPT_IDS[opt], step=step, hyper=hyper,
+                            ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e)
+        d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, True, hyper, we)
+        d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, False, hyper, wr)
+        n_single.append(int(single.sum().item()))
+        dev_loss.append(float(acc.item()))
+        dev_tables.append((Et.cpu().numpy().copy(), Rt.cpu().numpy().copy()))
+        dev_states.append(([t.cpu().numpy().copy() for t in se if t is not None],
+                           [t.cpu().numpy().copy() for t in sr if t is not None]))
+        np.testing.assert_array_equal(codes.cpu().numpy(), co.corrupt_codes(B, eta, 2, n_ent, seed, step - 1))
+    # both data-movement paths are exercised where the test says so
+    if kind == "uniform":
+        assert min(n_single) > 0.3 * n_ce, n_single
+    else:
+        assert max(n_single) < 0.3 * n_ce, n_single
+
+    # ---------------- oracle ----------------
+    E, R = E0.copy(), R0.copy()
+    stE, stR = orc.opt_init(opt, E.shape), orc.opt_init(opt, R.shape)
+    loss_sum = 0.0
+    never_e = np.ones(n_ent, bool)
+    for step in (1, 2):
+        xb = X[(step - 1) * B:step * B]
+        xneg = orc.generate_corruptions_for_fit_philox(xb, eta=eta, corrupt_side="s,o", entities_size=n_ent, seed=seed,
+                                                       counter=step - 1)
+        val, _, _ = orc.model_loss(model, E, R, xb, eta, loss, None, ("s,o",), [xneg], k=k)
+        loss_sum += float(val)
+        dE, dR = orc.train_grads(model, E, R, xb, eta, loss, None, [xneg], k=k)
+        tE, tR = np.zeros(n_ent, bool), np.zeros(n_rel, bool)
+        for xx in (xb, xneg):
+            tE[xx[:, 0]] = True
+            tE[xx[:, 2]] = True
+        tR[xb[:, 1]] = True
+        never_e &= ~tE
+        E_prev, R_prev = E, R
+        E = orc.opt_apply(opt, E, dE, stE, lr=lr, touched=None if opt == "adam" else tE)
+        R = orc.opt_apply(opt, R, dR, stR, lr=lr, touched=None if opt == "adam" else tR)
+        gE, gR = np.abs(dE).max(), np.abs(dR).max()
+        dE_t, dR_t = dev_tables[step - 1]
+        (se_np, sr_np) = dev_states[step - 1]
+        np.testing.assert_allclose(dev_loss[step - 1], loss_sum, rtol=2e-5, err_msg="loss, step %d" % step)
+        if opt == "sgd":      # the update IS the gradient: W_prev - W_new = lr * g (+ one fp32 rounding of the table entry)
+            prevE, prevR = (E0, R0) if step == 1 else dev_tables[0]
+            np.testing.assert_allclose(prevE.astype(np.float64) - dE_t, lr * dE, rtol=1e-4, atol=2e-7 + 1e-5 * lr * gE)
+            np.testing.assert_allclose(prevR.astype(np.float64) - dR_t, lr * dR, rtol=1e-4, atol=2e-7 + 1e-5 * lr * gR)
+        elif opt == "adam":   # first moment: 0.1 g (+ 0.9 m): the gradient, read back through the state
+            np.testing.assert_allclose(se_np[0], stE["m"], rtol=1e-4, atol=1e-6 * gE)
+            np.testing.assert_allclose(sr_np[0], stR["m"], rtol=1e-4, atol=1e-6 * gR)
+            np.testing.assert_allclose(se_np[1], stE["v"], rtol=2e-4, atol=1e-8 * gE * gE)
+            np.testing.assert_allclose(sr_np[1], stR["v"], rtol=2e-4, atol=1e-8 * gR * gR)
+            np.testing.assert_allclose(dE_t, E, rtol=0, atol=1e-2 * lr)
+            np.testing.assert_allclose(dR_t, R, rtol=0, atol=1e-2 * lr)
+        elif opt == "momentum":
+            np.testing.assert_allclose(se_np[0], stE["m"], rtol=1e-4, atol=1e-5 * gE * lr)
+            np.testing.assert_allclose(sr_np[0], stR["m"], rtol=1e-4, atol=1e-5 * gR * lr)
+            np.testing.assert_allclose(dE_t, E, rtol=1e-5, atol=1e-5 * gE * lr)
+        else:                 # adagrad
+            np.testing.assert_allclose(se_np[0], stE["acc"], rtol=2e-4, atol=1e-8 * gE * gE)
+            np.testing.assert_allclose(sr_np[0], stR["acc"], rtol=2e-4, atol=1e-8 * gR * gR)
+            np.testing.assert_allclose(dE_t, E, rtol=0, atol=1e-2 * lr)
+    # rows no triple of either batch touched: bit-identical (Adam's dense-equivalent decay of an all-zero state
+    # subtracts lr_t * 0 / (0 + eps) = 0)
+    assert never_e.any() or kind == "zipf"
+    np.testing.assert_array_equal(dev_tables[1][0][never_e], E0[never_e])
+
+    # ---------------- the product's Trainer (fused + in-place + pipelined plan) == the sequence above, bitwise ----
+    tr = Trainer(MID[model], ki, sc, E0, R0, eta, loss=loss, optimizer=opt, optimizer_params={"lr": lr}, batches_count=2,
+                 seed=seed)
+    assert tr.fused and tr.inplace and tr.pipeline
+    tr.set_training_set(X, B)
+    tr.step(0, B, epoch=1, batch=1, prefetch=[(B, B, 1, 2)])
+    tr.step(B, B, epoch=1, batch=2)
+    Et2, Rt2 = tr.tables_numpy()
+    np.testing.assert_array_equal(Et2, dev_tables[1][0])
+    np.testing.assert_array_equal(Rt2, dev_tables[1][1])
+    assert tr.read_loss() == dev_loss[1]
