@@ -189,35 +189,59 @@ def evaluate_performance(X, model, filter_triples=None, verbose=False, filter_un
                          corrupt_side="s,o", ranking_strategy="worst", use_default_protocol=False):
     """protocol.py:726-979.  Ranks of the positives in ``X`` against their corruptions.
 
+    ``X``: ndarray [n,3] of labels, or an EmgraphBaseDatasetAdaptor holding a mapped 'test' set (then
+    ``filter_triples`` is a bool: True = use the filter already set in the adapter, :923-929).
     Returns an int ndarray [n] ('s', 'o', 's+o') or [n,2] = [subject_rank, object_rank] ('s,o')."""
-    if use_default_protocol:
-        logger.warning("DeprecationWarning: use_default_protocol will be removed in future. "
-                       "Please use corrupt_side argument instead.")
-        corrupt_side = "s,o"
-    assert corrupt_side in ["s", "o", "s+o", "s,o"], "Invalid value for corrupt_side."
-    if not isinstance(X, np.ndarray):
-        msg = "X must be either a numpy array or an EmgraphBaseDatasetAdaptor."
-        logger.error(msg)
-        raise ValueError(msg)
-    if filter_unseen:
-        X = filter_unseen_entities(X, model, verbose=verbose)
-    else:
-        logger.warning("If your test set or filter triples contain unseen entities you may get a"
-                       "runtime error. You can filter them by setting filter_unseen=True")
-    X_idx = to_idx(X, ent_to_idx=model.ent_to_idx, rel_to_idx=model.rel_to_idx)
-    F_idx = None
-    if filter_triples is not None:
-        if not isinstance(filter_triples, np.ndarray):
-            raise Exception("Invalid datatype for filter. Expected a numpy array or preset data in the adapter.")
-        if filter_unseen:
-            filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
-        F_idx = to_idx(filter_triples, ent_to_idx=model.ent_to_idx, rel_to_idx=model.rel_to_idx)
-    check_filter_size(model, entities_subset)
-    idx_entities = None
-    if entities_subset is not None:
-        subset = set(entities_subset)
-        idx_entities = np.asarray([idx for uri, idx in model.ent_to_idx.items() if uri in subset])
-    assert ranking_strategy in ["worst", "best", "middle"], "Invalid ranking_strategy!"
-    return np.array(model.get_ranks_idx(X_idx, filter_idx=F_idx, corrupt_side=corrupt_side,
-                                        ranking_strategy=ranking_strategy, corruption_entities=idx_entities,
-                                        verbose=verbose))
+    from ..datasets import EmgraphBaseDatasetAdaptor, NumpyDatasetAdapter
+    dataset_handle = None
+    try:  # the reference's flow, call for call (:868-979); failures clean the adapter up and re-raise (:975-979)
+        if use_default_protocol:
+            logger.warning("DeprecationWarning: use_default_protocol will be removed in future. "
+                           "Please use corrupt_side argument instead.")
+            corrupt_side = "s,o"
+        assert corrupt_side in ["s", "o", "s+o", "s,o"], "Invalid value for corrupt_side."
+        if isinstance(X, np.ndarray):
+            if filter_unseen:
+                X = filter_unseen_entities(X, model, verbose=verbose)
+            else:
+                logger.warning("If your test set or filter triples contain unseen entities you may get a"
+                               "runtime error. You can filter them by setting filter_unseen=True")
+            dataset_handle = NumpyDatasetAdapter()
+            dataset_handle.use_mappings(model.rel_to_idx, model.ent_to_idx)
+            dataset_handle.set_data(X, "test")
+        elif isinstance(X, EmgraphBaseDatasetAdaptor):
+            dataset_handle = X
+        else:
+            msg = "X must be either a numpy array or an EmgraphBaseDatasetAdaptor."
+            logger.error(msg)
+            raise ValueError(msg)
+        if filter_triples is not None:
+            if isinstance(filter_triples, np.ndarray):
+                if filter_unseen:
+                    filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
+                dataset_handle.set_filter(filter_triples)
+                model.set_filter_for_eval()
+            elif isinstance(X, EmgraphBaseDatasetAdaptor):
+                if not isinstance(filter_triples, bool):
+                    raise Exception("Expected a boolean type")
+                if filter_triples is True:
+                    model.set_filter_for_eval()
+            else:
+                raise Exception("Invalid datatype for filter. Expected a numpy array or preset data in the adapter.")
+        eval_dict = {}
+        check_filter_size(model, entities_subset)
+        if entities_subset is not None:
+            subset = set(entities_subset)
+            eval_dict["corruption_entities"] = np.asarray([idx for uri, idx in model.ent_to_idx.items() if uri in subset])
+        eval_dict["corrupt_side"] = corrupt_side
+        assert ranking_strategy in ["worst", "best", "middle"], "Invalid ranking_strategy!"
+        eval_dict["ranking_strategy"] = ranking_strategy
+        model.configure_evaluation_protocol(eval_dict)
+        ranks = model.get_ranks(dataset_handle)
+        model.end_evaluation()
+        return np.array(ranks)
+    except BaseException as e:
+        model.end_evaluation()
+        if dataset_handle is not None:
+            dataset_handle.cleanup()
+        raise e

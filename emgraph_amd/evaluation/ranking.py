@@ -39,6 +39,7 @@ class FilterIndex:
     def __init__(self, filter_triples):
         F = np.asarray(filter_triples, dtype=np.int64).reshape(-1, 3)
         self.n_rel = int(F[:, 1].max()) + 1 if len(F) else 1
+        self.max_entity = int(max(F[:, 0].max(), F[:, 2].max())) if len(F) else -1
         self._sides = {}
         for name, kcol, vcol in (("obj", 0, 2), ("sub", 2, 0)):
             key = F[:, kcol] * self.n_rel + F[:, 1]

@@ -22,6 +22,7 @@ import torch
 from .. import _lib as L
 from .. import device as D
 from .. import parallel
+from ..datasets import EmgraphBaseDatasetAdaptor
 from ..evaluation.metrics import hits_at_n_score, mrr_score
 from ..evaluation.protocol import create_mappings_and_index, to_idx
 from ..evaluation.ranking import FilterIndex, rank_triples_device
@@ -283,19 +284,35 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             raise NotImplementedError("FocusE numeric edge values are outside the accelerated hot path")
         if self.embedding_model_params.get("non_linearity", "linear") != "linear":
             raise NotImplementedError("non_linearity other than 'linear' is outside the accelerated hot path")
-        if not isinstance(X, np.ndarray):
+        # EmbeddingModel.py:1218-1248: an ndarray is wrapped in a NumpyDatasetAdapter; an adapter is used as it is
+        if isinstance(X, np.ndarray):
+            if X.ndim != 2 or X.shape[1] != 3:
+                msg = "Invalid size for input X. Expected (n,3):  got {}".format(X.shape)
+                logger.error(msg)
+                raise ValueError(msg)
+            handle = None
+        elif isinstance(X, EmgraphBaseDatasetAdaptor):
+            handle = X
+        else:
             msg = "Invalid type for input X. Expected ndarray/EmgraphDataset object, got {}".format(type(X))
-            logger.error(msg)
-            raise ValueError(msg)
-        if X.ndim != 2 or X.shape[1] != 3:
-            msg = "Invalid size for input X. Expected (n,3):  got {}".format(X.shape)
             logger.error(msg)
             raise ValueError(msg)
         if self.k > MAX_TRAIN_K:
             # the gradient kernels keep a whole row in registers (emg_score.hip: 128 sixteen-byte chunks per lane
             # group); scoring / ranking have no such limit.  Fail here, not with EMG_ENOSUP inside the first step.
             raise ValueError("k={} is not supported for training by the HIP path (k <= {})".format(self.k, MAX_TRAIN_K))
-        self.rel_to_idx, self.ent_to_idx, X_idx = create_mappings_and_index(X)
+        if handle is None:
+            self.rel_to_idx, self.ent_to_idx, X_idx = create_mappings_and_index(X)
+        else:
+            # the adapter owns mapping and batching (abstract_dataset_adapter.py): ids come from ITS dictionaries and
+            # the training set is the concatenation of its batches, which stay contiguous slices of the resident copy
+            self.rel_to_idx, self.ent_to_idx = handle.generate_mappings()
+            handle.map_data()
+            parts = [np.asarray(b[0] if isinstance(b, (list, tuple)) else b, dtype=np.int32).reshape(-1, 3)
+                     for b in handle.get_next_batch(self.batches_count, "train")]
+            X_idx = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3), np.int32)
+            if X_idx.shape[0] != handle.get_size("train"):
+                raise ValueError("the adapter's batches do not add up to get_size('train')")
         n = X_idx.shape[0]
         batch_size = int(np.ceil(n / self.batches_count))  # EmbeddingModel.py:1297-1301
         self.batch_size = batch_size
@@ -413,7 +430,19 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             msg = "x_valid must be passed for early fitting."
             logger.error(msg)
             raise KeyError(msg)
-        if not isinstance(x_valid, np.ndarray):
+        if isinstance(x_valid, EmgraphBaseDatasetAdaptor):   # EmbeddingModel.py:868-880: validation data held by an adapter
+            if not x_valid.data_exists("valid"):
+                msg = "Dataset `valid` has not been set in the DatasetAdapter."
+                logger.error(msg)
+                raise ValueError(msg)
+            x_valid.use_mappings(self.rel_to_idx, self.ent_to_idx)
+            x_valid.map_data()
+            x_valid = np.concatenate([np.asarray(b[0]) for b in x_valid.get_next_batch(1, "valid")], axis=0)
+            p = dict(p, x_valid=None)
+            mapped_valid = x_valid
+        else:
+            mapped_valid = None
+        if mapped_valid is None and not isinstance(x_valid, np.ndarray):
             msg = "Invalid type for input X. Expected ndarray/EmgraphDataset object, got {}".format(type(x_valid))
             logger.error(msg)
             raise ValueError(msg)
@@ -439,7 +468,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                 logger.error(msg)
                 raise ValueError(msg)
             findex = FilterIndex(to_idx(x_filter, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx))
-        return {"x_valid": to_idx(x_valid, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx),
+        return {"x_valid": (mapped_valid if mapped_valid is not None else
+                            to_idx(x_valid, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx)),
                 "criteria": criteria, "subset": subset, "filter": findex,
                 "corrupt_side": p.get("corrupt_side", DEFAULT_CORRUPT_SIDE_EVAL),
                 "best": None, "first": None, "counter": 0, "epoch": None}
@@ -499,12 +529,74 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             X = to_idx(X, ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx)
         X = np.ascontiguousarray(X, dtype=np.int32)
         ent, rel = self._device_tables()
-        out = np.empty(X.shape[0], dtype=np.float32)
-        for c0 in range(0, X.shape[0], chunk):  # SURVEY A-17: chunk instead of one giant gather
-            xt = torch.from_numpy(X[c0:c0 + chunk]).cuda()
-            out[c0:c0 + chunk] = D.score_triples(self._model_id(), ent, rel, self.internal_k, self._scale(),
-                                                 xt).cpu().numpy()
+        out = np.zeros(X.shape[0], dtype=np.float32)
+        # multi-GPU (one process per GPU, tables replicated): rank r scores the r-th contiguous range of the triple
+        # list and the ranges are summed into place (predict shards trivially, no data-path exchange)
+        rank, world = parallel.rank_world()
+        r0, r1 = parallel.entity_range(X.shape[0], rank, world)
+        for c0 in range(r0, r1, chunk):  # SURVEY A-17: chunk instead of one giant gather
+            c1 = min(c0 + chunk, r1)
+            xt = torch.from_numpy(X[c0:c1]).cuda()
+            out[c0:c1] = D.score_triples(self._model_id(), ent, rel, self.internal_k, self._scale(), xt).cpu().numpy()
+        if world > 1:   # disjoint ranges, zeros elsewhere: the sum puts every range in place exactly
+            out = parallel.allreduce_sum_(torch.from_numpy(out).cuda()).cpu().numpy()
         return out
+
+    # ---- evaluation protocol plumbing (EmbeddingModel.py:1494-1518,2035-2099) ----
+    def set_filter_for_eval(self):
+        """Configures to use filter (:1494-1496)."""
+        self.is_filtered = True
+
+    def configure_evaluation_protocol(self, config=None):
+        """:1498-1518: keys corruption_entities ('all' | ids), corrupt_side, ranking_strategy."""
+        if config is None:
+            config = {"corruption_entities": DEFAULT_CORRUPTION_ENTITIES, "corrupt_side": DEFAULT_CORRUPT_SIDE_EVAL}
+        self.eval_config = config
+
+    def end_evaluation(self):
+        """:2035-2044."""
+        handle = getattr(self, "eval_dataset_handle", None)
+        if self.is_filtered and handle is not None:
+            handle.cleanup()
+        self.eval_dataset_handle = None
+        self.is_filtered = False
+        self.eval_config = {}
+
+    def get_ranks(self, dataset_handle):
+        """Ranks of the adapter's 'test' triples under the configured protocol (EmbeddingModel.py:2046-2099, with the
+        intended one-rank-per-test-triple semantics, SURVEY A-1).  The filter comes from the adapter: its FilterIndex
+        when it is this package's NumpyDatasetAdapter, otherwise the per-triple lists its
+        get_next_batch(-1, 'test', use_filter=True) yields (the protocol of numpy_adapter.py:79-131)."""
+        if not self.is_fitted:
+            msg = "Model has not been fitted."
+            logger.error(msg)
+            raise RuntimeError(msg)
+        self.eval_dataset_handle = dataset_handle
+        cfg = self.eval_config
+        corrupt_side = cfg.get("corrupt_side", DEFAULT_CORRUPT_SIDE_EVAL)
+        strategy = cfg.get("ranking_strategy", DEFAULT_RANK_COMPARE_STRATEGY)
+        subset = cfg.get("corruption_entities", DEFAULT_CORRUPTION_ENTITIES)
+        subset = None if isinstance(subset, str) else np.asarray(subset)
+        findex = None
+        if self.is_filtered:
+            findex = getattr(dataset_handle, "filter_index", None)
+        if self.is_filtered and findex is None:
+            # a foreign adapter: collect its per-triple filter lists into the filter triples they stand for
+            X_parts, rows = [], []
+            for out in dataset_handle.get_next_batch(-1, "test", use_filter=True):
+                x, objs, subs = np.asarray(out[0]).reshape(-1, 3), np.asarray(out[-2]).reshape(-1), np.asarray(out[-1]).reshape(-1)
+                X_parts.append(x)
+                rows.append(np.stack([np.full(len(objs), x[0, 0]), np.full(len(objs), x[0, 1]), objs], 1))
+                rows.append(np.stack([subs, np.full(len(subs), x[0, 1]), np.full(len(subs), x[0, 2])], 1))
+            X_idx = np.concatenate(X_parts, 0) if X_parts else np.zeros((0, 3), np.int64)
+            findex = FilterIndex(np.concatenate(rows, 0)) if rows else None
+        else:
+            parts = [np.asarray(b[0] if isinstance(b, (list, tuple)) else b).reshape(-1, 3)
+                     for b in dataset_handle.get_next_batch(1, "test")]
+            X_idx = np.concatenate(parts, 0) if parts else np.zeros((0, 3), np.int64)
+        ranks = self.get_ranks_idx(X_idx, filter_idx=findex, corrupt_side=corrupt_side, ranking_strategy=strategy,
+                                   corruption_entities=subset)
+        return [list(r) for r in ranks] if corrupt_side == "s,o" else list(ranks)
 
     def get_ranks_idx(self, X_idx, filter_idx=None, corrupt_side=DEFAULT_CORRUPT_SIDE_EVAL,
                       ranking_strategy=DEFAULT_RANK_COMPARE_STRATEGY, corruption_entities=None, verbose=False):

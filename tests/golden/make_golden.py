@@ -282,9 +282,114 @@ def gen_ranks():
     return out
 
 
+def gen_checkpoints():
+    """Model files written BY THE REFERENCE's save_model (utils/model_utils.py:22-87): a fitted-looking model object
+    of the reference's own class (hyper-parameters through its constructor, parameters and dictionaries set by hand,
+    numpy arrays as AmpliGraph-1.x stored them) is pickled by the reference's code.  The files hold plain python /
+    numpy data only (dict of str, int, bool, dict, list of ndarray): they load without the reference.
+    Beside them: the scores the reference's own _fn gives for a few labelled triples."""
+    from emgraph.utils import save_model
+    out = {}
+    labels_e = np.array(["ent_%02d" % i for i in range(12)])
+    labels_r = np.array(["rel_a", "rel_b", "rel_c"])
+    rs = np.random.RandomState(6000)
+    X = np.stack([labels_e[rs.randint(0, 12, 9)], labels_r[rs.randint(0, 3, 9)], labels_e[rs.randint(0, 12, 9)]], 1)
+    out["X"] = X
+    for name, cls, kw in (("TransE", TransE, dict(k=5, eta=3, epochs=7, batches_count=2, seed=11, loss="pairwise",
+                                                   loss_params={"margin": 2.0}, optimizer="adagrad",
+                                                   optimizer_params={"lr": 0.1},
+                                                   embedding_model_params={"norm": 2, "corrupt_sides": ["s", "o"]})),
+                          ("ComplEx", ComplEx, dict(k=4, eta=2, epochs=3, batches_count=1, seed=5, regularizer="LP",
+                                                     regularizer_params={"lambda": 0.01, "p": 3})),
+                          ("HolE", HolE, dict(k=6))):
+        m = cls(**kw)
+        kint = kw["k"] * (1 if name == "TransE" else 2)
+        E = (rs.randn(12, kint) * 0.4).astype(F32)
+        R = (rs.randn(3, kint) * 0.4).astype(F32)
+        m.is_fitted = True
+        m.ent_to_idx = {str(l): i for i, l in enumerate(labels_e)}
+        m.rel_to_idx = {str(l): i for i, l in enumerate(labels_r)}
+        m.trained_model_params = [E, R]
+        save_model(m, os.path.join(HERE, "ref_%s.model.pkl" % name))
+        Xi = to_idx(X, ent_to_idx=m.ent_to_idx, rel_to_idx=m.rel_to_idx)
+        out["scores_" + name] = np.asarray(m._fn(E[Xi[:, 0]], R[Xi[:, 1]], E[Xi[:, 2]]), F32)
+        out["E_" + name], out["R_" + name] = E, R
+    return out
+
+
+def gen_model_selection():
+    """The call pattern of select_best_model_ranking (evaluation/protocol.py:1317-1703), RECORDED while the
+    reference's own routine runs: a subclass of the reference's ComplEx records its constructor / fit arguments and
+    the module's evaluate_performance is replaced by a recorder that returns made-up ranks.  What is written is the
+    list of calls (JSON) — the contract a drop-in model class and evaluate_performance have to honour."""
+    import json
+
+    import emgraph.evaluation.protocol as proto
+    calls = []
+
+    def summ(v):
+        if isinstance(v, np.ndarray):
+            return {"ndarray": list(v.shape)}
+        if isinstance(v, dict):
+            return {k: summ(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [summ(x) for x in v]
+        if isinstance(v, (np.integer, np.floating)):
+            return v.item()
+        return v if isinstance(v, (int, float, str, bool, type(None))) else repr(type(v))
+
+    class Recording(ComplEx):
+        name = "ComplEx"
+
+        def __init__(self, **kw):
+            calls.append({"call": "init", "kwargs": summ(kw)})
+            super().__init__(**kw)
+
+        def fit(self, *a, **kw):
+            calls.append({"call": "fit", "args": summ(list(a)), "kwargs": summ(kw)})
+            self.is_fitted = True
+
+    Recording.__init__.__code__  # the routine inspects co_varnames (:1513)
+
+    def fake_eval(X, **kw):
+        m = kw["model"]
+        calls.append({"call": "evaluate_performance", "args": summ([X]), "kwargs": summ({k: v for k, v in kw.items() if k != "model"}),
+                      "model_k": m.all_params["k"]})
+        n = len(X)
+        base = 1 + (m.all_params["k"] % 7)
+        return np.stack([np.arange(n) % 5 + base, np.arange(n) % 3 + base], 1)
+
+    real_eval = proto.evaluate_performance
+    proto.evaluate_performance = fake_eval
+    try:
+        rs = np.random.RandomState(7000)
+        mk = lambda n: np.stack([rs.randint(0, 30, n), rs.randint(0, 3, n), rs.randint(0, 30, n)], 1)  # noqa: E731
+        Xtr, Xva, Xte = mk(200), mk(20), mk(25)
+        grid = {"batches_count": [2], "seed": 0, "epochs": [3], "k": [4, 8], "eta": [2, 4], "loss": ["nll"],
+                "loss_params": {}, "embedding_model_params": {}, "regularizer": [None, "LP"],
+                "regularizer_params": {"lambda": [1e-3]}, "optimizer": ["adam"], "optimizer_params": {"lr": [0.01]},
+                "verbose": False}
+        res = proto.select_best_model_ranking(Recording, Xtr, Xva, Xte, dict(grid), use_filter=True,
+                                              early_stopping=True, early_stopping_params={"burn_in": 1, "check_interval": 1},
+                                              retrain_best_model=True, corrupt_side="s,o", verbose=False)
+    finally:
+        proto.evaluate_performance = real_eval
+    best_model, best_params, best_mrr, ranks_test, test_eval, history = res
+    doc = {"param_grid": summ(grid), "shapes": {"train": list(Xtr.shape), "valid": list(Xva.shape), "test": list(Xte.shape)},
+           "calls": calls, "best_params": summ(best_params), "best_mrr_train": float(best_mrr),
+           "test_evaluation": summ(test_eval), "n_history": len(history),
+           "history_keys": sorted(history[0].keys()), "result_keys": sorted(history[0]["results"].keys()),
+           "init_varnames": list(ComplEx.__init__.__code__.co_varnames[1:ComplEx.__init__.__code__.co_argcount])}
+    path = os.path.join(HERE, "model_selection_calls.json")
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    print("wrote", path, len(calls), "calls")
+
+
 def main():
+    gen_model_selection()
     for name, fn in (("scores", gen_scores), ("losses", gen_losses), ("corruptions", gen_corruptions),
-                     ("misc", gen_misc), ("ranks", gen_ranks)):
+                     ("misc", gen_misc), ("ranks", gen_ranks), ("checkpoints", gen_checkpoints)):
         data = fn()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)

@@ -227,3 +227,73 @@ def test_eval_corruption_layout_matches_reference_golden(golden):
         np.testing.assert_array_equal(generate_corruptions_for_eval(x, np.arange(8), side), g["eval_" + side])
     with pytest.raises(ValueError):
         generate_corruptions_for_eval(x, np.arange(8), "x")
+
+
+# ---- checkpoint interchange and the model-selection call contract (fixtures written by the REFERENCE's own code,
+# ---- tests/golden/make_golden.py::gen_checkpoints / gen_model_selection) ---------------------------------------
+@pytest.mark.parametrize("name", ["TransE", "ComplEx", "HolE"])
+def test_restore_model_reads_files_written_by_the_reference(name, golden, tmp_path):
+    """utils/model_utils.py:63-87 layout: a file pickled by the reference's save_model restores into this package's
+    class with the same hyper-parameters, dictionaries and parameter arrays; and what this package's save_model
+    writes has the same keys and value types, so the reference's restore_model (:142-154) reads it the same way."""
+    import pickle
+
+    from emgraph_amd.utils import restore_model, save_model
+    path = os.path.join(ROOT, "tests", "golden", "ref_%s.model.pkl" % name)
+    with open(path, "rb") as f:
+        raw = pickle.load(f)   # plain python / numpy objects only: no class of the reference is needed to load it
+    assert sorted(raw) == ["calibration_parameters", "class_name", "ent_to_idx", "hyperparams", "is_calibrated",
+                           "is_fitted", "large_graph", "model_params", "rel_to_idx"]
+    m = restore_model(path)
+    g = golden("checkpoints")
+    assert type(m).__name__ == name == raw["class_name"] and m.is_fitted
+    assert m.all_params == raw["hyperparams"] and m.ent_to_idx == raw["ent_to_idx"] and m.rel_to_idx == raw["rel_to_idx"]
+    np.testing.assert_array_equal(m.trained_model_params[0], g["E_" + name])
+    np.testing.assert_array_equal(m.trained_model_params[1], g["R_" + name])
+    assert m.k == raw["hyperparams"]["k"] and m.internal_k == g["E_" + name].shape[1]
+    np.testing.assert_array_equal(m.get_embeddings(np.array(["ent_03"])), g["E_" + name][3:4])
+    if name == "TransE":
+        assert m.embedding_model_params["norm"] == 2 and m.loss_params == {"margin": 2.0}
+    out = os.path.join(tmp_path, "roundtrip.pkl")
+    save_model(m, out)
+    with open(out, "rb") as f:
+        again = pickle.load(f)
+    assert sorted(again) == sorted(raw)
+    for key in raw:
+        assert type(again[key]) is type(raw[key]), key
+    assert again["hyperparams"] == raw["hyperparams"] and again["class_name"] == raw["class_name"]
+    for a, b in zip(again["model_params"], raw["model_params"]):
+        assert isinstance(a, np.ndarray) and a.dtype == b.dtype
+        np.testing.assert_array_equal(a, b)
+
+
+def test_model_selection_call_contract():
+    """select_best_model_ranking (evaluation/protocol.py:1317-1703) is a pure caller of the model class and of
+    evaluate_performance.  tests/golden/model_selection_calls.json is the list of calls the reference's routine
+    made when it was run (with a recording subclass of its ComplEx) over a 2x2x2 grid with early stopping, a filter
+    and retrain_best_model: every one of them must bind to this package's signatures, and the class attributes the
+    routine inspects (`name`, `__init__.__code__.co_varnames`, :1513-1525) must be there."""
+    import inspect
+    import json
+
+    from emgraph_amd.evaluation import evaluate_performance, hits_at_n_score, mr_score, mrr_score
+    from emgraph_amd.models import ComplEx
+    with open(os.path.join(ROOT, "tests", "golden", "model_selection_calls.json")) as f:
+        doc = json.load(f)
+    assert ComplEx.name == "ComplEx"
+    ours = ComplEx.__init__.__code__.co_varnames[1:ComplEx.__init__.__code__.co_argcount]
+    assert list(ours) == doc["init_varnames"]                       # same constructor arguments, same order
+    kinds = [c["call"] for c in doc["calls"]]
+    assert kinds == ["init", "fit", "evaluate_performance"] * 8 + ["fit", "evaluate_performance"]
+    for c in doc["calls"]:
+        if c["call"] == "init":
+            m = ComplEx(**c["kwargs"])                              # accepted as they are (no GPU needed to construct)
+            assert m.get_hyperparameter_dict()["k"] == c["kwargs"]["k"]
+        elif c["call"] == "fit":
+            b = inspect.signature(ComplEx.fit).bind(None, *c["args"], **c["kwargs"])
+            assert list(b.arguments)[1:] == ["X", "early_stopping", "early_stopping_params"]   # passed POSITIONALLY
+        else:
+            inspect.signature(evaluate_performance).bind(*c["args"], model=None, **c["kwargs"])
+    ranks = np.stack([np.arange(25) % 5 + 2, np.arange(25) % 3 + 2], 1)     # what the recorder returned for k = 8
+    assert mrr_score(ranks) == pytest.approx(doc["test_evaluation"]["mrr"]) and mr_score(ranks) == doc["test_evaluation"]["mr"]
+    assert hits_at_n_score(ranks, n=3) == doc["test_evaluation"]["hits_3"]
