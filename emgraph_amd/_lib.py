@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE = range(5)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
@@ -101,6 +101,7 @@ class PrepareArgs(C.Structure):
         ("dest_rel", _p), ("n_extra_rel", _i64), ("n_rel", _i64),
         ("ws_ent", _p), ("ws_ent_bytes", _i64), ("ws_rel", _p), ("ws_rel_bytes", _i64),
         ("single_flags", _p),
+        ("B_global", _i64), ("row_offset", _i64),
     ]
 
 

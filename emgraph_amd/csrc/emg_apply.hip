@@ -419,6 +419,7 @@ struct PrepParams {
     uint64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t counter0;
     const int32_t* inj_mask; const int32_t* inj_repl;
     int32_t* codes; int32_t* dest_ent; int32_t* dest_rel;
+    int64_t B_global; int64_t row_offset;  // draw index of (negative je, local row i) = je * B_global + row_offset + i
 };
 
 __global__ void prepare_ids_kernel(const PrepParams P) {
@@ -431,7 +432,11 @@ __global__ void prepare_ids_kernel(const PrepParams P) {
     }
     if (j >= per_side * P.n_sides) return;
     const int sd = (int)(j / per_side);
-    const int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
+    int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
+    if (P.B_global != P.B) {          // this batch is rows [row_offset, row_offset + B) of a larger one: draw what IT would
+        const int64_t je = jj / P.B;
+        jj = je * P.B_global + P.row_offset + (jj - je * P.B);
+    }
     const int side = P.sides[sd];
     uint32_t keep, idx;
     if (P.inj_repl) {
@@ -483,6 +488,10 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     }
     P.n_choices = (uint64_t)a->n_choices; P.entities_list = a->entities_list; P.seed = a->seed; P.counter0 = a->draw_counter0;
     P.inj_mask = a->inj_mask; P.inj_repl = a->inj_repl; P.codes = a->codes;
+    EMG_REQUIRE(a->B_global == 0 || (a->row_offset >= 0 && a->row_offset + a->B <= a->B_global),
+                "emg_prepare_batch: rows [row_offset, row_offset + B) must lie inside the global batch");
+    P.B_global = a->B_global > 0 ? a->B_global : a->B;
+    P.row_offset = a->B_global > 0 ? a->row_offset : 0;
     P.dest_ent = a->dest_ent + a->n_extra_ent; P.dest_rel = a->dest_rel + a->n_extra_rel;
     const int64_t n_neg = a->B * (int64_t)a->eta * a->n_sides;
     hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)cdiv(n_neg > a->B ? n_neg : a->B, 256)), dim3(256), 0, st, P);

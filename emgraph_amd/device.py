@@ -223,8 +223,10 @@ def group_dest(dest, n, n_rows, workspace, single_flags=None):
 
 def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, n_rel, ws_ent, ws_rel,
                   entities_list=None, seed=0, counter0=0, inj_mask=None, inj_repl=None, n_extra_ent=0, n_extra_rel=0,
-                  single_flags=None):
-    """codes of all corruption sides + destination ids + stable grouping (+ singleton flags) in ONE library call"""
+                  single_flags=None, B_global=0, row_offset=0):
+    """codes of all corruption sides + destination ids + stable grouping (+ singleton flags) in ONE library call.
+    ``B_global`` / ``row_offset``: ``pos`` is rows [row_offset, row_offset + B) of a larger (multi-GPU) batch and
+    draws the negatives that batch would draw for those rows."""
     lib = L.load()
     B = pos.shape[0]
     n_neg = B * eta * len(sides)
@@ -245,6 +247,7 @@ def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, 
     a.ws_ent, a.ws_ent_bytes = ws_ent.data_ptr(), ws_ent.numel() * ws_ent.element_size()
     a.ws_rel, a.ws_rel_bytes = ws_rel.data_ptr(), ws_rel.numel() * ws_rel.element_size()
     a.single_flags = _chk_vec(single_flags, torch.uint8, "single_flags")
+    a.B_global, a.row_offset = int(B_global), int(row_offset)
     L.check(lib.emg_prepare_batch(C.byref(a), _stream()), "emg_prepare_batch")
 
 
@@ -258,6 +261,14 @@ def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_co
     L.check(lib.emg_apply_grouped(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc,
                                   ldc, n_contrib, int(skip_single), h, workspace.data_ptr(),
                                   workspace.numel() * workspace.element_size(), _stream()), "emg_apply_grouped")
+
+
+def apply_workspace_views(workspace, n_contrib):
+    """(sorted destination ids, contribution indices) int32 views of a grouping workspace filled by group_dest /
+    prepare_batch (layout of emg_apply.hip::ws_layout: keys at byte 0, values at 2 * align256(4 n))"""
+    kb = (4 * n_contrib + 255) // 256 * 256
+    w32 = workspace.view(torch.int32)
+    return w32[:n_contrib], w32[2 * kb // 4:2 * kb // 4 + n_contrib]
 
 
 def apply_workspace_bytes(n_contrib, n_rows):

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import abc
 import logging
+import os
 
 import numpy as np
 import torch
@@ -322,7 +323,12 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         rel0 = _initial_table(self.initializer, self.initializer_params, rnd, n_rel, self.internal_k, "r")
         normalize = self.embedding_model_params.get("normalize_ent_emb", DEFAULT_NORMALIZE_EMBEDDINGS)
         rank, world = parallel.rank_world()
-        self._sharded = world > 1
+        # multi-GPU plan (one process per GPU): "k" = column slabs + all-reduce of partial scores (default);
+        # "batch" = replicated tables, batch split over the ranks, sparse gradient-row exchange (parallel.py)
+        sharding = self.embedding_model_params.get("sharding", os.environ.get("EMG_SHARDING", "k")) if world > 1 else None
+        if sharding not in (None, "k", "batch"):
+            raise ValueError("Invalid sharding {!r}: expected 'k' or 'batch'".format(sharding))
+        self._sharded = sharding == "k"
         k_local = self.internal_k
         if self._sharded:
             # one process per GPU: this rank trains a COLUMN slab of both tables (parallel.py)
@@ -338,7 +344,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                      loss_params=self.loss_params, optimizer=self.optimizer, optimizer_params=self.optimizer_params,
                      corrupt_sides=self._corrupt_sides(), batches_count=self.batches_count, seed=self.seed,
                      regularizer=self.regularizer, regularizer_params=self.regularizer_params,
-                     normalize_ent_emb=normalize, sharded=self._sharded)
+                     normalize_ent_emb=normalize, sharded=sharding or False)
         tr.set_training_set(X_idx, batch_size)
         n_choices, fixed_list, batch_lists = self._negative_pool(X_idx, batch_size)
         if normalize:  # EmbeddingModel.py:1371-1380: both tables clipped once before the loop

@@ -142,3 +142,101 @@ def entity_range(n, rank, world):
     base, rem = divmod(int(n), int(world))
     e0 = rank * base + min(rank, rem)
     return e0, e0 + base + (1 if rank < rem else 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BATCH sharding of the training step (tables replicated, sparse gradient exchange)
+# ------------------------------------------------------------------------------------------------
+# The split north_star names: every rank holds both tables, rank r takes rows [r0, r1) of each (global) batch,
+# scores them with their negatives and produces one gradient row per (positive, role).  A table row is OWNED by
+# the rank whose contiguous id range holds it (entity_range); gradient rows travel to their owner
+# (all_to_all of (row id, global slot, gradient row), sparse: only touched rows move), the owner sums the rows
+# of each destination IN GLOBAL SLOT ORDER — the order a single GPU sums them in, so the result does not depend
+# on the number of ranks — applies the optimizer (its state exists only at the owner: entity-sharded optimizer
+# state) and the updated rows are all-gathered into every replica.
+#
+# Per step and rank this moves over xGMI about (2 + eta) * B_local gradient rows out and the batch's unique
+# touched rows in; for eta = 20 that is as many bytes as the scoring kernels read from HBM, which is why the
+# k-sharding above (scores only) is the default wherever k is wide.  `Trainer(sharded="batch")` reports the bytes.
+
+def _split_exchange(out, inp, out_splits, in_splits, group=None):
+    """all_to_all_single with per-rank row counts; CUDA tensors over gloo (test harness: several ranks on one GPU)
+    are staged through the host"""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(ho, inp.detach().cpu().contiguous(), out_splits, in_splits, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group)
+    return out
+
+
+def owner_bounds(n_rows, world):
+    """first row id of every rank's owned range, plus n_rows: int64 [world + 1]"""
+    return torch.tensor([entity_range(n_rows, r, world)[0] for r in range(world)] + [int(n_rows)], dtype=torch.int64)
+
+
+def exchange_rows(dest, gslot, rows, n_rows, group=None):
+    """Send every gradient row to the owner of its destination.
+
+    dest  int32 [n]   destination row ids of this rank's contribution rows
+    gslot int64 [n]   their slot numbers in the GLOBAL batch's contribution layout (defines the sum order)
+    rows  float [n,k]
+    Returns (dest_r int32 [m], gslot_r int64 [m], rows_r float [m,k], bytes_sent): all rows, from every rank, whose
+    destination this rank owns (grouped by sending rank).  Host sync: one small count exchange."""
+    rank, world = rank_world()
+    k = rows.shape[1]
+    order = torch.argsort(dest, stable=True)            # owners hold contiguous id ranges: sort = bucket
+    d_sorted = dest.index_select(0, order)
+    cuts = torch.searchsorted(d_sorted.to(torch.int64), owner_bounds(n_rows, world).to(dest.device))
+    send_counts = (cuts[1:] - cuts[:-1]).cpu()
+    if dist.get_backend(group) == "nccl":               # RCCL moves device buffers
+        rc_dev = torch.empty(world, dtype=torch.int64, device=dest.device)
+        dist.all_to_all_single(rc_dev, send_counts.to(dest.device), group=group)
+        recv_counts = rc_dev.cpu()
+    else:
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = [int(v) for v in send_counts], [int(v) for v in recv_counts]
+    m = sum(rc)
+    meta = torch.stack([d_sorted.to(torch.int64), gslot.index_select(0, order)], 1)
+    meta_r = _split_exchange(torch.empty((m, 2), dtype=torch.int64, device=dest.device), meta, rc, sc, group)
+    rows_r = _split_exchange(torch.empty((m, k), dtype=rows.dtype, device=rows.device), rows.index_select(0, order), rc, sc,
+                             group)
+    sent = (len(dest) - sc[rank]) * (k * rows.element_size() + 16)
+    return meta_r[:, 0].to(torch.int32).contiguous(), meta_r[:, 1].contiguous(), rows_r, sent
+
+
+def allgather_rows(ids, rows, group=None):
+    """every rank contributes (ids int32 [u], rows float [u,k]) of the rows it owns and has just updated; returns the
+    concatenation over the OTHER ranks (ids, rows) and the bytes received.  Variable u: padded to the largest."""
+    rank, world = rank_world()
+    k = rows.shape[1]
+    cnt = torch.tensor([ids.numel()], dtype=torch.int64)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    if dist.get_backend(group) == "nccl":
+        dc = [torch.zeros(1, dtype=torch.int64, device=ids.device) for _ in range(world)]
+        dist.all_gather(dc, cnt.to(ids.device), group=group)
+        cnts = [c.cpu() for c in dc]
+    else:
+        dist.all_gather(cnts, cnt, group=group)
+    cnts = [int(c) for c in cnts]
+    umax = max(cnts)
+    stage = ids.is_cuda and dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if stage else ids.device
+    pid = torch.zeros(umax, dtype=torch.int32, device=dev)
+    prow = torch.zeros((umax, k), dtype=rows.dtype, device=dev)
+    pid[:ids.numel()] = ids.to(dev)
+    prow[:ids.numel()] = rows.to(dev)
+    gid = [torch.empty_like(pid) for _ in range(world)]
+    grow = [torch.empty_like(prow) for _ in range(world)]
+    dist.all_gather(gid, pid, group=group)
+    dist.all_gather(grow, prow, group=group)
+    oid = torch.cat([gid[r][:cnts[r]] for r in range(world) if r != rank]).to(ids.device)
+    orow = torch.cat([grow[r][:cnts[r]] for r in range(world) if r != rank]).to(rows.device)
+    return oid, orow, int(oid.numel()) * (k * rows.element_size() + 4)
+
+
+def batch_rows(B, rank, world):
+    """rows [r0, r1) of a global batch of B positives that this rank scores"""
+    return entity_range(B, rank, world)

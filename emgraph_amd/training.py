@@ -95,8 +95,10 @@ class Trainer:
                  optimizer="adam", optimizer_params=None, corrupt_sides=("s,o",), batches_count=1, seed=0,
                  regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda", fused=True,
                  inplace=True, pipeline=True, sharded=False):
-        """``sharded=True``: ent_init / rel_init are this rank's COLUMN slabs (emgraph_amd.parallel.shard_columns)
-        and k_int is the local width; every step all-reduces the partial scores (see parallel.py)."""
+        """``sharded=True`` / ``"k"``: ent_init / rel_init are this rank's COLUMN slabs (emgraph_amd.parallel.shard_columns)
+        and k_int is the local width; every step all-reduces the partial scores.
+        ``sharded="batch"``: full tables on every rank; each rank scores its rows of the global batch, gradient rows
+        travel to the owner of their destination, which applies them and all-gathers the updated rows (parallel.py)."""
         D.require_gpu()
         self.device = torch.device(device)
         self.model_id, self.k_int, self.scale, self.eta = model_id, int(k_int), float(scale), int(eta)
@@ -166,10 +168,23 @@ class Trainer:
         #  inplace : rows whose destination is hit once in the batch are updated from registers
         #            (needs the pre-update tables for nothing else: off when a regulariser is set)
         #  pipeline: codes + destination grouping of batches t+1, t+2 run on a side stream while batch t computes
-        self.sharded = bool(sharded)
+        self.batch_sharded = sharded == "batch"
+        self.sharded = bool(sharded) and not self.batch_sharded          # k (column) sharding
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded
         self.inplace = inplace and self.reg is None
         self.pipeline = pipeline
+        if self.batch_sharded:
+            # a destination's contributions come from several ranks: no rank may update a row in place, and the
+            # step has collectives in the middle (single stream; the exchange is what bounds it, not the enqueue)
+            self.inplace = self.pipeline = pipeline = False
+            if optimizer == "adam":
+                raise ValueError("batch-sharded training cannot run Keras' dense-equivalent Adam (every row of the table "
+                                 "changes every step, i.e. the whole table would be exchanged): use 'adam_lazy', another "
+                                 "optimizer, or k-sharding")
+            if self.reg_rows:
+                raise NotImplementedError("LP regulariser with a stateful optimizer under batch sharding")
+            self.xgmi_bytes = 0          # bytes this rank sent + received over the interconnect (gradient rows + updated rows)
+            self._owner_ws = {}
         # high priority: the many small kernels must not queue behind the big ones.  TWO side streams used
         # alternately: a preparation chain is latency-bound (each small launch waits for a CU slot), so two
         # chains in flight double the rate at which prepared batches arrive
@@ -291,6 +306,8 @@ class Trainer:
         critical path."""
         if B <= 0:
             return
+        if self.batch_sharded:
+            return self._step_batch_sharded(start, B, epoch, batch, n_choices, entities_list)
         self._alloc_scratch(B)
         self.step_count += 1
         key = (start, B, epoch, batch)
@@ -393,12 +410,96 @@ class Trainer:
             # EmbeddingModel.py:1434-1440: tf.clip_by_norm(ent_emb, clip_norm=1, axes=1) after each batch
             D.clip_rows(self.ent, self.k_int, 1.0)
 
+    # ---- batch-sharded step (parallel.py: BATCH sharding) ----
+    def _step_batch_sharded(self, start, B, epoch, batch, n_choices, entities_list):
+        """[start, start + B) is the GLOBAL batch.  This rank scores rows [r0, r1) of it with the negatives the whole
+        batch draws for them, then: gradient rows -> owners (all_to_all) -> summed in global slot order + optimizer at
+        the owner -> updated rows all-gathered into every replica."""
+        rank, world = parallel.rank_world()
+        r0, r1 = parallel.batch_rows(B, rank, world)
+        Bl = r1 - r0
+        self.step_count += 1
+        et, eta, k = self.eta_total, self.eta, self.k_int
+        lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
+              else self.lr)
+        hyper = self._hyper(lr)
+        dev = self.device
+        n_ce = (2 + et) * Bl
+        if Bl > 0:
+            self._alloc_scratch(Bl)
+            sl = self.slots[0]
+            pos = self.X[start + r0:start + r1]
+            codes = sl["codes"][:Bl * et]
+            counter0 = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides
+            D.prepare_batch(pos, eta, self.sides, self.n_ent if n_choices is None else int(n_choices), codes,
+                            sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl], self.n_ent, self.n_rel, sl["ws_ent"], sl["ws_rel"],
+                            entities_list=entities_list, seed=self.seed, counter0=counter0, B_global=B, row_offset=r0)
+            ce, cr = self.contrib_ent[:n_ce], self.contrib_rel[:Bl]
+            if self.fused:
+                D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr,
+                                    fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum)
+            else:
+                sall = self.scores_all[:Bl * (1 + et)]
+                sp, sn = sall[:Bl], sall[Bl:]
+                D.train_forward(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, scores_pos=sp, scores_neg=sn)
+                gp, gn = self.g_pos[:Bl], self.g_neg[:Bl * et]
+                D.loss(self.loss_id, sp, sn, Bl, eta, self.n_sides, self.margin, self.alpha, self.loss_accum, gp, gn)
+                D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
+                                    g_pos=gp, g_neg=gn)
+            t = torch.arange(n_ce, dtype=torch.int64, device=dev)
+            gslot_e = (t // Bl) * B + r0 + (t % Bl)          # slot of the same row in the whole batch's layout
+            gslot_r = r0 + torch.arange(Bl, dtype=torch.int64, device=dev)
+            dest_e, dest_r = sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl]
+            rows_e, rows_r = ce, cr
+        else:
+            z32 = torch.zeros(0, dtype=torch.int32, device=dev)
+            z64 = torch.zeros(0, dtype=torch.int64, device=dev)
+            dest_e = dest_r = z32
+            gslot_e = gslot_r = z64
+            rows_e = rows_r = torch.zeros((0, k), dtype=torch.float32, device=dev)
+        if self.reg is not None:  # dense LP term + its SGD step: the same full pass on every replica, pre-update tables
+            D.lp_regularizer(self.ent, k, self.reg[0], self.reg[2], lr, self.reg_accum)
+            D.lp_regularizer(self.rel, k, self.reg[1], self.reg[2], lr, self.reg_accum)
+        self._exchange_apply(self.ent, self.n_ent, self.state_ent, self.tag_ent, dest_e, gslot_e, rows_e, hyper, "ent")
+        self._exchange_apply(self.rel, self.n_rel, self.state_rel, self.tag_rel, dest_r, gslot_r, rows_r, hyper, "rel")
+        if self.normalize:
+            D.clip_rows(self.ent, k, 1.0)
+
+    def _exchange_apply(self, table, n_rows, state, tag, dest, gslot, rows, hyper, which):
+        k = self.k_int
+        dest_o, gslot_o, rows_o, sent = parallel.exchange_rows(dest, gslot, rows, n_rows)
+        m = int(dest_o.numel())
+        if m:
+            # the order a single GPU sums a destination's rows in: by slot of the (global) batch layout; the stable
+            # grouping by destination below keeps it
+            perm = torch.argsort(gslot_o, stable=True)
+            dest_p = dest_o.index_select(0, perm).contiguous()
+            ws = self._owner_ws.get(which)
+            need = D.apply_workspace_bytes(m, n_rows)
+            if ws is None or ws.numel() < need:
+                ws = self._owner_ws[which] = torch.empty(int(need * 1.5) + 1024, dtype=torch.uint8, device=self.device)
+            D.group_dest(dest_p, m, n_rows, ws)
+            keys, vals = D.apply_workspace_views(ws, m)
+            vals.copy_(perm.index_select(0, vals.to(torch.int64)).to(torch.int32))   # positions in RECEIVE order
+            D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, rows_o, m, False, hyper, ws)
+            upd = torch.unique_consecutive(keys)
+            upd_rows = table.index_select(0, upd.to(torch.int64))
+        else:
+            upd = torch.zeros(0, dtype=torch.int32, device=self.device)
+            upd_rows = torch.zeros((0, k), dtype=torch.float32, device=self.device)
+        oid, orow, recvd = parallel.allgather_rows(upd, upd_rows)
+        if oid.numel():
+            table.index_copy_(0, oid.to(torch.int64), orow)
+        self.xgmi_bytes += sent + recvd
+
     def read_loss(self, reset=True):
         """data loss (identical on every rank) + LP term (summed over the column slabs when sharded)"""
-        reg = self.reg_accum
+        reg, data = self.reg_accum, self.loss_accum
         if self.sharded:  # sum a COPY over the ranks: the accumulator itself stays rank-local (reset=False calls)
             reg = parallel.allreduce_sum_(self.reg_accum.clone())
-        v = float(self.loss_accum.item()) + float(reg.item())
+        if self.batch_sharded:  # every rank saw its rows of each batch only; the LP term was computed by every replica
+            data = parallel.allreduce_sum_(self.loss_accum.clone())
+        v = float(data.item()) + float(reg.item())
         if reset:
             self.loss_accum.zero_()
             self.reg_accum.zero_()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 1
+#define EMG_ABI_VERSION 2
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */
@@ -136,7 +136,11 @@ int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const int32_t* co
  * side sd drawing with counter draw_counter0 + sd, codes side-major then eta-major), the destination ids of
  * all gradient rows (as emg_build_dest) and their stable grouping + singleton flags (as emg_group_dest) for
  * the entity and the relation table.  dest_ent / dest_rel start with n_extra_* caller-filled entries (the LP
- * regulariser's dense rows) followed by the batch's; the grouping covers both. */
+ * regulariser's dense rows) followed by the batch's; the grouping covers both.
+ * Batch-sharded multi-GPU training: `pos` holds rows [row_offset, row_offset + B) of a GLOBAL batch of B_global
+ * positives; the draw of (negative jj, local row i) is then the one the whole batch would use for its row
+ * jj * B_global + row_offset + i, so the negatives do not depend on how many GPUs share the batch.
+ * B_global == 0 means B_global = B, row_offset = 0 (single GPU). */
 typedef struct emg_prepare_args {
     const int32_t* pos; int64_t B; int32_t eta; int32_t n_sides; int32_t sides[4];
     int64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t draw_counter0;
@@ -146,6 +150,7 @@ typedef struct emg_prepare_args {
     int32_t* dest_rel; int64_t n_extra_rel; int64_t n_rel;   /* out [n_extra_rel + B] */
     void* ws_ent; int64_t ws_ent_bytes; void* ws_rel; int64_t ws_rel_bytes;  /* emg_apply_workspace_bytes */
     uint8_t* single_flags;                                   /* optional out, per entity contribution row */
+    int64_t B_global; int64_t row_offset;                    /* batch-sharded draws (see above); 0, 0 = whole batch */
 } emg_prepare_args;
 int emg_prepare_batch(const emg_prepare_args* args, void* stream);
 

@@ -146,3 +146,77 @@ def sharded_fit_worker(rank, world, out_dir, name, loss, opt):
                                                          filter_triples=X.astype(np.int32), precision=1)
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
              ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:]), **extra)
+
+
+def batch_exchange_worker(rank, world, out_dir):
+    """BATCH sharding plumbing on CPU tensors (gloo): every rank holds the same global batch of contribution rows,
+    keeps the rows of ITS positives, sends them to the owners of their destinations, owners sum each destination's
+    rows in GLOBAL SLOT order (sequential fp32, what emg_apply_grouped does) and apply SGD, updated rows are
+    all-gathered.  Every replica must end BIT-identical to the single-process result, whatever the rank count."""
+    import torch
+
+    from emgraph_amd import parallel
+    rs = np.random.RandomState(11)
+    n_rows, k, B, roles, lr = 37, 6, 23, 5, F32(0.1)     # uneven everything: 23 positives over `world` ranks, 37 rows
+    W0 = rs.randn(n_rows, k).astype(F32)
+    dest_g = rs.randint(0, n_rows - 4, roles * B).astype(np.int32)          # rows 33..36 are never touched
+    dest_g[rs.choice(roles * B, 40, replace=False)] = 7                      # a hot destination
+    rows_g = rs.randn(roles * B, k).astype(F32)
+    # single process: stable grouping by destination keeps slot order; sequential fp32 sums
+    exp = W0.copy()
+    order = np.argsort(dest_g, kind="stable")
+    for seg in np.split(order, np.flatnonzero(np.diff(dest_g[order])) + 1):
+        g = np.zeros(k, F32)
+        for i in seg:
+            g = g + rows_g[i]
+        exp[dest_g[seg[0]]] = W0[dest_g[seg[0]]] - lr * g
+    # this rank's share: positives [r0, r1) of every role block
+    r0, r1 = parallel.batch_rows(B, rank, world)
+    Bl = r1 - r0
+    t = np.arange(roles * Bl)
+    gslot = (t // max(Bl, 1)) * B + r0 + (t % max(Bl, 1))
+    dest_o, gslot_o, rows_o, sent = parallel.exchange_rows(torch.from_numpy(dest_g[gslot]), torch.from_numpy(gslot.astype(np.int64)),
+                                                           torch.from_numpy(rows_g[gslot]), n_rows)
+    e0, e1 = parallel.entity_range(n_rows, rank, world)
+    d = dest_o.numpy()
+    assert ((d >= e0) & (d < e1)).all()                                      # only rows this rank owns arrive
+    W = W0.copy()
+    perm = np.argsort(gslot_o.numpy(), kind="stable")
+    dp = d[perm]
+    order = np.argsort(dp, kind="stable")
+    upd = []
+    if len(dp):
+        for seg in np.split(order, np.flatnonzero(np.diff(dp[order])) + 1):
+            g = np.zeros(k, F32)
+            for i in seg:
+                g = g + rows_o.numpy()[perm[i]]
+            W[dp[seg[0]]] = W0[dp[seg[0]]] - lr * g
+            upd.append(dp[seg[0]])
+    upd = np.array(upd, dtype=np.int32)
+    oid, orow, recvd = parallel.allgather_rows(torch.from_numpy(upd), torch.from_numpy(W[upd] if len(upd) else np.zeros((0, k), F32)))
+    W[oid.numpy()] = orow.numpy()
+    np.testing.assert_array_equal(W, exp)
+    assert sent == (len(gslot) - int(((dest_g[gslot] >= e0) & (dest_g[gslot] < e1)).sum())) * (4 * k + 16)
+    np.save(os.path.join(out_dir, "W_%d.npy" % rank), W)
+
+
+def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt):
+    """the REAL batch-sharded training step (HIP kernels + exchange), two ranks sharing cuda:0 over gloo"""
+    import torch
+
+    from emgraph_amd import models
+    torch.cuda.set_device(0)
+    rs = np.random.RandomState(5)
+    n_ent, n_rel = 80, 4
+    X = np.stack([rs.randint(0, n_ent, 900), rs.randint(0, n_rel, 900), rs.randint(0, n_ent, 900)], 1)
+    X[:n_ent, 0] = np.arange(n_ent)
+    X[:n_rel, 1] = np.arange(n_rel)
+    kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    emp = {"sharding": "batch"}
+    if name == "TransE_L2":
+        m = models.TransE(embedding_model_params=dict(emp, norm=2), **kw)
+    else:
+        m = getattr(models, name)(embedding_model_params=emp, **kw)
+    m.fit(X[:803])       # 803 rows / 3 batches = 268 per batch (last one 267): odd splits over two ranks
+    np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
+             pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes))

@@ -72,6 +72,56 @@ def test_range_sharded_eval_counts_allreduce_gloo(tmp_path):
     _spawn(W.eval_counts_worker, 2, tmp_path)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_sharded_exchange_is_rank_count_independent_gloo(tmp_path, world):
+    _spawn(W.batch_exchange_worker, world, tmp_path)
+    Ws = [np.load(os.path.join(tmp_path, "W_%d.npy" % r)) for r in range(world)]
+    for w in Ws[1:]:
+        np.testing.assert_array_equal(w, Ws[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "sgd"), ("TransE_L2", "pairwise", "adagrad"),
+                                           ("HolE", "multiclass_nll", "momentum"), ("DistMult", "nll", "adam_lazy")])
+def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss, opt):
+    """north_star's training split: batch rows split over the ranks, gradient rows sent to the owner of their
+    destination, owner-side optimizer, updated rows all-gathered.  Negatives are drawn by GLOBAL row index and each
+    destination's rows are summed in global slot order, so two ranks must reproduce the single-process run with the
+    same kernels (contribution path, no in-place singletons) BIT for bit; the default single-process plan (in-place
+    singleton updates) differs from it by fp32 rounding only."""
+    from emgraph_amd import models
+    _spawn(W.batch_sharded_fit_worker, 2, tmp_path, name, loss, opt)
+    res = [np.load(os.path.join(tmp_path, "res_%d.npz" % r)) for r in range(2)]
+    for key in ("E", "R", "pred"):
+        np.testing.assert_array_equal(res[0][key], res[1][key])          # replicas stay identical
+    assert int(res[0]["xgmi"]) > 0
+    rs = np.random.RandomState(5)
+    n_ent, n_rel = 80, 4
+    X = np.stack([rs.randint(0, n_ent, 900), rs.randint(0, n_rel, 900), rs.randint(0, n_ent, 900)], 1)
+    X[:n_ent, 0] = np.arange(n_ent)
+    X[:n_rel, 1] = np.arange(n_rel)
+    kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    emp = {"norm": 2} if name == "TransE_L2" else {}
+    cls = models.TransE if name == "TransE_L2" else getattr(models, name)
+    import emgraph_amd.training as T
+    plain = T.Trainer.__init__
+    try:   # single process, every gradient row through the contribution buffer (what the sharded step does)
+        def no_inplace(self, *a, **k_):
+            k_["inplace"] = False
+            plain(self, *a, **k_)
+        T.Trainer.__init__ = no_inplace
+        m0 = cls(embedding_model_params=emp, **kw)
+        m0.fit(X[:803])
+    finally:
+        T.Trainer.__init__ = plain
+    np.testing.assert_array_equal(res[0]["E"], m0.trained_model_params[0])
+    np.testing.assert_array_equal(res[0]["R"], m0.trained_model_params[1])
+    m1 = cls(embedding_model_params=emp, **kw)
+    m1.fit(X[:803])
+    np.testing.assert_allclose(res[0]["E"], m1.trained_model_params[0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res[0]["R"], m1.trained_model_params[1], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "adam"), ("TransE_L2", "pairwise", "sgd"),
                                            ("HolE", "multiclass_nll", "adagrad"), ("DistMult", "nll", "momentum")])
