@@ -50,6 +50,7 @@ SIGNATURES = {
     "emg_train_backward": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _p, _p, _p,
                                   _p, _p, _i64, _p, _p, _p]),
     "emg_apply_workspace_bytes": (_i64, [_i64, _i64]),
+    "emg_apply_workspace_bytes_ex": (_i64, [_i64, _i64, _i32]),
     "emg_apply_rows": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _i64,
                               C.POINTER(_f32), _p, _i64, _p]),
     "emg_lp_regularizer": (_int, [_p, _i64, _i64, _i32, _f32, _i32, _f32, _p, _p]),
@@ -77,7 +78,7 @@ class BackwardArgs(C.Structure):
         ("bw_scores_pos", _p), ("bw_scores_neg", _p),
         ("scores_pos_out", _p), ("scores_neg_out", _p),
         ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
-        ("single_ent", _p), ("opt", _i32), ("step", _i32), ("hyper", _f32 * 6),
+        ("single_ent", _p), ("opt", _i32), ("step", _i32), ("hyper", _f32 * 8),
         ("ent_state0", _p), ("ent_state1", _p), ("tag_ent", _p),
     ]
 
@@ -87,7 +88,7 @@ SIGNATURES.update({
     "emg_train_backward_ex": (_int, [C.POINTER(BackwardArgs), _p]),
     "emg_group_dest": (_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
     "emg_apply_grouped": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,
-                                 C.POINTER(_f32), _p, _i64, _p]),
+                                 C.POINTER(_f32), _p, _p, _i64, _p]),
 })
 
 class PrepareArgs(C.Structure):
@@ -122,7 +123,7 @@ class StepArgs(C.Structure):
         ("ent", _p), ("n_ent", _i64), ("ld_ent", _i64), ("rel", _p), ("n_rel", _i64), ("ld_rel", _i64),
         ("ent_state0", _p), ("ent_state1", _p), ("rel_state0", _p), ("rel_state1", _p),
         ("tag_ent", _p), ("tag_rel", _p),
-        ("opt", _i32), ("step", _i32), ("hyper", _f32 * 6),
+        ("opt", _i32), ("step", _i32), ("hyper", _f32 * 8),
         ("pos", _p), ("B", _i64),
         ("n_choices", _i64), ("entities_list", _p), ("seed", _u64), ("draw_counter0", _u64),
         ("inj_mask", _p), ("inj_repl", _p),

@@ -139,8 +139,8 @@ static int step_layout(int64_t B, int32_t eta_total, int32_t k_int, int64_t n_en
     L->n_neg = B * (int64_t)eta_total;
     L->n_ce = 2 * B + L->n_neg;
     L->ldc = (k_int + 3) / 4 * 4;
-    L->ws_ent_bytes = emg_apply_workspace_bytes(L->n_ce, n_ent);
-    L->ws_rel_bytes = emg_apply_workspace_bytes(B, n_rel);
+    L->ws_ent_bytes = emg_apply_workspace_bytes_ex(L->n_ce, n_ent, k_int);
+    L->ws_rel_bytes = emg_apply_workspace_bytes_ex(B, n_rel, k_int);
     EMG_REQUIRE(L->ws_ent_bytes >= 0 && L->ws_rel_bytes >= 0, "emg_train_step: workspace size query failed");
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up256(bytes); return at; };
@@ -171,6 +171,7 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     if (a->B == 0) return EMG_OK;
     EMG_REQUIRE(a->ent && a->rel && a->pos && a->loss_accum && a->workspace, "emg_train_step: null pointer");
     EMG_REQUIRE(a->loss >= EMG_LOSS_PAIRWISE && a->loss <= EMG_LOSS_MULTICLASS_NLL, "emg_train_step: unknown loss %d", a->loss);
+    EMG_REQUIRE(a->hyper[6] == 0.f, "emg_train_step: runs without the LP regulariser (hyper[6] must be 0)");
     const int32_t et = a->eta * a->n_sides;
     StepLayout L;
     int rc = step_layout(a->B, et, a->k_int, a->n_ent, a->n_rel, &L);
@@ -208,7 +209,7 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     ba.pos = a->pos; ba.B = a->B; ba.codes = codes; ba.margin = a->margin; ba.loss_accum = a->loss_accum;
     ba.contrib_ent = ce; ba.contrib_rel = cr; ba.ldc = L.ldc;
     ba.single_ent = inplace ? single : nullptr; ba.opt = a->opt; ba.step = a->step;
-    for (int i = 0; i < 6; ++i) ba.hyper[i] = a->hyper[i];
+    for (int i = 0; i < 8; ++i) ba.hyper[i] = a->hyper[i];
     ba.ent_state0 = a->ent_state0; ba.ent_state1 = a->ent_state1; ba.tag_ent = a->tag_ent;
     const bool pair_local = a->loss == EMG_LOSS_PAIRWISE || a->loss == EMG_LOSS_NLL || a->loss == EMG_LOSS_ABSOLUTE_MARGIN;
     if (pair_local) {
@@ -224,8 +225,8 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     rc = emg_train_backward_ex(&ba, stream);
     if (rc != EMG_OK) return rc;
     rc = emg_apply_grouped(a->opt, a->ent, a->n_ent, a->ld_ent, a->k_int, a->ent_state0, a->ent_state1, a->tag_ent, a->step,
-                           ce, L.ldc, L.n_ce, inplace ? 1 : 0, a->hyper, ws + L.ws_ent, L.ws_ent_bytes, stream);
+                           ce, L.ldc, L.n_ce, inplace ? 1 : 0, a->hyper, nullptr, ws + L.ws_ent, L.ws_ent_bytes, stream);
     if (rc != EMG_OK) return rc;
     return emg_apply_grouped(a->opt, a->rel, a->n_rel, a->ld_rel, a->k_int, a->rel_state0, a->rel_state1, a->tag_rel, a->step,
-                             cr, L.ldc, a->B, 0, a->hyper, ws + L.ws_rel, L.ws_rel_bytes, stream);
+                             cr, L.ldc, a->B, 0, a->hyper, nullptr, ws + L.ws_rel, L.ws_rel_bytes, stream);
 }

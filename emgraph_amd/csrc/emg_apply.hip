@@ -11,6 +11,7 @@
 //   2. emg_apply_grouped: one wave per segment head sums the segment's rows (16-byte coalesced loads)
 //      and performs the optimizer update of that table row exactly once.  Singletons can be skipped:
 //      the backward kernel already updated them in place from registers (no contribution round trip).
+#include <stdlib.h>
 #include <string.h>
 #include <cstring>
 
@@ -29,6 +30,8 @@ struct ApplyParams {
     int32_t skip_single;
     int32_t win;  // sorted positions per wave
     OptParams opt;
+    uint32_t* long_list; uint32_t* long_count; uint32_t long_cap;  // segments longer than kLongSegment (head positions)
+    double* lp_accum;  // += sum |w_pre|^p over the rows this launch updates (the caller scales by lambda); may be null
 };
 
 // flags[original index] = 1 iff its destination occurs exactly once in the batch
@@ -47,7 +50,91 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
 // ~90 atomics/us, slower than the whole sort) and processes them one after the other.  A segment may run
 // past the window's end; its head's wave handles all of it.  Singleton segments are skipped when the
 // backward kernel already applied them in place.
-template <int W>
+//   DEPTH     : contribution rows in flight per trip beyond the 2-row tail loop (2 = none: 70 VGPRs, 7 waves/SIMD;
+//               the 8- and 16-deep forms of earlier versions ran at 4 and 2 waves/SIMD and were slower on both tables).
+//   LONG > 0  : a segment of more than LONG rows (a hub entity of a Zipf-distributed graph collects thousands) is
+//               NOT summed here by one wave (2 300 rows take 0.5 ms that way) but appended to a list for
+//               apply_long_kernel, which spreads its 64-row blocks over the waves of a workgroup.
+constexpr int kLongSegment = 64;   // rows; also the block size of the long-segment reduction tree
+
+template <int W, int DEPTH>
+__device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t key, int64_t t, int64_t end, int64_t w0,
+                                               int64_t wend, uint32_t myval, int lane, int nchunks, float& lp_acc) {
+    auto contrib_index = [&](int64_t u) -> int64_t {  // wave-uniform u
+        return u < wend ? (int64_t)__shfl(myval, (int)(u - w0), 64) : (int64_t)P.vals[u];
+    };
+    float* wrow = P.table + (int64_t)key * P.ld;
+    float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+    float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+    if constexpr (W == 4) {
+        // two row chunks per lane (columns 4*lane.. and 4*(lane+64)..) x DEPTH contributions per trip: independent
+        // 16-byte loads in flight, added in contribution order (bit-reproducible sums)
+        for (int c0 = 0; c0 < nchunks; c0 += 128) {
+            const int ca = c0 + lane, cb = c0 + 64 + lane;
+            const bool oa = ca < nchunks, ob = cb < nchunks;
+            float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA, wA = accA, wB = accA;
+            const float4 zero = accA;
+            if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
+            if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
+            int64_t u = t;
+            if constexpr (DEPTH > 2) {
+                for (; u + DEPTH <= end; u += DEPTH) {
+                    float4 va[DEPTH], vb[DEPTH];
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) {
+                        const float* rj = P.contrib + contrib_index(u + j) * P.ldc;
+                        va[j] = oa ? *reinterpret_cast<const float4*>(rj + 4 * ca) : zero;
+                        vb[j] = ob ? *reinterpret_cast<const float4*>(rj + 4 * cb) : zero;
+                    }
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) {  // added in contribution order
+                        if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
+                        if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
+                    }
+                }
+            }
+            for (; u < end; u += 2) {
+                const bool two = u + 1 < end;
+                const float* r0 = P.contrib + contrib_index(u) * P.ldc;
+                const float* r1 = two ? P.contrib + contrib_index(u + 1) * P.ldc : r0;
+                float4 v0a = zero, v0b = zero, v1a = zero, v1b = zero;
+                if (oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
+                if (ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
+                if (oa && two) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
+                if (ob && two) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
+                if (oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
+                if (ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
+                if (oa && two) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
+                if (ob && two) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
+            }
+            auto finish = [&](int c, float4 wv, const float4& g) {
+                const int64_t off = 4 * (int64_t)c;
+                float w[4] = {wv.x, wv.y, wv.z, wv.w};
+                float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lp_fold(P.opt, w[j], gg[j], lp_acc);
+                    opt_update_elem(P.opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+                }
+                *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
+            };
+            if (oa) finish(ca, wA, accA);
+            if (ob) finish(cb, wB, accB);
+        }
+    } else {
+        for (int c = lane; c < nchunks; c += 64) {
+            float acc = 0.f;
+            for (int64_t u = t; u < end; ++u) acc += P.contrib[contrib_index(u) * P.ldc + c];
+            float wv = wrow[c];
+            lp_fold(P.opt, wv, acc, lp_acc);
+            opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
+            wrow[c] = wv;
+        }
+    }
+    if (P.tag && lane == 0) P.tag[key] = P.step;
+}
+
+template <int W, int DEPTH>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -62,6 +149,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     unsigned long long todo = __ballot(head && !(P.skip_single && last));
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
+    float lp_acc = 0.f;
     while (todo) {
         const int b = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -75,78 +163,108 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
             for (;;) {
                 const int64_t q = end + lane;
                 const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
-                if (same == ~0ull) { end += 64; continue; }
+                if (same == ~0ull) {
+                    end += 64;
+                    if (P.long_list && end - t > kLongSegment) break;  // long: its exact end is found by apply_long_kernel
+                    continue;
+                }
                 end += __ffsll((long long)~same) - 1;
                 break;
             }
         }
-        auto contrib_index = [&](int64_t u) -> int64_t {  // wave-uniform u
-            return u < wend ? (int64_t)__shfl(myval, (int)(u - w0), 64) : (int64_t)P.vals[u];
-        };
-        float* wrow = P.table + (int64_t)key * P.ld;
-        float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
-        float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
-        if constexpr (W == 4) {
-            // two row chunks per lane (columns 4*lane.. and 4*(lane+64)..) x two contributions per trip: up to four
-            // independent 16-byte loads in flight, added in contribution order (bit-reproducible sums)
-            for (int c0 = 0; c0 < nchunks; c0 += 128) {
-                const int ca = c0 + lane, cb = c0 + 64 + lane;
-                const bool oa = ca < nchunks, ob = cb < nchunks;
-                float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = accA, wA = accA, wB = accA;
-                if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
-                if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
-                int64_t u = t;
-                // long segments (a relation row collects hundreds of contributions): eight rows in flight per trip
-                for (; u + 8 <= end; u += 8) {
-                    float4 va[8], vb[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float* rj = P.contrib + contrib_index(u + j) * P.ldc;
-                        va[j] = oa ? *reinterpret_cast<const float4*>(rj + 4 * ca) : accA;
-                        vb[j] = ob ? *reinterpret_cast<const float4*>(rj + 4 * cb) : accA;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {  // added in contribution order
-                        if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
-                        if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
-                    }
-                }
-                for (; u < end; u += 2) {
-                    const bool two = u + 1 < end;
-                    const float* r0 = P.contrib + contrib_index(u) * P.ldc;
-                    const float* r1 = two ? P.contrib + contrib_index(u + 1) * P.ldc : r0;
-                    float4 v0a = accA, v0b = accA, v1a = accA, v1b = accA;
-                    if (oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
-                    if (ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
-                    if (oa && two) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
-                    if (ob && two) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
-                    if (oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
-                    if (ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
-                    if (oa && two) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
-                    if (ob && two) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
-                }
-                auto finish = [&](int c, float4 wv, const float4& g) {
-                    const int64_t off = 4 * (int64_t)c;
-                    float w[4] = {wv.x, wv.y, wv.z, wv.w};
-                    const float gg[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        opt_update_elem(P.opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
-                    *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
-                };
-                if (oa) finish(ca, wA, accA);
-                if (ob) finish(cb, wB, accB);
+        if (P.long_list && end - t > kLongSegment) {  // hand the segment over (order of the list is irrelevant)
+            if (lane == 0) {
+                const unsigned slot = atomicAdd(P.long_count, 1u);
+                if (slot < P.long_cap) P.long_list[slot] = (uint32_t)t;
             }
-        } else {
+            continue;
+        }
+        sum_and_update<W, DEPTH>(P, key, t, end, w0, wend, myval, lane, nchunks, lp_acc);
+    }
+    if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
+}
+
+// Long segments (> kLongSegment rows; P.long_list holds the sorted position of each one's head): one WORKGROUP of 16
+// waves per segment.  The reduction tree is defined by the segment alone — block b = rows [64 b, 64 b + 64) of the
+// segment, summed left to right by one wave (16 rows in flight per trip), then the block sums are added left to
+// right and the optimizer update is applied — so the bits do not depend on which wave, window or GPU did what.
+template <int W>
+__global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, float* __restrict__ partial, int64_t ldp) {
+    __shared__ int64_t end_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const unsigned n_long = min(*P.long_count, P.long_cap);
+    const int nchunks = P.k_int / W;
+    for (unsigned i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const int64_t t = P.long_list[i];
+        const uint32_t key = P.keys[t];
+        if (threadIdx.x < 64) {  // end of the segment: first position whose key differs (keys are sorted)
+            int64_t end = t;
+            for (;;) {
+                const int64_t q = end + lane;
+                const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
+                if (same == ~0ull) { end += 64; continue; }
+                end += __ffsll((long long)~same) - 1;
+                break;
+            }
+            if (lane == 0) end_s = end;
+        }
+        __syncthreads();
+        const int64_t end = end_s;
+        const int64_t nblk = (end - t + kLongSegment - 1) / kLongSegment;
+        // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
+        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one first-block
+        // start (a long segment spans more than 64 positions).
+        for (int64_t b = wv; b < nblk; b += nwv) {
+            const int64_t u0 = t + b * kLongSegment, u1 = min(u0 + kLongSegment, end);
+            float* prow = partial + (2 * (u0 / kLongSegment) + (b == 0 ? 1 : 0)) * ldp;
             for (int c = lane; c < nchunks; c += 64) {
-                float acc = 0.f;
-                for (int64_t u = t; u < end; ++u) acc += P.contrib[contrib_index(u) * P.ldc + c];
-                float wv = wrow[c];
-                opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
-                wrow[c] = wv;
+                if constexpr (W == 4) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    int64_t u = u0;
+                    for (; u + 16 <= u1; u += 16) {
+                        float4 v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u + j] * P.ldc + 4 * c);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+                    }
+                    for (; u < u1; ++u) {
+                        const float4 v = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u] * P.ldc + 4 * c);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                    *reinterpret_cast<float4*>(prow + 4 * c) = acc;
+                } else {
+                    float acc = 0.f;
+                    for (int64_t u = u0; u < u1; ++u) acc += P.contrib[(int64_t)P.vals[u] * P.ldc + c];
+                    prow[c] = acc;
+                }
             }
         }
-        if (P.tag && lane == 0) P.tag[key] = P.step;
+        __syncthreads();  // block sums are in global memory, written and read by this workgroup only
+        if (wv == 0 && (int64_t)key < P.n_rows) {
+            float* wrow = P.table + (int64_t)key * P.ld;
+            float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+            float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+            const int64_t m0 = t / kLongSegment;   // (t + 64 b) / 64 = t / 64 + b
+            float lp_acc = 0.f;
+            for (int c = lane; c < nchunks * W; c += 64) {
+                float acc = 0.f;
+                for (int64_t b = 0; b < nblk; ++b) acc += partial[(2 * (m0 + b) + (b == 0 ? 1 : 0)) * ldp + c];
+                float wv_ = wrow[c];
+                lp_fold(P.opt, wv_, acc, lp_acc);
+                opt_update_elem(P.opt, wv_, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
+                wrow[c] = wv_;
+            }
+            if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
+            if (P.tag && lane == 0) P.tag[key] = P.step;
+        }
+        __syncthreads();
+    }
+    // the last workgroup to finish empties the list, so that a second emg_apply_grouped on the same grouping (or the
+    // next batch that reuses the workspace) starts from zero; every workgroup has read the count by then
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(P.long_count + 1, 1u) == gridDim.x - 1) { P.long_count[0] = 0u; P.long_count[1] = 0u; }
     }
 }
 
@@ -174,6 +292,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     const int ntodo = __popcll(todo);
+    float lp_acc = 0.f;
     for (int it = 0; it * NSUB < ntodo; ++it) {
         // this round's heads: ranks it*NSUB .. it*NSUB+NSUB-1 among the todo bits; subgroup `sub` takes the sub-th
         unsigned long long m = todo;
@@ -258,10 +377,12 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
                 auto finish = [&](int c, float4 wv, const float4& g) {
                     const int64_t off = 4 * (int64_t)c;
                     float w[4] = {wv.x, wv.y, wv.z, wv.w};
-                    const float gg[4] = {g.x, g.y, g.z, g.w};
+                    float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j) {
+                        lp_fold(P.opt, w[j], gg[j], lp_acc);
                         opt_update_elem(P.opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+                    }
                     *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
                 };
                 if (oa) finish(ca, wA, accA);
@@ -281,6 +402,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
                 }
                 if (oc) {
                     float wv = wrow[c];
+                    lp_fold(P.opt, wv, acc, lp_acc);
                     opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
                     wrow[c] = wv;
                 }
@@ -288,25 +410,31 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
         }
         if (P.tag && sl == 0 && has) P.tag[key] = P.step;
     }
+    if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-// Keras Adam's sparse apply is dense-equivalent (every row: m*=b1, v*=b2, w -= lr_t m/(sqrt v + eps));
-// rows touched this step were fully handled elsewhere and are skipped via tag.
-__global__ __launch_bounds__(256) void adam_untouched_kernel(const ApplyParams P) {
+// Rows no contribution of this step touched (tag[r] != step).  Two reasons to visit them:
+//   * Keras Adam's sparse apply is dense-equivalent: every row's m, v decay and every row moves (g = 0 there);
+//   * an LP regulariser makes the gradient dense (regularizers/lp.py:107-113: the penalty covers the FULL tables,
+//     EmbeddingModel.py:818-820): an untouched row still has g = lambda * p * |w|^(p-1) * sign(w), and its |w|^p
+//     belongs to the loss.  Touched rows got the same term folded into their update (lp_fold), so the regulariser
+//     costs ONE pass over the rows nothing else visited instead of n_rows extra contribution rows.
+__global__ __launch_bounds__(256) void untouched_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= P.n_rows) return;
-    if (P.tag[r] == P.step) return;
-    float* w = P.table + r * P.ld;
-    float* m = P.state0 + r * P.ld;
-    float* v = P.state1 + r * P.ld;
-    for (int c = lane; c < P.k_int; c += 64) {
-        const float mm = P.opt.beta1 * m[c];
-        const float vv = P.opt.beta2 * v[c];
-        m[c] = mm;
-        v[c] = vv;
-        w[c] = w[c] - P.opt.lr_t * mm / (sqrtf(vv) + P.opt.eps);
+    float lp_acc = 0.f;
+    if (r < P.n_rows && P.tag[r] != P.step) {
+        float* w = P.table + r * P.ld;
+        float* s0 = P.state0 ? P.state0 + r * P.ld : nullptr;
+        float* s1 = P.state1 ? P.state1 + r * P.ld : nullptr;
+        for (int c = lane; c < P.k_int; c += 64) {
+            float wv = w[c], g = 0.f;
+            lp_fold(P.opt, wv, g, lp_acc);
+            opt_update_elem(P.opt, wv, g, s0 ? s0 + c : nullptr, s1 ? s1 + c : nullptr);
+            w[c] = wv;
+        }
     }
+    if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -338,14 +466,19 @@ static int sort_temp_bytes(int64_t n, size_t* bytes) {
     return EMG_OK;
 }
 
-// workspace layout: [keys_sorted | (unused) | vals_sorted | (unused) | 256 B | rocprim temp]  (sizes kept: ABI)
+// workspace layout: [keys_sorted | long-segment list | vals_sorted | (unused) | 256 B: long-segment count | rocprim temp
+//                    | partial rows of the long-segment reduction (only in workspaces sized by emg_apply_workspace_bytes_ex)]
 struct WsLayout {
     size_t kb, temp;
     uint32_t *keys, *vals;
     void* tmp;
+    uint32_t *long_list, *long_count;
+    float* partial;       // nullptr when the workspace has no room for it (then long segments are summed by one wave)
 };
 
-static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayout* o) {
+static inline size_t partial_rows(int64_t n) { return 2 * ((size_t)n / kLongSegment + 2); }
+
+static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayout* o, int64_t ldp = 0) {
     size_t tmp = 0;
     int rc = sort_temp_bytes(n, &tmp);
     if (rc != EMG_OK) return rc;
@@ -358,6 +491,11 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
     o->keys = (uint32_t*)ws;
     o->vals = (uint32_t*)(ws + 2 * o->kb);
     o->tmp = ws + 4 * o->kb + 256;
+    o->long_list = (uint32_t*)(ws + o->kb);
+    o->long_count = (uint32_t*)(ws + 4 * o->kb);
+    const size_t base = 4 * o->kb + 256 + align256(tmp);
+    const size_t need = partial_rows(n) * (size_t)ldp * sizeof(float);
+    o->partial = (ldp > 0 && n > kLongSegment && (int64_t)(base + need) <= workspace_bytes) ? (float*)(ws + base) : nullptr;
     return EMG_OK;
 }
 
@@ -405,6 +543,7 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
                                                       rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
                                                       end_bit, st, false));
     }
+    EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));  // long-segment list of the apply that follows
     if (single_flags) {
         hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
                            single_flags);
@@ -464,6 +603,13 @@ extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) 
     return (int64_t)(4 * align256((size_t)n_contrib * 4) + 256 + align256(tmp) + 256);
 }
 
+extern "C" int64_t emg_apply_workspace_bytes_ex(int64_t n_contrib, int64_t n_rows, int32_t k_int) {
+    const int64_t base = emg_apply_workspace_bytes(n_contrib, n_rows);
+    if (base < 0 || n_contrib <= kLongSegment || k_int <= 0) return base;
+    const int64_t ldp = (k_int + 3) / 4 * 4;
+    return base + (int64_t)(partial_rows(n_contrib) * (size_t)ldp * sizeof(float));
+}
+
 extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace,
                               int64_t workspace_bytes, uint8_t* single_flags, void* stream) {
     EMG_REQUIRE(n >= 0 && n_rows > 0 && n_rows < ((int64_t)1 << 31), "emg_group_dest: bad sizes");
@@ -504,8 +650,8 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
 
 extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
                                  float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
-                                 int64_t n_contrib, int32_t skip_single, const float* hyper, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
+                                 int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
     EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
     EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
@@ -514,35 +660,54 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
     EMG_REQUIRE(!(opt == EMG_OPT_ADAM || opt == EMG_OPT_ADAM_LAZY) || (state0 && state1),
                 "emg_apply_grouped: adam needs state0 and state1");
     EMG_REQUIRE(opt != EMG_OPT_ADAM || tag, "emg_apply_grouped: dense-equivalent adam needs the tag array");
+    EMG_REQUIRE(hyper[6] == 0.f || (tag && hyper[7] >= 1.f), "emg_apply_grouped: a folded LP regulariser needs the tag array and p >= 1");
     hipStream_t st = (hipStream_t)stream;
     ApplyParams P{};
     P.table = table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
     P.state0 = state0; P.state1 = state1; P.tag = tag; P.step = step;
     P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
     P.opt = make_opt_params(opt, hyper);
+    P.lp_accum = lp_accum;
     if (n_contrib > 0) {
+        const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
+                         (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
+        const int64_t ldp = (k_int + 3) / 4 * 4;
         WsLayout w;
-        int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w);
+        int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w, ldp);
         if (rc != EMG_OK) return rc;
         P.keys = w.keys;
         P.vals = w.vals;
-        const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
-                         (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
         // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
         int win = 64;
         while (win > 1 && n_contrib / win < 16384) win >>= 1;
+        if (const char* e = getenv("EMG_APPLY_WIN")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) win = v; }  // A/B aid
         P.win = win;
         const dim3 grid((unsigned)cdiv(cdiv(n_contrib, win) * 64, 256)), block(256);
         const int nch = vec ? k_int / 4 : k_int;
-        if (nch <= 16) {  // skinny rows: four segments per wave
+        const bool skinny = nch <= 16;
+        static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aid
+        if (w.partial && !skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
+            P.long_list = w.long_list; P.long_count = w.long_count; P.long_cap = (uint32_t)(n_contrib / kLongSegment + 1);
+        }
+        // DEPTH 2 everywhere (measured, C3: relation table 0.121 ms vs 0.148 ms with 16 rows in flight at 2 waves/SIMD,
+        // entity table 0.112 vs 0.22): segments of up to 64 rows gain more from 7 waves/SIMD than from deeper trips
+        if (skinny) {  // skinny rows: four segments per wave
             if (vec) hipLaunchKernelGGL((apply_rows_sub_kernel<4, 16>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((apply_rows_sub_kernel<1, 16>), grid, block, 0, st, P);
-        } else if (vec) hipLaunchKernelGGL((apply_rows_kernel<4>), grid, block, 0, st, P);
-        else hipLaunchKernelGGL((apply_rows_kernel<1>), grid, block, 0, st, P);
+        } else if (vec) hipLaunchKernelGGL((apply_rows_kernel<4, 2>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((apply_rows_kernel<1, 2>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
+        if (P.long_list) {
+            // a handful of workgroups: long segments are few (an entity needs > 64 hits in ONE batch); with none the
+            // launch costs a few microseconds of an empty 32-block grid
+            const unsigned nb = (unsigned)(P.long_cap < 32u ? P.long_cap : 32u);
+            if (vec) hipLaunchKernelGGL((apply_long_kernel<4>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
+            else hipLaunchKernelGGL((apply_long_kernel<1>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
+            EMG_LAUNCH_CHECK();
+        }
     }
-    if (opt == EMG_OPT_ADAM) {
-        hipLaunchKernelGGL(adam_untouched_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, st, P);
+    if (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) {
+        hipLaunchKernelGGL(untouched_rows_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, st, P);
         EMG_LAUNCH_CHECK();
     }
     return EMG_OK;
@@ -557,5 +722,5 @@ extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld,
     int rc = emg_group_dest(dest, n_contrib, n_rows, workspace, workspace_bytes, nullptr, stream);
     if (rc != EMG_OK) return rc;
     return emg_apply_grouped(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, 0,
-                             hyper, workspace, workspace_bytes, stream);
+                             hyper, nullptr, workspace, workspace_bytes, stream);
 }

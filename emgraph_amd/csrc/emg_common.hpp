@@ -133,7 +133,30 @@ __device__ __forceinline__ float sgnf(float d) { return (float)(d > 0.f) - (floa
 struct OptParams {
     int opt;
     float lr, mu, beta1, beta2, eps, lr_t;
+    float lp_lambda;  // LP regulariser folded into the update (0 = none): g += lambda * p * |w|^(p-1) * sign(w)
+    int lp_p;
 };
+
+// LP regulariser (regularizers/lp.py:107-113), per element: value |w|^p and gradient of lambda * |w|^p
+__device__ __forceinline__ float lp_pow(float a, int p) {
+    if (p == 1) return a;
+    if (p == 2) return a * a;
+    if (p == 3) return a * a * a;
+    return powf(a, (float)p);
+}
+__device__ __forceinline__ float lp_grad(const OptParams& P, float w) {
+#pragma clang fp contract(off)
+    const float a = fabsf(w);
+    return P.lp_lambda * (float)P.lp_p * (P.lp_p == 1 ? 1.f : lp_pow(a, P.lp_p - 1)) * sgnf(w);
+}
+// every row's update sees the gradient of the WHOLE loss: data term (summed contributions, 0 for a row no triple of
+// the batch touches) + the regulariser's, both evaluated at the pre-update value (EmbeddingModel.py:786-820)
+__device__ __forceinline__ void lp_fold(const OptParams& P, float w, float& g, float& lp_acc) {
+    if (P.lp_lambda != 0.f) {
+        g += lp_grad(P, w);
+        lp_acc += lp_pow(fabsf(w), P.lp_p);
+    }
+}
 
 __device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float g) {
 #pragma clang fp contract(off)
@@ -212,10 +235,19 @@ __device__ __forceinline__ float local_loss_neg(int loss, float pos, const PosTe
     return v >= 0.f ? 1.f : 0.f;
 }
 
+// add the lanes' partial sums of a wave into *dst (double): one atomic per wave that has something to add
+__device__ __forceinline__ void wave_add_double(double* dst, float partial) {
+    double v = (double)partial;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (dst && (threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+}
+
 static inline OptParams make_opt_params(int opt, const float* hyper) {
     OptParams o;
     o.opt = opt == EMG_OPT_ADAM_LAZY ? EMG_OPT_ADAM : opt;
     o.lr = hyper[0]; o.mu = hyper[1]; o.beta1 = hyper[2]; o.beta2 = hyper[3]; o.eps = hyper[4]; o.lr_t = hyper[5];
+    o.lp_lambda = hyper[6]; o.lp_p = (int)hyper[7];
     return o;
 }
 

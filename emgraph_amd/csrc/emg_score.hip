@@ -249,10 +249,11 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     wv[w] = cur.x[h * E + it * W + w];
+                    const float g = grad.x[h * E + it * W + w];
                     if constexpr (IP == 1) {
-                        wv[w] = opt_sgd_elem(P.opt, wv[w], grad.x[h * E + it * W + w]);
+                        wv[w] = opt_sgd_elem(P.opt, wv[w], g);
                     } else {
-                        opt_update_elem(P.opt, wv[w], grad.x[h * E + it * W + w], &s0v[w], &s1v[w]);
+                        opt_update_elem(P.opt, wv[w], g, &s0v[w], &s1v[w]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -371,8 +372,20 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
     }
 }
 
+#ifndef EMG_BW_MINWAVES
+#define EMG_BW_MINWAVES 1
+#endif
+// KEEP: the s, p, o rows stay in registers across the loop over the negatives instead of being re-read at the end
+// (the re-read was 1.10x the algorithmic traffic by PMC: after 20 replacement rows per wave on every CU of the XCD
+// they are no longer in L2).  Only where it is free: instantiations whose occupancy does not drop (checked with
+// -Rpass-analysis=kernel-resource-usage: 16-byte single-chunk rows; complex rows only in the fused in-place form,
+// 140 -> 158 VGPRs at the same 3 waves/SIMD).
+template <int MODEL, int W, int NV, bool FUSED, int IP>
+struct keep_rows {
+    static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && IP != 0));
+};
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
-__global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupParams P) {
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P) {
     using R = Row<MODEL, W, NV>;
     const int lg = threadIdx.x % LPG;
     int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPG;
@@ -386,12 +399,15 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
     const float* orow = P.ent + (int64_t)o * P.ld_ent;
     R qo, qs, Ao, As;
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
+    constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
+    R ks, kp, ko;  // live across the loop only when KEEP (dead otherwise: no registers)
     {
         R rs, rp, ro;
         load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
         make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
+        if constexpr (KEEP) { ks = rs; kp = rp; ko = ro; }
         if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
             if (MODEL == EMG_TRANSE_L2 && P.bw_scores_pos) {
                 pos_nrm = -P.bw_scores_pos[g];
@@ -463,11 +479,15 @@ __global__ __launch_bounds__(kThreads) void train_backward_kernel(const GroupPar
         }
     }
     if (active) {
-        // kept rows: re-load s, p, o (just read: L2-hot) and form their gradients from the accumulators
+        // kept rows: form their gradients from the accumulators
         R rs, rp, ro, gs, gp, go;
-        load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
-        load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
-        load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        if constexpr (KEEP) {
+            rs = ks; rp = kp; ro = ko;
+        } else {  // re-load s, p, o (read a moment ago) instead of holding three more rows per group
+            load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
         if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[g])) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
@@ -709,6 +729,10 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
         P.ent_rw = const_cast<float*>(a->ent);
         P.ent_state0 = a->ent_state0; P.ent_state1 = a->ent_state1; P.tag_ent = a->tag_ent; P.step = a->step;
         P.opt = make_opt_params(a->opt, a->hyper);
+        // the in-place path stays free of the regulariser's pow / sign code (it costs the fused kernel a wave per SIMD):
+        // with an LP regulariser every gradient row goes through emg_apply_grouped, which folds it in
+        EMG_REQUIRE(a->hyper[6] == 0.f, "emg_train_backward_ex: in-place singleton updates cannot fold an LP regulariser "
+                                        "(pass single_ent = NULL and let emg_apply_grouped apply every row)");
     }
     return run_group_pass(fused ? Pass::Fused : Pass::Backward, a->model, P, (hipStream_t)stream);
 }

@@ -59,6 +59,12 @@ def _chk_table(t, name):
     return t.data_ptr(), t.shape[0], t.stride(0)
 
 
+def _hyper8(hyper):
+    """{lr, momentum, beta1, beta2, eps, lr_t, lp_lambda, lp_p}: six-value tuples mean 'no folded LP regulariser'"""
+    h = [float(x) for x in hyper] + [0.0] * (8 - len(hyper))
+    return (C.c_float * 8)(*h)
+
+
 def _chk_vec(t, dtype, name, n=None):
     if t is None:
         return None
@@ -251,15 +257,20 @@ def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, 
     L.check(lib.emg_prepare_batch(C.byref(a), _stream()), "emg_prepare_batch")
 
 
-def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace):
+def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace,
+                  lp_accum=None):
+    """``hyper`` = (lr, momentum, beta1, beta2, eps, lr_t[, lp_lambda, lp_p]); with lp_lambda != 0 the LP regulariser's
+    gradient is folded into every row's update and ``lp_accum`` (device double) receives sum |w|^p."""
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")
     p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
     p1 = _chk_table(state1, "state1")[0] if state1 is not None else None
     pc, _, ldc = _chk_table(contrib, "contrib")
-    h = (C.c_float * 6)(*[float(x) for x in hyper])
+    h = _hyper8(hyper)
     L.check(lib.emg_apply_grouped(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc,
-                                  ldc, n_contrib, int(skip_single), h, workspace.data_ptr(),
+                                  ldc, n_contrib, int(skip_single), h,
+                                  _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None,
+                                  workspace.data_ptr(),
                                   workspace.numel() * workspace.element_size(), _stream()), "emg_apply_grouped")
 
 
@@ -271,8 +282,10 @@ def apply_workspace_views(workspace, n_contrib):
     return w32[:n_contrib], w32[2 * kb // 4:2 * kb // 4 + n_contrib]
 
 
-def apply_workspace_bytes(n_contrib, n_rows):
-    n = L.load().emg_apply_workspace_bytes(n_contrib, n_rows)
+def apply_workspace_bytes(n_contrib, n_rows, k_int=0):
+    """grouping workspace; with ``k_int`` it also holds the scratch of the long-segment reduction (emg_apply_long)"""
+    lib = L.load()
+    n = lib.emg_apply_workspace_bytes_ex(n_contrib, n_rows, k_int) if k_int else lib.emg_apply_workspace_bytes(n_contrib, n_rows)
     if n < 0:
         L.check(-1, "emg_apply_workspace_bytes")
     return int(n)
@@ -285,7 +298,7 @@ def apply_rows(opt_id, table, k_int, state0, state1, tag, step, contrib, dest, n
     p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
     p1 = _chk_table(state1, "state1")[0] if state1 is not None else None
     pc, _, ldc = _chk_table(contrib, "contrib")
-    h = (C.c_float * 6)(*[float(x) for x in hyper])
+    h = _hyper8(hyper)
     L.check(lib.emg_apply_rows(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc, ldc,
                                _chk_vec(dest, torch.int32, "dest"), n_contrib, h, workspace.data_ptr(),
                                workspace.numel() * workspace.element_size(), _stream()), "emg_apply_rows")

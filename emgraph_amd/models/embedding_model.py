@@ -363,6 +363,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         except ImportError:  # pragma: no cover
             epochs_iter = range(1, self.epochs + 1)
         self._trainer = tr
+        self.epoch_losses = []   # sum of the batch losses of each epoch (what the progress message averages)
+
         def batch_args(epoch, batch):
             """(start, B, epoch, batch, n_choices, entities_list) of a batch, or None past the end"""
             epoch, batch = epoch + (batch - 1) // self.batches_count, (batch - 1) % self.batches_count + 1
@@ -383,6 +385,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                 tr.step(start, B, epoch, batch, n_choices=nc, entities_list=el,
                         prefetch=[batch_args(epoch, batch + j) for j in (1, 2, 3)])
             loss_epoch = tr.read_loss()
+            self.epoch_losses.append(loss_epoch)
             if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)
                 msg = "Loss is {}. Please change the hyperparameters.".format(loss_epoch)
                 logger.error(msg)

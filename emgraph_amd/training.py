@@ -154,12 +154,16 @@ class Trainer:
                 raise ValueError("Regularizer weight must be a scalar or a list with length equal to number of "
                                  "params passes")
             self.reg = (float(lam[0]), float(lam[1]), int(p))
-        # SGD folds the dense LP gradient into an in-place pass; every other optimizer needs the true
-        # per-element gradient sum, so the LP gradient is appended as one contribution row per table row
-        self.reg_rows = self.reg is not None and optimizer != "sgd"
+        # The LP penalty covers the full tables (lp.py:107-113), so its gradient is dense.  It is FOLDED into the
+        # optimizer step: rows with contributions (or updated in place) add lambda*p*|w|^(p-1)*sign(w) to their summed
+        # gradient, all other rows get it in one dense pass (emg_apply_grouped / untouched_rows_kernel) — no extra
+        # contribution rows, one update per row per step with the gradient of the whole loss.
+        self.reg_rows = False
 
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.reg_accum = torch.zeros(1, dtype=torch.float64, device=self.device)  # LP term (column-local when sharded)
+        # sum |w|^p per table, accumulated by the kernels that fold the regulariser (scaled by lambda in read_loss)
+        self.lp_sum = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.X = None
         self._cap = 0
         self.stage_events = None  # filled by enable_stage_timing()
@@ -171,6 +175,8 @@ class Trainer:
         self.batch_sharded = sharded == "batch"
         self.sharded = bool(sharded) and not self.batch_sharded          # k (column) sharding
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded
+        # (with an LP regulariser every row goes through the apply kernel, which folds its gradient in: the in-place
+        # path of the fused kernel stays free of the pow / sign code, which would cost it a wave per SIMD)
         self.inplace = inplace and self.reg is None
         self.pipeline = pipeline
         if self.batch_sharded:
@@ -181,7 +187,7 @@ class Trainer:
                 raise ValueError("batch-sharded training cannot run Keras' dense-equivalent Adam (every row of the table "
                                  "changes every step, i.e. the whole table would be exchanged): use 'adam_lazy', another "
                                  "optimizer, or k-sharding")
-            if self.reg_rows:
+            if self.reg is not None and optimizer != "sgd":
                 raise NotImplementedError("LP regulariser with a stateful optimizer under batch sharding")
             self.xgmi_bytes = 0          # bytes this rank sent + received over the interconnect (gradient rows + updated rows)
             self._owner_ws = {}
@@ -225,8 +231,8 @@ class Trainer:
                 "dest_ent": torch.empty(n_ce, dtype=torch.int32, device=dev),
                 "dest_rel": torch.empty(n_cr, dtype=torch.int32, device=dev),
                 "single": torch.empty(n_ce, dtype=torch.uint8, device=dev),
-                "ws_ent": torch.empty(D.apply_workspace_bytes(n_ce, self.n_ent), dtype=torch.uint8, device=dev),
-                "ws_rel": torch.empty(D.apply_workspace_bytes(n_cr, self.n_rel), dtype=torch.uint8, device=dev),
+                "ws_ent": torch.empty(D.apply_workspace_bytes(n_ce, self.n_ent, k), dtype=torch.uint8, device=dev),
+                "ws_rel": torch.empty(D.apply_workspace_bytes(n_cr, self.n_rel, k), dtype=torch.uint8, device=dev),
                 "ready": torch.cuda.Event(), "done": torch.cuda.Event(), "key": None,
             }
             if self.reg_rows:  # LP gradient rows come FIRST ([0, n_rows)); their destinations never change
@@ -260,10 +266,15 @@ class Trainer:
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.stage_events or {}).items()}
 
     # ---- one batch ----
-    def _hyper(self, lr):
+    def _hyper(self, lr, table=None):
+        """(lr, momentum, beta1, beta2, eps, lr_t) + (lambda, p) of the folded LP regulariser for table 0 (entities)
+        / 1 (relations); table=None: no regulariser folded in"""
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
-        return (lr, self.momentum, ADAM_BETA1, ADAM_BETA2, KERAS_EPS, lr_t)
+        h = (lr, self.momentum, ADAM_BETA1, ADAM_BETA2, KERAS_EPS, lr_t)
+        if table is None or self.reg is None or self.batch_sharded:
+            return h
+        return h + (self.reg[table], float(self.reg[2]))
 
     def _prepare(self, sl, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl):
         """Everything about a batch that does not depend on the tables: corruption codes (Philox, draw counter
@@ -344,8 +355,9 @@ class Trainer:
         single = sl["single"][:n_ce] if self.inplace else None
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
-        hyper = self._hyper(lr)
-        inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper,
+        hyper_e, hyper_r = self._hyper(lr, 0), self._hyper(lr, 1)
+        lp_e, lp_r = (self.lp_sum[0:1], self.lp_sum[1:2]) if len(hyper_e) == 8 else (None, None)
+        inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper_e[:6],
                           ent_state0=self.state_ent[0], ent_state1=self.state_ent[1], tag_ent=self.tag_ent)
         if self.fused:
             self._timed("fused", lambda: D.train_backward_ex(
@@ -370,25 +382,9 @@ class Trainer:
             self._timed("backward", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
                 g_pos=gp, g_neg=gn, **bw, **inplace_kw))
-        if self.reg is not None and not self.reg_rows:
-            # dense LP term: value + SGD-style in-place step, both evaluated at the pre-update tables
-            # (the sparse contributions above were also computed from the pre-update tables)
-            self._timed("regularizer", lambda: (
-                D.lp_regularizer(self.ent, self.k_int, self.reg[0], self.reg[2], lr, self.reg_accum),
-                D.lp_regularizer(self.rel, self.k_int, self.reg[1], self.reg[2], lr, self.reg_accum)))
-        elif self.reg_rows:
-            # LP gradient as one extra contribution row per table row (dense by definition, lp.py:107-113);
-            # their destinations (iota) are already part of the slot's grouping
-            self._timed("regularizer", lambda: (
-                D.lp_grad_rows(self.ent, self.k_int, self.reg[0], self.reg[2], self.contrib_ent[:xe],
-                               sl["dest_ent"][:xe], self.reg_accum),
-                D.lp_grad_rows(self.rel, self.k_int, self.reg[1], self.reg[2], self.contrib_rel[:xr],
-                               sl["dest_rel"][:xr], self.reg_accum)))
-            ce, cr = self.contrib_ent[:xe + n_ce], self.contrib_rel[:xr + B]
-            n_ce, n_cr = xe + n_ce, xr + B
         apply_rel = lambda: D.apply_grouped(self.opt_id, self.rel, self.k_int, self.state_rel[0],  # noqa: E731
                                             self.state_rel[1], self.tag_rel, self.step_count, cr, n_cr,
-                                            False, hyper, sl["ws_rel"])
+                                            False, hyper_r, sl["ws_rel"], lp_accum=lp_r)
         # (small batches stay on one stream: the fork/join costs ~60 us of host time, more than the overlap buys)
         use_aux = self.aux is not None and n_ce >= AUX_MIN_ROWS
         if use_aux:
@@ -401,7 +397,7 @@ class Trainer:
                 self.aux_join.record(self.aux)
         self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
                                                          self.state_ent[1], self.tag_ent, self.step_count, ce, n_ce,
-                                                         self.inplace, hyper, sl["ws_ent"]))
+                                                         self.inplace, hyper_e, sl["ws_ent"], lp_accum=lp_e))
         if use_aux:
             main.wait_event(self.aux_join)
         else:
@@ -475,7 +471,7 @@ class Trainer:
             perm = torch.argsort(gslot_o, stable=True)
             dest_p = dest_o.index_select(0, perm).contiguous()
             ws = self._owner_ws.get(which)
-            need = D.apply_workspace_bytes(m, n_rows)
+            need = D.apply_workspace_bytes(m, n_rows, k)
             if ws is None or ws.numel() < need:
                 ws = self._owner_ws[which] = torch.empty(int(need * 1.5) + 1024, dtype=torch.uint8, device=self.device)
             D.group_dest(dest_p, m, n_rows, ws)
@@ -500,9 +496,14 @@ class Trainer:
         if self.batch_sharded:  # every rank saw its rows of each batch only; the LP term was computed by every replica
             data = parallel.allreduce_sum_(self.loss_accum.clone())
         v = float(data.item()) + float(reg.item())
+        if self.reg is not None and not self.batch_sharded:
+            lp = self.lp_sum if not self.sharded else parallel.allreduce_sum_(self.lp_sum.clone())
+            lp = lp.cpu()
+            v += self.reg[0] * float(lp[0]) + self.reg[1] * float(lp[1])
         if reset:
             self.loss_accum.zero_()
             self.reg_accum.zero_()
+            self.lp_sum.zero_()
         return v
 
     def tables_numpy(self):

@@ -161,7 +161,7 @@ int emg_prepare_batch(const emg_prepare_args* args, void* stream);
  *   fused_loss < 0: dL/dscore is read from g_pos / g_neg (any loss; see emg_loss).
  *   single_ent != NULL: uint8 per entity contribution slot (from emg_group_dest); slots flagged 1 have a
  *       destination hit exactly once in this batch and are applied to the table IN PLACE (optimizer `opt`,
- *       hyper = HOST 6 floats as emg_apply_rows) instead of being written to contrib_ent — finish with
+ *       hyper = 8 floats as emg_apply_rows) instead of being written to contrib_ent — finish with
  *       emg_apply_grouped(..., skip_single=1).
  *   bw_scores_* : optional global final scores, used only by TransE-L2 when `ent`/`rel` are column
  *       slices (k-sharded multi-GPU) so that the norm is the full one.
@@ -176,9 +176,9 @@ typedef struct emg_backward_args {
     const float* bw_scores_pos; const float* bw_scores_neg;
     float* scores_pos_out; float* scores_neg_out;
     float* contrib_ent; float* contrib_rel; int64_t ldc;
-    const uint8_t* single_ent; int32_t opt; int32_t step; float hyper[6];
+    const uint8_t* single_ent; int32_t opt; int32_t step; float hyper[8];
     float* ent_state0; float* ent_state1; int32_t* tag_ent;
-} emg_backward_args;
+} emg_backward_args;   /* hyper[6] (folded LP, see emg_apply_grouped) must be 0 when single_ent != NULL */
 int emg_train_backward_ex(const emg_backward_args* args, void* stream);
 
 /* ---- K8 in two halves (emg_apply_rows = both):
@@ -190,16 +190,27 @@ int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspa
 int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
                       float* state0, float* state1, int32_t* tag, int32_t step,
                       const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
-                      const float* hyper, void* workspace, int64_t workspace_bytes, void* stream);
+                      const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, void* stream);
+/* LP regulariser folded into the optimizer step (hyper[6] = lambda != 0, hyper[7] = p): the penalty covers the FULL
+ * table (regularizers/lp.py:107-113, EmbeddingModel.py:818-820), so its gradient lambda*p*|w|^(p-1)*sign(w) reaches
+ * every row.  Rows with contributions (and rows the backward kernel updates in place) add it to their summed
+ * gradient; rows nothing touched in this step (tag[r] != step) are visited by ONE dense pass that applies the
+ * optimizer with that gradient alone.  *lp_accum (device double, may be NULL) += sum of |w|^p over all rows at their
+ * pre-update values — the caller multiplies by lambda for the loss.  Needs `tag`. */
 
 /* ---- K8: deterministic row-sparse optimizer apply.  Sorts (dest, index) (stable radix sort),
  * sums each destination's contribution rows in index order and updates that table row once.
  * state0/state1: momentum buffer | adagrad accumulator | adam m, v  (same shape/stride as the table;
  * NULL when unused).  `tag` int32[n_rows] scratch owned by the caller (persistently, zero-initialised
  * once) marks rows touched in step `step` (>=1) — needed by EMG_OPT_ADAM's dense pass.
- * hyper: HOST pointer to 6 floats {lr, momentum, beta1, beta2, eps, lr_t} read at call time
- * (lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), Adam only). */
+ * hyper: HOST pointer to 8 floats {lr, momentum, beta1, beta2, eps, lr_t, lp_lambda, lp_p} read at call time
+ * (lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t), Adam only; lp_lambda = 0: no regulariser folded in, see emg_apply_grouped). */
 int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows);
+/* the same plus scratch for the long-segment reduction (destinations hit by more than 64 contributions in a batch —
+ * hub entities of a skewed graph, relation rows — are summed as 64-row blocks by a whole workgroup instead of by one
+ * wave); with the smaller workspace above such segments are summed by a single wave (slow, same reduction order only
+ * for segments of up to 64 rows) */
+int64_t emg_apply_workspace_bytes_ex(int64_t n_contrib, int64_t n_rows, int32_t k_int);
 int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
                    float* state0, float* state1, int32_t* tag, int32_t step,
                    const float* contrib, int64_t ldc, const int32_t* dest, int64_t n_contrib,
@@ -334,7 +345,7 @@ typedef struct emg_step_args {
     float* ent; int64_t n_ent; int64_t ld_ent; float* rel; int64_t n_rel; int64_t ld_rel;
     float* ent_state0; float* ent_state1; float* rel_state0; float* rel_state1;   /* optimizer state, NULL if unused */
     int32_t* tag_ent; int32_t* tag_rel;                                           /* int32[n_rows], zeroed once */
-    int32_t opt; int32_t step; float hyper[6];                                    /* as emg_apply_rows */
+    int32_t opt; int32_t step; float hyper[8];                                    /* as emg_apply_rows (hyper[6] = 0) */
     const int32_t* pos; int64_t B;                                                /* device int32 [B,3] */
     int64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t draw_counter0;
     const int32_t* inj_mask; const int32_t* inj_repl;                             /* optional injected draws */

@@ -91,8 +91,8 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
     tag_e = torch.zeros(n_ent, dtype=torch.int32, device=dev)
     tag_r = torch.zeros(n_rel, dtype=torch.int32, device=dev)
     n_ce = (2 + eta) * B
-    we = torch.empty(d.apply_workspace_bytes(n_ce, n_ent), dtype=torch.uint8, device=dev)
-    wr = torch.empty(d.apply_workspace_bytes(B, n_rel), dtype=torch.uint8, device=dev)
+    we = torch.empty(d.apply_workspace_bytes(n_ce, n_ent, ki), dtype=torch.uint8, device=dev)   # incl. long-segment scratch
+    wr = torch.empty(d.apply_workspace_bytes(B, n_rel, ki), dtype=torch.uint8, device=dev)
     codes = torch.empty(B * eta, dtype=torch.int32, device=dev)
     de = torch.empty(n_ce, dtype=torch.int32, device=dev)
     dr = torch.empty(B, dtype=torch.int32, device=dev)

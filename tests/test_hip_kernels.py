@@ -311,7 +311,8 @@ def test_apply_rows_vs_oracle(opt):
 def test_apply_rows_sums_in_contribution_order(k, n_rows, n_c, hot):
     """bit-exact: every destination row gets w - lr * (fp32 sum of its contributions IN INDEX ORDER).  Covers the
     16 / 32 / 64 lanes-per-segment variants, the scalar (k % 4 != 0) kernels, segments longer than a wave's window
-    (one hot destination collecting `hot` rows) and untouched rows."""
+    (one hot destination collecting `hot` rows; the workspace here is the small one of emg_apply_workspace_bytes, so
+    the long-segment block tree of test_apply_rows_long_segments_block_tree is not engaged) and untouched rows."""
     d = dev()
     from emgraph_amd import _lib as L
     rs = np.random.RandomState(k + n_c)
@@ -774,3 +775,60 @@ def test_ranks_vs_reference_pieces_on_device(golden, name, precision):
         got = d.rank_1vsall(MID[om], Et, Rt, ki, sc, cu(T), L.EVAL_S_O, strategy=si, filt_ptr=cu(ptr), filt_idx=cu(idx),
                             precision_mode=precision)
         np.testing.assert_array_equal(got.cpu().numpy(), exp_so)
+
+
+@pytest.mark.parametrize("k,opt", [(400, "sgd"), (100, "adam_lazy"), (50, "sgd"), (72, "adagrad")])
+def test_apply_rows_long_segments_block_tree(k, opt):
+    """destinations hit by more than 64 contributions (hub entities of a skewed graph, relation rows) are reduced by
+    apply_long_kernel: 64-row blocks of the segment summed left to right, then the block sums added left to right —
+    a tree defined by the segment alone.  Bit-exact against that definition; segments of <= 64 rows keep the plain
+    left-to-right sum.  Long segments sit on ADJACENT destination ids (adjacent sorted positions: the partial-row
+    indexing must not collide) and have lengths around the block boundaries."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(k)
+    n_rows = 300
+    lens = {3: 65, 4: 64, 5: 129, 6: 128, 7: 1000, 8: 5003, 9: 66, 10: 63, 200: 70, 201: 777}
+    dest = [rs.randint(20, 190, 4000)]
+    for row, n in lens.items():
+        dest.append(np.full(n, row))
+    dest = np.concatenate(dest).astype(np.int32)
+    rs.shuffle(dest)
+    n_c = len(dest)
+    contrib = rs.randn(n_c, k).astype(F32)
+    W = rs.randn(n_rows, k).astype(F32)
+    Wt = cu(W)
+    s0 = s1 = None
+    if opt == "adagrad":
+        s0 = torch.full_like(Wt, 0.1)
+    elif opt == "adam_lazy":
+        s0, s1 = torch.zeros_like(Wt), torch.zeros_like(Wt)
+    ws = torch.empty(d.apply_workspace_bytes(n_c, n_rows, k), dtype=torch.uint8, device="cuda")
+    assert ws.numel() > d.apply_workspace_bytes(n_c, n_rows)
+    lr, b1, b2, eps = F32(0.05), F32(0.9), F32(0.999), F32(1e-7)
+    d.apply_rows(L.OPT_IDS[opt], Wt, k, s0, s1, None, 1, cu(contrib), cu(dest), n_c, (float(lr), 0.9, 0.9, 0.999, 1e-7, float(lr)), ws)
+    exp = W.copy()
+    order = np.argsort(dest, kind="stable")
+    for seg in np.split(order, np.flatnonzero(np.diff(dest[order])) + 1):
+        def seq(idx):
+            g = np.zeros(k, F32)
+            for i in idx:
+                g = g + contrib[i]
+            return g
+        if len(seg) > 64:
+            g = np.zeros(k, F32)
+            for b0 in range(0, len(seg), 64):
+                g = g + seq(seg[b0:b0 + 64])
+        else:
+            g = seq(seg)
+        r = dest[seg[0]]
+        if opt == "sgd":
+            exp[r] = W[r] - lr * g
+        elif opt == "adagrad":
+            a = F32(0.1) + g * g
+            exp[r] = W[r] - lr * g / (np.sqrt(a) + eps)
+        else:
+            m = (F32(1) - b1) * g
+            v = (F32(1) - b2) * g * g
+            exp[r] = W[r] - lr * m / (np.sqrt(v) + eps)
+    np.testing.assert_array_equal(Wt.cpu().numpy(), exp)
