@@ -141,6 +141,45 @@ SIGNATURES.update({
     "emg_train_step": (_int, [C.POINTER(StepArgs), _p]),
 })
 
+class PlanSlot(C.Structure):
+    """mirror of `emg_plan_slot`"""
+    _fields_ = [("codes", _p), ("dest_ent", _p), ("dest_rel", _p), ("single", _p),
+                ("ws_ent", _p), ("ws_ent_bytes", _i64), ("ws_rel", _p), ("ws_rel_bytes", _i64)]
+
+
+class PlanConfig(C.Structure):
+    """mirror of `emg_plan_config`"""
+    _fields_ = [
+        ("model", _i32), ("k_int", _i32), ("scale", _f32), ("eta", _i32), ("n_sides", _i32), ("sides", _i32 * 4),
+        ("ent", _p), ("n_ent", _i64), ("ld_ent", _i64), ("rel", _p), ("n_rel", _i64), ("ld_rel", _i64),
+        ("ent_state0", _p), ("ent_state1", _p), ("rel_state0", _p), ("rel_state1", _p), ("tag_ent", _p), ("tag_rel", _p),
+        ("opt", _i32), ("loss", _i32), ("margin", _f32), ("alpha", _f32),
+        ("seed", _u64), ("batches_count", _i64),
+        ("X", _p), ("n_triples", _i64),
+        ("cap_B", _i64),
+        ("scores", _p), ("g", _p), ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
+        ("loss_accum", _p), ("lp_sum", _p),
+        ("lp_lambda_ent", _f32), ("lp_lambda_rel", _f32), ("lp_p", _i32),
+        ("fused", _i32), ("inplace", _i32), ("normalize", _i32),
+        ("n_slots", _i32), ("slots", PlanSlot * 4),
+        ("aux_min_rows", _i64),
+    ]
+
+
+class PlanBatch(C.Structure):
+    """mirror of `emg_plan_batch`"""
+    _fields_ = [("start", _i64), ("B", _i64), ("epoch", _i32), ("batch", _i32),
+                ("n_choices", _i64), ("entities_list", _p), ("inj_mask", _p), ("inj_repl", _p)]
+
+
+SIGNATURES.update({
+    "emg_plan_create": (_int, [C.POINTER(PlanConfig), C.POINTER(_p)]),
+    "emg_plan_step": (_int, [_p, C.POINTER(PlanBatch), _i32, C.POINTER(_f32), C.POINTER(PlanBatch), _i32, _p]),
+    "emg_plan_timing": (_int, [_p, _i32]),
+    "emg_plan_stage_ms": (_int, [_p, C.POINTER(_f32), C.POINTER(_i32)]),
+    "emg_plan_destroy": (_int, [_p]),
+})
+
 _lib = None
 
 

@@ -36,8 +36,9 @@ struct ApplyParams {
 
 // flags[original index] = 1 iff its destination occurs exactly once in the batch
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
-                                   uint8_t* __restrict__ flags) {
+                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_count) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { long_count[0] = 0u; long_count[1] = 0u; }  // long-segment list of the apply that follows (saves a memset launch)
     if (t >= n) return;
     const uint32_t key = keys[t];
     const bool head = (t == 0) || keys[t - 1] != key;
@@ -506,7 +507,9 @@ constexpr int BS_THREADS = 1024, BS_ITEMS = 16, BS_MAX = BS_THREADS * BS_ITEMS;
 
 __global__ __launch_bounds__(BS_THREADS) void block_group_kernel(const int32_t* __restrict__ dest, int n, int end_bit,
                                                                  uint32_t* __restrict__ keys_out,
-                                                                 uint32_t* __restrict__ vals_out) {
+                                                                 uint32_t* __restrict__ vals_out,
+                                                                 uint32_t* __restrict__ long_count) {
+    if (threadIdx.x == 0) { long_count[0] = 0u; long_count[1] = 0u; }
     using sort_t = rocprim::block_radix_sort<uint16_t, BS_THREADS, BS_ITEMS, uint16_t>;
     __shared__ typename sort_t::storage_type storage;
     uint16_t k[BS_ITEMS], v[BS_ITEMS];
@@ -533,9 +536,12 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
     if (rc != EMG_OK) return rc;
     int end_bit = 1;
     while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
+    bool counted = false;  // the long-segment counters have been zeroed by one of the kernels below
     if (n <= BS_MAX && end_bit <= 15) {
-        hipLaunchKernelGGL(block_group_kernel, dim3(1), dim3(BS_THREADS), 0, st, dest, (int)n, end_bit, w.keys, w.vals);
+        hipLaunchKernelGGL(block_group_kernel, dim3(1), dim3(BS_THREADS), 0, st, dest, (int)n, end_bit, w.keys, w.vals,
+                           w.long_count);
         EMG_LAUNCH_CHECK();
+        counted = true;
     } else {
         size_t tmp = w.temp;
         // values = original positions, generated on the fly (no iota array)
@@ -543,12 +549,13 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
                                                       rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
                                                       end_bit, st, false));
     }
-    EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));  // long-segment list of the apply that follows
     if (single_flags) {
         hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                           single_flags);
+                           single_flags, w.long_count);
         EMG_LAUNCH_CHECK();
+        counted = true;
     }
+    if (!counted) EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));  // long-segment list of the apply that follows
     return EMG_OK;
 }
 

@@ -1,0 +1,296 @@
+// emg_plan.hip — the per-batch training step as ONE library call on several HIP streams.
+//
+// What EmbeddingModel.fit's inner loop (EmbeddingModel.py:1388-1440: tf.data batch -> _get_model_loss ->
+// optimizer.minimize) costs per batch here is a dozen kernel launches on four streams:
+//
+//   side streams (2, high priority, alternating): everything about batches t+1, t+2 that does not depend on the
+//       tables — Philox corruption codes, destination ids, their stable grouping, singleton flags (emg_prepare_batch)
+//   main stream:  fused gather + score + loss + gradient kernel (in-place singleton updates)  ->  entity apply
+//   aux stream :  relation apply, underneath the entity apply
+//
+// Round 1 issued this plan from Python (ctypes call + torch stream / event objects per launch): 0.14-0.24 ms of host
+// time per step, more than the GPU needs for the small configurations (C1: B = 1725, C2: B = 2722).  Here the whole
+// step is enqueued by one call: the slots, events and streams live in the plan object, the host cost is the launches.
+//
+// The plan owns streams and events only; every buffer is the caller's (emg_plan_config), as everywhere in this ABI.
+// Not covered: the k-sharded multi-GPU step (it needs a collective between forward and loss: host-driven).
+#include <vector>
+
+#include "emg_common.hpp"
+
+namespace emg {
+
+enum Stage { ST_PREPARE = 0, ST_FUSED, ST_FORWARD, ST_LOSS, ST_BACKWARD, ST_APPLY_ENT, ST_APPLY_REL, ST_CLIP, ST_COUNT };
+
+struct SlotState {
+    emg_plan_slot buf;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool has_key = false, ready_recorded = false;
+    int64_t key[4] = {0, 0, 0, 0};
+};
+
+struct Plan {
+    emg_plan_config cfg;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    SlotState slots[4];
+    int n_side = 0, side_rr = 0;
+    int timing_max = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ST_COUNT];
+};
+
+static bool same_key(const SlotState& s, const emg_plan_batch& b) {
+    return s.has_key && s.key[0] == b.start && s.key[1] == b.B && s.key[2] == b.epoch && s.key[3] == b.batch;
+}
+
+struct Timed {  // HIP events around one stage (only the first `timing_max` launches of each stage are sampled)
+    Plan* p; int st; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(Plan* p_, int st_, hipStream_t s_) : p(p_), st(st_), s(s_) {
+        if (p->timing_max > 0 && (int)p->ev[st].size() < p->timing_max) {
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, s);
+            else e0 = e1 = nullptr;
+        }
+    }
+    ~Timed() {
+        if (e0 && e1) { (void)hipEventRecord(e1, s); p->ev[st].push_back({e0, e1}); }
+    }
+};
+
+static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t main) {
+    const emg_plan_config& c = P->cfg;
+    hipStream_t st = main;
+    if (P->n_side > 0) {
+        st = P->side[P->side_rr];
+        P->side_rr = (P->side_rr + 1) % P->n_side;
+        EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));                           // the compute that last used this slot
+        if (sl.has_key && sl.ready_recorded) EMG_HIP(hipStreamWaitEvent(st, sl.ready, 0));  // evicted, never consumed
+    }
+    emg_prepare_args a{};
+    a.pos = c.X + 3 * b.start; a.B = b.B; a.eta = c.eta; a.n_sides = c.n_sides;
+    for (int i = 0; i < c.n_sides; ++i) a.sides[i] = c.sides[i];
+    a.n_choices = b.n_choices > 0 ? b.n_choices : c.n_ent; a.entities_list = b.entities_list;
+    a.seed = c.seed;
+    a.draw_counter0 = (uint64_t)(((int64_t)(b.epoch - 1) * c.batches_count + (b.batch - 1)) * c.n_sides);
+    a.inj_mask = b.inj_mask; a.inj_repl = b.inj_repl;
+    a.codes = sl.buf.codes; a.dest_ent = sl.buf.dest_ent; a.n_ent = c.n_ent; a.dest_rel = sl.buf.dest_rel; a.n_rel = c.n_rel;
+    a.ws_ent = sl.buf.ws_ent; a.ws_ent_bytes = sl.buf.ws_ent_bytes; a.ws_rel = sl.buf.ws_rel; a.ws_rel_bytes = sl.buf.ws_rel_bytes;
+    a.single_flags = c.inplace ? sl.buf.single : nullptr;
+    int rc;
+    {
+        Timed t(P, ST_PREPARE, st);
+        rc = emg_prepare_batch(&a, st);
+    }
+    if (rc != EMG_OK) return rc;
+    if (P->n_side > 0) { EMG_HIP(hipEventRecord(sl.ready, st)); sl.ready_recorded = true; }
+    sl.has_key = true;
+    sl.key[0] = b.start; sl.key[1] = b.B; sl.key[2] = b.epoch; sl.key[3] = b.batch;
+    return EMG_OK;
+}
+
+static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step, const float* hyper6, hipStream_t main) {
+    const emg_plan_config& c = P->cfg;
+    const int32_t et = c.eta * c.n_sides;
+    const int64_t B = b.B, n_ce = (2 + et) * B;
+    const bool lp = c.lp_lambda_ent != 0.f || c.lp_lambda_rel != 0.f;
+    float he[8], hr[8];
+    for (int i = 0; i < 6; ++i) he[i] = hr[i] = hyper6[i];
+    he[6] = c.lp_lambda_ent; hr[6] = c.lp_lambda_rel; he[7] = hr[7] = (float)c.lp_p;
+    const int32_t* pos = c.X + 3 * b.start;
+
+    emg_backward_args ba{};
+    ba.model = c.model; ba.k_int = c.k_int; ba.scale = c.scale; ba.eta = et;
+    ba.ent = c.ent; ba.n_ent = c.n_ent; ba.ld_ent = c.ld_ent; ba.rel = c.rel; ba.n_rel = c.n_rel; ba.ld_rel = c.ld_rel;
+    ba.pos = pos; ba.B = B; ba.codes = sl.buf.codes; ba.margin = c.margin; ba.loss_accum = c.loss_accum;
+    ba.contrib_ent = c.contrib_ent; ba.contrib_rel = c.contrib_rel; ba.ldc = c.ldc;
+    ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
+    for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
+    ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
+    int rc;
+    if (c.fused) {
+        ba.fused_loss = c.loss;
+        Timed t(P, ST_FUSED, main);
+        rc = emg_train_backward_ex(&ba, main);
+        if (rc != EMG_OK) return rc;
+    } else {
+        float* sp = c.scores; float* sn = sp + B;
+        float* gp = c.g; float* gn = gp + B;
+        {
+            Timed t(P, ST_FORWARD, main);
+            rc = emg_train_forward(c.model, c.ent, c.n_ent, c.ld_ent, c.rel, c.n_rel, c.ld_rel, c.k_int, c.scale, pos, B, et,
+                                   sl.buf.codes, EMG_SCORE_FINAL, sp, sn, main);
+            if (rc != EMG_OK) return rc;
+        }
+        {
+            Timed t(P, ST_LOSS, main);
+            rc = emg_loss(c.loss, sp, sn, B, c.eta, c.n_sides, c.margin, c.alpha, c.loss_accum, gp, gn, main);
+            if (rc != EMG_OK) return rc;
+        }
+        ba.fused_loss = -1; ba.g_pos = gp; ba.g_neg = gn;
+        Timed t(P, ST_BACKWARD, main);
+        rc = emg_train_backward_ex(&ba, main);
+        if (rc != EMG_OK) return rc;
+    }
+    // the relation table's apply is independent of the entity table's: on its own stream underneath it, when the
+    // batch is large enough for the overlap to pay for the fork / join
+    const bool use_aux = P->aux != nullptr && n_ce >= c.aux_min_rows;
+    hipStream_t rst = main;
+    if (use_aux) {
+        EMG_HIP(hipEventRecord(P->fork, main));
+        EMG_HIP(hipStreamWaitEvent(P->aux, P->fork, 0));
+        rst = P->aux;
+    }
+    auto apply_rel = [&]() {
+        Timed t(P, ST_APPLY_REL, rst);
+        return emg_apply_grouped(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, step,
+                                 c.contrib_rel, c.ldc, B, 0, hr, lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, rst);
+    };
+    if (use_aux) {
+        rc = apply_rel();
+        if (rc != EMG_OK) return rc;
+        EMG_HIP(hipEventRecord(P->join, P->aux));
+    }
+    {
+        Timed t(P, ST_APPLY_ENT, main);
+        rc = emg_apply_grouped(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, step,
+                               c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr, sl.buf.ws_ent,
+                               sl.buf.ws_ent_bytes, main);
+        if (rc != EMG_OK) return rc;
+    }
+    if (use_aux) EMG_HIP(hipStreamWaitEvent(main, P->join, 0));
+    else {
+        rc = apply_rel();
+        if (rc != EMG_OK) return rc;
+    }
+    if (c.normalize) {  // EmbeddingModel.py:1434-1440: tf.clip_by_norm(ent_emb, clip_norm=1, axes=1) after each batch
+        Timed t(P, ST_CLIP, main);
+        rc = emg_clip_rows(c.ent, c.n_ent, c.ld_ent, c.k_int, 1.0f, main);
+        if (rc != EMG_OK) return rc;
+    }
+    return EMG_OK;
+}
+
+}  // namespace emg
+
+using namespace emg;
+
+extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
+    EMG_REQUIRE(cfg && out, "emg_plan_create: null pointer");
+    EMG_REQUIRE(cfg->n_slots >= 1 && cfg->n_slots <= 4, "emg_plan_create: 1..4 slots (1 + batches prepared ahead)");
+    EMG_REQUIRE(cfg->n_sides >= 1 && cfg->n_sides <= 4 && cfg->eta >= 1, "emg_plan_create: bad eta / sides");
+    EMG_REQUIRE(cfg->ent && cfg->rel && cfg->X && cfg->contrib_ent && cfg->contrib_rel && cfg->loss_accum && cfg->tag_ent && cfg->tag_rel,
+                "emg_plan_create: null buffer");
+    EMG_REQUIRE(cfg->fused || (cfg->scores && cfg->g), "emg_plan_create: the unfused step needs the score / gradient buffers");
+    EMG_REQUIRE(!(cfg->inplace && (cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f)),
+                "emg_plan_create: in-place singleton updates and a folded LP regulariser exclude each other");
+    EMG_REQUIRE((cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f) || cfg->lp_sum, "emg_plan_create: LP needs lp_sum");
+    Plan* P = new Plan();
+    P->cfg = *cfg;
+    P->n_side = cfg->n_slots - 1 > 2 ? 2 : cfg->n_slots - 1;
+    auto bail = [&](const char* what) { emg_plan_destroy(P); return fail(EMG_EHIP, "emg_plan_create: %s failed", what); };
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = highest priority
+    for (int i = 0; i < P->n_side; ++i)
+        // high priority: the many small kernels of a preparation chain must not queue behind the big ones
+        if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, hi) != hipSuccess) return bail("hipStreamCreateWithPriority");
+    if (P->n_side > 0) {
+        if (hipStreamCreateWithFlags(&P->aux, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+        if (hipEventCreateWithFlags(&P->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&P->join, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    }
+    for (int i = 0; i < cfg->n_slots; ++i) {
+        P->slots[i].buf = cfg->slots[i];
+        if (hipEventCreateWithFlags(&P->slots[i].ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&P->slots[i].done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    }
+    *out = P;
+    return EMG_OK;
+}
+
+extern "C" int emg_plan_destroy(void* plan) {
+    if (!plan) return EMG_OK;
+    Plan* P = (Plan*)plan;
+    for (auto& v : P->ev)
+        for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int i = 0; i < 4; ++i) {
+        if (P->slots[i].ready) (void)hipEventDestroy(P->slots[i].ready);
+        if (P->slots[i].done) (void)hipEventDestroy(P->slots[i].done);
+    }
+    if (P->fork) (void)hipEventDestroy(P->fork);
+    if (P->join) (void)hipEventDestroy(P->join);
+    for (int i = 0; i < 2; ++i)
+        if (P->side[i]) { (void)hipStreamSynchronize(P->side[i]); (void)hipStreamDestroy(P->side[i]); }
+    if (P->aux) { (void)hipStreamSynchronize(P->aux); (void)hipStreamDestroy(P->aux); }
+    delete P;
+    return EMG_OK;
+}
+
+extern "C" int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step, const float* hyper6,
+                             const emg_plan_batch* next, int32_t n_next, void* stream) {
+    EMG_REQUIRE(plan && cur && hyper6, "emg_plan_step: null pointer");
+    Plan* P = (Plan*)plan;
+    const emg_plan_config& c = P->cfg;
+    if (cur->B <= 0) return EMG_OK;
+    EMG_REQUIRE(cur->B <= c.cap_B && cur->start >= 0 && cur->start + cur->B <= c.n_triples, "emg_plan_step: batch [%lld, +%lld) outside the resident training set / scratch capacity",
+                (long long)cur->start, (long long)cur->B);
+    hipStream_t main = (hipStream_t)stream;
+    SlotState* sl = nullptr;
+    for (int i = 0; i < c.n_slots; ++i)
+        if (same_key(P->slots[i], *cur)) { sl = &P->slots[i]; break; }
+    int rc;
+    if (!sl) {  // not prepared ahead: take a free slot (else the first one) and prepare now
+        sl = &P->slots[0];
+        for (int i = 0; i < c.n_slots; ++i)
+            if (!P->slots[i].has_key) { sl = &P->slots[i]; break; }
+        rc = prepare(P, *sl, *cur, main);
+        if (rc != EMG_OK) return rc;
+    }
+    // batches ahead (nearest first): each goes to a free slot unless already held
+    for (int j = 0; j < n_next && P->n_side > 0; ++j) {
+        const emg_plan_batch& nb = next[j];
+        if (nb.B <= 0 || nb.B > c.cap_B || nb.start < 0 || nb.start + nb.B > c.n_triples) continue;
+        bool held = false;
+        for (int i = 0; i < c.n_slots; ++i) held = held || same_key(P->slots[i], nb);
+        if (held) continue;
+        SlotState* fr = nullptr;
+        for (int i = 0; i < c.n_slots; ++i)
+            if (&P->slots[i] != sl && !P->slots[i].has_key) { fr = &P->slots[i]; break; }
+        if (!fr) break;
+        rc = prepare(P, *fr, nb, main);
+        if (rc != EMG_OK) return rc;
+    }
+    if (P->n_side > 0) EMG_HIP(hipStreamWaitEvent(main, sl->ready, 0));
+    rc = compute(P, *sl, *cur, step, hyper6, main);
+    if (rc != EMG_OK) return rc;
+    if (P->n_side > 0) EMG_HIP(hipEventRecord(sl->done, main));
+    sl->has_key = false;
+    return EMG_OK;
+}
+
+extern "C" int emg_plan_timing(void* plan, int32_t max_samples) {
+    EMG_REQUIRE(plan, "emg_plan_timing: null plan");
+    Plan* P = (Plan*)plan;
+    for (auto& v : P->ev) {
+        for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        v.clear();
+    }
+    P->timing_max = max_samples > 0 ? max_samples : 0;
+    return EMG_OK;
+}
+
+extern "C" int emg_plan_stage_ms(void* plan, float* avg_ms, int32_t* counts) {
+    EMG_REQUIRE(plan && avg_ms && counts, "emg_plan_stage_ms: null pointer");
+    Plan* P = (Plan*)plan;
+    EMG_HIP(hipDeviceSynchronize());
+    for (int s = 0; s < ST_COUNT; ++s) {
+        double tot = 0.0;
+        for (auto& e : P->ev[s]) {
+            float ms = 0.f;
+            EMG_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+            tot += ms;
+        }
+        counts[s] = (int32_t)P->ev[s].size();
+        avg_ms[s] = counts[s] ? (float)(tot / counts[s]) : 0.f;
+    }
+    return EMG_OK;
+}

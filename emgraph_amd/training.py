@@ -160,6 +160,7 @@ class Trainer:
         # contribution rows, one update per row per step with the gradient of the whole loss.
         self.reg_rows = False
 
+        self.plan = None
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.reg_accum = torch.zeros(1, dtype=torch.float64, device=self.device)  # LP term (column-local when sharded)
         # sum |w|^p per table, accumulated by the kernels that fold the regulariser (scaled by lambda in read_loss)
@@ -208,6 +209,8 @@ class Trainer:
         """Upload the whole mapped training set once; allocate per-batch scratch for ``batch_size``."""
         X_idx = np.ascontiguousarray(X_idx, dtype=np.int32)
         self.X = torch.from_numpy(X_idx).to(self.device)
+        if int(batch_size) <= self._cap:
+            self._make_plan()            # the plan points at the resident training set
         self._alloc_scratch(int(batch_size))
 
     def _alloc_scratch(self, B):
@@ -220,8 +223,8 @@ class Trainer:
         xr = self.n_rel if self.reg_rows else 0
         n_ce, n_cr = (2 + et) * B + xe, B + xr
         self.scores_all = torch.empty(B * (1 + et), dtype=torch.float32, device=dev)  # [pos | neg], one all-reduce
-        self.g_pos = torch.empty(B, dtype=torch.float32, device=dev)
-        self.g_neg = torch.empty(B * et, dtype=torch.float32, device=dev)
+        self.g_all = torch.empty(B * (1 + et), dtype=torch.float32, device=dev)       # dL/dscore, same layout
+        self.g_pos, self.g_neg = self.g_all[:B], self.g_all[B:]
         self.contrib_ent = torch.empty((n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.contrib_rel = torch.empty((n_cr, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.slots = []
@@ -242,6 +245,88 @@ class Trainer:
         self._cap = B
         self._xe, self._xr = xe, xr
         torch.cuda.synchronize()
+        self._make_plan()
+
+    # ---- the step plan in the library (emg_plan.hip): one call per batch instead of a dozen ----
+    def _make_plan(self):
+        import ctypes as C
+        if self.plan is not None:
+            L.check(L.load().emg_plan_destroy(self.plan), "emg_plan_destroy")
+            self.plan = None
+        if self.sharded or self.batch_sharded or self.X is None or os.environ.get("EMG_PY_PLAN"):
+            return   # multi-GPU steps have a collective in the middle: driven from the host (see step / _compute)
+        c = L.PlanConfig()
+        c.model, c.k_int, c.scale, c.eta, c.n_sides = self.model_id, self.k_int, self.scale, self.eta, self.n_sides
+        for i, sd in enumerate(self.sides):
+            c.sides[i] = sd
+        c.ent, c.n_ent, c.ld_ent = self.ent.data_ptr(), self.n_ent, self.ent.stride(0)
+        c.rel, c.n_rel, c.ld_rel = self.rel.data_ptr(), self.n_rel, self.rel.stride(0)
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        c.ent_state0, c.ent_state1 = ptr(self.state_ent[0]), ptr(self.state_ent[1])
+        c.rel_state0, c.rel_state1 = ptr(self.state_rel[0]), ptr(self.state_rel[1])
+        c.tag_ent, c.tag_rel = self.tag_ent.data_ptr(), self.tag_rel.data_ptr()
+        c.opt, c.loss, c.margin, c.alpha = self.opt_id, self.loss_id, self.margin, self.alpha
+        c.seed, c.batches_count = self.seed & 0xFFFFFFFFFFFFFFFF, self.batches_count
+        c.X, c.n_triples, c.cap_B = self.X.data_ptr(), self.X.shape[0], self._cap
+        c.scores, c.g = self.scores_all.data_ptr(), self.g_all.data_ptr()
+        c.contrib_ent, c.contrib_rel, c.ldc = self.contrib_ent.data_ptr(), self.contrib_rel.data_ptr(), self.contrib_ent.stride(0)
+        c.loss_accum, c.lp_sum = self.loss_accum.data_ptr(), self.lp_sum.data_ptr()
+        if self.reg is not None:
+            c.lp_lambda_ent, c.lp_lambda_rel, c.lp_p = self.reg[0], self.reg[1], self.reg[2]
+        c.fused, c.inplace, c.normalize = int(self.fused), int(self.inplace), int(self.normalize)
+        c.n_slots = len(self.slots)
+        for i, sl in enumerate(self.slots):
+            ps = c.slots[i]
+            ps.codes, ps.dest_ent, ps.dest_rel = sl["codes"].data_ptr(), sl["dest_ent"].data_ptr(), sl["dest_rel"].data_ptr()
+            ps.single = sl["single"].data_ptr()
+            ps.ws_ent, ps.ws_ent_bytes = sl["ws_ent"].data_ptr(), sl["ws_ent"].numel()
+            ps.ws_rel, ps.ws_rel_bytes = sl["ws_rel"].data_ptr(), sl["ws_rel"].numel()
+        c.aux_min_rows = AUX_MIN_ROWS
+        h = C.c_void_p()
+        L.check(L.load().emg_plan_create(C.byref(c), C.byref(h)), "emg_plan_create")
+        self.plan = h
+        self._plan_cfg = c   # keeps nothing alive the tensors do not, but documents what the plan points at
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None) is not None:
+                L.load().emg_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _plan_batch(self, out, spec):
+        start, B, epoch, batch = spec[:4]
+        out.start, out.B, out.epoch, out.batch = int(start), int(B), int(epoch), int(batch)
+        nc = spec[4] if len(spec) > 4 else None
+        el = spec[5] if len(spec) > 5 else None
+        out.n_choices = int(nc) if nc is not None else 0
+        out.entities_list = el.data_ptr() if el is not None else None
+        out.inj_mask = out.inj_repl = None
+        return el
+
+    def _plan_step(self, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch):
+        import ctypes as C
+        self.step_count += 1
+        lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
+              else self.lr)
+        cur = L.PlanBatch()
+        keep = [self._plan_batch(cur, (start, B, epoch, batch, n_choices, entities_list)), inj_mask, inj_repl]
+        if inj_repl is not None:
+            cur.inj_repl = inj_repl.data_ptr()
+            cur.inj_mask = inj_mask.data_ptr() if inj_mask is not None else None
+        nxt = (L.PlanBatch * 3)()
+        n_next = 0
+        if prefetch is not None:
+            for pf in ([prefetch] if isinstance(prefetch, tuple) else list(prefetch))[:3]:
+                if pf is None or pf[1] <= 0:
+                    continue
+                spec = tuple(pf) if len(pf) > 4 else tuple(pf[:4]) + (n_choices, entities_list)
+                keep.append(self._plan_batch(nxt[n_next], spec))
+                n_next += 1
+        h6 = (C.c_float * 6)(*self._hyper(lr))
+        L.check(L.load().emg_plan_step(self.plan, C.byref(cur), self.step_count, h6, nxt, n_next,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "emg_plan_step")
 
     # ---- optional per-stage HIP-event timing (bench.py) ----
     def enable_stage_timing(self, max_samples=16):
@@ -249,6 +334,8 @@ class Trainer:
         timing events per step costs ~0.1 ms of host time: sampling keeps long runs from turning host-bound)"""
         self.stage_events = {}
         self._stage_max = int(max_samples)
+        if self.plan is not None:
+            L.check(L.load().emg_plan_timing(self.plan, int(max_samples)), "emg_plan_timing")
 
     def _timed(self, name, fn):
         if self.stage_events is None or len(self.stage_events.get(name, ())) >= self._stage_max:
@@ -263,6 +350,12 @@ class Trainer:
 
     def stage_times_ms(self):
         torch.cuda.synchronize()
+        if self.plan is not None:
+            import ctypes as C
+            ms, cnt = (C.c_float * 9)(), (C.c_int32 * 9)()
+            L.check(L.load().emg_plan_stage_ms(self.plan, ms, cnt), "emg_plan_stage_ms")
+            names = ("prepare", "fused", "forward", "loss", "backward", "apply_ent", "apply_rel", "clip")
+            return {n: [float(ms[i])] for i, n in enumerate(names) if cnt[i] > 0}
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.stage_events or {}).items()}
 
     # ---- one batch ----
@@ -320,6 +413,8 @@ class Trainer:
         if self.batch_sharded:
             return self._step_batch_sharded(start, B, epoch, batch, n_choices, entities_list)
         self._alloc_scratch(B)
+        if self.plan is not None:
+            return self._plan_step(start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch)
         self.step_count += 1
         key = (start, B, epoch, batch)
         sl = next((s for s in self.slots if s["key"] == key), None)

@@ -356,6 +356,52 @@ typedef struct emg_step_args {
 int64_t emg_train_step_workspace_bytes(int64_t B, int32_t eta_total, int32_t k_int, int64_t n_ent, int64_t n_rel);
 int emg_train_step(const emg_step_args* args, void* stream);
 
+/* ====================== the training step as one call on several streams (emg_plan.hip) ======================
+ * emg_train_step above is a single-stream composition.  A plan object additionally owns two high-priority side
+ * streams (batch preparation of the NEXT batches runs there while the current one computes), a stream for the
+ * relation table's apply, and the events between them, so that the multi-stream step emgraph_amd's fit() runs is
+ * ONE library call per batch (EmbeddingModel.py:1388-1440 is the loop it stands for).  All buffers are the caller's;
+ * the plan owns streams and events only.  Scratch is sized for cap_B positives per batch:
+ *   scores, g : float [(1 + eta_total) * cap_B] each (only the unfused step — losses that couple a positive's
+ *               negatives — uses them);  contrib_ent [(2 + eta_total) * cap_B, ldc], contrib_rel [cap_B, ldc];
+ *   per slot  : codes int32 [eta_total * cap_B], dest_ent int32 [(2 + eta_total) * cap_B], dest_rel int32 [cap_B],
+ *               single uint8 [(2 + eta_total) * cap_B], ws_* from emg_apply_workspace_bytes_ex.
+ * n_slots = 1 + number of batches prepared ahead (0..2; 1 slot = everything on the caller's stream). */
+typedef struct emg_plan_slot {
+    int32_t* codes; int32_t* dest_ent; int32_t* dest_rel; uint8_t* single;
+    void* ws_ent; int64_t ws_ent_bytes; void* ws_rel; int64_t ws_rel_bytes;
+} emg_plan_slot;
+typedef struct emg_plan_config {
+    int32_t model; int32_t k_int; float scale; int32_t eta; int32_t n_sides; int32_t sides[4];
+    float* ent; int64_t n_ent; int64_t ld_ent; float* rel; int64_t n_rel; int64_t ld_rel;
+    float* ent_state0; float* ent_state1; float* rel_state0; float* rel_state1; int32_t* tag_ent; int32_t* tag_rel;
+    int32_t opt; int32_t loss; float margin; float alpha;
+    uint64_t seed; int64_t batches_count;            /* draw counter of (epoch, batch, side): see emg_prepare_args */
+    const int32_t* X; int64_t n_triples;             /* the resident, id-mapped training set [n_triples, 3] */
+    int64_t cap_B;
+    float* scores; float* g; float* contrib_ent; float* contrib_rel; int64_t ldc;
+    double* loss_accum; double* lp_sum;              /* lp_sum[2]: sum |w|^p of the entity / relation table */
+    float lp_lambda_ent; float lp_lambda_rel; int32_t lp_p;   /* folded LP regulariser (0 = none; excludes inplace) */
+    int32_t fused; int32_t inplace; int32_t normalize;
+    int32_t n_slots; emg_plan_slot slots[4];
+    int64_t aux_min_rows;                            /* entity contribution rows above which apply_rel gets its stream */
+} emg_plan_config;
+typedef struct emg_plan_batch {
+    int64_t start; int64_t B; int32_t epoch; int32_t batch;   /* rows [start, start + B) of X; 1-based epoch / batch */
+    int64_t n_choices; const int32_t* entities_list;           /* corruption pool (0 / NULL: all n_ent entities) */
+    const int32_t* inj_mask; const int32_t* inj_repl;          /* optional injected draws */
+} emg_plan_batch;
+int emg_plan_create(const emg_plan_config* cfg, void** plan);
+/* train on `cur`; `next[0..n_next)` (nearest first) are prepared ahead on the side streams if a slot is free.
+ * step >= 1 is the optimizer step number, hyper6 = {lr, momentum, beta1, beta2, eps, lr_t} for it. */
+int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step, const float* hyper6,
+                  const emg_plan_batch* next, int32_t n_next, void* stream);
+/* HIP-event timing of the next max_samples launches of every stage (0 = off); avg_ms / counts: 9 entries =
+ * prepare, fused, forward, loss, backward, apply_ent, apply_rel, clip, (unused) */
+int emg_plan_timing(void* plan, int32_t max_samples);
+int emg_plan_stage_ms(void* plan, float* avg_ms, int32_t* counts);
+int emg_plan_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ while (( "$#" )); do
   REPL[$f]=1
 done
 objs=()
-for f in emg_abi emg_score emg_train emg_apply emg_rank emg_rank_bf16 emg_api; do
+for f in emg_abi emg_score emg_train emg_apply emg_rank emg_rank_bf16 emg_api emg_plan; do
   if [[ -n "${REPL[$f]:-}" ]]; then objs+=("${TMP}/${f}.o"); else objs+=("${OBJ}/${f}.o"); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "${OUT}/libemgraph_hip_${NAME}.so" "${objs[@]}"
