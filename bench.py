@@ -6,17 +6,28 @@ workload (N=1 default) : C3 = ComplEx k=200 (k_int=400) eta=20 on synthetic |E|=
           (BASELINE.json configs[2]; the config the metric's k=200/eta=20 is quoted on and which
           fits one GPU).  A "step" = one full pass of the hot path over one batch of B positives:
           Philox corruptions -> fused gather+score of B*(1+eta) triples -> NLL loss + dL/dscore
-          -> fused backward -> deterministic row-sparse SGD apply (the reference forces SGD for
+          -> gradients -> deterministic row-sparse SGD apply (the reference forces SGD for
           |E| > 5e5, EmbeddingModel.py:1267-1274).  value = B*(1+eta)*steps*N / time.
           The second half of the metric (filtered ranks/sec, config C4) is reported in "eval".
 
 Contract: W untimed warm-up steps, exactly K timed steps bracketed by barrier + synchronize,
-max over ranks, rank 0 prints ONE JSON line.  Inputs are resident in HBM before timing starts.
+max over ranks, rank 0 prints ONE JSON line.  Inputs are resident in HBM before timing starts
+(64 batches of the id-mapped training set; steps cycle over them, one Philox stream per pass).
+
+Beside the contract's number the line carries (all measured in the same process, after the timed region):
+  sustained : a >= 1 s window of the same step (the K-step window is milliseconds long at the driver's K = 20)
+  stages    : per-stage HIP-event times of 16 instrumented steps (instrumentation is OFF in the timed regions)
+  roofline  : the dominant byte-moving kernel against the HBM peak
+  others    : C3 on Zipf(1.0)-skewed triples, C3 at B = 131072, C3' (TransE k=200 on the 1M table, with the
+              gather+score kernel alone), C1, C2, C5 — same step, fewer steps
+  eval      : filtered ranks/s (C4): exact f32, bf16 MFMA, query-tile sweep, TransE 1-vs-all
+  cpu_baseline : the oracle's C port on the host cores (bounded sample)
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -28,17 +39,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA == f32 vector peak
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA (not the 2:1-sparse headline)
+N_RESIDENT = 64              # resident batches the steps cycle over
 
 WORKLOADS = {
     # name: model, k, eta, n_ent, n_rel, B, loss, optimizer
     "C3": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
                desc="ComplEx k=200 (k_int=400) eta=20, synthetic |E|=1M |R|=1k, B=16384/GPU, NLL, SGD"),
+    "C3z": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd", zipf=True,
+                desc="C3 with Zipf(1.0)-skewed subjects/objects (hub entities: hot rows, long segments, few singletons)"),
+    "C3b": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=131072, loss="nll", optimizer="sgd",
+                desc="C3 at B=131072 (SURVEY 8d's second batch size)", resident=8),
     "C3p": dict(model="TransE", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
-                desc="TransE-L1 k=200 eta=20 on the |E|=1M table (HBM-roofline target run)"),
+                desc="C3': TransE-L1 k=200 eta=20 on the |E|=1M table (north_star's HBM-roofline target kernel)"),
     "C2": dict(model="DistMult", k=200, eta=10, n_ent=14541, n_rel=237, B=2722, loss="nll", optimizer="adam",
-               desc="DistMult k=200 eta=10 NLL, FB15k-237-shaped, B=2722"),
+               desc="DistMult k=200 eta=10 NLL Adam, FB15k-237-shaped, B=2722 (batches_count=100)"),
     "C1": dict(model="TransE", k=100, eta=20, n_ent=38600, n_rel=11, B=1725, loss="pairwise", optimizer="adam",
-               desc="TransE-L1 k=100 eta=20 pairwise, WN11-shaped, B=1725"),
+               desc="TransE-L1 k=100 eta=20 pairwise Adam, WN11-shaped, B=1725 (batches_count=64)"),
+    "C5": dict(model="HolE", k=200, eta=20, n_ent=14951, n_rel=1345, B=4832, loss="nll", optimizer="adam",
+               desc="HolE k=200 = (2/k) x ComplEx (HolE.py:189; the reference has no FFT HolE, SURVEY A-12) eta=20 NLL Adam, "
+                    "FB15k-shaped, B=4832 (batches_count=100)"),
 }
 MODEL_IDS = {"TransE": 0, "TransE_L2": 1, "DistMult": 2, "ComplEx": 3, "HolE": 4}
 
@@ -66,206 +85,303 @@ def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None
     return 0
 
 
-def pmc_traffic(stage, args, world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_d_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
-    doubled per MI355X_MICROARCH.md).  Only valid for the configuration it was collected on; else null."""
-    if stage != "fused" or args.workload != "C3" or args.batch or world != 1 or args.no_inplace or args.no_fused:
-        return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_d_pmc_traffic.json")))
-        k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
-        return k[0]["hbm_bytes_per_launch"] if k else None
-    except (OSError, ValueError, KeyError):
-        return None
+def pmc_traffic(stage, name, B, world, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command
+    (profiles/r2_pmc_traffic.json; separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
+    if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
+        return None, None
+    for fn in ("r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
+            if k:
+                return k[0]["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc pass of this command, not measured in this run)" % fn
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
-def run_train(args, rank, world):
-    import torch
+def make_triples(w, n, seed):
+    rs = np.random.RandomState(seed)
+    if w.get("zipf"):   # Zipf(1.0) over a random permutation of the entity ids (hubs are not the low ids)
+        wts = 1.0 / np.arange(1, w["n_ent"] + 1)
+        perm = rs.permutation(w["n_ent"])
+        s, o = perm[rs.choice(w["n_ent"], n, p=wts / wts.sum())], perm[rs.choice(w["n_ent"], n, p=wts / wts.sum())]
+    else:
+        s, o = rs.randint(0, w["n_ent"], n), rs.randint(0, w["n_ent"], n)
+    return np.stack([s, rs.randint(0, w["n_rel"], n), o], 1).astype(np.int32)
 
-    from emgraph_amd import device as D
-    from emgraph_amd.training import Trainer
 
-    w = WORKLOADS[args.workload]
-    cplx = w["model"] in ("ComplEx", "HolE")
-    k_int = 2 * w["k"] if cplx else w["k"]
-    scale = float(np.float32(2 / w["k"])) if w["model"] == "HolE" else 1.0
-    from emgraph_amd import parallel
-    # weak scaling: the per-GPU batch is fixed, the GLOBAL batch grows with N.  With k-sharding every rank
-    # walks all B_global groups but only its 1/N column slab of each row => per-GPU bytes stay constant.
-    B0, eta = (args.batch or w["B"]), w["eta"]
-    real_world = world
-    sim = max(1, args.simulate_ranks)   # profiling aid: ONE GPU runs rank 0's share of an N-rank job (no collective)
-    if sim > 1:
-        world, rank = sim, 0
-    B = B0 * world
-    steps, warm = args.steps, args.warmup
-    rs = np.random.RandomState(0)  # init seed 0 (constants.py:52)
-    ent0 = glorot(rs, w["n_ent"], k_int)
-    rel0 = glorot(rs, w["n_rel"], k_int)
-    drs = np.random.RandomState(1234)  # the SAME triples on every rank
-    n_tr = (steps + warm) * B
-    X = np.stack([drs.randint(0, w["n_ent"], n_tr), drs.randint(0, w["n_rel"], n_tr),
-                  drs.randint(0, w["n_ent"], n_tr)], 1).astype(np.int32)
-    k_full = k_int
-    ent_l, rel_l = ent0, rel0
-    if world > 1:
-        ent_l = parallel.shard_columns(ent0, rank, world, cplx)
-        rel_l = parallel.shard_columns(rel0, rank, world, cplx)
-        k_int = ent_l.shape[1]
-    tr = Trainer(MODEL_IDS[w["model"]], k_int, scale, ent_l, rel_l, eta, loss=w["loss"], optimizer=w["optimizer"],
-                 optimizer_params={"lr": 0.0005}, batches_count=steps + warm, seed=0, fused=not args.no_fused,
-                 inplace=not args.no_inplace, pipeline=not args.no_pipeline, sharded=world > 1)
-    tr.set_training_set(X, B)
-    nxt = lambda i: [((j) * B, B, 1, j + 1) for j in (i + 1, i + 2, i + 3) if j < warm + steps]  # noqa: E731  (batches ahead)
-    for i in range(warm):
-        tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
-    torch.cuda.synchronize()
-    if real_world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    tr.enable_stage_timing()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        tr.step(i * B, B, epoch=1, batch=i + 1, prefetch=nxt(i))
-    t_issue = time.perf_counter() - t0  # host time to enqueue the timed steps (host-bound if ~= dt)
-    torch.cuda.synchronize()
-    if real_world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if real_world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = tr.read_loss()
-    assert math.isfinite(loss), "loss is not finite"
-    stage_ms = {k: float(np.mean(v)) for k, v in tr.stage_times_ms().items()}
-    # unique touched rows of the last timed batch (for the apply kernel's algorithmic bytes)
-    n_ce = (2 + eta) * B
-    sl = tr.slots[0]  # any slot: both hold a full prepared batch of the same shape
-    n_ue = int(torch.unique(sl["dest_ent"][:n_ce]).numel())
-    n_ur = int(torch.unique(sl["dest_rel"][:B]).numel())
-    n_single = int(sl["single"][:n_ce].sum().item()) if tr.inplace else 0
-    stages = {}
-    for name, ms in stage_ms.items():
-        ab = algorithmic_bytes(name, B, eta, k_int, n_ue, n_ur, n_single)
-        stages[name] = {"ms": round(ms, 4), "alg_bytes": ab, "GBps": round(ab / (ms * 1e-3) / 1e9, 1) if ab else None}
-    stages["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur}
-    dom = max((s for s in stages if stages[s].get("alg_bytes")), key=lambda s: stages[s]["ms"])
-    ach = stages[dom]["GBps"]
-    # on-box streaming-copy rate (1 GiB read + 1 GiB written per copy): the practical HBM ceiling next to the
-    # 8 TB/s datasheet peak the fraction below is quoted against (SURVEY 8d asks for both denominators)
+class StepRunner:
+    """tables + resident batches of one workload; run(n) enqueues n steps cycling over the resident batches"""
+
+    def __init__(self, name, args, rank, world, sharding=None, batch=0):
+        import torch
+
+        from emgraph_amd import parallel
+        from emgraph_amd.training import Trainer
+        self.torch = torch
+        w = self.w = WORKLOADS[name]
+        self.name = name
+        cplx = w["model"] in ("ComplEx", "HolE")
+        self.k_full = k_int = 2 * w["k"] if cplx else w["k"]
+        self.scale = float(np.float32(2 / w["k"])) if w["model"] == "HolE" else 1.0
+        self.B0, self.eta = (batch or w["B"]), w["eta"]
+        self.world, self.rank = world, rank
+        # weak scaling: the per-GPU batch is fixed, the GLOBAL batch grows with N
+        self.B = self.B0 * world
+        self.nb = w.get("resident", N_RESIDENT)
+        rs = np.random.RandomState(0)  # init seed 0 (constants.py:52)
+        self.ent0 = ent0 = glorot(rs, w["n_ent"], k_int)
+        self.rel0 = rel0 = glorot(rs, w["n_rel"], k_int)
+        self.X = make_triples(w, self.nb * self.B, 1234)  # the SAME triples on every rank
+        ent_l, rel_l, self.sharding = ent0, rel0, None
+        if world > 1:
+            self.sharding = sharding or "k"
+            if self.sharding == "k":   # column slabs: every rank walks all B_global groups, 1/N of every row
+                ent_l = parallel.shard_columns(ent0, rank, world, cplx)
+                rel_l = parallel.shard_columns(rel0, rank, world, cplx)
+                k_int = ent_l.shape[1]
+        self.k_local = k_int
+        self.tr = Trainer(MODEL_IDS[w["model"]], k_int, self.scale, ent_l, rel_l, self.eta, loss=w["loss"],
+                          optimizer=w["optimizer"] if not (self.sharding == "batch" and w["optimizer"] == "adam") else "adam_lazy",
+                          optimizer_params={"lr": 0.0005}, batches_count=self.nb, seed=0, fused=not args.no_fused,
+                          inplace=not args.no_inplace, pipeline=not args.no_pipeline,
+                          sharded=(self.sharding if self.sharding == "batch" else bool(self.sharding)))
+        self.tr.set_training_set(self.X, self.B)
+        self.i = 0
+
+    def spec(self, i):
+        return ((i % self.nb) * self.B, self.B, i // self.nb + 1, i % self.nb + 1)
+
+    def run(self, n):
+        for _ in range(n):
+            i = self.i
+            s = self.spec(i)
+            self.tr.step(s[0], s[1], epoch=s[2], batch=s[3], prefetch=[self.spec(i + 1), self.spec(i + 2), self.spec(i + 3)])
+            self.i += 1
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.torch.distributed.barrier()
+
+    def timed(self, n):
+        """n steps bracketed by barrier + synchronize; returns (seconds = max over ranks, host enqueue seconds)"""
+        torch = self.torch
+        self.sync()
+        t0 = time.perf_counter()
+        self.run(n)
+        t_issue = time.perf_counter() - t0
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_issue
+
+    def stages(self, samples=16):
+        """per-stage HIP-event times of `samples` instrumented steps + the batch statistics the byte counts need"""
+        torch, tr = self.torch, self.tr
+        tr.enable_stage_timing(samples)
+        self.run(samples)
+        ms = {k: float(np.mean(v)) for k, v in tr.stage_times_ms().items()}
+        tr.enable_stage_timing(0)
+        B, eta = self.B if self.sharding != "batch" else self.B // self.world, self.eta
+        out = {}
+        n_ce = (2 + eta) * B
+        if self.sharding != "batch":
+            sl = tr.slots[0]  # any slot holds a full prepared batch of this shape
+            n_ue = int(torch.unique(sl["dest_ent"][:n_ce]).numel())
+            n_ur = int(torch.unique(sl["dest_rel"][:B]).numel())
+            n_single = int(sl["single"][:n_ce].sum().item()) if tr.inplace else 0
+            cnt = torch.bincount(sl["dest_ent"][:n_ce].long())
+            out["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur,
+                             "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
+            for name, v in ms.items():
+                ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single)
+                out[name] = {"ms": round(v, 4), "alg_bytes": ab, "GBps": round(ab / (v * 1e-3) / 1e9, 1) if ab else None}
+        else:
+            out.update({name: {"ms": round(v, 4)} for name, v in ms.items()})
+        return out
+
+    def close(self):
+        torch = self.torch
+        torch.cuda.synchronize()
+        del self.tr
+        torch.cuda.empty_cache()
+
+
+def copy_rate(torch):
+    """on-box streaming-copy rate (1 GiB read + 1 GiB written per copy): the practical HBM ceiling next to the
+    8 TB/s datasheet peak (SURVEY 8d asks for both denominators)"""
     src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
     dst = torch.empty_like(src)
     dst.copy_(src)
-    ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ce0.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(5):
         dst.copy_(src)
-    ce1.record()
+    e1.record()
     torch.cuda.synchronize()
-    copy_gbs = 5 * 2 * src.numel() * 4 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
-    del src, dst
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "copy_rate_measured": round(copy_gbs, 1),
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args, world),
-                "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"]}
-    return dict(dt=dt, t_issue=t_issue, fused=tr.fused, sim=sim, B=B, B0=B0, eta=eta, k_int=k_full, k_local=k_int, stages=stages, roofline=roofline, loss=loss,
-                w=w, tr=tr, ent0=ent0, rel0=rel0, X=X, scale=scale)
+    return 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def run_eval(res, args):
-    """C4: filtered 1-vs-all ranks/sec on the same tables ('s+o', worst), exact f32 MFMA path."""
+def step_summary(r, dt, t_issue, steps):
+    return {"value": round(r.B * (1 + r.eta) * steps / dt, 1), "unit": "triples scored/s", "steps": steps,
+            "seconds": round(dt, 4), "ms_per_step": round(dt / steps * 1e3, 4),
+            "host_issue_ms_per_step": round(t_issue / steps * 1e3, 4)}
+
+
+def score_kernel_alone(r, reps=50):
+    """the gather+score kernel by itself (emg_train_forward: positives + eta negatives per group, scores written):
+    HIP events over `reps` back-to-back launches on the current stream"""
     import torch
 
+    from emgraph_amd import _lib as L
+    from emgraph_amd import device as D
+    tr = r.tr
+    B, eta = r.B, r.eta
+    pos = tr.X[:B]
+    codes = D.corrupt_codes(B, eta, L.SIDE_SO, r.w["n_ent"], "cuda", seed=0, counter=12345)
+    sp = torch.empty(B, dtype=torch.float32, device="cuda")
+    sn = torch.empty(B * eta, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        D.train_forward(tr.model_id, tr.ent, tr.rel, tr.k_int, tr.scale, pos, eta, codes, scores_pos=sp, scores_neg=sn)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        D.train_forward(tr.model_id, tr.ent, tr.rel, tr.k_int, tr.scale, pos, eta, codes, scores_pos=sp, scores_neg=sn)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ab = algorithmic_bytes("forward", B, eta, tr.k_int)
+    traffic = None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n]
+        traffic = k[0]["hbm_bytes_per_launch"] if k else None
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"kernel": "train_forward_kernel (gather + score of %d x %d triples)" % (B, 1 + eta), "bound": "hbm",
+            "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": ab, "achieved": round(ab / (ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": "static: profiles/r2_pmc_traffic.json" if traffic else None,
+            "triples_per_s": round(B * (1 + eta) / (ms * 1e-3), 1)}
+
+
+def run_eval(r, args):
+    """C4: filtered 1-vs-all ranks/sec on trained-scale tables ('s+o', worst)"""
+    import torch
+
+    from emgraph_amd import device as D
     from emgraph_amd import parallel
     from emgraph_amd.evaluation import FilterIndex, rank_triples_device
     from emgraph_amd.training import alloc_table
-    w = res["w"]
+    w = r.w
     rank, world = parallel.rank_world()
     n_test = args.eval_triples
     rs = np.random.RandomState(99)
-    T = res["X"][rs.choice(len(res["X"]), n_test, replace=False)]
-    F = FilterIndex(res["X"])  # one-off index of the filter triples (not timed: built once per evaluation run)
+    T = r.X[rs.choice(len(r.X), n_test, replace=False)]
+    F = FilterIndex(r.X)  # one-off index of the filter triples (not timed: built once per evaluation run)
     mid = MODEL_IDS[w["model"]]
+    k_int = r.k_full
     # trained-scale tables (N(0, 0.1)): the Glorot start values are ~1e-3, whose scores all truncate to the
     # same int32(score*1e5) — legal but unrepresentative of a ranking workload
     ers = np.random.RandomState(7)
     dev = torch.device("cuda")
-    ent = alloc_table(w["n_ent"], res["k_int"], dev, init=(ers.randn(w["n_ent"], res["k_int"]) * 0.1).astype(np.float32))
-    rel = alloc_table(w["n_rel"], res["k_int"], dev, init=(ers.randn(w["n_rel"], res["k_int"]) * 0.1).astype(np.float32))
+    ent = alloc_table(w["n_ent"], k_int, dev, init=(ers.randn(w["n_ent"], k_int) * 0.1).astype(np.float32))
+    rel = alloc_table(w["n_rel"], k_int, dev, init=(ers.randn(w["n_rel"], k_int) * 0.1).astype(np.float32))
     shard = (rank, world) if world > 1 else None
-    rank_triples_device(mid, ent, rel, res["k_int"], res["scale"], T[:64], "s+o", "worst", filter_triples=F, shard=shard)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    st = {}
-    t0 = time.perf_counter()
-    ranks = rank_triples_device(mid, ent, rel, res["k_int"], res["scale"], T, "s+o", "worst", filter_triples=F, shard=shard,
-                                stats=st)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     n_ranks = 2 * n_test  # one rank = one (test triple, side)
-    flops = 2.0 * res["k_int"] * w["n_ent"] * n_ranks
-    cplx = w["model"] in ("ComplEx", "HolE", "DistMult")
-    out = {"metric": "filtered ranks/sec", "value": round(n_ranks / dt, 1), "unit": "ranks/s", "test_triples": n_test,
-           "corrupt_side": "s+o", "precision": "f32 (exact, v_mfma_f32_32x32x2_f32)" if cplx else "f32 VALU",
-           "seconds": round(dt, 4), "mean_rank": float(np.mean(ranks))}
-    if cplx:
-        kflops = flops / world  # each rank's count kernels cover its candidate range
-        kt = st["count_ms"] * 1e-3
-        out["roofline"] = {"bound": "mfma", "kernel": "count_mfma_pipe_kernel", "achieved": round(kflops / kt / 1e12, 2),
-                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(kflops / kt / 1e12 / MFMA_F32_PEAK_TF, 4),
-                           "launches": st["count_launches"], "kernel_ms": round(st["count_ms"], 3),
-                           "end_to_end_TFLOPs": round(flops / dt / 1e12, 2),
-                           "note": "kernel time from HIP events around the count launches; end-to-end adds query build, "
-                                   "filter CSR + H2D, filter kernel, D2H; f32-input MFMA peak"}
-        # bf16 MFMA throughput mode (statistical rank agreement, see emg_rank_bf16.hip); the bf16 copy of the
-        # table is made once per evaluation run, like the filter index
-        from emgraph_amd import device as D
-        eb = D.to_bf16(ent, res["k_int"], ld_dst=D.bf16_ld(res["k_int"]))
-        kw = dict(filter_triples=F, shard=shard, precision=1, ent_bf16=eb)
-        rank_triples_device(mid, ent, rel, res["k_int"], res["scale"], T[:64], "s+o", "worst", **kw)
+    flops = 2.0 * k_int * w["n_ent"] * n_ranks
+    kflops = flops / world  # each rank's count kernels cover its candidate range
+
+    def timed(T_, **kw):
+        rank_triples_device(mid, ent, rel, k_int, r.scale, T_[:64], "s+o", "worst", filter_triples=F, shard=shard, **kw)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        stb = {}
+        st = {}
         t0 = time.perf_counter()
-        rb = rank_triples_device(mid, ent, rel, res["k_int"], res["scale"], T, "s+o", "worst", stats=stb, **kw)
+        rk = rank_triples_device(mid, ent, rel, k_int, r.scale, T_, "s+o", "worst", filter_triples=F, shard=shard, stats=st, **kw)
         torch.cuda.synchronize()
-        dtb = time.perf_counter() - t0
-        ktb = stb["count_ms"] * 1e-3
-        out["bf16"] = {"value": round(n_ranks / dtb, 1), "unit": "ranks/s", "seconds": round(dtb, 4),
-                       "precision": "bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16)",
-                       "median_rel_rank_error_vs_exact": float(np.median(np.abs(rb - ranks) / (2.0 * w["n_ent"]))),
-                       "roofline": {"bound": "mfma", "kernel": "count_mfma_bf16_v3_kernel",
-                                    "achieved": round(kflops / ktb / 1e12, 2), "peak": MFMA_BF16_PEAK_TF,
-                                    "unit": "TFLOP/s", "frac": round(kflops / ktb / 1e12 / MFMA_BF16_PEAK_TF, 4),
-                                    "launches": stb["count_launches"], "kernel_ms": round(stb["count_ms"], 3),
-                                    "end_to_end_TFLOPs": round(flops / dtb / 1e12, 2)}}
+        return rk, time.perf_counter() - t0, st
+
+    ranks, dt, st = timed(T)
+    out = {"metric": "filtered ranks/sec", "value": round(n_ranks / dt, 1), "unit": "ranks/s", "test_triples": n_test,
+           "corrupt_side": "s+o", "precision": "f32 (exact, v_mfma_f32_32x32x2_f32)", "seconds": round(dt, 4),
+           "mean_rank": float(np.mean(ranks))}
+    kt = st["count_ms"] * 1e-3
+    out["roofline"] = {"bound": "mfma", "kernel": "count_mfma_pipe_kernel", "achieved": round(kflops / kt / 1e12, 2),
+                       "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(kflops / kt / 1e12 / MFMA_F32_PEAK_TF, 4),
+                       "launches": st["count_launches"], "kernel_ms": round(st["count_ms"], 3),
+                       "end_to_end_TFLOPs": round(flops / dt / 1e12, 2),
+                       "note": "kernel time from HIP events around the count launches; end-to-end adds query build, "
+                               "filter CSR + H2D, filter kernel, D2H; f32-input MFMA peak"}
+    # bf16 MFMA throughput mode (statistical rank agreement); the bf16 copy of the table is made once per
+    # evaluation run, like the filter index
+    eb = D.to_bf16(ent, k_int, ld_dst=D.bf16_ld(k_int))
+    rb, dtb, stb = timed(T, precision=1, ent_bf16=eb)
+    ktb = stb["count_ms"] * 1e-3
+    out["bf16"] = {"value": round(n_ranks / dtb, 1), "unit": "ranks/s", "seconds": round(dtb, 4),
+                   "precision": "bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16)",
+                   "median_rel_rank_error_vs_exact": float(np.median(np.abs(rb - ranks) / (2.0 * w["n_ent"]))),
+                   "roofline": {"bound": "mfma", "kernel": "count_mfma_bf16_v3_kernel",
+                                "achieved": round(kflops / ktb / 1e12, 2), "peak": MFMA_BF16_PEAK_TF,
+                                "unit": "TFLOP/s", "frac": round(kflops / ktb / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                                "launches": stb["count_launches"], "kernel_ms": round(stb["count_ms"], 3),
+                                "end_to_end_TFLOPs": round(flops / dtb / 1e12, 2)}}
+    if not args.quick:
+        # query-tile sweep (SURVEY 8d: B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode
+        sweep = {}
+        for bq in (128, 512, 2048):
+            Tq = T[:1024]            # 2048 query rows: 16 / 4 / 1 passes over the table
+            _, dq, sq = timed(Tq, precision=1, ent_bf16=eb, query_chunk=bq // 2)
+            nr = 2 * len(Tq)
+            sweep["B_q=%d" % bq] = {"ranks_per_s": round(nr / dq, 1), "kernel_ms_per_pass": round(sq["count_ms"] / sq["count_launches"], 3),
+                                    "MFMA_frac": round(2.0 * k_int * w["n_ent"] * nr / world / (sq["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}
+        out["bf16"]["query_tile_sweep"] = sweep
+        # TransE-L1 1-vs-all (not a contraction: LDS-tiled f32 VALU kernel), k=200 on the same number of entities
+        kt_ = 200
+        ent_t = alloc_table(w["n_ent"], kt_, dev, init=(ers.randn(w["n_ent"], kt_) * 0.1).astype(np.float32))
+        rel_t = alloc_table(w["n_rel"], kt_, dev, init=(ers.randn(w["n_rel"], kt_) * 0.1).astype(np.float32))
+        Tt = T[:512]
+        rank_triples_device(0, ent_t, rel_t, kt_, 1.0, Tt[:32], "s+o", "worst", filter_triples=F, shard=shard)
+        torch.cuda.synchronize()
+        stt = {}
+        t0 = time.perf_counter()
+        rank_triples_device(0, ent_t, rel_t, kt_, 1.0, Tt, "s+o", "worst", filter_triples=F, shard=shard, stats=stt)
+        torch.cuda.synchronize()
+        dtt = time.perf_counter() - t0
+        lane_ops = 2.0 * kt_ * w["n_ent"] * 2 * len(Tt) / world   # one subtract + one |.|-accumulate per (row, entity, k)
+        out["transe_l1"] = {"value": round(2 * len(Tt) / dtt, 1), "unit": "ranks/s", "test_triples": len(Tt), "k": kt_,
+                            "kernel": "count_transe_kernel (f32 VALU)", "kernel_ms": round(stt["count_ms"], 3),
+                            "roofline": {"bound": "valu", "achieved": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12, 2),
+                                         "peak": MFMA_F32_PEAK_TF / 2, "unit": "T lane-op/s (f32 VALU: 157.3 TFLOP/s counts an FMA as 2)",
+                                         "frac": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12 / (MFMA_F32_PEAK_TF / 2), 4)}}
     return out
 
 
-def cpu_baseline(res, args):
+def cpu_baseline(r, args):
     """The oracle's fused C port (OpenMP, all host cores) on a bounded sample of the same workload:
     forward scoring of B*(1+eta) triples per batch.  A reported baseline, not the target."""
     from oracle import c_oracle as co
-    w = res["w"]
-    B, eta, k_int = res["B"], res["eta"], res["k_int"]
+    w = r.w
+    B, eta, k_int = r.B, r.eta, r.k_full
     mid = MODEL_IDS[w["model"]]
-    X = res["X"]
+    X = r.X
     nb = max(1, min(args.cpu_batches, len(X) // B))
     co.lib()
     codes = [co.corrupt_codes(B, eta, 2, w["n_ent"], 0, i) for i in range(nb)]
-    co.train_forward(mid, res["ent0"], res["rel0"], k_int, res["scale"], X[:256], eta, codes[0][:256 * eta])  # warm
+    co.train_forward(mid, r.ent0, r.rel0, k_int, r.scale, X[:256], eta, codes[0][:256 * eta])  # warm
     t0 = time.perf_counter()
     done = 0
     while True:  # cycle over the sample's batches until ~args.cpu_seconds of CPU work has been timed
         for i in range(nb):
-            co.train_forward(mid, res["ent0"], res["rel0"], k_int, res["scale"], X[i * B:(i + 1) * B], eta, codes[i])
+            co.train_forward(mid, r.ent0, r.rel0, k_int, r.scale, X[i * B:(i + 1) * B], eta, codes[i])
         done += nb
         if time.perf_counter() - t0 >= args.cpu_seconds:
             break
@@ -282,37 +398,58 @@ def cpu_baseline(res, args):
     xn = orc.generate_corruptions_for_fit_philox(xp, eta=eta, corrupt_side="s,o", entities_size=w["n_ent"], seed=0, counter=0)
     kk = w["k"]
     t0 = time.perf_counter()
-    orc.score_triples(w["model"], res["ent0"], res["rel0"], xp, k=kk)
-    orc.score_triples(w["model"], res["ent0"], res["rel0"], xn, k=kk)
+    orc.score_triples(w["model"], r.ent0, r.rel0, xp, k=kk)
+    orc.score_triples(w["model"], r.ent0, r.rel0, xn, k=kk)
     dtn = time.perf_counter() - t0
     out["numpy_unfused_1thread"] = {"value": round(Bs * (1 + eta) / dtn, 1), "unit": "triples scored/s",
                                     "sample": "%d triples scored" % (Bs * (1 + eta)), "seconds": round(dtn, 3)}
     return out
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` started as a plain process: start the N ranks as CHILD processes (torch.distributed.run)
+    BEFORE anything here touches the GPU, pass their output through and exit with their code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3000, help="timed steps (default: > 1 s of C3 steps)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--sharding", default="k", choices=["k", "batch"],
+                    help="multi-GPU training plan: k = column slabs + all-reduce of partial scores; batch = batch rows split, "
+                         "sparse gradient-row exchange to the owning rank, updated rows all-gathered (emgraph_amd/parallel.py)")
     ap.add_argument("--eval-triples", type=int, default=4096)
+    ap.add_argument("--sustained-seconds", type=float, default=1.2, help="length of the extra sustained window (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work timed for cpu_baseline")
-    ap.add_argument("--simulate-ranks", type=int, default=1,
-                    help="profiling aid: run rank 0's share (column slab, N-fold batch) of an N-rank job on one GPU; "
-                         "the all-reduce is a no-op, results are not a valid bench line")
     ap.add_argument("--cpu-batches", type=int, default=4)
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the secondary workloads (C3z, C3b, C3p, C1, C2, C5)")
+    ap.add_argument("--quick", action="store_true", help="--no-others + no sweeps + no sustained window")
     ap.add_argument("--no-fused", action="store_true", help="A/B: separate forward / loss / backward kernels")
     ap.add_argument("--no-inplace", action="store_true", help="A/B: every gradient row through the contribution buffer")
     ap.add_argument("--no-pipeline", action="store_true", help="A/B: batch preparation on the compute stream")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.quick:
+        args.no_others, args.sustained_seconds = True, 0.0
+
+    world_env = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and world_env == 0:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # nothing has touched the GPU in this process
+    if world_env and world_env != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_env))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = max(1, world_env)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # EMG_BENCH_ONE_DEVICE: smoke-testing the N>1 code path on a 1-GPU box (all ranks on cuda:0, gloo)
     torch.cuda.set_device(0 if os.environ.get("EMG_BENCH_ONE_DEVICE") else local)
@@ -320,31 +457,70 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if os.environ.get("EMG_BENCH_ONE_DEVICE") else "nccl")
-    res = run_train(args, rank, world)
-    n = world
-    w = res["w"]
-    triples = res["B"] * (1 + res["eta"]) * args.steps  # B is the GLOBAL batch
+
+    r = StepRunner(args.workload, args, rank, world, sharding=args.sharding, batch=args.batch)
+    w = r.w
+    r.run(args.warmup)
+    dt, t_issue = r.timed(args.steps)                              # THE contract's number
+    head = step_summary(r, dt, t_issue, args.steps)
+    loss = r.tr.read_loss()
+    assert math.isfinite(loss), "loss is not finite"
     line = {
         "metric": "positive+negative triples scored/sec at k=200, eta=20; filtered ranks/sec",
-        "value": round(triples / res["dt"], 1), "unit": "triples scored/s", "n_gpus": n, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(res["dt"] / args.steps * 1e3, 4), "host_issue_ms_per_step": round(res["t_issue"] / args.steps * 1e3, 4), "higher_is_better": True,
+        "value": head["value"], "unit": "triples scored/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "host_issue_ms_per_step": head["host_issue_ms_per_step"],
+        "timed_seconds": head["seconds"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload + ": " + w["desc"], "step": ("corrupt+group | fused score+loss+grad (+in-place singleton SGD) | segmented apply" if res["fused"] else
-                            "corrupt+group | partial scores | all-reduce | loss | backward (+in-place singleton SGD) | segmented apply"),
-                   "B_per_gpu": res["B0"], "global_batch": res["B"], "eta": res["eta"], "k_int": res["k_int"],
-                   "k_int_per_gpu": res["k_local"], "n_ent": w["n_ent"], "n_rel": w["n_rel"],
-                   "parallelism": ("k-sharded x%d: all-reduce of partial scores only" % n) if n > 1 else "single"},
-        "roofline": res["roofline"], "stages": res["stages"], "loss_sum": res["loss"],
+        "config": {"workload": args.workload + ": " + w["desc"],
+                   "step": ("one emg_plan_step call: corrupt+group (2 batches ahead, side streams) | fused score+loss+grad "
+                            "(+in-place singleton SGD) | segmented apply (entities || relations)" if r.tr.plan is not None else
+                            "host-driven: corrupt+group | scores | collective | loss | gradients | apply"),
+                   "B_per_gpu": r.B0, "global_batch": r.B, "eta": r.eta, "k_int": r.k_full,
+                   "k_int_per_gpu": r.k_local, "n_ent": w["n_ent"], "n_rel": w["n_rel"], "resident_batches": r.nb,
+                   "parallelism": ("single" if world == 1 else
+                                   ("k-sharded x%d: all-reduce of partial scores only" % world if r.sharding == "k" else
+                                    "batch-sharded x%d: sparse gradient rows to owners, updated rows all-gathered" % world))},
+        "loss_sum": loss,
     }
-    if res["sim"] > 1:
-        line["simulated_ranks"] = res["sim"]
-        line["note"] = "PROFILING AID, not a bench line: one GPU ran rank 0's share of a %d-rank job without the collective" % res["sim"]
-    if not args.no_eval and res["sim"] == 1:
-        ev = run_eval(res, args)  # every rank takes part (range-sharded candidates + counter all-reduce)
-        line["eval"] = ev
+    if world > 1 and r.sharding == "batch":
+        line["xgmi_bytes_per_step_per_rank"] = int(r.tr.xgmi_bytes / max(1, r.tr.step_count))
+    if args.sustained_seconds > 0:
+        n = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
+        dts, tis = r.timed(n)
+        line["sustained"] = step_summary(r, dts, tis, n)
+    stages = r.stages()
+    line["stages"] = stages
+    byte_stages = [s for s in stages if isinstance(stages[s], dict) and stages[s].get("alg_bytes")]
+    if byte_stages:
+        dom = max(byte_stages, key=lambda s: stages[s]["ms"])
+        ach = stages[dom]["GBps"]
+        traffic, src = pmc_traffic(dom, args.workload, r.B, world, args)
+        line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "copy_rate_measured": round(copy_rate(torch), 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": traffic, "traffic_source": src,
+                            "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"]}
+    if not args.no_eval:
+        line["eval"] = run_eval(r, args)                           # every rank takes part (range-sharded candidates)
+    cpu = cpu_baseline(r, args) if (rank == 0 and world == 1 and not args.no_cpu) else None
+    r.close()
+    if not args.no_others and world == 1 and args.workload == "C3":
+        others = {}
+        for name in ("C3z", "C3b", "C3p", "C1", "C2", "C5"):
+            ro = StepRunner(name, args, rank, world)
+            ro.run(20)
+            n = 300 if name != "C3b" else 60
+            d, ti = ro.timed(n)
+            o = step_summary(ro, d, ti, n)
+            o["workload"] = WORKLOADS[name]["desc"]
+            o["stages"] = ro.stages()
+            if name == "C3p":
+                o["score_kernel_alone"] = score_kernel_alone(ro)
+            ro.close()
+            others[name] = o
+        line["others"] = others
     if rank == 0:
-        if not args.no_cpu and world == 1:  # CPU baseline: rank 0, N=1 only
-            line["cpu_baseline"] = cpu_baseline(res, args)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

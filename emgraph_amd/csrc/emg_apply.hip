@@ -32,6 +32,7 @@ struct ApplyParams {
     OptParams opt;
     uint32_t* long_list; uint32_t* long_count; uint32_t long_cap;  // segments longer than kLongSegment (head positions)
     double* lp_accum;  // += sum |w_pre|^p over the rows this launch updates (the caller scales by lambda); may be null
+    int32_t defer;     // segments longer than this go to apply_long_kernel
 };
 
 // flags[original index] = 1 iff its destination occurs exactly once in the batch
@@ -56,7 +57,10 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
 //   LONG > 0  : a segment of more than LONG rows (a hub entity of a Zipf-distributed graph collects thousands) is
 //               NOT summed here by one wave (2 300 rows take 0.5 ms that way) but appended to a list for
 //               apply_long_kernel, which spreads its 64-row blocks over the waves of a workgroup.
-constexpr int kLongSegment = 64;   // rows; also the block size of the long-segment reduction tree
+constexpr int kLongSegment = 64;   // rows; the block size of the long-segment reduction tree
+constexpr int kDeferSegment = 32;  // segments longer than this leave the window kernel (2 rows in flight per trip: a
+                                   // 60-row segment would keep ONE wave busy for 30 dependent trips, ~0.1 ms)
+constexpr uint32_t kMediumFlag = 0x80000000u;  // list entry: the segment has <= kLongSegment rows (one block, one wave)
 
 template <int W, int DEPTH>
 __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t key, int64_t t, int64_t end, int64_t w0,
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
                 break;
             }
         }
-        if (P.long_list && end - t > kLongSegment) {  // hand the segment over (order of the list is irrelevant)
+        if (P.long_list && end - t > P.defer) {  // hand the segment over (order of the list is irrelevant)
             if (lane == 0) {
                 const unsigned slot = atomicAdd(P.long_count, 1u);
-                if (slot < P.long_cap) P.long_list[slot] = (uint32_t)t;
+                if (slot < P.long_cap) P.long_list[slot] = (uint32_t)t | (end - t <= kLongSegment ? kMediumFlag : 0u);
             }
             continue;
         }
@@ -185,84 +189,125 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-// Long segments (> kLongSegment rows; P.long_list holds the sorted position of each one's head): one WORKGROUP of 16
-// waves per segment.  The reduction tree is defined by the segment alone — block b = rows [64 b, 64 b + 64) of the
-// segment, summed left to right by one wave (16 rows in flight per trip), then the block sums are added left to
-// right and the optimizer update is applied — so the bits do not depend on which wave, window or GPU did what.
+// Deferred segments (P.long_list: sorted position of each one's head, kMediumFlag set for <= kLongSegment rows).
+//   medium (17..64 rows): ONE wave sums the rows left to right, 16 in flight per trip, and updates the table row;
+//   long (> 64 rows)    : the whole 16-wave workgroup.  The reduction tree is defined by the segment alone — block b =
+//       rows [64 b, 64 b + 64) of the segment, summed left to right by one wave, then the block sums are added left
+//       to right and the optimizer update is applied — so the bits do not depend on which wave, window or GPU did what
+//       (a medium segment is the one-block case of the same tree: plain left to right, like the window kernel's).
+template <int W>
+__device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, float (&out)[W]) {
+    if constexpr (W == 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t u = u0;
+        for (; u + 16 <= u1; u += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u + j] * P.ldc + 4 * c);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+        }
+        for (; u < u1; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u] * P.ldc + 4 * c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
+    } else {
+        float acc = 0.f;
+        for (int64_t u = u0; u < u1; ++u) acc += P.contrib[(int64_t)P.vals[u] * P.ldc + c];
+        out[0] = acc;
+    }
+}
+
+__device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, uint32_t key, int lane) {
+    int64_t end = t;  // first position whose key differs (keys are sorted); wave-uniform result
+    for (;;) {
+        const int64_t q = end + lane;
+        const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
+        if (same == ~0ull) { end += 64; continue; }
+        return end + (__ffsll((long long)~same) - 1);
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, float* __restrict__ partial, int64_t ldp) {
     __shared__ int64_t end_s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const unsigned n_long = min(*P.long_count, P.long_cap);
     const int nchunks = P.k_int / W;
-    for (unsigned i = blockIdx.x; i < n_long; i += gridDim.x) {
-        const int64_t t = P.long_list[i];
+    float lp_acc = 0.f;
+    for (unsigned i = blockIdx.x; i < n_long; i += gridDim.x) {  // one list entry per workgroup at a time
+        const uint32_t entry = P.long_list[i];                     // (workgroup-uniform)
+        const int64_t t = entry & ~kMediumFlag;
         const uint32_t key = P.keys[t];
-        if (threadIdx.x < 64) {  // end of the segment: first position whose key differs (keys are sorted)
-            int64_t end = t;
-            for (;;) {
-                const int64_t q = end + lane;
-                const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
-                if (same == ~0ull) { end += 64; continue; }
-                end += __ffsll((long long)~same) - 1;
-                break;
+        float* wrow = P.table + (int64_t)key * P.ld;
+        float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+        float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+        if (entry & kMediumFlag) {  // <= 64 rows: wave 0 alone, left to right, 16 rows in flight per trip
+            if (wv == 0 && (int64_t)key < P.n_rows) {
+                const int64_t end = segment_end(P, t, key, lane);
+                for (int c = lane; c < nchunks; c += 64) {
+                    float g[W], w[W];
+                    sum_block<W>(P, t, end, c, g);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        w[j] = wrow[W * c + j];
+                        lp_fold(P.opt, w[j], g[j], lp_acc);
+                        opt_update_elem(P.opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
+                        wrow[W * c + j] = w[j];
+                    }
+                }
+                if (P.tag && lane == 0) P.tag[key] = P.step;
             }
-            if (lane == 0) end_s = end;
+            continue;
+        }
+        __syncthreads();                         // end_s / the partial rows of the previous long segment are done with
+        if (threadIdx.x < 64) {
+            const int64_t e = segment_end(P, t, key, lane);
+            if (lane == 0) end_s = e;
         }
         __syncthreads();
         const int64_t end = end_s;
         const int64_t nblk = (end - t + kLongSegment - 1) / kLongSegment;
         // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
-        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one first-block
-        // start (a long segment spans more than 64 positions).
+        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one
+        // first-block start (a long segment spans more than 64 positions).
         for (int64_t b = wv; b < nblk; b += nwv) {
             const int64_t u0 = t + b * kLongSegment, u1 = min(u0 + kLongSegment, end);
             float* prow = partial + (2 * (u0 / kLongSegment) + (b == 0 ? 1 : 0)) * ldp;
             for (int c = lane; c < nchunks; c += 64) {
-                if constexpr (W == 4) {
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    int64_t u = u0;
-                    for (; u + 16 <= u1; u += 16) {
-                        float4 v[16];
+                float g[W];
+                sum_block<W>(P, u0, u1, c, g);
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u + j] * P.ldc + 4 * c);
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
-                    }
-                    for (; u < u1; ++u) {
-                        const float4 v = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u] * P.ldc + 4 * c);
-                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                    }
-                    *reinterpret_cast<float4*>(prow + 4 * c) = acc;
-                } else {
-                    float acc = 0.f;
-                    for (int64_t u = u0; u < u1; ++u) acc += P.contrib[(int64_t)P.vals[u] * P.ldc + c];
-                    prow[c] = acc;
-                }
+                for (int j = 0; j < W; ++j) prow[W * c + j] = g[j];
             }
         }
         __syncthreads();  // block sums are in global memory, written and read by this workgroup only
-        if (wv == 0 && (int64_t)key < P.n_rows) {
-            float* wrow = P.table + (int64_t)key * P.ld;
-            float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
-            float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+        if ((int64_t)key < P.n_rows) {
             const int64_t m0 = t / kLongSegment;   // (t + 64 b) / 64 = t / 64 + b
-            float lp_acc = 0.f;
-            for (int c = lane; c < nchunks * W; c += 64) {
-                float acc = 0.f;
-                for (int64_t b = 0; b < nblk; ++b) acc += partial[(2 * (m0 + b) + (b == 0 ? 1 : 0)) * ldp + c];
+            for (int c = threadIdx.x; c < nchunks * W; c += blockDim.x) {   // columns over the whole workgroup
+                float acc = partial[(2 * m0 + 1) * ldp + c];                // 0 + first block sum, then left to right
+                int64_t bq = 1;
+                for (; bq + 8 <= nblk; bq += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = partial[2 * (m0 + bq + j) * ldp + c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc += v[j];
+                }
+                for (; bq < nblk; ++bq) acc += partial[2 * (m0 + bq) * ldp + c];
                 float wv_ = wrow[c];
                 lp_fold(P.opt, wv_, acc, lp_acc);
                 opt_update_elem(P.opt, wv_, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
                 wrow[c] = wv_;
             }
-            if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
-            if (P.tag && lane == 0) P.tag[key] = P.step;
+            if (P.tag && threadIdx.x == 0) P.tag[key] = P.step;
         }
-        __syncthreads();
     }
+    if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
     // the last workgroup to finish empties the list, so that a second emg_apply_grouped on the same grouping (or the
     // next batch that reuses the workspace) starts from zero; every workgroup has read the count by then
+    __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(P.long_count + 1, 1u) == gridDim.x - 1) { P.long_count[0] = 0u; P.long_count[1] = 0u; }
@@ -692,9 +737,11 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         const dim3 grid((unsigned)cdiv(cdiv(n_contrib, win) * 64, 256)), block(256);
         const int nch = vec ? k_int / 4 : k_int;
         const bool skinny = nch <= 16;
-        static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aid
+        static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aids
+        static const int defer_env = getenv("EMG_DEFER") ? atoi(getenv("EMG_DEFER")) : 0;
+        P.defer = defer_env > 0 ? defer_env : kDeferSegment;
         if (w.partial && !skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
-            P.long_list = w.long_list; P.long_count = w.long_count; P.long_cap = (uint32_t)(n_contrib / kLongSegment + 1);
+            P.long_list = w.long_list; P.long_count = w.long_count; P.long_cap = (uint32_t)(n_contrib / kDeferSegment + 1);
         }
         // DEPTH 2 everywhere (measured, C3: relation table 0.121 ms vs 0.148 ms with 16 rows in flight at 2 waves/SIMD,
         // entity table 0.112 vs 0.22): segments of up to 64 rows gain more from 7 waves/SIMD than from deeper trips
@@ -705,9 +752,12 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         else hipLaunchKernelGGL((apply_rows_kernel<1, 2>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
         if (P.long_list) {
-            // a handful of workgroups: long segments are few (an entity needs > 64 hits in ONE batch); with none the
-            // launch costs a few microseconds of an empty 32-block grid
-            const unsigned nb = (unsigned)(P.long_cap < 32u ? P.long_cap : 32u);
+            // one workgroup (16 waves = a whole CU) per list entry.  Tables with few rows (relations) defer most of
+            // their segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller
+            // grid, whose cost when the list is empty is a few microseconds
+            const int64_t possible = n_contrib / (kDeferSegment + 1) < n_rows ? n_contrib / (kDeferSegment + 1) : n_rows;
+            const int64_t most = n_rows <= 4096 ? 256 : 64;
+            const unsigned nb = (unsigned)(possible < 1 ? 1 : (possible < most ? possible : most));
             if (vec) hipLaunchKernelGGL((apply_long_kernel<4>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
             else hipLaunchKernelGGL((apply_long_kernel<1>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
             EMG_LAUNCH_CHECK();
