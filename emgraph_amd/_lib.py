@@ -64,6 +64,7 @@ SIGNATURES = {
     "emg_eval_scores_dense": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _int, _p, _i64, _p,
                                      _i64, _p]),
     "emg_to_bf16": (_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
+    "emg_to_f16": (_int, [_p, _i64, _i64, _i32, _p, _i64, _p]),
 }
 
 class BackwardArgs(C.Structure):
@@ -114,6 +115,9 @@ SIGNATURES.update({
     "emg_eval_filter_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p,
                                           _p, _p, _p]),
     "emg_eval_scores_dense_bf16": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _p, _i64, _p]),
+    "emg_eval_prefilter_f16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i64, _p]),
+    "emg_eval_prefilter_segments": (_i64, [_i64, _i64]),
+    "emg_eval_rescore_pairs": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _p, _p, _p]),
 })
 
 class StepArgs(C.Structure):

@@ -414,6 +414,114 @@ __global__ __launch_bounds__(256) void filter_count_kernel(int model, const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// exact re-scoring of the (row, entity) pairs the bf16 prefilter could not decide (emg_rank_bf16.hip, MODE 2):
+// one thread per pair, the canonical chain and comparison of the parity path, counters updated atomically
+// ---------------------------------------------------------------------------------------------
+struct RescoreParams {
+    int model; const float* Q; int64_t ldq; const int32_t* pos_int; const float* ent; int64_t ld_ent; int64_t ent_offset;
+    int k_int; float scale; const uint64_t* pairs; uint32_t cap; const uint32_t* seg_count; uint32_t n_seg;  // segment s: pairs[s*cap ..+min(count, cap))
+    int32_t* cnt_gt; int32_t* cnt_eq;
+};
+
+__device__ __forceinline__ void rescore_finish(const RescoreParams& P, int64_t row, float acc) {
+    const float score = P.model == EMG_HOLE ? __fmul_rn(acc, P.scale) : acc;
+    const int ci = cmp_int(score), p = P.pos_int[row];
+    if (ci > p) atomicAdd(&P.cnt_gt[row], 1);
+    else if (ci == p) atomicAdd(&P.cnt_eq[row], 1);
+}
+
+// One WAVE per segment of the pair buffer (= the pairs one wave of the prefilter emitted: a handful of query rows
+// against the entities of a few tiles), 64 pairs at a time.  16-byte-aligned rows (VEC): 16-float slices of the 64
+// query and entity rows are staged through the wave's own LDS region with COALESCED loads (4 lanes x 16 B per row
+// slice: 16 pairs per load instruction, the next slice in flight under the current slice's chain), then every lane
+// runs the canonical chain over ITS pair's slice.  One thread per pair reading global memory directly issues 64
+// scattered 16-byte requests per load instruction (measured 0.4-0.8 G pairs/s against 3 G pairs/s staged).
+constexpr int RS_KC = 16, RS_LD = RS_KC + 4;
+
+__device__ __forceinline__ void wave_lds_sync() {   // this wave's LDS writes are visible to its own later reads
+    __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams P) {
+    __shared__ __attribute__((aligned(16))) float qs[4][64 * RS_LD];
+    __shared__ __attribute__((aligned(16))) float es[4][64 * RS_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* myq = qs[wave];
+    float* mye = es[wave];
+    const int sub = lane >> 2, part = lane & 3;   // loader role: pair (16 it + sub) of the wave's 64, 16-byte piece `part`
+    for (uint32_t seg = blockIdx.x * 4u + wave; seg < P.n_seg; seg += gridDim.x * 4u) {
+        const uint32_t n = min(P.seg_count[seg], P.cap);
+        const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const bool live = c0 + lane < n;
+            int64_t row = 0, e = 0;
+            if (live) {
+                const uint64_t pr = sp[c0 + lane];
+                row = (int64_t)(pr >> 32);
+                e = (int64_t)(uint32_t)pr - P.ent_offset;
+            }
+            float acc = 0.f;
+            if constexpr (!VEC) {
+                const float* q = P.Q + row * P.ldq;
+                const float* er = P.ent + e * P.ld_ent;
+                for (int k = 0; k < P.k_int; ++k) acc = __fmaf_rn(q[k], er[k], acc);
+            } else {
+                const float* qp[4];
+                const float* ep[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    qp[it] = P.Q + __shfl(row, 16 * it + sub, 64) * P.ldq + 4 * part;
+                    ep[it] = P.ent + __shfl(e, 16 * it + sub, 64) * P.ld_ent + 4 * part;
+                }
+                float4 qv[4], ev[4];
+                auto fetch = [&](int k0) {   // k_int % 4 == 0: a 4-float piece is whole or absent
+                    const bool pin = k0 + 4 * part < P.k_int;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        qv[it] = pin ? *reinterpret_cast<const float4*>(qp[it] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        ev[it] = pin ? *reinterpret_cast<const float4*>(ep[it] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                };
+                fetch(0);
+                for (int k0 = 0; k0 < P.k_int; k0 += RS_KC) {
+                    wave_lds_sync();   // the previous slice has been consumed by every lane
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        *reinterpret_cast<float4*>(myq + (16 * it + sub) * RS_LD + 4 * part) = qv[it];
+                        *reinterpret_cast<float4*>(mye + (16 * it + sub) * RS_LD + 4 * part) = ev[it];
+                    }
+                    wave_lds_sync();
+                    if (k0 + RS_KC < P.k_int) fetch(k0 + RS_KC);   // the next slice flies while this one is multiplied
+                    const int kn = min(RS_KC, P.k_int - k0);
+#pragma unroll
+                    for (int c = 0; c < RS_KC / 4; ++c) {
+                        if (4 * c < kn) {
+                            const float4 a = *reinterpret_cast<const float4*>(myq + lane * RS_LD + 4 * c);
+                            const float4 b2 = *reinterpret_cast<const float4*>(mye + lane * RS_LD + 4 * c);
+                            acc = __fmaf_rn(a.x, b2.x, acc); acc = __fmaf_rn(a.y, b2.y, acc);
+                            acc = __fmaf_rn(a.z, b2.z, acc); acc = __fmaf_rn(a.w, b2.w, acc);
+                        }
+                    }
+                }
+            }
+            if (live) rescore_finish(P, row, acc);
+        }
+    }
+}
+
+__global__ void to_f16_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
+                              _Float16* __restrict__ dst, int64_t ld_dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * ld_dst) return;
+    const int64_t r = t / ld_dst;
+    const int c = (int)(t - r * ld_dst);
+    dst[t] = c < k_int ? (_Float16)src[r * ld_src + c] : (_Float16)0.f;   // v_cvt_f16_f32: round to nearest even
+}
+
 __global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
                                uint16_t* __restrict__ dst, int64_t ld_dst) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -687,6 +795,38 @@ extern "C" int emg_eval_filter_count(int model, const float* Q, int64_t ldq, con
     hipLaunchKernelGGL(filter_count_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, (hipStream_t)stream,
                        model, Q, ldq, pos_int, n_rows, ent, n_local, ld_ent, ent_offset, (int)k_int, scale, filt_ptr,
                        filt_idx, fcnt_gt, fcnt_eq);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                      int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
+                                      const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
+                                      int64_t n_segments, int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
+    EMG_REQUIRE(model >= EMG_DISTMULT && model <= EMG_HOLE, "emg_eval_rescore_pairs: contraction models only");
+    EMG_REQUIRE(Q && pos_int && ent && pairs && pair_count && cnt_gt && cnt_eq, "emg_eval_rescore_pairs: null pointer");
+    if (n_segments <= 0) return EMG_OK;
+    EMG_REQUIRE(pairs_capacity >= n_segments, "emg_eval_rescore_pairs: pair buffer smaller than one entry per segment");
+    RescoreParams P{};
+    P.model = model; P.Q = Q; P.ldq = ldq; P.pos_int = pos_int; P.ent = ent; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
+    P.k_int = k_int; P.scale = scale; P.pairs = pairs; P.cap = (uint32_t)(pairs_capacity / n_segments);
+    P.seg_count = pair_count; P.n_seg = (uint32_t)n_segments;
+    P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
+    const bool vec = (k_int % 4 == 0) && (ldq % 4 == 0) && (ld_ent % 4 == 0) && aligned16(Q) && aligned16(ent);
+    const int64_t blocks = cdiv(n_segments, 4);
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384)), block(256);
+    if (vec) hipLaunchKernelGGL(rescore_pairs_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(rescore_pairs_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_to_f16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, void* dst_f16, int64_t ld_dst,
+                          void* stream) {
+    EMG_REQUIRE(src && dst_f16 && n_rows >= 0 && ld_src >= k_int && ld_dst >= k_int, "emg_to_f16: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)cdiv(n_rows * ld_dst, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       n_rows, ld_src, (int)k_int, (_Float16*)dst_f16, ld_dst);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

@@ -27,6 +27,7 @@ namespace emg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,6 +43,12 @@ struct CountBf16Params {
     float* S; int64_t lds;
     int32_t* pos_out;
     int64_t n_qb; int64_t n_cb; int64_t n_tiles; int32_t tiles_per_chunk;
+    // prefilter mode (exact ranks at MFMA speed, see count_mfma_bf16_v3_kernel MODE 2)
+    const float* band;         // per query row: rigorous bound on |bf16 accumulator - exact f32 chain| over all candidates
+    uint64_t* pairs;           // (row << 32 | global entity id) of the candidates the bound cannot decide:
+    uint32_t* pair_count;      //   wave w of the grid owns pairs[w * pair_cap ...), pair_count[w] = how many it wrote
+    uint32_t pair_cap;         //   (no atomics: a returning atomic per emission cost more than the MFMAs of the tile);
+    uint32_t n_segments;       //   pair_count[n_segments] != 0: some wave ran out of room
 };
 
 constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64;
@@ -522,8 +529,15 @@ constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
 
 // ONE: only one comparison per score (P.need = 1: count `>=`, the 'worst' strategy's only input; 2: count `>`,
 // 'best'): half the epilogue's VALU work.  Both counters are produced only when the caller needs ties ('middle').
-template <int NQ, int SQ, bool ONE>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4)
+// MODE 2 (PREFILTER): exact ranks at MFMA speed.  The caller passes, per query row, a rigorous bound `band` on the
+// distance between this kernel's accumulator (bf16-rounded operands) and the exact f32 chain of the parity path.
+// A candidate whose accumulator clears the `>` threshold by more than the band is counted here (cnt_gt); one that
+// misses the `>=` threshold by more than the band is dropped; the few in between are EMITTED as (row, entity) pairs
+// and re-scored exactly by emg_eval_rescore_pairs — so the counters, and the ranks, equal the exact path's bit for bit.
+template <int NQ, int SQ, int MODE>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter
 __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
+    constexpr bool ONE = MODE == 1;
+    constexpr bool PRE = MODE == 2;
     constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
     constexpr int SPR = SQ * 2;                 // 16-byte slots per slice row
     constexpr int RPB = 256 / RB;               // rows per 256-byte LDS bank row
@@ -554,6 +568,12 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
             const int p = P.pos_int[qr];
             const bool want_gt = ONE ? P.need == 2 : tid < V3_BM;
             t = acc_threshold(want_gt ? gt_threshold(p) : ge_threshold(p), P.cmul);
+            if constexpr (PRE) {
+                // widen by the band (+ the few ulps by which the exact path's two roundings, fl(fl(acc*scale)*1e5), can
+                // differ from this kernel's single one), rounding outwards
+                const float b = P.band[qr] + 1e-6f * fabsf(t) + 1e-30f;
+                t = want_gt ? nextafterf(t + b, INFINITY) : nextafterf(t - b, -INFINITY);
+            }
         }
         thr_s[tid] = t;
     }
@@ -622,6 +642,9 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
 
     bf16x8 X[4], Y[4];
     int cslot = 0;
+    // prefilter: this wave's private segment of the pair buffer
+    unsigned pair_n = 0u, pair_over = 0u;
+    uint64_t* const pair_base = PRE ? P.pairs + ((uint64_t)blockIdx.x * 8u + (unsigned)wave) * P.pair_cap : nullptr;
     auto load_step = [&](bf16x8 (&dst)[4], int slot, int ks) {
         const unsigned char* st = bptr + slot * STAGE + sl[ks];
 #pragma unroll
@@ -630,7 +653,12 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     };
     auto mma_step = [&](const bf16x8& a, bf16x8 (&bq)[4]) {
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[tb], acc[tb], 0, 0, 0);
+        for (int tb = 0; tb < 4; ++tb) {
+            // the prefilter's operands are IEEE half (11 significant bits: an 8x narrower error band than bf16, same
+            // MFMA rate); the fragments are bit containers, only the instruction differs
+            if constexpr (PRE) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[tb]), acc[tb], 0, 0, 0);
+            else acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[tb], acc[tb], 0, 0, 0);
+        }
     };
     __builtin_amdgcn_s_waitcnt(0x0F70 | (G * (NS - 2)));  // slice 0 landed (mine) ...
     __builtin_amdgcn_s_barrier();                          // ... and everyone's
@@ -670,8 +698,46 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb) X[tb] = Y[tb];
         }
+        // ---- prefilter: (row, entity) pairs of the accumulators inside [lo, hi) of their row, once per tile ------
+        auto emit_tile = [&](bool full) {
+            unsigned long long m = 0ull;   // bit (16 j + 4 tb + i): this lane's value (j, tb, i) is undecided
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = wave * 32 + 8 * j + 4 * lhi;
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V3_BM + r0);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const bool cok = full || (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[tb][4 * j + i];
+                        m |= (cok && v >= e4[i] && !(v >= g4[i])) ? (1ull << (16 * j + 4 * tb + i)) : 0ull;
+                    }
+                }
+            }
+            const int n_l = __popcll(m);
+            int incl = n_l;  // inclusive prefix over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (pair_n + (unsigned)total > P.pair_cap) { pair_over = 1u; return; }   // the caller falls back to the exact kernel
+            uint64_t* dst = pair_base + pair_n + (unsigned)(incl - n_l);
+            pair_n += (unsigned)total;
+            const uint64_t row0 = (uint64_t)(qb * V3_BM + wave * 32 + 4 * lhi);
+            const uint64_t col0 = (uint64_t)(P.ent_offset + (tile0 + ctile) * V3_BN + l31);
+            while (m) {   // row = row0 + 8 j + i, entity = col0 + 32 tb
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                *dst++ = ((row0 + (uint64_t)(8 * (bit >> 4) + (bit & 3))) << 32) | (uint32_t)(col0 + 32u * (unsigned)((bit >> 2) & 3));
+            }
+        };
         // ---- tile epilogue: compare-and-count, clear -----------------------------------------------------
         auto epilogue = [&](auto FULL) {
+            bool any_tie = false;   // (wave-uniform) some accumulator of this tile lies inside its row's band
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r0 = wave * 32 + 8 * j + 4 * lhi;  // query rows of accumulator registers 4j..4j+3
@@ -696,13 +762,16 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                             tie |= __builtin_amdgcn_fcmpf(v, g4[i], 3) ^ __builtin_amdgcn_fcmpf(v, e4[i], 3);
                         }
                     if (tie) {
+                        if constexpr (PRE) any_tie = true;
+                        else {
 #pragma unroll
-                        for (int tb = 0; tb < 4; ++tb)
+                            for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = acc[tb][4 * j + i];
-                                cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
-                            }
+                                for (int i = 0; i < 4; ++i) {
+                                    const float v = acc[tb][4 * j + i];
+                                    cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
+                                }
+                        }
                     }
                 } else {
 #pragma unroll
@@ -713,10 +782,14 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                             const float v = acc[tb][4 * j + i];
                             const bool gt = v >= g4[i], ge = v >= e4[i];
                             cnt[2 * j + (i >> 1)] += (cok && gt) ? (1u << (16 * (i & 1))) : 0u;
-                            cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
+                            if constexpr (!PRE) cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
                         }
                     }
+                    if constexpr (PRE) any_tie = true;
                 }
+            }
+            if constexpr (PRE) {
+                if (any_tie) emit_tile(FULL.value);
             }
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb)
@@ -727,6 +800,12 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
         else epilogue(std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
+    if constexpr (PRE) {
+        if (lane == 0) {
+            P.pair_count[blockIdx.x * 8u + (unsigned)wave] = pair_n;
+            if (pair_over) atomicOr(P.pair_count + P.n_segments, 1u);
+        }
+    }
 
     // ---- rows are private to the wave: lane shuffle, one global atomic per row and counter ----------------
 #pragma unroll
@@ -758,13 +837,13 @@ static int allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
     return EMG_OK;
 }
 
-template <int NQ, int SQ, bool ONE>
+template <int NQ, int SQ, int MODE>
 static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
     const size_t lds_bytes = (size_t)V3_RING + 2 * V3_BM * sizeof(float);
     static std::atomic<uint64_t> devices_done{0};  // one flag per template instance and device
-    int rc = allow_full_lds((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, ONE>, devices_done);
+    int rc = allow_full_lds((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, MODE>, devices_done);
     if (rc != EMG_OK) return rc;
-    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, ONE>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
+    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, MODE>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
     return EMG_OK;
 }
 
@@ -851,11 +930,15 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
         EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
         int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
-        const bool one = P.need != 0;
-        if (P.k16 == 25) rc = one ? launch_v3<25, 4, true>(P, nblk, st) : launch_v3<25, 4, false>(P, nblk, st);
-        else if (P.k16 == 13) rc = one ? launch_v3<13, 4, true>(P, nblk, st) : launch_v3<13, 4, false>(P, nblk, st);
-        else rc = one ? launch_v3<8, 4, true>(P, nblk, st) : launch_v3<8, 4, false>(P, nblk, st);
+        const int md = P.pairs ? 2 : (P.need != 0 ? 1 : 0);
+#define EMG_V3(NQ_) (md == 2 ? launch_v3<NQ_, 4, 2>(P, nblk, st) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
+        if (P.k16 == 25) rc = EMG_V3(25);
+        else if (P.k16 == 13) rc = EMG_V3(13);
+        else rc = EMG_V3(8);
+#undef EMG_V3
         if (rc != EMG_OK) return rc;
+    } else if (P.pairs) {
+        return fail(EMG_ENOSUP, "bf16 prefilter: only k_int in (112..128], (192..208], (384..400], more than 128 query rows, no candidate list");
     } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
         // query-stationary LDS-DMA kernel (see its header); anything else takes the v1 tile kernel above
         const int m = P.k_pad / 32;
@@ -911,6 +994,35 @@ extern "C" int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, c
     P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq; P.need = need;
     // the tile kernels always produce both counters: for need = 1 their ties are added into cnt_gt as well
     if (need == 1) P.cnt_eq = cnt_gt;
+    return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
+}
+
+// grid of the register-stationary kernel for (n_rows, n_cand): the prefilter's pair buffer has one segment per wave
+static int64_t v3_blocks(int64_t n_rows, int64_t n_cand) {
+    const int64_t n_qb = cdiv(n_rows, V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), 32);
+    return 8 * n_qb * cdiv(n_cb, 8);
+}
+
+extern "C" int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand) {
+    return (n_rows <= 0 || n_cand <= 0) ? 0 : 8 * v3_blocks(n_rows, n_cand);
+}
+
+extern "C" int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
+                                      int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent,
+                                      int64_t ent_offset, int32_t k_pad, float scale, int32_t* cnt_gt, uint64_t* pairs,
+                                      uint32_t* pair_count, int64_t pairs_capacity, void* stream) {
+    EMG_REQUIRE(q_f16 && pos_int && band && ent_f16 && cnt_gt && pairs && pair_count, "emg_eval_prefilter_f16: null pointer");
+    EMG_REQUIRE(n_rows < ((int64_t)1 << 31) && ent_offset + n_cand < ((int64_t)1 << 31), "emg_eval_prefilter_f16: ids must fit 31 bits");
+    if (n_rows == 0 || n_cand == 0) return EMG_OK;
+    const int64_t n_seg = emg_eval_prefilter_segments(n_rows, n_cand);
+    EMG_REQUIRE(pairs_capacity >= n_seg && pairs_capacity / n_seg < ((int64_t)1 << 31), "emg_eval_prefilter_f16: pair buffer smaller than one entry per wave (%lld)", (long long)n_seg);
+    CountBf16Params P{};
+    P.Q = (const uint16_t*)q_f16; P.ldq = ldq; P.pos_int = pos_int; P.n_rows = n_rows;
+    P.ent = (const uint16_t*)ent_f16; P.n_cand = n_cand; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
+    P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_gt; P.need = 0;
+    P.band = band; P.pairs = pairs; P.pair_count = pair_count; P.pair_cap = (uint32_t)(pairs_capacity / n_seg);
+    P.n_segments = (uint32_t)n_seg;
+    EMG_HIP(hipMemsetAsync(pair_count, 0, (size_t)(n_seg + 1) * sizeof(uint32_t), (hipStream_t)stream));
     return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
 }
 

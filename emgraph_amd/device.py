@@ -399,6 +399,16 @@ def to_bf16(table, k_int, ld_dst=None):
     return out
 
 
+def to_f16(table, k_int, ld_dst=None):
+    """IEEE-half copy (RNE) of a table / query matrix, rows zero-padded to ``ld_dst`` (precision mode 2)"""
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    ld_dst = ld_dst or bf16_ld(k_int)
+    out = torch.empty((nrows, ld_dst), dtype=torch.float16, device=table.device)
+    L.check(lib.emg_to_f16(pt, nrows, ld, k_int, out.data_ptr(), ld_dst, _stream()), "emg_to_f16")
+    return out
+
+
 # ---- bf16 MFMA evaluation path (throughput mode) -------------------------------------------------
 def bf16_pad(k_int):
     """contraction length handed to the bf16 kernels: k_int rounded up to a whole MFMA k-step (16)"""
@@ -456,6 +466,45 @@ def eval_filter_count_bf16(model_id, q_bf16, pos_int, self_ent, ent_bf16, ent_of
                                            _chk_vec(fcnt_gt, torch.int32, "fcnt_gt", n_rows),
                                            _chk_vec(fcnt_eq, torch.int32, "fcnt_eq", n_rows), _stream()),
             "emg_eval_filter_count_bf16")
+
+
+def _chk_f16(t, name):
+    if not (t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError("%s must be a 2-D float16 CUDA tensor with unit column stride" % name)
+    return t.data_ptr(), t.shape[0], t.stride(0)
+
+
+def eval_prefilter_segments(n_rows, n_cand):
+    """number of segments (= waves of the prefilter kernel) the pair buffer is cut into; pair_count has one more entry"""
+    return int(L.load().emg_eval_prefilter_segments(n_rows, n_cand))
+
+
+def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_int, scale, cnt_gt, pairs, pair_count):
+    """half-precision MFMA prefilter of precision mode 2: definite `>` counts into cnt_gt, undecided (row, entity)
+    pairs into ``pairs`` (int64 [capacity]), per-segment counts + overflow flag into ``pair_count`` (int32
+    [segments + 1]).  Raises EmgError(EMG_ENOSUP) for shapes the register-stationary kernel does not cover."""
+    lib = L.load()
+    pq, n_rows, ldq = _chk_f16(q_f16, "q_f16")
+    pe, ne, lde = _chk_f16(ent_f16, "ent_f16")
+    n_seg = eval_prefilter_segments(n_rows, ne)
+    L.check(lib.emg_eval_prefilter_f16(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
+                                       _chk_vec(band, torch.float32, "band", n_rows), n_rows, pe, ne, lde, ent_offset,
+                                       bf16_pad(k_int), scale, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                       _chk_vec(pairs, torch.int64, "pairs"), _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1),
+                                       pairs.numel(), _stream()), "emg_eval_prefilter_f16")
+    return n_seg
+
+
+def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pairs, pair_count, n_seg, cnt_gt, cnt_eq):
+    """exact re-scoring of the prefilter's undecided pairs (counts read on the device)"""
+    lib = L.load()
+    pq, n_rows, ldq = _chk_table(Q, "Q")
+    pe, ne, lde = _chk_table(ent, "ent")
+    L.check(lib.emg_eval_rescore_pairs(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset,
+                                       k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
+                                       _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg,
+                                       _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                       _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs")
 
 
 def eval_scores_dense_bf16(model_id, q_bf16, ent_bf16, k_int, scale, cand=None):

@@ -149,9 +149,78 @@ def _ev_collect(stats):
     stats["count_launches"] = stats.get("count_launches", 0) + len(evs)
 
 
+# ------------------------------------------------------------------------------------------------
+# precision 2: exact ranks at MFMA speed (bf16 prefilter + exact re-scoring of the undecided candidates)
+# ------------------------------------------------------------------------------------------------
+_U32 = 2.0 ** -24   # unit roundoff of fp32
+
+
+def table_norm_bounds(ent, ent_bf16, k_int, rows=1 << 16):
+    """(max ||e||, max ||e~||, max ||e~ - e||) over the rows of the fp32 table and of its bf16 copy, in float64 —
+    computed from the tensors as they are NOW (a stale bf16 copy only widens the band, it never breaks it)."""
+    e_max = eb_max = de_max = 0.0
+    for r0 in range(0, ent.shape[0], rows):
+        e = ent[r0:r0 + rows, :k_int].double()
+        eb = ent_bf16[r0:r0 + rows, :k_int].double()
+        e_max = max(e_max, float(e.norm(dim=1).max()))
+        eb_max = max(eb_max, float(eb.norm(dim=1).max()))
+        de_max = max(de_max, float((eb - e).norm(dim=1).max()))
+    return e_max, eb_max, de_max
+
+
+def prefilter_band(Q, Qb, k_int, bounds):
+    """Per query row r, a RIGOROUS bound on |a - s| for every candidate e, where
+        a = fp32-accumulated MFMA product of the half-ROUNDED operands  (what emg_eval_prefilter_f16 compares),
+        s = the exact path's k-ordered fp32 fmaf chain of the fp32 operands (what decides the reference rank).
+    With q~ = q + dq, e~ = e + de:   sum q~e~ - sum qe = dq.e~ + q.de,  so by Cauchy-Schwarz
+        |a - s| <= ||dq|| ||e~|| + ||q|| ||de||  +  g (||q~|| ||e~|| + ||q|| ||e||),
+    g = 2 (k + 32) 2^-24 bounding the accumulation error of either sum (standard gamma_k, doubled).  The norms of the
+    residuals are the ACTUAL ones of this query tile / this table, not worst-case roundoff: ~0.4 x 2^-11 relative."""
+    e_max, eb_max, de_max = bounds
+    q = Q[:, :k_int].double()
+    qb = Qb[:, :k_int].double()
+    nq, nqb, ndq = q.norm(dim=1), qb.norm(dim=1), (qb - q).norm(dim=1)
+    g = 2.0 * (k_int + 32) * _U32
+    band = ndq * eb_max + nq * de_max + g * (nqb * eb_max + nq * e_max)
+    return (band * (1.0 + 1e-6)).float().contiguous() + 1e-37   # rounded outwards
+
+
+class PrefilterTables:
+    """what precision 2 derives from the entity table, built once per evaluation run (like the FilterIndex): the
+    half-precision copy and the norm bounds of prefilter_band.  Valid while the table does not change."""
+
+    def __init__(self, ent, k_int):
+        self.ent_f16 = D.to_f16(ent, k_int, ld_dst=D.bf16_ld(k_int))
+        self.k_int = k_int
+        self._bounds = {}
+        self._ent = ent
+
+    def bounds(self, e0, n):
+        if (e0, n) not in self._bounds:
+            self._bounds[(e0, n)] = table_norm_bounds(self._ent[e0:e0 + n], self.ent_f16[e0:e0 + n], self.k_int)
+        return self._bounds[(e0, n)]
+
+
+_pair_buffers = {}
+
+
+def _pair_buffer(device, n_seg):
+    """(pairs int64 [cap], per-segment counts int32 [n_seg + 1]) scratch of the prefilter, cached per device.
+    A wave of the prefilter covers 32 query rows x up to 4096 entities; 2048 entries hold 1.5 % of them undecided
+    (random positives on Gaussian tables leave ~0.7 %, a trained model a tenth of that); at most 1 GiB in total."""
+    per = max(64, min(2048, (1 << 27) // max(n_seg, 1)))
+    cap = n_seg * per
+    key = (device.type, device.index)
+    buf = _pair_buffers.get(key)
+    if buf is None or buf[0].numel() < cap or buf[1].numel() < n_seg + 1:
+        buf = (torch.empty(cap, dtype=torch.int64, device=device), torch.zeros(n_seg + 1, dtype=torch.int32, device=device))
+        _pair_buffers[key] = buf
+    return buf[0][:cap], buf[1][:n_seg + 1]
+
+
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
                         filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None,
-                        ent_bf16=None, stats=None):
+                        ent_bf16=None, stats=None, ent_f16=None):
     """Ranks of ``test_triples`` (int ids) against all entities (or ``entities_subset``).
 
     ``shard=(rank, world)`` (multi-GPU, see parallel.py): every rank holds the tables, scores the query tile
@@ -161,10 +230,17 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     ``precision=1``: bf16 MFMA throughput mode for DistMult/ComplEx/HolE (ranks agree with the exact f32 path
     statistically, not bit for bit); ``ent_bf16`` optionally passes a cached bf16 copy of the table.
 
+    ``precision=2``: EXACT ranks (bit-equal to precision 0) at MFMA speed for DistMult/ComplEx/HolE: a half-precision MFMA kernel
+    decides every candidate whose score is farther from the positive's than a rigorous per-row error bound
+    (prefilter_band), the others — typically 0.1-3 % — are re-scored with the exact f32 chain; shapes the prefilter
+    kernel does not cover, and query tiles with too many undecided candidates, take the exact kernel (stats['fallback']).
+
     ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
     (HIP events on the launch stream) and ``count_launches``."""
-    if precision not in (0, 1):
-        raise ValueError("precision must be 0 (exact f32) or 1 (bf16 MFMA)")
+    if precision not in (0, 1, 2):
+        raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA) or 2 (exact via bf16 prefilter)")
+    if precision == 2 and (model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE) or entities_subset is not None):
+        precision = 0   # TransE is not a contraction; candidate lists go through the exact kernel: same ranks
     if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):
         raise ValueError("the bf16 MFMA mode needs a contraction model (DistMult, ComplEx, HolE)")
     if corrupt_side not in L.EVAL_SIDE_IDS:
@@ -193,6 +269,14 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     findex = None
     if filter_triples is not None:
         findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
+    bounds = None
+    if precision == 2:
+        if isinstance(ent_f16, PrefilterTables):   # built once per evaluation run by the caller
+            bounds, ent_f16 = ent_f16.bounds(e0, slab.shape[0]), ent_f16.ent_f16
+        else:
+            if ent_f16 is None:   # half-precision copy of the table for the prefilter
+                ent_f16 = D.to_f16(ent, k_int, ld_dst=D.bf16_ld(k_int))
+            bounds = table_norm_bounds(slab, ent_f16[e0:e0 + slab.shape[0]], k_int)
     pending = []  # (counters on the device, nq) per chunk: every launch is asynchronous, ONE D2H at the end
     for c0 in range(0, n, query_chunk):
         Tc = T[c0:c0 + query_chunk]
@@ -219,24 +303,54 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
                                                                scale, fp_, fi_, cnt[2], cnt[3])
         else:
             tab, off = (ent, 0) if cand is not None else (slab, e0)
-            count = lambda: D.eval_count(model_id, Q, pos_int, tab, k_int, scale, cnt[0], cnt[1], cand=cand,  # noqa: E731
-                                         precision=precision)
+            count = lambda Q=Q, pos_int=pos_int, cnt=cnt, tab=tab: D.eval_count(  # noqa: E731  (bound now: re-run at the end on overflow)
+                model_id, Q, pos_int, tab, k_int, scale, cnt[0], cnt[1], cand=cand)
             fcount = lambda fp_, fi_: D.eval_filter_count(model_id, Q, pos_int, tab, off, k_int, scale, fp_, fi_,  # noqa: E731
-                                                          cnt[2], cnt[3], precision=precision)
-        if have_cands:
+                                                          cnt[2], cnt[3])
+        pre = None    # (overflow flag, undecided pairs) of this tile on the device + what an exact re-run needs
+        if precision == 2 and have_cands:
+            # half-precision MFMA prefilter, then exact re-scoring of the undecided pairs: both asynchronous; whether a
+            # wave ran out of pair room (-> this tile is redone by the exact kernel) is read with the counters at the end
+            kp = D.bf16_ld(k_int)
+            Qb = D.to_f16(Q, k_int, ld_dst=kp)
+            band = prefilter_band(Q, Qb, k_int, bounds)
+            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0])
+            pairs, pcount = _pair_buffer(ent.device, n_seg)
+            ev = _ev_start(stats)
+            try:
+                D.eval_prefilter_f16(model_id, Qb, pos_int, band, ent_f16[e0:e0 + slab.shape[0]], e0, k_int, scale, cnt[0],
+                                     pairs, pcount)
+            except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
+                pre = None
+            else:
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+                _ev_stop(stats, ev)
+                pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
+        if have_cands and pre is None:
             ev = _ev_start(stats)
             count()  # the big kernel goes first: the host-side filter CSR below is built underneath it
             _ev_stop(stats, ev)
-        if findex is not None:
-            ptr, idx = findex.csr(Tc, side_mode, n_ent, subset_local)
+        csr = findex.csr(Tc, side_mode, n_ent, subset_local) if findex is not None else None
+        if csr is not None:
+            ptr, idx = csr
             if have_cands:
                 fcount(torch.from_numpy(ptr).to(ent.device, non_blocking=True),
                        torch.from_numpy(idx).to(ent.device, non_blocking=True))
         if world > 1:
             parallel.allreduce_sum_(cnt)
-        pending.append((cnt, nq, precision == 1 and strategy != "middle"))
+        pending.append((cnt, nq, precision == 1 and strategy != "middle", pre))
     out = []
-    for cnt, nq, single in pending:
+    for cnt, nq, single, pre in pending:
+        if pre is not None:
+            over, n_pairs = (int(v) for v in pre[0].cpu())
+            if stats is not None:
+                stats["pairs"] = stats.get("pairs", 0) + (0 if over else n_pairs)
+                stats["fallback"] = stats.get("fallback", 0) + int(bool(over))
+            if over:   # too many undecided candidates for the pair buffer: this tile again, by the exact kernel
+                if world > 1:
+                    raise RuntimeError("prefilter pair buffer overflow under sharded evaluation: use precision=0")
+                cnt[0:2].zero_()
+                pre[1]()
         c = cnt.cpu().numpy().astype(np.int64)
         if single:
             c[1] = 0  # single-counter mode: c[0] already is what the strategy reads (see `need` above)

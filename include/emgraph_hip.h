@@ -309,6 +309,33 @@ int emg_eval_filter_count_bf16(int model, const void* q_bf16, int64_t ldq, const
                                int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
                                const int64_t* filt_ptr, const int32_t* filt_idx, int32_t* fcnt_gt,
                                int32_t* fcnt_eq, void* stream);
+/* f32 -> IEEE half (round-to-nearest-even) copy of a table / query matrix for precision mode 2; same layout rules
+ * as emg_to_bf16 (rows zero-padded to ld_dst >= round_up(k_int, 64)) */
+int emg_to_f16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, void* dst_f16, int64_t ld_dst, void* stream);
+
+/* ---- exact ranks at MFMA speed (precision mode 2): half-precision MFMA prefilter (v_mfma_f32_32x32x16_f16: 11
+ * significant bits, an 8x narrower error band than bf16 at the same rate) + exact re-scoring of the undecided.
+ * `band[r]` is a rigorous upper bound, for query row r and EVERY candidate, on |accumulator of the f16 kernel -
+ * accumulator of the exact f32 chain| (the host derives it from the rounding residuals of the operands, see
+ * emgraph_amd/evaluation/ranking.py::prefilter_band).  emg_eval_prefilter_f16 adds to cnt_gt the candidates that
+ * beat the positive by more than the band, drops those that lose by more than it, and writes the rest as
+ * (row << 32 | global entity id) into `pairs`: the buffer is cut into emg_eval_prefilter_segments(n_rows, n_cand)
+ * segments of pairs_capacity / segments entries, one per wave of the kernel (no atomics); pair_count[s] = entries
+ * written to segment s, pair_count[segments] != 0 if some wave ran out of room (then the caller must use
+ * emg_eval_count for these rows instead).  pair_count (uint32 [segments + 1]) is zeroed by the call.  EMG_ENOSUP for
+ * shapes the register-stationary kernel does not cover.  emg_eval_rescore_pairs scores the pairs with the parity
+ * path's arithmetic (k-ordered fmaf chain, int32(score*1e5)) and adds them to cnt_gt / cnt_eq, reading the counts
+ * on the device (no host round trip between the two calls).  The resulting counters equal
+ * emg_eval_count(precision 0) bit for bit. */
+int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand);
+int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
+                           int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset,
+                           int32_t k_pad, float scale, int32_t* cnt_gt, uint64_t* pairs, uint32_t* pair_count,
+                           int64_t pairs_capacity, void* stream);
+int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                           int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
+                           int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments, int32_t* cnt_gt,
+                           int32_t* cnt_eq, void* stream);
 int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64_t n_rows, const void* ent_bf16,
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);

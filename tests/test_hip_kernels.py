@@ -832,3 +832,41 @@ def test_apply_rows_long_segments_block_tree(k, opt):
             v = (F32(1) - b2) * g * g
             exp[r] = W[r] - lr * m / (np.sqrt(v) + eps)
     np.testing.assert_array_equal(Wt.cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# precision 2: exact ranks through the bf16 prefilter (must equal precision 0 bit for bit)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,k,n_ent,nq,scale", [("ComplEx", 200, 30000, 300, 0.1), ("HolE", 200, 9000, 200, 0.3),
+                                                     ("DistMult", 200, 20000, 150, 0.1), ("DistMult", 128, 5000, 140, 0.05),
+                                                     ("ComplEx", 64, 12000, 260, 1.0), ("ComplEx", 100, 7000, 80, 0.1),
+                                                     ("ComplEx", 200, 5000, 40, 0.1)])
+def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
+    """precision=2 (bf16 MFMA prefilter with a rigorous per-row error band + exact f32 re-scoring of the undecided
+    candidates) == precision=0 (exact f32 MFMA chain) for every side, strategy and filter setting; exact ties are
+    planted (other entities carry the true entity's row) and the scales make the comparison integers dense
+    (scale 1.0: scores of order 10, quantum 1e-5) or sparse.  Shapes outside the prefilter kernel (k_int = 200 real,
+    <= 128 query rows) silently take the exact kernel and must agree as well."""
+    from emgraph_amd.evaluation import rank_triples_device
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 5, seed=k + n_ent, scale=scale)
+    rs = np.random.RandomState(n_ent)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 5, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 4):
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+        E[rs.randint(0, n_ent, 1)] = E[T[j, 0]]
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 5000), rs.randint(0, 5, 5000), rs.randint(0, n_ent, 5000)], 1)]).astype(np.int32)
+    sc = scale_of(model, k)
+    Et, Rt = cu(E), cu(R)
+    used = 0
+    for side in ("s,o", "s+o", "o"):
+        for strategy in ("worst", "best", "middle"):
+            for filt in (None, F):
+                st = {}
+                exact = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt)
+                fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, stats=st)
+                np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None)))
+                used += st.get("pairs", 0)
+    kint_ok = (ki + 15) // 16 in (8, 13, 25)
+    if kint_ok and 2 * nq > 128:
+        assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
