@@ -33,7 +33,30 @@ struct ApplyParams {
     uint32_t* long_list; uint32_t* long_count; uint32_t long_cap;  // segments longer than kLongSegment (head positions)
     double* lp_accum;  // += sum |w_pre|^p over the rows this launch updates (the caller scales by lambda); may be null
     int32_t defer;     // segments longer than this go to apply_long_kernel
+    // FACTORED contributions (bilinear models; emg_backward_args.coef_neg): the gradient row of a negative's replacement
+    // entity is  coef * q  with q one of the two query rows of its triple group, so the backward kernel stores q once
+    // per group and one float per negative.  contrib rows: [0,B) subject rows, [B,2B) object rows, [2B,3B) q of the
+    // object side, [3B,4B) q of the subject side; contribution slot 2B + n (n = j*B + g) -> row (codes[n] < 0 ? 2B : 3B) + g
+    const int32_t* fac_codes; const float* fac_coef; uint32_t fac_B;
 };
+
+// where a contribution slot's gradient row lives and what it is multiplied by (1 for a row stored in full)
+struct Src { uint32_t row; float coef; };
+__device__ __forceinline__ Src contrib_src(const ApplyParams& P, uint32_t slot) {
+    if (!P.fac_codes || slot < 2u * P.fac_B) return Src{slot, 1.f};
+    const uint32_t n = slot - 2u * P.fac_B;
+    return Src{(P.fac_codes[n] < 0 ? 2u : 3u) * P.fac_B + n % P.fac_B, P.fac_coef[n]};
+}
+// acc += coef * v, the product rounded on its own (never contracted into an fma): the same bits as adding a row the
+// backward kernel stored as coef * q
+__device__ __forceinline__ void add_scaled(float4& acc, const float4& v, float coef) {
+#pragma clang fp contract(off)
+    acc.x += coef * v.x; acc.y += coef * v.y; acc.z += coef * v.z; acc.w += coef * v.w;
+}
+__device__ __forceinline__ void add_scaled(float& acc, float v, float coef) {
+#pragma clang fp contract(off)
+    acc += coef * v;
+}
 
 // flags[original index] = 1 iff its destination occurs exactly once in the batch
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
@@ -64,9 +87,10 @@ constexpr uint32_t kMediumFlag = 0x80000000u;  // list entry: the segment has <=
 
 template <int W, int DEPTH>
 __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t key, int64_t t, int64_t end, int64_t w0,
-                                               int64_t wend, uint32_t myval, int lane, int nchunks, float& lp_acc) {
-    auto contrib_index = [&](int64_t u) -> int64_t {  // wave-uniform u
-        return u < wend ? (int64_t)__shfl(myval, (int)(u - w0), 64) : (int64_t)P.vals[u];
+                                               int64_t wend, Src mysrc, int lane, int nchunks, float& lp_acc) {
+    auto source = [&](int64_t u) -> Src {  // wave-uniform u
+        if (u < wend) return Src{(uint32_t)__shfl(mysrc.row, (int)(u - w0), 64), __shfl(mysrc.coef, (int)(u - w0), 64)};
+        return contrib_src(P, P.vals[u]);
     };
     float* wrow = P.table + (int64_t)key * P.ld;
     float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
@@ -85,32 +109,36 @@ __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t ke
             if constexpr (DEPTH > 2) {
                 for (; u + DEPTH <= end; u += DEPTH) {
                     float4 va[DEPTH], vb[DEPTH];
+                    float cf[DEPTH];
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) {
-                        const float* rj = P.contrib + contrib_index(u + j) * P.ldc;
+                        const Src sj = source(u + j);
+                        const float* rj = P.contrib + (int64_t)sj.row * P.ldc;
+                        cf[j] = sj.coef;
                         va[j] = oa ? *reinterpret_cast<const float4*>(rj + 4 * ca) : zero;
                         vb[j] = ob ? *reinterpret_cast<const float4*>(rj + 4 * cb) : zero;
                     }
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) {  // added in contribution order
-                        if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
-                        if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
+                        if (oa) add_scaled(accA, va[j], cf[j]);
+                        if (ob) add_scaled(accB, vb[j], cf[j]);
                     }
                 }
             }
             for (; u < end; u += 2) {
                 const bool two = u + 1 < end;
-                const float* r0 = P.contrib + contrib_index(u) * P.ldc;
-                const float* r1 = two ? P.contrib + contrib_index(u + 1) * P.ldc : r0;
+                const Src s0 = source(u), s1 = two ? source(u + 1) : s0;
+                const float* r0 = P.contrib + (int64_t)s0.row * P.ldc;
+                const float* r1 = P.contrib + (int64_t)s1.row * P.ldc;
                 float4 v0a = zero, v0b = zero, v1a = zero, v1b = zero;
                 if (oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
                 if (ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
                 if (oa && two) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
                 if (ob && two) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
-                if (oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
-                if (ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
-                if (oa && two) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
-                if (ob && two) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
+                if (oa) add_scaled(accA, v0a, s0.coef);
+                if (ob) add_scaled(accB, v0b, s0.coef);
+                if (oa && two) add_scaled(accA, v1a, s1.coef);
+                if (ob && two) add_scaled(accB, v1b, s1.coef);
             }
             auto finish = [&](int c, float4 wv, const float4& g) {
                 const int64_t off = 4 * (int64_t)c;
@@ -129,7 +157,10 @@ __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t ke
     } else {
         for (int c = lane; c < nchunks; c += 64) {
             float acc = 0.f;
-            for (int64_t u = t; u < end; ++u) acc += P.contrib[contrib_index(u) * P.ldc + c];
+            for (int64_t u = t; u < end; ++u) {
+                const Src su = source(u);
+                add_scaled(acc, P.contrib[(int64_t)su.row * P.ldc + c], su.coef);
+            }
             float wv = wrow[c];
             lp_fold(P.opt, wv, acc, lp_acc);
             opt_update_elem(P.opt, wv, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
@@ -148,6 +179,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const bool in = lane < P.win && t0 < P.n;
     const uint32_t mykey = in ? P.keys[t0] : 0u;
     const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
+    const Src mysrc = in ? contrib_src(P, myval) : Src{0u, 0.f};   // and where their rows live (one gather per window)
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
             }
             continue;
         }
-        sum_and_update<W, DEPTH>(P, key, t, end, w0, wend, myval, lane, nchunks, lp_acc);
+        sum_and_update<W, DEPTH>(P, key, t, end, w0, wend, mysrc, lane, nchunks, lp_acc);
     }
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
@@ -202,19 +234,27 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
         int64_t u = u0;
         for (; u + 16 <= u1; u += 16) {
             float4 v[16];
+            float cf[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u + j] * P.ldc + 4 * c);
+            for (int j = 0; j < 16; ++j) {
+                const Src sj = contrib_src(P, P.vals[u + j]);
+                cf[j] = sj.coef;
+                v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)sj.row * P.ldc + 4 * c);
+            }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+            for (int j = 0; j < 16; ++j) add_scaled(acc, v[j], cf[j]);
         }
         for (; u < u1; ++u) {
-            const float4 v = *reinterpret_cast<const float4*>(P.contrib + (int64_t)P.vals[u] * P.ldc + 4 * c);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            const Src su = contrib_src(P, P.vals[u]);
+            add_scaled(acc, *reinterpret_cast<const float4*>(P.contrib + (int64_t)su.row * P.ldc + 4 * c), su.coef);
         }
         out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
     } else {
         float acc = 0.f;
-        for (int64_t u = u0; u < u1; ++u) acc += P.contrib[(int64_t)P.vals[u] * P.ldc + c];
+        for (int64_t u = u0; u < u1; ++u) {
+            const Src su = contrib_src(P, P.vals[u]);
+            add_scaled(acc, P.contrib[(int64_t)su.row * P.ldc + c], su.coef);
+        }
         out[0] = acc;
     }
 }
@@ -331,6 +371,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
     const bool in = lane < P.win && t0 < P.n;
     const uint32_t mykey = in ? P.keys[t0] : 0u;
     const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
+    const Src mysrc = in ? contrib_src(P, myval) : Src{0u, 0.f};   // and where their rows live (one gather per window)
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
@@ -366,9 +407,10 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
             }
         }
         if (!has) end = t;  // nothing to do for this subgroup in this round
-        auto contrib_index = [&](int64_t u) -> int64_t {  // u is uniform inside a subgroup
-            const uint32_t inwin = __shfl(myval, (int)(u < wend ? u - w0 : 0), 64);
-            return u < wend ? (int64_t)inwin : (int64_t)P.vals[u];
+        auto source = [&](int64_t u) -> Src {  // u is uniform inside a subgroup
+            const int from = (int)(u < wend ? u - w0 : 0);
+            const Src inwin{(uint32_t)__shfl(mysrc.row, from, 64), __shfl(mysrc.coef, from, 64)};
+            return u < wend ? inwin : contrib_src(P, P.vals[u]);
         };
         float* wrow = P.table + (int64_t)key * P.ld;
         float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
@@ -376,7 +418,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
         if constexpr (W == 4) {
             // two row chunks per lane x two contributions per trip (eight for long segments): independent 16-byte
             // loads in flight, added in contribution order (bit-reproducible sums).  The trip counts depend on the
-            // subgroup's segment: the shuffles inside contrib_index need every lane, so all subgroups run the
+            // subgroup's segment: the shuffles inside source() need every lane, so all subgroups run the
             // longest trip count and idle ones repeat their last row into a discarded sum.
             for (int c0 = 0; c0 < nchunks; c0 += 2 * LPS) {
                 const int ca = c0 + sl, cb = c0 + LPS + sl;
@@ -388,36 +430,38 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
                 while (__ballot(u + 8 <= end)) {  // (wave-uniform loop: see above)
                     const bool act = u + 8 <= end;
                     float4 va[8], vb[8];
+                    float cf[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int64_t ci = contrib_index(act ? u + j : t);
-                        const float* rj = P.contrib + ci * P.ldc;
+                        const Src sj = source(act ? u + j : t);
+                        const float* rj = P.contrib + (int64_t)sj.row * P.ldc;
+                        cf[j] = sj.coef;
                         va[j] = (act && oa) ? *reinterpret_cast<const float4*>(rj + 4 * ca) : accA;
                         vb[j] = (act && ob) ? *reinterpret_cast<const float4*>(rj + 4 * cb) : accA;
                     }
                     if (act) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {  // added in contribution order
-                            if (oa) { accA.x += va[j].x; accA.y += va[j].y; accA.z += va[j].z; accA.w += va[j].w; }
-                            if (ob) { accB.x += vb[j].x; accB.y += vb[j].y; accB.z += vb[j].z; accB.w += vb[j].w; }
+                            if (oa) add_scaled(accA, va[j], cf[j]);
+                            if (ob) add_scaled(accB, vb[j], cf[j]);
                         }
                         u += 8;
                     }
                 }
                 while (__ballot(u < end)) {
                     const bool act = u < end, two = u + 1 < end;
-                    const int64_t i0 = contrib_index(act ? u : t), i1 = contrib_index(two ? u + 1 : t);
-                    const float* r0 = P.contrib + i0 * P.ldc;
-                    const float* r1 = P.contrib + i1 * P.ldc;
+                    const Src s0 = source(act ? u : t), s1 = source(two ? u + 1 : t);
+                    const float* r0 = P.contrib + (int64_t)s0.row * P.ldc;
+                    const float* r1 = P.contrib + (int64_t)s1.row * P.ldc;
                     float4 v0a = accA, v0b = accA, v1a = accA, v1b = accA;
                     if (act && oa) v0a = *reinterpret_cast<const float4*>(r0 + 4 * ca);
                     if (act && ob) v0b = *reinterpret_cast<const float4*>(r0 + 4 * cb);
                     if (two && oa) v1a = *reinterpret_cast<const float4*>(r1 + 4 * ca);
                     if (two && ob) v1b = *reinterpret_cast<const float4*>(r1 + 4 * cb);
-                    if (act && oa) { accA.x += v0a.x; accA.y += v0a.y; accA.z += v0a.z; accA.w += v0a.w; }
-                    if (act && ob) { accB.x += v0b.x; accB.y += v0b.y; accB.z += v0b.z; accB.w += v0b.w; }
-                    if (two && oa) { accA.x += v1a.x; accA.y += v1a.y; accA.z += v1a.z; accA.w += v1a.w; }
-                    if (two && ob) { accB.x += v1b.x; accB.y += v1b.y; accB.z += v1b.z; accB.w += v1b.w; }
+                    if (act && oa) add_scaled(accA, v0a, s0.coef);
+                    if (act && ob) add_scaled(accB, v0b, s0.coef);
+                    if (two && oa) add_scaled(accA, v1a, s1.coef);
+                    if (two && ob) add_scaled(accB, v1b, s1.coef);
                     if (act) u += 2;
                 }
                 auto finish = [&](int c, float4 wv, const float4& g) {
@@ -442,8 +486,8 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
                 int64_t u = t;
                 while (__ballot(u < end)) {
                     const bool act = u < end;
-                    const int64_t ci = contrib_index(act ? u : t);
-                    if (act && oc) acc += P.contrib[ci * P.ldc + c];
+                    const Src su = source(act ? u : t);
+                    if (act && oc) add_scaled(acc, P.contrib[(int64_t)su.row * P.ldc + c], su.coef);
                     if (act) ++u;
                 }
                 if (oc) {
@@ -700,10 +744,11 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     return group_dest_impl(a->dest_rel, n_cr, a->n_rel, a->ws_rel, a->ws_rel_bytes, nullptr, st);
 }
 
-extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
-                                 float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
-                                 int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                              int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                              void* workspace, int64_t workspace_bytes, const int32_t* fac_codes, const float* fac_coef,
+                              int64_t fac_B, void* stream) {
     EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
     EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
@@ -720,6 +765,7 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
     P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = lp_accum;
+    P.fac_codes = fac_codes; P.fac_coef = fac_coef; P.fac_B = (uint32_t)fac_B;
     if (n_contrib > 0) {
         const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
                          (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
@@ -768,6 +814,26 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
         EMG_LAUNCH_CHECK();
     }
     return EMG_OK;
+}
+
+extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                                 float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                                 int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    return apply_grouped_impl(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single,
+                              hyper, lp_accum, workspace, workspace_bytes, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int emg_apply_grouped_factored(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                                          float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                                          int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                                          void* workspace, int64_t workspace_bytes, const int32_t* codes,
+                                          const float* coef_neg, int64_t B, void* stream) {
+    EMG_REQUIRE(codes && coef_neg && B > 0, "emg_apply_grouped_factored: null codes / coef_neg");
+    EMG_REQUIRE(n_contrib >= 2 * B && n_contrib % B == 0 && n_contrib < ((int64_t)1 << 31),
+                "emg_apply_grouped_factored: n_contrib must be (2 + eta) * B");
+    return apply_grouped_impl(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single,
+                              hyper, lp_accum, workspace, workspace_bytes, codes, coef_neg, B, stream);
 }
 
 extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,

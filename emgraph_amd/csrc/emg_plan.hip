@@ -106,6 +106,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
     for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
+    ba.coef_neg = c.coef_neg;
     int rc;
     if (c.fused) {
         ba.fused_loss = c.loss;
@@ -152,9 +153,14 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     }
     {
         Timed t(P, ST_APPLY_ENT, main);
-        rc = emg_apply_grouped(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, step,
-                               c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr, sl.buf.ws_ent,
-                               sl.buf.ws_ent_bytes, main);
+        if (c.coef_neg)
+            rc = emg_apply_grouped_factored(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent,
+                                            step, c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr,
+                                            sl.buf.ws_ent, sl.buf.ws_ent_bytes, sl.buf.codes, c.coef_neg, B, main);
+        else
+            rc = emg_apply_grouped(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, step,
+                                   c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr, sl.buf.ws_ent,
+                                   sl.buf.ws_ent_bytes, main);
         if (rc != EMG_OK) return rc;
     }
     if (use_aux) EMG_HIP(hipStreamWaitEvent(main, P->join, 0));

@@ -159,6 +159,7 @@ struct GroupParams {
     const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
     float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
     OptParams opt;
+    float* coef_neg;                                     // FACTORED contributions (bilinear models): see emg_backward_args
 };
 
 constexpr int kThreads = 256;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
     const bool active = g < P.B;
     if (!active) g = P.B - 1;
     const int64_t B = P.B;
+    constexpr bool kBilinear = !(MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2);   // replacement row's gradient = gi * q
 
     const int32_t s = P.pos[3 * g + 0], p = P.pos[3 * g + 1], o = P.pos[3 * g + 2];
     const float* srow = P.ent + (int64_t)s * P.ld_ent;
@@ -474,9 +476,14 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
                 if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[slot])) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
+                else if (kBilinear && P.coef_neg) { if (lg == 0) P.coef_neg[(int64_t)j * B + g] = gi; }   // row = gi * q: q is stored once, below
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }
         }
+    }
+    if (kBilinear && P.coef_neg && active) {   // the two query rows every factored negative of this group points at
+        store_row<MODEL, W, NV, LPG>(qo, P.contrib_ent + (2 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        store_row<MODEL, W, NV, LPG>(qs, P.contrib_ent + (3 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
     if (active) {
         // kept rows: form their gradients from the accumulators
@@ -719,6 +726,10 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
     P.fused_loss = a->fused_loss; P.margin = a->margin; P.loss_accum = a->loss_accum;
     P.scores_pos = a->scores_pos_out; P.scores_neg = a->scores_neg_out;
     P.contrib_ent = a->contrib_ent; P.contrib_rel = a->contrib_rel; P.ldc = a->ldc;
+    EMG_REQUIRE(!a->coef_neg || !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
+                "emg_train_backward_ex: factored contributions (coef_neg) need a bilinear model — a TransE gradient row "
+                "depends on the replacement entity");
+    P.coef_neg = a->coef_neg;
     P.single_ent = a->single_ent;
     if (a->single_ent) {
         EMG_REQUIRE(a->opt >= EMG_OPT_SGD && a->opt <= EMG_OPT_ADAM_LAZY, "emg_train_backward_ex: unknown optimizer");

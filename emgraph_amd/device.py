@@ -160,7 +160,7 @@ def train_backward(model_id, ent, rel, k_int, scale, pos, eta, codes, g_pos, g_n
     B = pos.shape[0]
     pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
     pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
-    if ldc != ldc2 or nce < (2 + eta) * B or ncr < B:
+    if ldc != ldc2 or nce < (4 if coef_neg is not None else 2 + eta) * B or ncr < B:
         raise ValueError("contribution buffers have the wrong shape")
     L.check(lib.emg_train_backward(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
                                    _chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
@@ -183,9 +183,11 @@ def build_dest(pos, eta, codes, dest_ent, dest_rel):
 def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
                       margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
                       scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
-                      ent_state0=None, ent_state1=None, tag_ent=None):
+                      ent_state0=None, ent_state1=None, tag_ent=None, coef_neg=None):
     """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
-    singleton updates (single_ent flags from group_dest)."""
+    singleton updates (single_ent flags from group_dest).  ``coef_neg`` (float32 [eta*B], bilinear models): FACTORED
+    entity contributions — ``contrib_ent`` then holds 4*B rows (see include/emgraph_hip.h) and the entity apply is
+    ``apply_grouped(..., factored=(codes, coef_neg, B))``."""
     lib = L.load()
     B = pos.shape[0]
     a = L.BackwardArgs()
@@ -204,7 +206,7 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     a.scores_neg_out = _chk_vec(scores_neg_out, torch.float32, "scores_neg_out", B * eta if scores_neg_out is not None else None)
     pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
     pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
-    if ldc != ldc2 or nce < (2 + eta) * B or ncr < B:
+    if ldc != ldc2 or nce < (4 if coef_neg is not None else 2 + eta) * B or ncr < B:
         raise ValueError("contribution buffers have the wrong shape")
     a.contrib_ent, a.contrib_rel, a.ldc = pce, pcr, ldc
     a.single_ent = _chk_vec(single_ent, torch.uint8, "single_ent", (2 + eta) * B if single_ent is not None else None)
@@ -217,6 +219,7 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     if ent_state1 is not None:
         a.ent_state1 = _chk_table(ent_state1, "ent_state1")[0]
     a.tag_ent = _chk_vec(tag_ent, torch.int32, "tag_ent")
+    a.coef_neg = _chk_vec(coef_neg, torch.float32, "coef_neg", B * eta if coef_neg is not None else None)
     L.check(lib.emg_train_backward_ex(C.byref(a), _stream()), "emg_train_backward_ex")
 
 
@@ -258,19 +261,30 @@ def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, 
 
 
 def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace,
-                  lp_accum=None):
+                  lp_accum=None, factored=None):
     """``hyper`` = (lr, momentum, beta1, beta2, eps, lr_t[, lp_lambda, lp_p]); with lp_lambda != 0 the LP regulariser's
-    gradient is folded into every row's update and ``lp_accum`` (device double) receives sum |w|^p."""
+    gradient is folded into every row's update and ``lp_accum`` (device double) receives sum |w|^p.
+    ``factored`` = (codes, coef_neg, B): the contributions were written by ``train_backward_ex(..., coef_neg=...)``."""
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")
     p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
     p1 = _chk_table(state1, "state1")[0] if state1 is not None else None
     pc, _, ldc = _chk_table(contrib, "contrib")
     h = _hyper8(hyper)
+    lp = _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None
+    if factored is not None:
+        codes, coef, B = factored
+        if n_contrib % B or n_contrib < 2 * B:
+            raise ValueError("factored contributions: n_contrib must be (2 + eta) * B")
+        n_neg = n_contrib - 2 * B
+        L.check(lib.emg_apply_grouped_factored(
+            opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc, ldc, n_contrib,
+            int(skip_single), h, lp, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+            _chk_vec(codes, torch.int32, "codes", n_neg), _chk_vec(coef, torch.float32, "coef_neg", n_neg), B,
+            _stream()), "emg_apply_grouped_factored")
+        return
     L.check(lib.emg_apply_grouped(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc,
-                                  ldc, n_contrib, int(skip_single), h,
-                                  _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None,
-                                  workspace.data_ptr(),
+                                  ldc, n_contrib, int(skip_single), h, lp, workspace.data_ptr(),
                                   workspace.numel() * workspace.element_size(), _stream()), "emg_apply_grouped")
 
 

@@ -185,3 +185,104 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
     np.testing.assert_array_equal(Et2, dev_tables[1][0])
     np.testing.assert_array_equal(Rt2, dev_tables[1][1])
     assert tr.read_loss() == dev_loss[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# factored entity contributions: a negative's gradient row is (one float) x (a query row of its triple group)
+# ------------------------------------------------------------------------------------------------
+def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kind, steps=3, seed=5):
+    """the C-ABI sequence of fit(): emg_prepare_batch -> emg_train_backward_ex -> emg_apply_grouped[_factored] (entities)
+    -> emg_apply_grouped (relations); returns tables, optimizer state, tags and the loss after `steps` batches"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd import device as d
+    from emgraph_amd.training import alloc_table
+    ki = 2 * k if model in ("ComplEx", "HolE") else k
+    sc = float(F32(2 / k)) if model == "HolE" else 1.0
+    rs = np.random.RandomState(101)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = _batch(kind, n_ent, n_rel, steps * B, seed=23)
+    dev = torch.device("cuda")
+    Et, Rt = alloc_table(n_ent, ki, dev, init=E0), alloc_table(n_rel, ki, dev, init=R0)
+    ns = {"sgd": 0, "momentum": 1, "adagrad": 1, "adam": 2, "adam_lazy": 2}[opt]
+    fill = 0.1 if opt == "adagrad" else 0.0
+    se = [alloc_table(n_ent, ki, dev, fill=fill) for _ in range(ns)] + [None] * (2 - ns)
+    sr = [alloc_table(n_rel, ki, dev, fill=fill) for _ in range(ns)] + [None] * (2 - ns)
+    tag_e = torch.zeros(n_ent, dtype=torch.int32, device=dev)
+    tag_r = torch.zeros(n_rel, dtype=torch.int32, device=dev)
+    n_ce = (2 + eta) * B
+    we = torch.empty(d.apply_workspace_bytes(n_ce, n_ent, ki), dtype=torch.uint8, device=dev)
+    wr = torch.empty(d.apply_workspace_bytes(B, n_rel, ki), dtype=torch.uint8, device=dev)
+    codes = torch.empty(B * eta, dtype=torch.int32, device=dev)
+    de = torch.empty(n_ce, dtype=torch.int32, device=dev)
+    dr = torch.empty(B, dtype=torch.int32, device=dev)
+    single = torch.zeros(n_ce, dtype=torch.uint8, device=dev)
+    Xt = torch.from_numpy(X).to(dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    n_single = 0
+    for step in range(1, steps + 1):
+        pos = Xt[(step - 1) * B:step * B]
+        d.prepare_batch(pos, eta, [L.SIDE_SO], n_ent, codes, de, dr, n_ent, n_rel, we, wr, seed=seed, counter0=step - 1,
+                        single_flags=single if inplace else None)
+        # poison: nothing may be read that this step did not write
+        ce = torch.full((4 * B if factored else n_ce, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
+        cr = torch.full((B, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
+        coef = torch.full((B * eta,), float("nan"), dtype=torch.float32, device=dev) if factored else None
+        hyper = _hyper(0.002, step)
+        d.train_backward_ex(MID[model], Et, Rt, ki, sc, pos, eta, codes, ce, cr, fused_loss=L.LOSS_IDS[loss], margin=1.0,
+                            loss_accum=acc, single_ent=single if inplace else None, opt_id=L.OPT_IDS[opt], step=step,
+                            hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, coef_neg=coef)
+        d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, inplace, hyper, we,
+                        factored=(codes, coef, B) if factored else None)
+        d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, 0, hyper, wr)
+        if inplace:
+            n_single += int(single.sum().item())
+    torch.cuda.synchronize()
+    return ([Et.cpu().numpy(), Rt.cpu().numpy()] + [t.cpu().numpy() for t in se + sr if t is not None]
+            + [tag_e.cpu().numpy(), np.array([acc.item()])]), n_single
+
+
+FACTORED_CASES = {
+    # name: model, k, eta, loss, optimizer, n_ent, n_rel, B, batch kind
+    "C3-sgd": ("ComplEx", 200, 20, "nll", "sgd", 60000, 1000, 4096, "uniform"),
+    "C3-zipf": ("ComplEx", 200, 20, "nll", "sgd", 3000, 1000, 4096, "zipf"),        # hub rows: deferred / block-tree sums
+    "C2-adam": ("DistMult", 200, 10, "nll", "adam", 15000, 237, 4096, "uniform"),
+    "C2-adagrad-zipf": ("DistMult", 200, 10, "nll", "adagrad", 1500, 237, 4096, "zipf"),
+    "C5-adam_lazy": ("HolE", 200, 20, "nll", "adam_lazy", 8000, 1345, 2048, "zipf"),
+    "k32-momentum": ("DistMult", 32, 5, "pairwise", "momentum", 3000, 7, 2048, "uniform"),       # skinny rows: sub-wave segments
+    "k50-sgd": ("DistMult", 50, 8, "pairwise", "sgd", 4000, 7, 2048, "uniform"),                 # k % 4 != 0: scalar path
+    "k512-adam": ("ComplEx", 256, 4, "nll", "adam", 5000, 20, 1024, "uniform"),                  # two 16-byte chunks per lane
+}
+
+
+@pytest.mark.parametrize("inplace", [1, 0])
+@pytest.mark.parametrize("case", list(FACTORED_CASES))
+def test_factored_contributions_are_bit_identical_to_full_rows(case, inplace):
+    """eta full gradient rows per triple group (emg_apply_grouped) == two query rows per group + one float per
+    negative (emg_backward_args.coef_neg + emg_apply_grouped_factored), BIT for BIT over three steps: tables, optimizer
+    state, tags, loss.  The factored apply adds the separately rounded product coef * q exactly where the other path
+    adds the stored row coef * q, in the same order."""
+    from emgraph_amd import device as d
+    d.require_gpu()
+    full, n1 = _run_steps(False, inplace, *FACTORED_CASES[case])
+    fac, n2 = _run_steps(True, inplace, *FACTORED_CASES[case])
+    assert n1 == n2
+    for a, b in zip(full, fac):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+
+
+def test_factored_contributions_refused_for_transe():
+    from emgraph_amd import _lib as L
+    from emgraph_amd import device as d
+    from emgraph_amd.training import alloc_table
+    d.require_gpu()
+    dev = torch.device("cuda")
+    Et, Rt = alloc_table(50, 8, dev, fill=0.1), alloc_table(3, 8, dev, fill=0.1)
+    pos = torch.zeros((4, 3), dtype=torch.int32, device=dev)
+    codes = torch.zeros(8, dtype=torch.int32, device=dev)
+    ce, cr = alloc_table(16, 8, dev), alloc_table(4, 8, dev)
+    with pytest.raises(RuntimeError, match="bilinear"):
+        d.train_backward_ex(MID["TransE_L1"], Et, Rt, 8, 1.0, pos, 2, codes, ce, cr, fused_loss=L.LOSS_IDS["pairwise"],
+                            loss_accum=torch.zeros(1, dtype=torch.float64, device=dev),
+                            coef_neg=torch.zeros(8, dtype=torch.float32, device=dev))
