@@ -85,6 +85,21 @@ def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None
     return 0
 
 
+def moved_bytes_model(stage, B, eta, k_int, n_single_neg, n_single_so, n_ns_rows, n_ns_dest):
+    """bytes the FACTORED path has to move (bilinear models): a negative's gradient row is one float times
+    one of its group's two query rows, so the backward kernel writes 2 query rows + 1 relation row per group, the
+    subject / object rows, one float per negative that is not applied in place, and the singleton rows in place."""
+    row = 4 * k_int
+    if stage == "fused":
+        return (B * (12 + 4 * eta + (2 + eta) + (3 + eta) * row)        # ids, codes, flags, rows read
+                + B * 3 * row                                             # relation row + the two query rows
+                + 2 * B * row                                             # subject / object rows (in place or contribution)
+                + n_single_neg * row + (eta * B - n_single_neg) * 4)      # singleton negatives in place; else one float
+    if stage == "apply_ent":   # every non-singleton slot reads one (query or kept) row + its factor; RMW of the destination
+        return n_ns_rows * (row + 8) + 2 * n_ns_dest * row + (2 + eta) * B * 8
+    return 0
+
+
 def pmc_traffic(stage, name, B, world, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command
     (profiles/r2_pmc_traffic.json; separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
@@ -203,6 +218,12 @@ class StepRunner:
             for name, v in ms.items():
                 ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single)
                 out[name] = {"ms": round(v, 4), "alg_bytes": ab, "GBps": round(ab / (v * 1e-3) / 1e9, 1) if ab else None}
+                if getattr(tr, "factored", False) and tr.inplace and name in ("fused", "apply_ent"):
+                    flags = sl["single"][:n_ce]
+                    n_s_so, n_s_neg = int(flags[:2 * B].sum().item()), int(flags[2 * B:].sum().item())
+                    mb = moved_bytes_model(name, B, eta, self.k_local, n_s_neg, n_s_so, n_ce - n_single, n_ue - n_single)
+                    out[name]["factored_bytes_model"] = mb
+                    out[name]["factored_GBps"] = round(mb / (v * 1e-3) / 1e9, 1)
         else:
             out.update({name: {"ms": round(v, 4)} for name, v in ms.items()})
         return out

@@ -16,6 +16,8 @@
 // Not covered: the k-sharded multi-GPU step (it needs a collective between forward and loss: host-driven).
 #include <vector>
 
+#include <stdlib.h>
+
 #include "emg_common.hpp"
 
 namespace emg {
@@ -269,7 +271,10 @@ extern "C" int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step
     rc = compute(P, *sl, *cur, step, hyper6, main);
     if (rc != EMG_OK) return rc;
     if (P->n_side > 0) EMG_HIP(hipEventRecord(sl->done, main));
-    sl->has_key = false;
+    // EMG_PLAN_KEEP (timing experiment: what does the preparation chain cost the compute kernels it runs beside?):
+    // a consumed slot stays valid, so stepping the same few batches again skips their preparation
+    static const bool keep = getenv("EMG_PLAN_KEEP") != nullptr;
+    if (!keep) sl->has_key = false;
     return EMG_OK;
 }
 

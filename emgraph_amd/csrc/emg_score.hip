@@ -145,6 +145,13 @@ __device__ __forceinline__ int uniform_if_wave(int v) {
     return v;
 }
 
+// value held by lane `first + j` of the wave (first = the group's lane 0), j uniform within the group
+template <int LPG>
+__device__ __forceinline__ int group_lane_value(int v, int first, int j) {
+    if constexpr (LPG == 64) return __builtin_amdgcn_readlane(v, j);
+    return __shfl(v, first + j, 64);
+}
+
 struct GroupParams {
     const float* ent; int64_t n_ent; int64_t ld_ent;
     const float* rel; int64_t n_rel; int64_t ld_rel;
@@ -162,7 +169,10 @@ struct GroupParams {
     float* coef_neg;                                     // FACTORED contributions (bilinear models): see emg_backward_args
 };
 
-constexpr int kThreads = 256;
+#ifndef EMG_BW_THREADS
+#define EMG_BW_THREADS 256
+#endif
+constexpr int kThreads = EMG_BW_THREADS;
 constexpr int kUnroll = 4;
 
 // ---------------------------------------------------------------------------------------------
@@ -376,6 +386,14 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 #ifndef EMG_BW_MINWAVES
 #define EMG_BW_MINWAVES 1
 #endif
+// U = replacement rows in flight per wave and trip.  Measured on C3 (MI355X, fused kernel alone): U = 2: 0.302 ms,
+// 4: 0.263, 5: 0.302, 6: 0.314, 8: 0.311, 10: 0.305; a software pipeline (next U rows in flight during the arithmetic
+// of this trip) 0.285 (U = 2) / 0.300 (U = 4: 194 VGPRs, 2 waves/SIMD); workgroups of 64 / 128 / 512 threads 0.288 /
+// 0.239 / 0.274 against 0.223 with 256 on the same box.
+#ifndef EMG_BW_U
+#define EMG_BW_U 4
+#endif
+
 // KEEP: the s, p, o rows stay in registers across the loop over the negatives instead of being re-read at the end
 // (the re-read was 1.10x the algorithmic traffic by PMC: after 20 replacement rows per wave on every CU of the XCD
 // they are no longer in L2).  Only where it is free: instantiations whose occupancy does not drop (checked with
@@ -399,6 +417,18 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
     const float* srow = P.ent + (int64_t)s * P.ld_ent;
     const float* prow = P.rel + (int64_t)p * P.ld_rel;
     const float* orow = P.ent + (int64_t)o * P.ld_ent;
+    // ALL corruption codes and in-place flags of the group in ONE gather each, issued together with the s, p, o rows
+    // and before anything is stored: lane j holds negative j's code and flag, lanes eta / eta+1 the flags of the
+    // subject / object slot.  Loaded where they are used, each sits behind the previous negative's stores (a byte load
+    // may alias them as far as the compiler knows): a serialised round trip per negative (C3: 0.265 -> 0.251 ms).
+    const bool gathered = P.eta + 2 <= LPG;   // kernel-uniform
+    const int first = (threadIdx.x & 63) / LPG * LPG;
+    int my_code = 0, my_flag = 0;
+    if (gathered) {
+        if (lg < P.eta) my_code = P.codes[(int64_t)lg * B + g];
+        if (IP != 0 && lg < P.eta + 2)
+            my_flag = P.single_ent[lg < P.eta ? 2 * B + (int64_t)lg * B + g : (int64_t)(lg - P.eta) * B + g];
+    }
     R qo, qs, Ao, As;
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
@@ -430,21 +460,32 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
         gpos = P.g_pos[g];
     }
 
-    constexpr int U = 4;
-    for (int j0 = 0; j0 < P.eta; j0 += U) {
-        int32_t code[U];
-        float gj[U];
-        R re[U];
+    constexpr int U = EMG_BW_U;
+    auto code_of = [&](int j) -> int32_t {
+        return gathered ? group_lane_value<LPG>(my_code, first, j) : uniform_if_wave<LPG>(P.codes[(int64_t)j * B + g]);
+    };
+    auto flag_of = [&](int i, int64_t slot) -> int {   // i: negative index, eta = subject slot, eta + 1 = object slot
+        if constexpr (IP == 0) return 0;
+        return gathered ? group_lane_value<LPG>(my_flag, first, i) : uniform_if_wave<LPG>((int)P.single_ent[slot]);
+    };
+    // the replacement rows of negatives j0 .. j0+U-1
+    auto fetch = [&](int j0, int32_t (&code)[U], R (&re)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = min(j0 + u, P.eta - 1);
-            code[u] = uniform_if_wave<LPG>(P.codes[(int64_t)j * B + g]);
-            if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)j * B + g];
-        }
+        for (int u = 0; u < U; ++u) code[u] = code_of(min(j0 + u, P.eta - 1));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int32_t repl = code[u] & 0x7fffffff;
             load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+        }
+    };
+    for (int j0 = 0; j0 < P.eta; j0 += U) {
+        int32_t code[U];
+        float gj[U];
+        R re[U];
+        fetch(j0, code, re);
+        if constexpr (!FUSED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, P.eta - 1) * B + g];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -475,7 +516,7 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
             else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
-                if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[slot])) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
+                if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
                 else if (kBilinear && P.coef_neg) { if (lg == 0) P.coef_neg[(int64_t)j * B + g] = gi; }   // row = gi * q: q is stored once, below
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }
@@ -497,9 +538,9 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[g])) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
+        if (IP != 0 && flag_of(P.eta, g)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && uniform_if_wave<LPG>((int)P.single_ent[B + g])) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
+        if (IP != 0 && flag_of(P.eta + 1, B + g)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
     if constexpr (FUSED) {

@@ -160,7 +160,7 @@ def train_backward(model_id, ent, rel, k_int, scale, pos, eta, codes, g_pos, g_n
     B = pos.shape[0]
     pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
     pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
-    if ldc != ldc2 or nce < (4 if coef_neg is not None else 2 + eta) * B or ncr < B:
+    if ldc != ldc2 or nce < (2 + eta) * B or ncr < B:
         raise ValueError("contribution buffers have the wrong shape")
     L.check(lib.emg_train_backward(model_id, pe, ne, lde, pr, nr, ldr, k_int, scale,
                                    _chk_vec(pos, torch.int32, "pos", 3 * B), B, eta,
