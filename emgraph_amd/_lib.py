@@ -81,7 +81,7 @@ class BackwardArgs(C.Structure):
         ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
         ("single_ent", _p), ("opt", _i32), ("step", _i32), ("hyper", _f32 * 8),
         ("ent_state0", _p), ("ent_state1", _p), ("tag_ent", _p),
-        ("coef_neg", _p),
+        ("fac_ws_ent", _p), ("fac_ws_ent_bytes", _i64),
     ]
 
 
@@ -92,7 +92,7 @@ SIGNATURES.update({
     "emg_apply_grouped": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,
                                  C.POINTER(_f32), _p, _p, _i64, _p]),
     "emg_apply_grouped_factored": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,
-                                          C.POINTER(_f32), _p, _p, _i64, _p, _p, _i64, _p]),
+                                          C.POINTER(_f32), _p, _p, _i64, _p]),
 })
 
 class PrepareArgs(C.Structure):
@@ -107,6 +107,7 @@ class PrepareArgs(C.Structure):
         ("ws_ent", _p), ("ws_ent_bytes", _i64), ("ws_rel", _p), ("ws_rel_bytes", _i64),
         ("single_flags", _p),
         ("B_global", _i64), ("row_offset", _i64),
+        ("factored", _i32), ("reserved0", _i32),
     ]
 
 
@@ -166,7 +167,7 @@ class PlanConfig(C.Structure):
         ("cap_B", _i64),
         ("scores", _p), ("g", _p), ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
         ("loss_accum", _p), ("lp_sum", _p),
-        ("coef_neg", _p),
+        ("factored", _i32), ("reserved0", _i32),
         ("lp_lambda_ent", _f32), ("lp_lambda_rel", _f32), ("lp_p", _i32),
         ("fused", _i32), ("inplace", _i32), ("normalize", _i32),
         ("n_slots", _i32), ("slots", PlanSlot * 4),

@@ -33,19 +33,20 @@ struct ApplyParams {
     uint32_t* long_list; uint32_t* long_count; uint32_t long_cap;  // segments longer than kLongSegment (head positions)
     double* lp_accum;  // += sum |w_pre|^p over the rows this launch updates (the caller scales by lambda); may be null
     int32_t defer;     // segments longer than this go to apply_long_kernel
-    // FACTORED contributions (bilinear models; emg_backward_args.coef_neg): the gradient row of a negative's replacement
-    // entity is  coef * q  with q one of the two query rows of its triple group, so the backward kernel stores q once
-    // per group and one float per negative.  contrib rows: [0,B) subject rows, [B,2B) object rows, [2B,3B) q of the
-    // object side, [3B,4B) q of the subject side; contribution slot 2B + n (n = j*B + g) -> row (codes[n] < 0 ? 2B : 3B) + g
-    const int32_t* fac_codes; const float* fac_coef; uint32_t fac_B;
+    // Where the gradient row of the contribution at SORTED position t lives and what it is multiplied by.
+    //   full rows (emg_apply_grouped):  srcrow = vals (the contribution's own row), coef = nullptr (1)
+    //   FACTORED (bilinear models; emg_prepare_args.factored + emg_backward_args.fac_ws_ent): the gradient row of a
+    //   negative's replacement entity is  coef * q  with q one of the two query rows of its triple group, so the
+    //   backward kernel stores q once per group and one float per negative.  contrib rows: [0,B) subject rows, [B,2B)
+    //   object rows, [2B,3B) q of the object side, [3B,4B) q of the subject side.  srcrow[t] is resolved by the
+    //   grouping (mark_single_kernel: the codes are known there), coef[t] is written by the backward kernel straight
+    //   into sorted order (pos_of_slot) — so a window's sources are ONE coalesced load each, like its keys.
+    const uint32_t* srcrow; const float* coef;
 };
 
-// where a contribution slot's gradient row lives and what it is multiplied by (1 for a row stored in full)
 struct Src { uint32_t row; float coef; };
-__device__ __forceinline__ Src contrib_src(const ApplyParams& P, uint32_t slot) {
-    if (!P.fac_codes || slot < 2u * P.fac_B) return Src{slot, 1.f};
-    const uint32_t n = slot - 2u * P.fac_B;
-    return Src{(P.fac_codes[n] < 0 ? 2u : 3u) * P.fac_B + n % P.fac_B, P.fac_coef[n]};
+__device__ __forceinline__ Src contrib_src(const ApplyParams& P, int64_t t) {
+    return Src{P.srcrow[t], P.coef ? P.coef[t] : 1.f};
 }
 // acc += coef * v, the product rounded on its own (never contracted into an fma): the same bits as adding a row the
 // backward kernel stored as coef * q
@@ -58,16 +59,34 @@ __device__ __forceinline__ void add_scaled(float& acc, float v, float coef) {
     acc += coef * v;
 }
 
-// flags[original index] = 1 iff its destination occurs exactly once in the batch
+// flags[original index] = 1 iff its destination occurs exactly once in the batch (flags may be null).
+// fac_codes != null (factored contributions): srcrow[t] = the row of the 4B-row contribution buffer the slot at sorted
+// position t points at, pos_of_slot[slot - 2B] = t for the negatives' slots (where the backward kernel puts their factor),
+// coef[t] = 1 for the subject / object slots.
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
-                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_count) {
+                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_count,
+                                   const int32_t* __restrict__ fac_codes, uint32_t fac_B, uint32_t* __restrict__ srcrow,
+                                   uint32_t* __restrict__ pos_of_slot, float* __restrict__ coef) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { long_count[0] = 0u; long_count[1] = 0u; }  // long-segment list of the apply that follows (saves a memset launch)
     if (t >= n) return;
     const uint32_t key = keys[t];
-    const bool head = (t == 0) || keys[t - 1] != key;
-    const bool last = (t + 1 == n) || keys[t + 1] != key;
-    flags[vals[t]] = (head && last) ? 1 : 0;
+    const uint32_t slot = vals[t];
+    if (flags) {
+        const bool head = (t == 0) || keys[t - 1] != key;
+        const bool last = (t + 1 == n) || keys[t + 1] != key;
+        flags[slot] = (head && last) ? 1 : 0;
+    }
+    if (fac_codes) {
+        if (slot < 2u * fac_B) {
+            srcrow[t] = slot;
+            coef[t] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
+        } else {
+            const uint32_t i = slot - 2u * fac_B;
+            srcrow[t] = (fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
+            pos_of_slot[i] = (uint32_t)t;
+        }
+    }
 }
 
 // One wave per WIN (a power of two <= 64) consecutive SORTED positions: the wave finds the segment heads inside its window with
@@ -90,7 +109,7 @@ __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t ke
                                                int64_t wend, Src mysrc, int lane, int nchunks, float& lp_acc) {
     auto source = [&](int64_t u) -> Src {  // wave-uniform u
         if (u < wend) return Src{(uint32_t)__shfl(mysrc.row, (int)(u - w0), 64), __shfl(mysrc.coef, (int)(u - w0), 64)};
-        return contrib_src(P, P.vals[u]);
+        return contrib_src(P, u);
     };
     float* wrow = P.table + (int64_t)key * P.ld;
     float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
@@ -178,8 +197,7 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int64_t t0 = w0 + lane;
     const bool in = lane < P.win && t0 < P.n;
     const uint32_t mykey = in ? P.keys[t0] : 0u;
-    const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
-    const Src mysrc = in ? contrib_src(P, myval) : Src{0u, 0.f};   // and where their rows live (one gather per window)
+    const Src mysrc = in ? contrib_src(P, t0) : Src{0u, 0.f};   // the window's contribution rows: one coalesced load
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
@@ -237,7 +255,7 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
             float cf[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const Src sj = contrib_src(P, P.vals[u + j]);
+                const Src sj = contrib_src(P, u + j);
                 cf[j] = sj.coef;
                 v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)sj.row * P.ldc + 4 * c);
             }
@@ -245,14 +263,14 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
             for (int j = 0; j < 16; ++j) add_scaled(acc, v[j], cf[j]);
         }
         for (; u < u1; ++u) {
-            const Src su = contrib_src(P, P.vals[u]);
+            const Src su = contrib_src(P, u);
             add_scaled(acc, *reinterpret_cast<const float4*>(P.contrib + (int64_t)su.row * P.ldc + 4 * c), su.coef);
         }
         out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
     } else {
         float acc = 0.f;
         for (int64_t u = u0; u < u1; ++u) {
-            const Src su = contrib_src(P, P.vals[u]);
+            const Src su = contrib_src(P, u);
             add_scaled(acc, P.contrib[(int64_t)su.row * P.ldc + c], su.coef);
         }
         out[0] = acc;
@@ -370,8 +388,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
     const int64_t t0 = w0 + lane;
     const bool in = lane < P.win && t0 < P.n;
     const uint32_t mykey = in ? P.keys[t0] : 0u;
-    const uint32_t myval = in ? P.vals[t0] : 0u;  // the window's contribution indices, one coalesced load
-    const Src mysrc = in ? contrib_src(P, myval) : Src{0u, 0.f};   // and where their rows live (one gather per window)
+    const Src mysrc = in ? contrib_src(P, t0) : Src{0u, 0.f};   // the window's contribution rows: one coalesced load
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
         auto source = [&](int64_t u) -> Src {  // u is uniform inside a subgroup
             const int from = (int)(u < wend ? u - w0 : 0);
             const Src inwin{(uint32_t)__shfl(mysrc.row, from, 64), __shfl(mysrc.coef, from, 64)};
-            return u < wend ? inwin : contrib_src(P, P.vals[u]);
+            return u < wend ? inwin : contrib_src(P, u);
         };
         float* wrow = P.table + (int64_t)key * P.ld;
         float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
@@ -564,6 +581,10 @@ struct WsLayout {
     void* tmp;
     uint32_t *long_list, *long_count;
     float* partial;       // nullptr when the workspace has no room for it (then long segments are summed by one wave)
+    // factored contributions: srcrow in the 4th key-sized region; pos_of_slot | coef in the radix sort's temporary
+    // storage (sized >= 2 key regions), which is free once the sort has run
+    uint32_t *srcrow, *pos_of_slot;
+    float* coef;
 };
 
 static inline size_t partial_rows(int64_t n) { return 2 * ((size_t)n / kLongSegment + 2); }
@@ -574,18 +595,30 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
     if (rc != EMG_OK) return rc;
     o->kb = align256((size_t)n * 4);
     o->temp = tmp;
-    EMG_REQUIRE((int64_t)(4 * o->kb + 256 + align256(tmp)) <= workspace_bytes,
+    const size_t tmp_region = align256(tmp) > 2 * o->kb ? align256(tmp) : 2 * o->kb;   // also holds pos_of_slot | coef
+    EMG_REQUIRE((int64_t)(4 * o->kb + 256 + tmp_region) <= workspace_bytes,
                 "apply workspace too small (%lld < %lld)", (long long)workspace_bytes,
-                (long long)(4 * o->kb + 256 + align256(tmp)));
+                (long long)(4 * o->kb + 256 + tmp_region));
     char* ws = (char*)workspace;
     o->keys = (uint32_t*)ws;
     o->vals = (uint32_t*)(ws + 2 * o->kb);
     o->tmp = ws + 4 * o->kb + 256;
     o->long_list = (uint32_t*)(ws + o->kb);
     o->long_count = (uint32_t*)(ws + 4 * o->kb);
-    const size_t base = 4 * o->kb + 256 + align256(tmp);
+    o->srcrow = (uint32_t*)(ws + 3 * o->kb);
+    o->pos_of_slot = (uint32_t*)o->tmp;
+    o->coef = (float*)((char*)o->tmp + o->kb);
+    const size_t base = 4 * o->kb + 256 + tmp_region;
     const size_t need = partial_rows(n) * (size_t)ldp * sizeof(float);
     o->partial = (ldp > 0 && n > kLongSegment && (int64_t)(base + need) <= workspace_bytes) ? (float*)(ws + base) : nullptr;
+    return EMG_OK;
+}
+
+int factor_view(void* workspace, int64_t workspace_bytes, int64_t n, FactorView* out) {
+    WsLayout w;
+    int rc = ws_layout(workspace, workspace_bytes, n, &w);
+    if (rc != EMG_OK) return rc;
+    out->pos_of_slot = w.pos_of_slot; out->coef = w.coef;
     return EMG_OK;
 }
 
@@ -619,7 +652,7 @@ __global__ __launch_bounds__(BS_THREADS) void block_group_kernel(const int32_t* 
 
 // stable grouping of n destination ids: sorted keys + original positions into the workspace
 static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
-                           uint8_t* single_flags, hipStream_t st) {
+                           uint8_t* single_flags, hipStream_t st, const int32_t* fac_codes = nullptr, int64_t fac_B = 0) {
     WsLayout w;
     int rc = ws_layout(workspace, workspace_bytes, n, &w);
     if (rc != EMG_OK) return rc;
@@ -638,9 +671,9 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
                                                       rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
                                                       end_bit, st, false));
     }
-    if (single_flags) {
+    if (single_flags || fac_codes) {
         hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                           single_flags, w.long_count);
+                           single_flags, w.long_count, fac_codes, (uint32_t)fac_B, w.srcrow, w.pos_of_slot, w.coef);
         EMG_LAUNCH_CHECK();
         counted = true;
     }
@@ -696,7 +729,8 @@ extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) 
     if (n_contrib <= 0) return 256;
     size_t tmp = 0;
     if (sort_temp_bytes(n_contrib, &tmp) != EMG_OK) return -1;
-    return (int64_t)(4 * align256((size_t)n_contrib * 4) + 256 + align256(tmp) + 256);
+    const size_t kb = align256((size_t)n_contrib * 4);
+    return (int64_t)(4 * kb + 256 + (align256(tmp) > 2 * kb ? align256(tmp) : 2 * kb) + 256);
 }
 
 extern "C" int64_t emg_apply_workspace_bytes_ex(int64_t n_contrib, int64_t n_rows, int32_t k_int) {
@@ -739,7 +773,10 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)cdiv(n_neg > a->B ? n_neg : a->B, 256)), dim3(256), 0, st, P);
     EMG_LAUNCH_CHECK();
     const int64_t n_ce = a->n_extra_ent + 2 * a->B + n_neg, n_cr = a->n_extra_rel + a->B;
-    int rc = group_dest_impl(a->dest_ent, n_ce, a->n_ent, a->ws_ent, a->ws_ent_bytes, a->single_flags, st);
+    EMG_REQUIRE(!a->factored || (a->n_extra_ent == 0 && n_ce < ((int64_t)1 << 31)),
+                "emg_prepare_batch: factored contributions exclude caller-filled extra entity rows");
+    int rc = group_dest_impl(a->dest_ent, n_ce, a->n_ent, a->ws_ent, a->ws_ent_bytes, a->single_flags, st,
+                             a->factored ? a->codes : nullptr, a->B);
     if (rc != EMG_OK) return rc;
     return group_dest_impl(a->dest_rel, n_cr, a->n_rel, a->ws_rel, a->ws_rel_bytes, nullptr, st);
 }
@@ -747,8 +784,7 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
 static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
                               float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
                               int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
-                              void* workspace, int64_t workspace_bytes, const int32_t* fac_codes, const float* fac_coef,
-                              int64_t fac_B, void* stream) {
+                              void* workspace, int64_t workspace_bytes, bool factored, void* stream) {
     EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
     EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
@@ -765,7 +801,6 @@ static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld,
     P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = lp_accum;
-    P.fac_codes = fac_codes; P.fac_coef = fac_coef; P.fac_B = (uint32_t)fac_B;
     if (n_contrib > 0) {
         const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
                          (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
@@ -775,6 +810,8 @@ static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld,
         if (rc != EMG_OK) return rc;
         P.keys = w.keys;
         P.vals = w.vals;
+        P.srcrow = factored ? w.srcrow : w.vals;
+        P.coef = factored ? w.coef : nullptr;
         // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
         int win = 64;
         while (win > 1 && n_contrib / win < 16384) win >>= 1;
@@ -821,19 +858,15 @@ extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t 
                                  int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
                                  void* workspace, int64_t workspace_bytes, void* stream) {
     return apply_grouped_impl(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single,
-                              hyper, lp_accum, workspace, workspace_bytes, nullptr, nullptr, 0, stream);
+                              hyper, lp_accum, workspace, workspace_bytes, false, stream);
 }
 
 extern "C" int emg_apply_grouped_factored(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
                                           float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
                                           int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
-                                          void* workspace, int64_t workspace_bytes, const int32_t* codes,
-                                          const float* coef_neg, int64_t B, void* stream) {
-    EMG_REQUIRE(codes && coef_neg && B > 0, "emg_apply_grouped_factored: null codes / coef_neg");
-    EMG_REQUIRE(n_contrib >= 2 * B && n_contrib % B == 0 && n_contrib < ((int64_t)1 << 31),
-                "emg_apply_grouped_factored: n_contrib must be (2 + eta) * B");
+                                          void* workspace, int64_t workspace_bytes, void* stream) {
     return apply_grouped_impl(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single,
-                              hyper, lp_accum, workspace, workspace_bytes, codes, coef_neg, B, stream);
+                              hyper, lp_accum, workspace, workspace_bytes, true, stream);
 }
 
 extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,

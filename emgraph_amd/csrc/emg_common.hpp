@@ -243,6 +243,11 @@ __device__ __forceinline__ void wave_add_double(double* dst, float partial) {
     if (dst && (threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
 }
 
+// What the backward kernel needs of an entity grouping workspace (emg_apply.hip::ws_layout) when contributions are
+// FACTORED: where each negative's slot landed in the sorted order, and the per-position factor array it fills.
+struct FactorView { const uint32_t* pos_of_slot; float* coef; };
+int factor_view(void* workspace, int64_t workspace_bytes, int64_t n, FactorView* out);   // emg_apply.hip
+
 static inline OptParams make_opt_params(int opt, const float* hyper) {
     OptParams o;
     o.opt = opt == EMG_OPT_ADAM_LAZY ? EMG_OPT_ADAM : opt;

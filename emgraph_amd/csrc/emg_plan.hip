@@ -78,6 +78,7 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     a.codes = sl.buf.codes; a.dest_ent = sl.buf.dest_ent; a.n_ent = c.n_ent; a.dest_rel = sl.buf.dest_rel; a.n_rel = c.n_rel;
     a.ws_ent = sl.buf.ws_ent; a.ws_ent_bytes = sl.buf.ws_ent_bytes; a.ws_rel = sl.buf.ws_rel; a.ws_rel_bytes = sl.buf.ws_rel_bytes;
     a.single_flags = c.inplace ? sl.buf.single : nullptr;
+    a.factored = c.factored;
     int rc;
     {
         Timed t(P, ST_PREPARE, st);
@@ -108,7 +109,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
     for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
-    ba.coef_neg = c.coef_neg;
+    if (c.factored) { ba.fac_ws_ent = sl.buf.ws_ent; ba.fac_ws_ent_bytes = sl.buf.ws_ent_bytes; }
     int rc;
     if (c.fused) {
         ba.fused_loss = c.loss;
@@ -155,10 +156,10 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     }
     {
         Timed t(P, ST_APPLY_ENT, main);
-        if (c.coef_neg)
+        if (c.factored)
             rc = emg_apply_grouped_factored(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent,
                                             step, c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr,
-                                            sl.buf.ws_ent, sl.buf.ws_ent_bytes, sl.buf.codes, c.coef_neg, B, main);
+                                            sl.buf.ws_ent, sl.buf.ws_ent_bytes, main);
         else
             rc = emg_apply_grouped(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, step,
                                    c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr, sl.buf.ws_ent,

@@ -166,7 +166,7 @@ struct GroupParams {
     const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
     float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
     OptParams opt;
-    float* coef_neg;                                     // FACTORED contributions (bilinear models): see emg_backward_args
+    FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
 };
 
 #ifndef EMG_BW_THREADS
@@ -423,9 +423,10 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
     // may alias them as far as the compiler knows): a serialised round trip per negative (C3: 0.265 -> 0.251 ms).
     const bool gathered = P.eta + 2 <= LPG;   // kernel-uniform
     const int first = (threadIdx.x & 63) / LPG * LPG;
-    int my_code = 0, my_flag = 0;
+    int my_code = 0, my_flag = 0, my_pos = 0;   // my_pos: where negative lg's factor goes (its slot's sorted position)
     if (gathered) {
         if (lg < P.eta) my_code = P.codes[(int64_t)lg * B + g];
+        if (kBilinear && P.fac.coef && lg < P.eta) my_pos = (int)P.fac.pos_of_slot[(int64_t)lg * B + g];
         if (IP != 0 && lg < P.eta + 2)
             my_flag = P.single_ent[lg < P.eta ? 2 * B + (int64_t)lg * B + g : (int64_t)(lg - P.eta) * B + g];
     }
@@ -517,12 +518,15 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
                 if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
-                else if (kBilinear && P.coef_neg) { if (lg == 0) P.coef_neg[(int64_t)j * B + g] = gi; }   // row = gi * q: q is stored once, below
+                else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
+                    const int at = gathered ? group_lane_value<LPG>(my_pos, first, j) : (int)P.fac.pos_of_slot[(int64_t)j * B + g];
+                    if (lg == 0) P.fac.coef[at] = gi;
+                }
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }
         }
     }
-    if (kBilinear && P.coef_neg && active) {   // the two query rows every factored negative of this group points at
+    if (kBilinear && P.fac.coef && active) {   // the two query rows every factored negative of this group points at
         store_row<MODEL, W, NV, LPG>(qo, P.contrib_ent + (2 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
         store_row<MODEL, W, NV, LPG>(qs, P.contrib_ent + (3 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
@@ -767,10 +771,13 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
     P.fused_loss = a->fused_loss; P.margin = a->margin; P.loss_accum = a->loss_accum;
     P.scores_pos = a->scores_pos_out; P.scores_neg = a->scores_neg_out;
     P.contrib_ent = a->contrib_ent; P.contrib_rel = a->contrib_rel; P.ldc = a->ldc;
-    EMG_REQUIRE(!a->coef_neg || !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
-                "emg_train_backward_ex: factored contributions (coef_neg) need a bilinear model — a TransE gradient row "
-                "depends on the replacement entity");
-    P.coef_neg = a->coef_neg;
+    if (a->fac_ws_ent) {
+        EMG_REQUIRE(!(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
+                    "emg_train_backward_ex: factored contributions need a bilinear model — a TransE gradient row depends "
+                    "on the replacement entity");
+        int rc = factor_view(a->fac_ws_ent, a->fac_ws_ent_bytes, (2 + (int64_t)a->eta) * a->B, &P.fac);
+        if (rc != EMG_OK) return rc;
+    }
     P.single_ent = a->single_ent;
     if (a->single_ent) {
         EMG_REQUIRE(a->opt >= EMG_OPT_SGD && a->opt <= EMG_OPT_ADAM_LAZY, "emg_train_backward_ex: unknown optimizer");

@@ -183,11 +183,11 @@ def build_dest(pos, eta, codes, dest_ent, dest_rel):
 def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
                       margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
                       scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
-                      ent_state0=None, ent_state1=None, tag_ent=None, coef_neg=None):
+                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None):
     """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
-    singleton updates (single_ent flags from group_dest).  ``coef_neg`` (float32 [eta*B], bilinear models): FACTORED
-    entity contributions — ``contrib_ent`` then holds 4*B rows (see include/emgraph_hip.h) and the entity apply is
-    ``apply_grouped(..., factored=(codes, coef_neg, B))``."""
+    singleton updates (single_ent flags from group_dest).  ``fac_ws_ent`` (bilinear models): FACTORED entity
+    contributions — the entity workspace of ``prepare_batch(..., factored=True)`` for this batch; ``contrib_ent`` then
+    holds 4*B rows (see include/emgraph_hip.h) and the entity apply is ``apply_grouped(..., factored=True)``."""
     lib = L.load()
     B = pos.shape[0]
     a = L.BackwardArgs()
@@ -206,7 +206,7 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     a.scores_neg_out = _chk_vec(scores_neg_out, torch.float32, "scores_neg_out", B * eta if scores_neg_out is not None else None)
     pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
     pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
-    if ldc != ldc2 or nce < (4 if coef_neg is not None else 2 + eta) * B or ncr < B:
+    if ldc != ldc2 or nce < (4 if fac_ws_ent is not None else 2 + eta) * B or ncr < B:
         raise ValueError("contribution buffers have the wrong shape")
     a.contrib_ent, a.contrib_rel, a.ldc = pce, pcr, ldc
     a.single_ent = _chk_vec(single_ent, torch.uint8, "single_ent", (2 + eta) * B if single_ent is not None else None)
@@ -219,7 +219,8 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     if ent_state1 is not None:
         a.ent_state1 = _chk_table(ent_state1, "ent_state1")[0]
     a.tag_ent = _chk_vec(tag_ent, torch.int32, "tag_ent")
-    a.coef_neg = _chk_vec(coef_neg, torch.float32, "coef_neg", B * eta if coef_neg is not None else None)
+    if fac_ws_ent is not None:
+        a.fac_ws_ent, a.fac_ws_ent_bytes = fac_ws_ent.data_ptr(), fac_ws_ent.numel() * fac_ws_ent.element_size()
     L.check(lib.emg_train_backward_ex(C.byref(a), _stream()), "emg_train_backward_ex")
 
 
@@ -232,7 +233,7 @@ def group_dest(dest, n, n_rows, workspace, single_flags=None):
 
 def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, n_rel, ws_ent, ws_rel,
                   entities_list=None, seed=0, counter0=0, inj_mask=None, inj_repl=None, n_extra_ent=0, n_extra_rel=0,
-                  single_flags=None, B_global=0, row_offset=0):
+                  single_flags=None, B_global=0, row_offset=0, factored=False):
     """codes of all corruption sides + destination ids + stable grouping (+ singleton flags) in ONE library call.
     ``B_global`` / ``row_offset``: ``pos`` is rows [row_offset, row_offset + B) of a larger (multi-GPU) batch and
     draws the negatives that batch would draw for those rows."""
@@ -257,14 +258,15 @@ def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, 
     a.ws_rel, a.ws_rel_bytes = ws_rel.data_ptr(), ws_rel.numel() * ws_rel.element_size()
     a.single_flags = _chk_vec(single_flags, torch.uint8, "single_flags")
     a.B_global, a.row_offset = int(B_global), int(row_offset)
+    a.factored = 1 if factored else 0
     L.check(lib.emg_prepare_batch(C.byref(a), _stream()), "emg_prepare_batch")
 
 
 def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace,
-                  lp_accum=None, factored=None):
+                  lp_accum=None, factored=False):
     """``hyper`` = (lr, momentum, beta1, beta2, eps, lr_t[, lp_lambda, lp_p]); with lp_lambda != 0 the LP regulariser's
     gradient is folded into every row's update and ``lp_accum`` (device double) receives sum |w|^p.
-    ``factored`` = (codes, coef_neg, B): the contributions were written by ``train_backward_ex(..., coef_neg=...)``."""
+    ``factored``: the contributions were written by ``train_backward_ex(..., fac_ws_ent=workspace)``."""
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")
     p0 = _chk_table(state0, "state0")[0] if state0 is not None else None
@@ -272,20 +274,10 @@ def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_co
     pc, _, ldc = _chk_table(contrib, "contrib")
     h = _hyper8(hyper)
     lp = _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None
-    if factored is not None:
-        codes, coef, B = factored
-        if n_contrib % B or n_contrib < 2 * B:
-            raise ValueError("factored contributions: n_contrib must be (2 + eta) * B")
-        n_neg = n_contrib - 2 * B
-        L.check(lib.emg_apply_grouped_factored(
-            opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc, ldc, n_contrib,
-            int(skip_single), h, lp, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-            _chk_vec(codes, torch.int32, "codes", n_neg), _chk_vec(coef, torch.float32, "coef_neg", n_neg), B,
-            _stream()), "emg_apply_grouped_factored")
-        return
-    L.check(lib.emg_apply_grouped(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc,
-                                  ldc, n_contrib, int(skip_single), h, lp, workspace.data_ptr(),
-                                  workspace.numel() * workspace.element_size(), _stream()), "emg_apply_grouped")
+    fn = lib.emg_apply_grouped_factored if factored else lib.emg_apply_grouped
+    L.check(fn(opt_id, pt, nrows, ld, k_int, p0, p1, _chk_vec(tag, torch.int32, "tag"), step, pc, ldc, n_contrib,
+               int(skip_single), h, lp, workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
+            "emg_apply_grouped_factored" if factored else "emg_apply_grouped")
 
 
 def apply_workspace_views(workspace, n_contrib):

@@ -180,7 +180,7 @@ class Trainer:
         # path of the fused kernel stays free of the pow / sign code, which would cost it a wave per SIMD)
         self.inplace = inplace and self.reg is None
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
-        #            rows) instead of eta full rows per group (emg_backward_args.coef_neg); EMG_FACTORED=0 = A/B switch
+        #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
                          and os.environ.get("EMG_FACTORED", "1") != "0")
         self.pipeline = pipeline
@@ -231,7 +231,6 @@ class Trainer:
         self.g_pos, self.g_neg = self.g_all[:B], self.g_all[B:]
         # factored: subject rows | object rows | query rows (object side) | query rows (subject side)
         self.contrib_ent = torch.empty((4 * B if self.factored else n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
-        self.coef_neg = torch.empty(B * et, dtype=torch.float32, device=dev) if self.factored else None
         self.contrib_rel = torch.empty((n_cr, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.slots = []
         for _ in range(1 + self.lookahead):  # current batch + the ones being prepared ahead
@@ -277,7 +276,7 @@ class Trainer:
         c.scores, c.g = self.scores_all.data_ptr(), self.g_all.data_ptr()
         c.contrib_ent, c.contrib_rel, c.ldc = self.contrib_ent.data_ptr(), self.contrib_rel.data_ptr(), self.contrib_ent.stride(0)
         c.loss_accum, c.lp_sum = self.loss_accum.data_ptr(), self.lp_sum.data_ptr()
-        c.coef_neg = self.coef_neg.data_ptr() if self.factored else None
+        c.factored = int(self.factored)
         if self.reg is not None:
             c.lp_lambda_ent, c.lp_lambda_rel, c.lp_p = self.reg[0], self.reg[1], self.reg[2]
         c.fused, c.inplace, c.normalize = int(self.fused), int(self.inplace), int(self.normalize)
@@ -393,7 +392,8 @@ class Trainer:
             D.prepare_batch(pos, eta, self.sides, n_choices, codes, sl["dest_ent"][:xe + n_ce], sl["dest_rel"][:xr + B],
                             self.n_ent, self.n_rel, sl["ws_ent"], sl["ws_rel"], entities_list=entities_list,
                             seed=self.seed, counter0=counter0, inj_mask=inj_mask, inj_repl=inj_repl, n_extra_ent=xe,
-                            n_extra_rel=xr, single_flags=sl["single"][:n_ce] if self.inplace else None)
+                            n_extra_rel=xr, single_flags=sl["single"][:n_ce] if self.inplace else None,
+                            factored=self.factored)
 
         if self.pipeline:
             side = self.sides_st[self._side_rr]
@@ -454,7 +454,6 @@ class Trainer:
         codes = sl["codes"][:B * et]
         n_ce, n_cr, xe, xr = (2 + et) * B, B, self._xe, self._xr
         ce, cr = self.contrib_ent[xe:xe + n_ce], self.contrib_rel[xr:xr + B]   # batch rows follow the LP rows
-        coef = self.coef_neg[:B * et] if self.factored else None
         if self.factored:
             ce = self.contrib_ent[:4 * B]
         single = sl["single"][:n_ce] if self.inplace else None
@@ -464,7 +463,7 @@ class Trainer:
         lp_e, lp_r = (self.lp_sum[0:1], self.lp_sum[1:2]) if len(hyper_e) == 8 else (None, None)
         inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper_e[:6],
                           ent_state0=self.state_ent[0], ent_state1=self.state_ent[1], tag_ent=self.tag_ent,
-                          coef_neg=coef)
+                          fac_ws_ent=sl["ws_ent"] if self.factored else None)
         if self.fused:
             self._timed("fused", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr,
@@ -504,7 +503,7 @@ class Trainer:
         self._timed("apply_ent", lambda: D.apply_grouped(self.opt_id, self.ent, self.k_int, self.state_ent[0],
                                                          self.state_ent[1], self.tag_ent, self.step_count, ce, n_ce,
                                                          self.inplace, hyper_e, sl["ws_ent"], lp_accum=lp_e,
-                                                         factored=(codes, coef, B) if self.factored else None))
+                                                         factored=self.factored))
         if use_aux:
             main.wait_event(self.aux_join)
         else:

@@ -151,6 +151,10 @@ typedef struct emg_prepare_args {
     void* ws_ent; int64_t ws_ent_bytes; void* ws_rel; int64_t ws_rel_bytes;  /* emg_apply_workspace_bytes */
     uint8_t* single_flags;                                   /* optional out, per entity contribution row */
     int64_t B_global; int64_t row_offset;                    /* batch-sharded draws (see above); 0, 0 = whole batch */
+    /* factored != 0 (bilinear models, n_extra_ent = 0): the entity workspace also receives, per sorted position, the
+     * row of the 4*B-row contribution buffer its slot points at, and per negative slot its sorted position — what
+     * emg_train_backward_ex (fac_ws_ent) and emg_apply_grouped_factored work from. */
+    int32_t factored; int32_t reserved0;
 } emg_prepare_args;
 int emg_prepare_batch(const emg_prepare_args* args, void* stream);
 
@@ -181,11 +185,12 @@ typedef struct emg_backward_args {
     /* FACTORED entity contributions (NULL = off; DistMult / ComplEx / HolE only).  The gradient row of a negative's
      * replacement entity is  gi * q, q being one of the TWO query rows of its triple group (object side: q(s, p);
      * subject side: q(p, o)) — so instead of eta full rows per group the kernel writes q once per side and ONE float
-     * per negative: coef_neg[j*B + g] = gi (float32 [eta*B]; slots updated in place are left unwritten).
+     * per negative.  fac_ws_ent = the entity workspace of the emg_prepare_batch call (factored = 1) for this batch: the
+     * float goes straight to the sorted position of the negative's slot there (slots updated in place write nothing).
      * contrib_ent then has 4*B rows: [0,B) subject rows, [B,2B) object rows, [2B,3B) q object side, [3B,4B) q subject
      * side, and the table apply is emg_apply_grouped_factored (same sums, same order, same bits: it adds the rounded
      * product gi * q exactly where the unfactored path adds the stored row). */
-    float* coef_neg;
+    void* fac_ws_ent; int64_t fac_ws_ent_bytes;
 } emg_backward_args;   /* hyper[6] (folded LP, see emg_apply_grouped) must be 0 when single_ent != NULL */
 int emg_train_backward_ex(const emg_backward_args* args, void* stream);
 
@@ -200,13 +205,12 @@ int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t
                       const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
                       const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, void* stream);
 /* emg_apply_grouped for an entity table whose contributions the backward kernel wrote FACTORED (emg_backward_args.
- * coef_neg): n_contrib = (2 + eta) * B contribution slots as grouped by emg_prepare_batch, `contrib` the 4*B-row
- * buffer, `codes` the batch's corruption codes (bit 31 picks the query row), `coef_neg` the per-negative factors. */
+ * fac_ws_ent = this workspace, grouped by emg_prepare_batch with factored = 1): n_contrib = (2 + eta) * B contribution
+ * slots, `contrib` the 4*B-row buffer. */
 int emg_apply_grouped_factored(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
                                float* state0, float* state1, int32_t* tag, int32_t step,
                                const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
-                               const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes,
-                               const int32_t* codes, const float* coef_neg, int64_t B, void* stream);
+                               const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, void* stream);
 /* LP regulariser folded into the optimizer step (hyper[6] = lambda != 0, hyper[7] = p): the penalty covers the FULL
  * table (regularizers/lp.py:107-113, EmbeddingModel.py:818-820), so its gradient lambda*p*|w|^(p-1)*sign(w) reaches
  * every row.  Rows with contributions (and rows the backward kernel updates in place) add it to their summed
@@ -424,7 +428,7 @@ typedef struct emg_plan_config {
     int64_t cap_B;
     float* scores; float* g; float* contrib_ent; float* contrib_rel; int64_t ldc;
     double* loss_accum; double* lp_sum;              /* lp_sum[2]: sum |w|^p of the entity / relation table */
-    float* coef_neg;                                 /* non-NULL: factored entity contributions (emg_backward_args), float[cap_B * eta * n_sides]; contrib_ent then needs 4 * cap_B rows */
+    int32_t factored; int32_t reserved0;             /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows */
     float lp_lambda_ent; float lp_lambda_rel; int32_t lp_p;   /* folded LP regulariser (0 = none; excludes inplace) */
     int32_t fused; int32_t inplace; int32_t normalize;
     int32_t n_slots; emg_plan_slot slots[4];

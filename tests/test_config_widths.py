@@ -223,17 +223,16 @@ def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kin
     for step in range(1, steps + 1):
         pos = Xt[(step - 1) * B:step * B]
         d.prepare_batch(pos, eta, [L.SIDE_SO], n_ent, codes, de, dr, n_ent, n_rel, we, wr, seed=seed, counter0=step - 1,
-                        single_flags=single if inplace else None)
+                        single_flags=single if inplace else None, factored=factored)
         # poison: nothing may be read that this step did not write
         ce = torch.full((4 * B if factored else n_ce, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
         cr = torch.full((B, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
-        coef = torch.full((B * eta,), float("nan"), dtype=torch.float32, device=dev) if factored else None
         hyper = _hyper(0.002, step)
         d.train_backward_ex(MID[model], Et, Rt, ki, sc, pos, eta, codes, ce, cr, fused_loss=L.LOSS_IDS[loss], margin=1.0,
                             loss_accum=acc, single_ent=single if inplace else None, opt_id=L.OPT_IDS[opt], step=step,
-                            hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, coef_neg=coef)
+                            hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, fac_ws_ent=we if factored else None)
         d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, inplace, hyper, we,
-                        factored=(codes, coef, B) if factored else None)
+                        factored=factored)
         d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, 0, hyper, wr)
         if inplace:
             n_single += int(single.sum().item())
@@ -259,7 +258,7 @@ FACTORED_CASES = {
 @pytest.mark.parametrize("case", list(FACTORED_CASES))
 def test_factored_contributions_are_bit_identical_to_full_rows(case, inplace):
     """eta full gradient rows per triple group (emg_apply_grouped) == two query rows per group + one float per
-    negative (emg_backward_args.coef_neg + emg_apply_grouped_factored), BIT for BIT over three steps: tables, optimizer
+    negative (emg_prepare_args.factored + emg_backward_args.fac_ws_ent + emg_apply_grouped_factored), BIT for BIT over three steps: tables, optimizer
     state, tags, loss.  The factored apply adds the separately rounded product coef * q exactly where the other path
     adds the stored row coef * q, in the same order."""
     from emgraph_amd import device as d
@@ -282,7 +281,7 @@ def test_factored_contributions_refused_for_transe():
     pos = torch.zeros((4, 3), dtype=torch.int32, device=dev)
     codes = torch.zeros(8, dtype=torch.int32, device=dev)
     ce, cr = alloc_table(16, 8, dev), alloc_table(4, 8, dev)
+    ws = torch.empty(d.apply_workspace_bytes(16, 50, 8), dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError, match="bilinear"):
         d.train_backward_ex(MID["TransE_L1"], Et, Rt, 8, 1.0, pos, 2, codes, ce, cr, fused_loss=L.LOSS_IDS["pairwise"],
-                            loss_accum=torch.zeros(1, dtype=torch.float64, device=dev),
-                            coef_neg=torch.zeros(8, dtype=torch.float32, device=dev))
+                            loss_accum=torch.zeros(1, dtype=torch.float64, device=dev), fac_ws_ent=ws)
