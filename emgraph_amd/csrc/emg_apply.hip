@@ -22,6 +22,11 @@
 
 namespace emg {
 
+constexpr int kLongSegment = 64;   // rows; the block size of the long-segment reduction tree
+constexpr int kDeferSegment = 32;  // segments longer than this leave the window kernel (2 rows in flight per trip: a
+                                   // 60-row segment would keep ONE wave busy for 30 dependent trips, ~0.1 ms)
+struct LongTask { uint32_t head, block, len; };   // sorted position of the segment's head, block index, rows of the segment (0 = void)
+
 struct ApplyParams {
     float* table; int64_t n_rows; int64_t ld; int32_t k_int;
     float* state0; float* state1; int32_t* tag; int32_t step;
@@ -30,7 +35,9 @@ struct ApplyParams {
     int32_t skip_single;
     int32_t win;  // sorted positions per wave
     OptParams opt;
-    uint32_t* long_list; uint32_t* long_count; uint32_t long_cap;  // segments longer than kLongSegment (head positions)
+    // segments longer than `defer` rows leave the window kernel as BLOCK TASKS (apply_long_kernel): 64-row blocks of
+    // the segment, summed by independent waves anywhere on the chip; arrive[head / 64] counts a segment's finished blocks
+    LongTask* long_list; uint32_t* long_count; uint32_t long_cap; int32_t* arrive;
     double* lp_accum;  // += sum |w_pre|^p over the rows this launch updates (the caller scales by lambda); may be null
     int32_t defer;     // segments longer than this go to apply_long_kernel
     // Where the gradient row of the contribution at SORTED position t lives and what it is multiplied by.
@@ -66,9 +73,11 @@ __device__ __forceinline__ void add_scaled(float& acc, float v, float coef) {
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ long_count,
                                    const int32_t* __restrict__ fac_codes, uint32_t fac_B, uint32_t* __restrict__ srcrow,
-                                   uint32_t* __restrict__ pos_of_slot, float* __restrict__ coef) {
+                                   uint32_t* __restrict__ pos_of_slot, float* __restrict__ coef,
+                                   int32_t* __restrict__ arrive) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) { long_count[0] = 0u; long_count[1] = 0u; }  // long-segment list of the apply that follows (saves a memset launch)
+    if (t == 0) { long_count[0] = 0u; long_count[1] = 0u; }  // task list of the apply that follows (saves a memset launch)
+    if (t <= n / kLongSegment) arrive[t] = 0;                 // and its per-segment block counters
     if (t >= n) return;
     const uint32_t key = keys[t];
     const uint32_t slot = vals[t];
@@ -99,10 +108,6 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
 //   LONG > 0  : a segment of more than LONG rows (a hub entity of a Zipf-distributed graph collects thousands) is
 //               NOT summed here by one wave (2 300 rows take 0.5 ms that way) but appended to a list for
 //               apply_long_kernel, which spreads its 64-row blocks over the waves of a workgroup.
-constexpr int kLongSegment = 64;   // rows; the block size of the long-segment reduction tree
-constexpr int kDeferSegment = 32;  // segments longer than this leave the window kernel (2 rows in flight per trip: a
-                                   // 60-row segment would keep ONE wave busy for 30 dependent trips, ~0.1 ms)
-constexpr uint32_t kMediumFlag = 0x80000000u;  // list entry: the segment has <= kLongSegment rows (one block, one wave)
 
 template <int W, int DEPTH>
 __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t key, int64_t t, int64_t end, int64_t w0,
@@ -189,6 +194,22 @@ __device__ __forceinline__ void sum_and_update(const ApplyParams& P, uint32_t ke
     if (P.tag && lane == 0) P.tag[key] = P.step;
 }
 
+// first position after `lo` whose key differs, keys[lo] == key given (sorted keys): 64 probes per trip
+__device__ __forceinline__ int64_t segment_end_search(const ApplyParams& P, int64_t lo, uint32_t key, int lane) {
+    int64_t hi = P.n;   // keys[hi] != key or hi == n
+    for (;;) {
+        const int64_t span = hi - lo;          // > 0
+        if (span == 1) return hi;
+        const int64_t step = (span + 63) / 64;  // probes lo + step, lo + 2 step, ...: the last one may reach past hi
+        const int64_t q = lo + (int64_t)(lane + 1) * step;
+        const unsigned long long same = __ballot(q < hi && P.keys[q] == key);   // a prefix of ones
+        const int cnt = __popcll(same);
+        const int64_t lo2 = lo + (int64_t)cnt * step;
+        if (cnt < 64 && lo2 + step < hi) hi = lo2 + step;
+        lo = lo2;
+    }
+}
+
 template <int W, int DEPTH>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     const int lane = threadIdx.x & 63;
@@ -220,31 +241,38 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
                 const unsigned long long same = __ballot(q < P.n && P.keys[q] == key);
                 if (same == ~0ull) {
                     end += 64;
-                    if (P.long_list && end - t > kLongSegment) break;  // long: its exact end is found by apply_long_kernel
+                    if (P.long_list && end - t > kLongSegment) {   // long (a hub row may have thousands): 64-ary search
+                        end = segment_end_search(P, end - 1, key, lane);
+                        break;
+                    }
                     continue;
                 }
                 end += __ffsll((long long)~same) - 1;
                 break;
             }
         }
-        if (P.long_list && end - t > P.defer) {  // hand the segment over (order of the list is irrelevant)
-            if (lane == 0) {
-                const unsigned slot = atomicAdd(P.long_count, 1u);
-                if (slot < P.long_cap) P.long_list[slot] = (uint32_t)t | (end - t <= kLongSegment ? kMediumFlag : 0u);
-            }
-            continue;
+        if (P.long_list && end - t > P.defer) {  // hand the segment over as block tasks (their order is irrelevant)
+            const uint32_t len = (uint32_t)(end - t), nblk = (len + kLongSegment - 1) / kLongSegment;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(P.long_count, nblk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const bool room = base + nblk <= P.long_cap;   // (always: sum of ceil(len / 64) over segments > defer <= n / defer)
+            for (uint32_t b = lane; b < nblk && base + b < P.long_cap; b += 64)
+                P.long_list[base + b] = LongTask{(uint32_t)t, b, room ? len : 0u};
+            if (room) continue;
         }
         sum_and_update<W, DEPTH>(P, key, t, end, w0, wend, mysrc, lane, nchunks, lp_acc);
     }
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-// Deferred segments (P.long_list: sorted position of each one's head, kMediumFlag set for <= kLongSegment rows).
-//   medium (17..64 rows): ONE wave sums the rows left to right, 16 in flight per trip, and updates the table row;
-//   long (> 64 rows)    : the whole 16-wave workgroup.  The reduction tree is defined by the segment alone — block b =
-//       rows [64 b, 64 b + 64) of the segment, summed left to right by one wave, then the block sums are added left
-//       to right and the optimizer update is applied — so the bits do not depend on which wave, window or GPU did what
-//       (a medium segment is the one-block case of the same tree: plain left to right, like the window kernel's).
+// Deferred segments arrive here as BLOCK TASKS (P.long_list): block b = rows [64 b, 64 b + 64) of its segment.
+//   one block (33..64 rows): the task's wave sums the rows left to right, 16 in flight per trip, and updates the table row;
+//   more blocks            : each task's wave — any wave of the launch, so a hub row's thousands of contributions spread
+//       over the whole chip instead of one workgroup — sums its block left to right into the block's partial row; the
+//       wave that finishes a segment's LAST block (arrival counter) adds the block sums left to right and applies the
+//       optimizer.  The reduction tree is defined by the segment alone, so the bits do not depend on which wave, window
+//       or GPU did what (a one-block segment is the same tree: plain left to right, like the window kernel's).
 template <int W>
 __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, float (&out)[W]) {
     if constexpr (W == 4) {
@@ -289,78 +317,104 @@ __device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, 
 
 template <int W>
 __global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, float* __restrict__ partial, int64_t ldp) {
-    __shared__ int64_t end_s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    const unsigned n_long = min(*P.long_count, P.long_cap);
+    const unsigned n_tasks = min(*P.long_count, P.long_cap);
     const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
-    for (unsigned i = blockIdx.x; i < n_long; i += gridDim.x) {  // one list entry per workgroup at a time
-        const uint32_t entry = P.long_list[i];                     // (workgroup-uniform)
-        const int64_t t = entry & ~kMediumFlag;
+    for (unsigned i = blockIdx.x * nwv + wv; i < n_tasks; i += gridDim.x * nwv) {   // one task per wave at a time
+        const LongTask tk = P.long_list[i];                                         // (wave-uniform)
+        if (tk.len == 0) continue;
+        const int64_t t = tk.head, end = t + tk.len;
         const uint32_t key = P.keys[t];
+        if ((int64_t)key >= P.n_rows) continue;  // defensive: never write outside the table
         float* wrow = P.table + (int64_t)key * P.ld;
         float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
         float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
-        if (entry & kMediumFlag) {  // <= 64 rows: wave 0 alone, left to right, 16 rows in flight per trip
-            if (wv == 0 && (int64_t)key < P.n_rows) {
-                const int64_t end = segment_end(P, t, key, lane);
-                for (int c = lane; c < nchunks; c += 64) {
-                    float g[W], w[W];
-                    sum_block<W>(P, t, end, c, g);
+        auto update = [&](int c, float (&g)[W]) {   // optimizer step of columns [W c, W c + W) with summed gradient g
+            float w[W];
 #pragma unroll
-                    for (int j = 0; j < W; ++j) {
-                        w[j] = wrow[W * c + j];
-                        lp_fold(P.opt, w[j], g[j], lp_acc);
-                        opt_update_elem(P.opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
-                        wrow[W * c + j] = w[j];
-                    }
-                }
-                if (P.tag && lane == 0) P.tag[key] = P.step;
+            for (int j = 0; j < W; ++j) {
+                w[j] = wrow[W * c + j];
+                lp_fold(P.opt, w[j], g[j], lp_acc);
+                opt_update_elem(P.opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
+                wrow[W * c + j] = w[j];
             }
-            continue;
-        }
-        __syncthreads();                         // end_s / the partial rows of the previous long segment are done with
-        if (threadIdx.x < 64) {
-            const int64_t e = segment_end(P, t, key, lane);
-            if (lane == 0) end_s = e;
-        }
-        __syncthreads();
-        const int64_t end = end_s;
-        const int64_t nblk = (end - t + kLongSegment - 1) / kLongSegment;
-        // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
-        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one
-        // first-block start (a long segment spans more than 64 positions).
-        for (int64_t b = wv; b < nblk; b += nwv) {
-            const int64_t u0 = t + b * kLongSegment, u1 = min(u0 + kLongSegment, end);
-            float* prow = partial + (2 * (u0 / kLongSegment) + (b == 0 ? 1 : 0)) * ldp;
+        };
+        const int64_t nblk = (tk.len + kLongSegment - 1) / kLongSegment;
+        if (nblk == 1) {
             for (int c = lane; c < nchunks; c += 64) {
                 float g[W];
-                sum_block<W>(P, u0, u1, c, g);
-#pragma unroll
-                for (int j = 0; j < W; ++j) prow[W * c + j] = g[j];
+                sum_block<W>(P, t, end, c, g);
+                update(c, g);
             }
+            if (P.tag && lane == 0) P.tag[key] = P.step;
+            continue;
         }
-        __syncthreads();  // block sums are in global memory, written and read by this workgroup only
-        if ((int64_t)key < P.n_rows) {
-            const int64_t m0 = t / kLongSegment;   // (t + 64 b) / 64 = t / 64 + b
-            for (int c = threadIdx.x; c < nchunks * W; c += blockDim.x) {   // columns over the whole workgroup
-                float acc = partial[(2 * m0 + 1) * ldp + c];                // 0 + first block sum, then left to right
-                int64_t bq = 1;
-                for (; bq + 8 <= nblk; bq += 8) {
-                    float v[8];
+        // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
+        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one
+        // first-block start (a long segment spans more than 64 positions) — and for the same reason t / 64 names the
+        // segment's arrival counter.
+        const int64_t u0 = t + (int64_t)tk.block * kLongSegment, u1 = min(u0 + kLongSegment, end);
+        float* prow = partial + (2 * (u0 / kLongSegment) + (tk.block == 0 ? 1 : 0)) * ldp;
+        for (int c = lane; c < nchunks; c += 64) {
+            float g[W];
+            sum_block<W>(P, u0, u1, c, g);
+            if constexpr (W == 4) store4_through(prow + 4 * c, g[0], g[1], g[2], g[3]);
+            else __hip_atomic_store(prow + c, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wait_memory();   // this wave's block sum has left for memory
+        int before = 0;
+        if (lane == 0) before = atomicAdd(P.arrive + t / kLongSegment, 1);
+        before = __builtin_amdgcn_readfirstlane(before);
+        if (before != (int)nblk - 1) continue;
+        // the segment's last block: every block sum is in memory
+        if (lane == 0) P.arrive[t / kLongSegment] = 0;   // ready for the next apply on this workspace
+        const int64_t m0 = t / kLongSegment;             // (t + 64 b) / 64 = t / 64 + b
+        if constexpr (W == 4) {
+            // two chunks per lane x 8 block sums per trip in flight, added left to right: 0 + first block sum + ...
+            for (int c0 = 0; c0 < nchunks; c0 += 128) {
+                const int ca = c0 + lane, cb = c0 + 64 + lane;
+                const bool oa = ca < nchunks, ob = cb < nchunks;
+                vfloat4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+                const float* first = partial + (2 * m0 + 1) * ldp;
+                if (oa) a = load4_through(first + 4 * ca);
+                if (ob) b = load4_through(first + 4 * cb);
+                wait_memory();
+                landed(a); landed(b);
+                for (int64_t bq = 1; bq < nblk; bq += 8) {
+                    const int cnt = (int)min((int64_t)8, nblk - bq);
+                    vfloat4 va[8], vb[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = partial[2 * (m0 + bq + j) * ldp + c];
+                    for (int j = 0; j < 8; ++j) {
+                        va[j] = vfloat4{0.f, 0.f, 0.f, 0.f}; vb[j] = va[j];
+                        if (j < cnt) {
+                            const float* r = partial + 2 * (m0 + bq + j) * ldp;
+                            if (oa) va[j] = load4_through(r + 4 * ca);
+                            if (ob) vb[j] = load4_through(r + 4 * cb);
+                        }
+                    }
+                    wait_memory();
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc += v[j];
+                    for (int j = 0; j < 8; ++j) {
+                        landed(va[j]); landed(vb[j]);
+                        if (j < cnt) { a += va[j]; b += vb[j]; }
+                    }
                 }
-                for (; bq < nblk; ++bq) acc += partial[2 * (m0 + bq) * ldp + c];
-                float wv_ = wrow[c];
-                lp_fold(P.opt, wv_, acc, lp_acc);
-                opt_update_elem(P.opt, wv_, acc, s0row ? s0row + c : nullptr, s1row ? s1row + c : nullptr);
-                wrow[c] = wv_;
+                float ga[4] = {a.x, a.y, a.z, a.w}, gb[4] = {b.x, b.y, b.z, b.w};
+                if (oa) update(ca, ga);
+                if (ob) update(cb, gb);
             }
-            if (P.tag && threadIdx.x == 0) P.tag[key] = P.step;
+        } else {
+            for (int c = lane; c < nchunks; c += 64) {
+                float acc[W];
+                float a = __hip_atomic_load(partial + (2 * m0 + 1) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int64_t bq = 1; bq < nblk; ++bq)
+                    a += __hip_atomic_load(partial + 2 * (m0 + bq) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[0] = a;
+                update(c, acc);
+            }
         }
+        if (P.tag && lane == 0) P.tag[key] = P.step;
     }
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
     // the last workgroup to finish empties the list, so that a second emg_apply_grouped on the same grouping (or the
@@ -579,7 +633,9 @@ struct WsLayout {
     size_t kb, temp;
     uint32_t *keys, *vals;
     void* tmp;
-    uint32_t *long_list, *long_count;
+    LongTask* long_list;  // first half of the 2nd key-sized region (room for n / 6 tasks; at most n / 8 are ever needed)
+    int32_t* arrive;      // second half of it: n / 64 + 1 per-segment block counters
+    uint32_t* long_count;
     float* partial;       // nullptr when the workspace has no room for it (then long segments are summed by one wave)
     // factored contributions: srcrow in the 4th key-sized region; pos_of_slot | coef in the radix sort's temporary
     // storage (sized >= 2 key regions), which is free once the sort has run
@@ -603,7 +659,8 @@ static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayo
     o->keys = (uint32_t*)ws;
     o->vals = (uint32_t*)(ws + 2 * o->kb);
     o->tmp = ws + 4 * o->kb + 256;
-    o->long_list = (uint32_t*)(ws + o->kb);
+    o->long_list = (LongTask*)(ws + o->kb);
+    o->arrive = (int32_t*)(ws + o->kb + o->kb / 2);
     o->long_count = (uint32_t*)(ws + 4 * o->kb);
     o->srcrow = (uint32_t*)(ws + 3 * o->kb);
     o->pos_of_slot = (uint32_t*)o->tmp;
@@ -630,8 +687,10 @@ constexpr int BS_THREADS = 1024, BS_ITEMS = 16, BS_MAX = BS_THREADS * BS_ITEMS;
 __global__ __launch_bounds__(BS_THREADS) void block_group_kernel(const int32_t* __restrict__ dest, int n, int end_bit,
                                                                  uint32_t* __restrict__ keys_out,
                                                                  uint32_t* __restrict__ vals_out,
-                                                                 uint32_t* __restrict__ long_count) {
+                                                                 uint32_t* __restrict__ long_count,
+                                                                 int32_t* __restrict__ arrive) {
     if (threadIdx.x == 0) { long_count[0] = 0u; long_count[1] = 0u; }
+    for (int i = threadIdx.x; i <= n / kLongSegment; i += BS_THREADS) arrive[i] = 0;
     using sort_t = rocprim::block_radix_sort<uint16_t, BS_THREADS, BS_ITEMS, uint16_t>;
     __shared__ typename sort_t::storage_type storage;
     uint16_t k[BS_ITEMS], v[BS_ITEMS];
@@ -661,7 +720,7 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
     bool counted = false;  // the long-segment counters have been zeroed by one of the kernels below
     if (n <= BS_MAX && end_bit <= 15) {
         hipLaunchKernelGGL(block_group_kernel, dim3(1), dim3(BS_THREADS), 0, st, dest, (int)n, end_bit, w.keys, w.vals,
-                           w.long_count);
+                           w.long_count, w.arrive);
         EMG_LAUNCH_CHECK();
         counted = true;
     } else {
@@ -673,11 +732,14 @@ static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void*
     }
     if (single_flags || fac_codes) {
         hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                           single_flags, w.long_count, fac_codes, (uint32_t)fac_B, w.srcrow, w.pos_of_slot, w.coef);
+                           single_flags, w.long_count, fac_codes, (uint32_t)fac_B, w.srcrow, w.pos_of_slot, w.coef, w.arrive);
         EMG_LAUNCH_CHECK();
         counted = true;
     }
-    if (!counted) EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));  // long-segment list of the apply that follows
+    if (!counted) {  // task list / block counters of the apply that follows
+        EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));
+        EMG_HIP(hipMemsetAsync(w.arrive, 0, (size_t)(n / kLongSegment + 1) * sizeof(int32_t), st));
+    }
     return EMG_OK;
 }
 
@@ -822,9 +884,10 @@ static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld,
         const bool skinny = nch <= 16;
         static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aids
         static const int defer_env = getenv("EMG_DEFER") ? atoi(getenv("EMG_DEFER")) : 0;
-        P.defer = defer_env > 0 ? defer_env : kDeferSegment;
+        P.defer = defer_env >= 8 ? defer_env : kDeferSegment;   // (>= 8: the task list has room for n / 8 tasks)
         if (w.partial && !skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
-            P.long_list = w.long_list; P.long_count = w.long_count; P.long_cap = (uint32_t)(n_contrib / kDeferSegment + 1);
+            P.long_list = w.long_list; P.long_count = w.long_count; P.arrive = w.arrive;
+            P.long_cap = (uint32_t)(n_contrib / (P.defer < kDeferSegment ? P.defer : kDeferSegment) + 1);
         }
         // DEPTH 2 everywhere (measured, C3: relation table 0.121 ms vs 0.148 ms with 16 rows in flight at 2 waves/SIMD,
         // entity table 0.112 vs 0.22): segments of up to 64 rows gain more from 7 waves/SIMD than from deeper trips
@@ -835,9 +898,9 @@ static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld,
         else hipLaunchKernelGGL((apply_rows_kernel<1, 2>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
         if (P.long_list) {
-            // one workgroup (16 waves = a whole CU) per list entry.  Tables with few rows (relations) defer most of
-            // their segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller
-            // grid, whose cost when the list is empty is a few microseconds
+            // one wave per block task, 16 waves per workgroup.  Tables with few rows (relations) defer most of their
+            // segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller grid,
+            // whose cost when the list is empty is a few microseconds
             const int64_t possible = n_contrib / (kDeferSegment + 1) < n_rows ? n_contrib / (kDeferSegment + 1) : n_rows;
             const int64_t most = n_rows <= 4096 ? 256 : 64;
             const unsigned nb = (unsigned)(possible < 1 ? 1 : (possible < most ? possible : most));

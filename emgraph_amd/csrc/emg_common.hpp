@@ -243,6 +243,24 @@ __device__ __forceinline__ void wave_add_double(double* dst, float partial) {
     if (dst && (threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hand-off of rows between waves of ONE launch that may sit on different CUs / XCDs (whose L2s are not coherent):
+// the producer writes THROUGH to memory (sc1), waits until its stores have left (s_waitcnt vmcnt(0)) and bumps a
+// device-scope atomic counter; the consumer that sees the final count reads past its caches (sc1 loads).
+// ---------------------------------------------------------------------------------------------
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4_through(float* p, float a, float b, float c, float d) {
+    const vfloat4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ vfloat4 load4_through(const float* p) {   // issue only: wait_memory() + landed() before use
+    vfloat4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void landed(vfloat4& v) { asm volatile("" : "+v"(v)); }   // orders uses of v behind wait_memory()
+
 // What the backward kernel needs of an entity grouping workspace (emg_apply.hip::ws_layout) when contributions are
 // FACTORED: where each negative's slot landed in the sorted order, and the per-position factor array it fills.
 struct FactorView { const uint32_t* pos_of_slot; float* coef; };

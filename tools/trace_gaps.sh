@@ -3,7 +3,7 @@
 # GPU box: bash tools/trace_gaps.sh
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/trace_gaps; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 bench.py --quick --no-eval --no-cpu --steps 300 --warmup 30 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 bench.py --quick --no-eval --no-cpu --steps 300 --warmup 30 "$@" > $OUT/log.txt 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 rows = []
