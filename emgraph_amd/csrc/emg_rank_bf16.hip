@@ -861,43 +861,59 @@ __global__ void self_ent_kernel(const int32_t* __restrict__ test, int64_t n_q, i
     self_ent[r] = obj ? test[3 * qi + 2] : test[3 * qi + 0];
 }
 
-// filter counts on the bf16-rounded operands; the row's own entity is one tie by construction (see header)
+// Filter counts of the bf16 mode, scored through the SAME MFMA arithmetic as the count kernels: one wave takes 32
+// (query row, filter entity) pairs of the CSR, puts pair i's query row in row i of the A fragments and its entity row in
+// column i of the B fragments and multiplies k-step by k-step in the count kernels' order — element (i, i) of the
+// 32 x 32 product is pair i's score with exactly the bits the count kernel produced for that (row, entity), so what the
+// filter subtracts is what was counted (a sequential fmaf chain differs from the MFMA's internal order in the last
+// bit, which flips (int)(score * 1e5) for a few candidates per million).  31/32 of the product is discarded; filter
+// sets are a few entities per row.  The row's own entity is one tie by construction (see header).
 __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const uint16_t* __restrict__ Q, int64_t ldq,
                                                                 const int32_t* __restrict__ pos_int,
                                                                 const int32_t* __restrict__ self_ent, int64_t n_rows,
                                                                 const uint16_t* __restrict__ ent, int64_t n_local,
-                                                                int64_t ld_ent, int64_t ent_offset, int k_int,
+                                                                int64_t ld_ent, int64_t ent_offset, int k16,
                                                                 float scale, const int64_t* __restrict__ fptr,
                                                                 const int32_t* __restrict__ fidx,
                                                                 int32_t* __restrict__ fgt, int32_t* __restrict__ feq) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= n_rows) return;
-    const int p = pos_int[r];
-    const int self = self_ent[r];
-    const float cmul = (model == EMG_HOLE ? scale : 1.0f) * 100000.0f;
-    const uint16_t* q = Q + r * ldq;
-    int gt = 0, eq = 0;
-    for (int64_t u = fptr[r] + lane; u < fptr[r + 1]; u += 64) {
-        const int gidx = fidx[u];
-        const int64_t e = (int64_t)gidx - ent_offset;
-        if (e < 0 || e >= n_local) continue;
-        if (gidx == self) { eq += 1; continue; }
-        const uint16_t* er = ent + e * ld_ent;
-        float acc = 0.f;
-        for (int k = 0; k < k_int; ++k) acc = fmaf(bf16_to_f32(q[k]), bf16_to_f32(er[k]), acc);
-        const int ci = (int)(acc * cmul);
-        gt += ci > p;
-        eq += ci == p;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int64_t total = fptr[n_rows];  // (the host does not know it: the grid is fixed and strides over the pairs)
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave * 32 < total; wave += n_waves) {
+    const int64_t u = wave * 32 + l31;   // this lane's pair (both half-waves hold the same 32 pairs)
+    // the pair's row: the last r with fptr[r] <= u
+    int64_t lo = 0, hi = n_rows;         // fptr[lo] <= u < fptr[hi]
+    const int64_t uu = min(u, total - 1);
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (fptr[mid] <= uu) lo = mid; else hi = mid;
     }
+    const int64_t r = lo;
+    const int gidx = fidx[uu];
+    const int64_t e = (int64_t)gidx - ent_offset;
+    const bool in_range = u < total && e >= 0 && e < n_local;
+    const bool is_self = in_range && gidx == self_ent[r];
+    const uint16_t* qp = Q + r * ldq + 8 * lhi;
+    const uint16_t* ep = ent + (in_range ? e : 0) * ld_ent + 8 * lhi;
+    f32x16 acc;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        gt += __shfl_xor(gt, off, 64);
-        eq += __shfl_xor(eq, off, 64);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int q = 0; q < k16; ++q) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + q * 16));
+        const bf16x8 b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ep + q * 16));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
-    if (lane == 0) {
-        if (gt) atomicAdd(&fgt[r], gt);
-        if (eq) atomicAdd(&feq[r], eq);
+    // element (row i, column i): column = l31 = i; row i sits in register (i & 3) + 4 (i >> 3) of the half-wave (i >> 2) & 1
+    const int want = (l31 & 3) + 4 * (l31 >> 3);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v = want == i ? acc[i] : v;
+    if (lhi != ((l31 >> 2) & 1) || !in_range) continue;
+    if (is_self) { atomicAdd(&feq[r], 1); continue; }
+    const float cmul = (model == EMG_HOLE ? scale : 1.0f) * 100000.0f;
+    const int ci = (int)(v * cmul), p = pos_int[r];
+    if (ci > p) atomicAdd(&fgt[r], 1);
+    else if (ci == p) atomicAdd(&feq[r], 1);
     }
 }
 
@@ -1046,9 +1062,14 @@ extern "C" int emg_eval_filter_count_bf16(int model, const void* q_bf16, int64_t
     if (n_rows == 0) return EMG_OK;
     EMG_REQUIRE(q_bf16 && pos_int && self_ent && ent_bf16 && filt_ptr && fcnt_gt && fcnt_eq,
                 "emg_eval_filter_count_bf16: null pointer");
-    hipLaunchKernelGGL(filter_count_bf16_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0,
+    EMG_REQUIRE(filt_idx, "emg_eval_filter_count_bf16: null filter index");
+    const int k16 = (k_int + 15) / 16;   // rows are stored zero-padded to a multiple of 64 (emg_eval_count_bf16's contract)
+    EMG_REQUIRE(ldq >= 16 * k16 && ld_ent >= 16 * k16 && ldq % 8 == 0 && ld_ent % 8 == 0 && aligned16(q_bf16) && aligned16(ent_bf16),
+                "emg_eval_filter_count_bf16: rows must be 16-byte aligned and zero-padded to a multiple of 16");
+    const int64_t waves = n_rows < 4096 ? (n_rows < 64 ? 64 : n_rows) : 4096;   // 32 pairs per wave and trip
+    hipLaunchKernelGGL(filter_count_bf16_kernel, dim3((unsigned)cdiv(waves * 64, 256)), dim3(256), 0,
                        (hipStream_t)stream, model, (const uint16_t*)q_bf16, ldq, pos_int, self_ent, n_rows,
-                       (const uint16_t*)ent_bf16, n_local, ld_ent, ent_offset, (int)k_int, scale, filt_ptr, filt_idx,
+                       (const uint16_t*)ent_bf16, n_local, ld_ent, ent_offset, k16, scale, filt_ptr, filt_idx,
                        fcnt_gt, fcnt_eq);
     EMG_LAUNCH_CHECK();
     return EMG_OK;

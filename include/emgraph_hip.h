@@ -312,7 +312,9 @@ int emg_to_bf16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int,
  * with ld >= round_up(k_pad, 64).  emg_eval_pos_int_bf16 writes the true entity of each row (self_ent) and the
  * positive's comparison integer computed by the SAME MFMA arithmetic as the count pass, so the true entity
  * counts as exactly one tie (as in the f32 path); emg_eval_filter_count_bf16 counts a filter list's self entry
- * as that same tie by index, so the filtered rank's self-cancellation stays exact.
+ * as that same tie by index, so the filtered rank's self-cancellation stays exact, and scores every other filter
+ * entry through the same MFMA k-step sequence as the count pass (32 (row, entity) pairs on the diagonal of one
+ * 32x32 product), so a filter entity is subtracted with exactly the comparison result it was counted with.
  * ent_offset: global id of row 0 of `ent_bf16` (slabs); cand: optional row indices. */
 int emg_eval_pos_int_bf16(int model, const void* ent_bf16, int64_t ld_ent, int32_t k_int, float scale,
                           const int32_t* test_spo, int64_t n_q, int side_mode, const void* q_bf16, int64_t ldq,

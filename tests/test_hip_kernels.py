@@ -609,6 +609,71 @@ def test_bf16_stationary_kernel_equals_tile_kernel(model, k, n_ent, nq):
     np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy())
 
 
+@pytest.mark.parametrize("model,k,n_ent", [("ComplEx", 200, 6000), ("DistMult", 200, 3000), ("HolE", 100, 2500),
+                                           ("ComplEx", 64, 1500)])
+def test_bf16_filter_counts_are_what_the_count_kernel_counted(model, k, n_ent):
+    """bf16 mode: the filter correction must cancel EXACTLY what the count pass counted.  For every query row, the
+    (gt, eq) the filter kernel reports over the row's filter list equal the (gt, eq) the MFMA count kernel itself
+    reports over the same entities (candidate list) — same MFMA k-step order, same bits, also on near-ties (rows of
+    E are perturbed copies of the true entity's row, so many scores land within an ulp of the positive's) — and a slab
+    (ent_offset) sees only its own entities."""
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k + n_ent, scale=0.2)
+    rs = np.random.RandomState(k + 1)
+    nq = 48
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    near = []
+    for j in range(nq):            # near-ties: copies of the true object's row, some nudged by one bf16 ulp in one column
+        ids = rs.randint(0, n_ent, 6)
+        E[ids] = E[T[j, 2]]
+        E[ids[:3], rs.randint(0, ki, 3)] *= np.float32(1.0078125)
+        near.append(ids)
+    sc = scale_of(model, k)
+    Q, _ = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    ld = d.bf16_ld(ki)
+    Eb, Qb = d.to_bf16(cu(E), ki, ld_dst=ld), d.to_bf16(Q, ki, ld_dst=ld)
+    pos_int, self_ent = d.eval_pos_int_bf16(MID[model], Eb, ki, sc, cu(T), 3, Qb)
+    n_rows = Qb.shape[0]
+    self_np = self_ent.cpu().numpy()
+    lists = []
+    for r in range(n_rows):        # ragged filter lists: the row's own entity, near-ties of its triple, random others, one empty
+        if r == 5:
+            lists.append(np.zeros(0, np.int32))
+            continue
+        ids = np.concatenate([[self_np[r]], near[r % nq], rs.randint(0, n_ent, rs.randint(0, 40))])
+        lists.append(np.unique(ids).astype(np.int32))
+    ptr = np.zeros(n_rows + 1, np.int64)
+    ptr[1:] = np.cumsum([len(x) for x in lists])
+    idx = np.concatenate(lists).astype(np.int32)
+    got = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    d.eval_filter_count_bf16(MID[model], Qb, pos_int, self_ent, Eb, 0, ki, sc, cu(ptr), cu(idx), got[0], got[1])
+    exp = np.zeros((2, n_rows), np.int32)
+    for r in range(n_rows):
+        if len(lists[r]) == 0:
+            continue
+        one = torch.zeros((2, 1), dtype=torch.int32, device="cuda")
+        d.eval_count_bf16(MID[model], Qb[r:r + 1], pos_int[r:r + 1], self_ent[r:r + 1], Eb, ki, sc, one[0], one[1],
+                          cand=cu(lists[r]))
+        exp[:, r] = one.cpu().numpy()[:, 0]
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    assert exp[1].max() >= 2 and exp[0].sum() > 0            # planted ties and ordinary hits are both exercised
+    # slab: entities [off, off + n_local) only
+    off, n_local = n_ent // 3, n_ent // 2
+    slab = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+    d.eval_filter_count_bf16(MID[model], Qb, pos_int, self_ent, Eb[off:off + n_local], off, ki, sc, cu(ptr), cu(idx),
+                             slab[0], slab[1])
+    exp2 = np.zeros((2, n_rows), np.int32)
+    for r in range(n_rows):
+        inside = lists[r][(lists[r] >= off) & (lists[r] < off + n_local)]
+        if len(inside) == 0:
+            continue
+        one = torch.zeros((2, 1), dtype=torch.int32, device="cuda")
+        d.eval_count_bf16(MID[model], Qb[r:r + 1], pos_int[r:r + 1], self_ent[r:r + 1], Eb, ki, sc, one[0], one[1],
+                          cand=cu(inside))
+        exp2[:, r] = one.cpu().numpy()[:, 0]
+    np.testing.assert_array_equal(slab.cpu().numpy(), exp2)
+
+
 def test_bf16_rank_agreement_with_exact_path():
     """random trained-scale embeddings: bf16 ranks track the exact f32 ranks (statistical contract)"""
     from emgraph_amd.evaluation import rank_triples_device
