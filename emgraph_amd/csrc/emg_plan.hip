@@ -131,6 +131,8 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             if (rc != EMG_OK) return rc;
         }
         ba.fused_loss = -1; ba.g_pos = gp; ba.g_neg = gn;
+        // rows wider than the register-tiled kernel run as column blocks: TransE-L2's gradient then needs the full norms
+        if (c.model == EMG_TRANSE_L2 && c.k_int > 512) { ba.bw_scores_pos = sp; ba.bw_scores_neg = sn; }
         Timed t(P, ST_BACKWARD, main);
         rc = emg_train_backward_ex(&ba, main);
         if (rc != EMG_OK) return rc;

@@ -156,6 +156,7 @@ struct GroupParams {
     const float* ent; int64_t n_ent; int64_t ld_ent;
     const float* rel; int64_t n_rel; int64_t ld_rel;
     int32_t k_int; int32_t khalf; int32_t nchunks; float scale;
+    int32_t width;                                       // columns (per half for complex models) this launch covers; 0 = all
     const int32_t* pos; int64_t B; int32_t eta; const int32_t* codes; int32_t flags;
     float* scores_pos; float* scores_neg;
     // backward / fused
@@ -644,7 +645,7 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st) {
 // returns false when no register-tiled variant fits
 template <int MODEL>
 static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st) {
-    const int n = is_complex<MODEL>::value ? P.khalf : P.k_int;
+    const int n = P.width > 0 ? P.width : (is_complex<MODEL>::value ? P.khalf : P.k_int);
     if (vec) {
         P.nchunks = n / 4;
         const int c = P.nchunks;
@@ -689,9 +690,38 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) 
         case EMG_COMPLEX: ok = dispatch_model<EMG_COMPLEX>(pass, P, vec, st); break;
         case EMG_HOLE: ok = dispatch_model<EMG_HOLE>(pass, P, vec, st); break;
     }
+    if (!ok && pass == Pass::Backward) {
+        // WIDE rows (more than 512 columns per half): given dL/dscore every gradient is separable by column, so the
+        // register-tiled kernel runs once per block of 512 columns on offset pointers (the k-sharded multi-GPU step
+        // does the same across ranks).  TransE-L2's gradient needs the FULL norm: the caller passes the final scores.
+        EMG_REQUIRE(model != EMG_TRANSE_L2 || (P.bw_scores_pos && (P.eta == 0 || P.bw_scores_neg)),
+                    "train backward: TransE-L2 rows wider than 512 columns need bw_scores_pos / bw_scores_neg (the full norms)");
+        constexpr int kBlock = 512;
+        for (int c0 = 0; c0 < n; c0 += kBlock) {
+            GroupParams Q = P;
+            Q.width = n - c0 < kBlock ? n - c0 : kBlock;
+            Q.ent += c0; Q.rel += c0; Q.contrib_ent += c0; Q.contrib_rel += c0;
+            if (Q.ent_rw) Q.ent_rw += c0;
+            if (Q.ent_state0) Q.ent_state0 += c0;
+            if (Q.ent_state1) Q.ent_state1 += c0;
+            bool ok2 = false;
+            switch (model) {
+                case EMG_TRANSE_L1: ok2 = dispatch_model<EMG_TRANSE_L1>(pass, Q, vec, st); break;
+                case EMG_TRANSE_L2: ok2 = dispatch_model<EMG_TRANSE_L2>(pass, Q, vec, st); break;
+                case EMG_DISTMULT: ok2 = dispatch_model<EMG_DISTMULT>(pass, Q, vec, st); break;
+                case EMG_COMPLEX: ok2 = dispatch_model<EMG_COMPLEX>(pass, Q, vec, st); break;
+                case EMG_HOLE: ok2 = dispatch_model<EMG_HOLE>(pass, Q, vec, st); break;
+            }
+            if (!ok2) return fail(EMG_ENOSUP, "train backward: column block of %d does not fit", Q.width);
+            EMG_LAUNCH_CHECK();
+        }
+        return EMG_OK;
+    }
     if (!ok) {
         if (pass != Pass::Forward)
-            return fail(EMG_ENOSUP, "train backward/fused: k_int=%d exceeds the register-tiled limit", P.k_int);
+            return fail(EMG_ENOSUP, "fused score+loss+gradient: rows of k_int=%d are wider than the register-tiled kernel holds "
+                                    "(512 columns per half) — use emg_train_forward + emg_loss + emg_train_backward_ex(fused_loss = -1), "
+                                    "which splits wide rows into column blocks", P.k_int);
         const unsigned grid = (unsigned)cdiv(P.B, kThreads / 64);
         switch (model) {
             case EMG_TRANSE_L1: hipLaunchKernelGGL(train_forward_generic_kernel<EMG_TRANSE_L1>, dim3(grid), dim3(kThreads), 0, st, P); break;

@@ -60,7 +60,6 @@ DEFAULT_UNIFORM_LOW, DEFAULT_UNIFORM_HIGH = -0.05, 0.05
 DEFAULT_NORMAL_MEAN, DEFAULT_NORMAL_STD = 0, 0.05
 DEFAULT_GLOROT_IS_UNIFORM = False
 
-MAX_TRAIN_K = 512  # widest row the register-tiled gradient kernels hold (csrc/emg_score.hip::dispatch_model)
 ENTITY_THRESHOLD = 5e5  # EmbeddingModel.py:37 (kept for API parity; no host paging here)
 
 LOSSES = ("pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll")
@@ -298,10 +297,6 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             msg = "Invalid type for input X. Expected ndarray/EmgraphDataset object, got {}".format(type(X))
             logger.error(msg)
             raise ValueError(msg)
-        if self.k > MAX_TRAIN_K:
-            # the gradient kernels keep a whole row in registers (emg_score.hip: 128 sixteen-byte chunks per lane
-            # group); scoring / ranking have no such limit.  Fail here, not with EMG_ENOSUP inside the first step.
-            raise ValueError("k={} is not supported for training by the HIP path (k <= {})".format(self.k, MAX_TRAIN_K))
         if handle is None:
             self.rel_to_idx, self.ent_to_idx, X_idx = create_mappings_and_index(X)
         else:

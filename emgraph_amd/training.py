@@ -175,7 +175,10 @@ class Trainer:
         #  pipeline: codes + destination grouping of batches t+1, t+2 run on a side stream while batch t computes
         self.batch_sharded = sharded == "batch"
         self.sharded = bool(sharded) and not self.batch_sharded          # k (column) sharding
-        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded
+        # rows wider than 512 columns (per half for ComplEx / HolE) do not fit the register-tiled kernels: the separate
+        # forward / loss / backward path handles them in column blocks (emg_score.hip::run_group_pass)
+        self.wide = (self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int) > 512
+        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide
         # (with an LP regulariser every row goes through the apply kernel, which folds its gradient in: the in-place
         # path of the fused kernel stays free of the pow / sign code, which would cost it a wave per SIMD)
         self.inplace = inplace and self.reg is None
@@ -481,6 +484,8 @@ class Trainer:
                                                   D.finalize_scores(self.model_id, self.scale, sall)))
                 if self.model_id == L.TRANSE_L2:  # its gradient needs the full norm, not the slab's
                     bw = dict(bw_scores_pos=sp, bw_scores_neg=sn)
+            elif self.wide and self.model_id == L.TRANSE_L2:   # column blocks: the same need
+                bw = dict(bw_scores_pos=sp, bw_scores_neg=sn)
             gp, gn = self.g_pos[:B], self.g_neg[:B * et]
             self._timed("loss", lambda: D.loss(self.loss_id, sp, sn, B, eta, self.n_sides, self.margin, self.alpha,
                                                self.loss_accum, gp, gn))

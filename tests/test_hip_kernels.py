@@ -262,6 +262,32 @@ def test_train_backward_vs_oracle(model, k, eta):
     np.testing.assert_allclose(dR, eR, rtol=1e-4, atol=1e-5 * max(np.abs(eR).max(), 1e-6))
 
 
+@pytest.mark.parametrize("model,k", [("TransE_L1", 700), ("TransE_L2", 1030), ("DistMult", 601), ("ComplEx", 520),
+                                     ("HolE", 1100)])
+def test_wide_rows_train_in_column_blocks(model, k):
+    """rows wider than the register-tiled gradient kernels hold (512 columns per half) — the reference accepts any k:
+    the separate forward / loss / backward path splits them into column blocks (TransE-L2 with the full norms from the
+    forward pass).  Trainer.step (plan path) vs the oracle's gradients through one SGD step, tables within fp32 noise."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    n_ent, n_rel, B, eta, lr = 60, 4, 48, 3, 0.5
+    E, R, ki = make_tables(model, k, n_ent, n_rel, seed=k, scale=0.05)   # (scores inside NLL's [-75, 75] clip, nll.py:55-59)
+    rs = np.random.RandomState(k)
+    X = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    tr = Trainer(MID[model], ki, scale_of(model, k), E, R, eta, loss="nll", optimizer="sgd", optimizer_params={"lr": lr},
+                 batches_count=1, seed=3)
+    assert tr.wide and not tr.fused
+    tr.set_training_set(X, B)
+    tr.step(0, B, 1, 1)
+    gotE, gotR = tr.tables_numpy()
+    xneg = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side="s,o", entities_size=n_ent, seed=3, counter=0)
+    dE, dR = orc.train_grads(model, E, R, X, eta, "nll", None, [xneg], k=k)
+    expE, expR = E - lr * dE, R - lr * dR
+    np.testing.assert_allclose(gotE, expE, rtol=2e-4, atol=2e-5 * max(np.abs(dE).max(), 1e-6) * lr + 1e-7)
+    np.testing.assert_allclose(gotR, expR, rtol=2e-4, atol=2e-5 * max(np.abs(dR).max(), 1e-6) * lr + 1e-7)
+    assert np.abs(dE).max() > 0 and np.abs(gotE - E).max() > 0.5 * lr * np.abs(dE).max()      # the step moved the tables
+
+
 @pytest.mark.parametrize("opt", ["sgd", "momentum", "adagrad", "adam", "adam_lazy"])
 def test_apply_rows_vs_oracle(opt):
     d = dev()
