@@ -379,6 +379,9 @@ def run_eval(r, args):
                      "tiles_redone_by_exact_kernel": stf.get("fallback", 0), "kernel_ms": round(stf["count_ms"], 3),
                      "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
     out["exact_fast"] = ex
+    out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
+                              "DistMult / ComplEx / HolE at k_int in {113..128, 193..208, 385..400}, >= 128 test triples, >= 32768 "
+                              "entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
     if not args.quick:
         # query-tile sweep (B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode
         sweep = {}

@@ -235,10 +235,20 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     (prefilter_band), the others — typically 0.1-3 % — are re-scored with the exact f32 chain; shapes the prefilter
     kernel does not cover, and query tiles with too many undecided candidates, take the exact kernel (stats['fallback']).
 
+    ``precision='auto'``: 2 where it applies and pays (contraction model, no candidate list, k_int the prefilter kernel covers, at
+    least 128 test triples against at least 32768 entities), else 0 — the ranks are the same either way.
+
     ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
     (HIP events on the launch stream) and ``count_launches``."""
+    if precision == "auto":
+        # the exact-fast mode returns the SAME ranks as precision 0 (bit for bit) and pays off once the 1-vs-all
+        # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
+        n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
+        wide_enough = any(lo < k_int <= hi for lo, hi in ((112, 128), (192, 208), (384, 400)))
+        precision = 2 if (model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and entities_subset is None and wide_enough
+                          and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
     if precision not in (0, 1, 2):
-        raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA) or 2 (exact via bf16 prefilter)")
+        raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA), 2 (exact via half-precision prefilter) or 'auto' (0 or 2)")
     if precision == 2 and (model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE) or entities_subset is not None):
         precision = 0   # TransE is not a contraction; candidate lists go through the exact kernel: same ranks
     if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):

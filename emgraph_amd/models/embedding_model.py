@@ -131,7 +131,9 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         }
         self.seed = seed
         self.loss_params = loss_params
-        self.embedding_model_params = embedding_model_params
+        # a copy: the subclasses' default dictionaries are shared objects (EmbeddingModel.py has the same mutable defaults;
+        # there a model that edits its params edits every later model's defaults)
+        self.embedding_model_params = dict(embedding_model_params)
         self.k = k
         self.internal_k = k
         self.epochs = epochs
@@ -487,7 +489,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         ranks = rank_triples_device(self._model_id(), ent_f, rel_f, self.internal_k, self._scale(), es["x_valid"],
                                     es["corrupt_side"], DEFAULT_RANK_COMPARE_STRATEGY, filter_triples=es["filter"],
                                     entities_subset=es["subset"],
-                                    shard=parallel.rank_world() if parallel.is_active() else None)
+                                    shard=parallel.rank_world() if parallel.is_active() else None,
+                                    precision=self._eval_precision())
         crit = es["criteria"]
         cur = mrr_score(ranks) if crit == "mrr" else hits_at_n_score(ranks, int(crit[4:]))
         if es["best"] is None:
@@ -612,7 +615,19 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         ent, rel = self._device_tables()
         return rank_triples_device(self._model_id(), ent, rel, self.internal_k, self._scale(), X_idx, corrupt_side,
                                    ranking_strategy, filter_triples=filter_idx, entities_subset=corruption_entities,
-                                   shard=parallel.rank_world() if parallel.is_active() else None)
+                                   shard=parallel.rank_world() if parallel.is_active() else None,
+                                   precision=self._eval_precision())
+
+    def _eval_precision(self):
+        """embedding_model_params['eval_precision'] / EMG_EVAL_PRECISION: 0 exact f32 kernel, 2 exact ranks through the
+        half-precision MFMA prefilter (bit-equal to 0), 1 bf16 throughput mode (statistical agreement only: never picked
+        implicitly), 'auto' (default) = 2 where it applies and pays, else 0."""
+        v = self.embedding_model_params.get("eval_precision", os.environ.get("EMG_EVAL_PRECISION", "auto"))
+        if v in ("auto", 0, 1, 2):
+            return v
+        if str(v) in ("0", "1", "2"):
+            return int(v)
+        raise ValueError("eval_precision must be 0, 1, 2 or 'auto', got {!r}".format(v))
 
 
 @register_model("TransE")

@@ -490,6 +490,37 @@ def test_reference_written_checkpoint_predicts_reference_scores(name, golden):
     assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0))
 
 
+@pytest.mark.parametrize("name,k", [("DistMult", 200), ("ComplEx", 100), ("HolE", 200)])
+def test_default_eval_precision_returns_the_exact_ranks(name, k):
+    """evaluate_performance's default ('auto') takes the half-precision prefilter + exact re-scoring path on large
+    tables: the ranks must equal the exact f32 kernel's (eval_precision=0) for every triple, side and strategy"""
+    import emgraph_amd.models as M
+    from emgraph_amd.evaluation import evaluate_performance
+    X = synth_graph(n_ent=40000, n_rel=7, n=60000, seed=5)
+    m = getattr(M, name)(k=k, eta=2, epochs=2, batches_count=4, seed=1, optimizer="adam", optimizer_params={"lr": 0.05})
+    m.fit(X)
+    Xte = X[:300]
+    for strategy in ("worst", "best", "middle"):
+        m.embedding_model_params["eval_precision"] = 0
+        exact = evaluate_performance(Xte, m, filter_triples=X, corrupt_side="s,o", ranking_strategy=strategy)
+        m.embedding_model_params["eval_precision"] = 2
+        forced = evaluate_performance(Xte, m, filter_triples=X, corrupt_side="s,o", ranking_strategy=strategy)
+        del m.embedding_model_params["eval_precision"]
+        auto = evaluate_performance(Xte, m, filter_triples=X, corrupt_side="s,o", ranking_strategy=strategy)
+        np.testing.assert_array_equal(np.asarray(forced), np.asarray(exact))
+        np.testing.assert_array_equal(np.asarray(auto), np.asarray(exact))
+    # 'auto' really is the prefilter path here (undecided pairs were re-scored, no tile fell back to the exact kernel)
+    from emgraph_amd.evaluation import rank_triples_device
+    ent, rel = m._device_tables()
+    st = {}
+    rank_triples_device(m._model_id(), ent, rel, m.internal_k, m._scale(), Xte, "s,o", "worst", filter_triples=X,
+                        precision="auto", stats=st)
+    assert st.get("pairs", 0) > 0 and st.get("fallback", 0) == 0, st
+    m.embedding_model_params["eval_precision"] = "fast"
+    with pytest.raises(ValueError):
+        evaluate_performance(Xte, m, filter_triples=X)
+
+
 def test_fit_and_evaluate_accept_dataset_adapters(fitted_complex):
     """EmgraphBaseDatasetAdaptor inputs (EmbeddingModel.py:1218-1248, protocol.py:903-929): an adapter holding the
     train / test sets and the filter gives the same parameters and ranks as the bare arrays"""
