@@ -119,6 +119,8 @@ SIGNATURES.update({
     "emg_eval_filter_count_bf16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p,
                                           _p, _p, _p]),
     "emg_eval_scores_dense_bf16": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _p, _i32, _f32, _p, _i64, _p]),
+    "emg_eval_prefilter_bounds": (_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p]),
+    "emg_eval_prefilter_band": (_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p, _p]),
     "emg_eval_prefilter_f16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i64, _p]),
     "emg_eval_prefilter_segments": (_i64, [_i64, _i64]),
     "emg_eval_rescore_pairs": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _p, _p, _p]),

@@ -522,6 +522,60 @@ __global__ void to_f16_kernel(const float* __restrict__ src, int64_t n_rows, int
     dst[t] = c < k_int ? (_Float16)src[r * ld_src + c] : (_Float16)0.f;   // v_cvt_f16_f32: round to nearest even
 }
 
+// ---------------------------------------------------------------------------------------------
+// precision mode 2: the error band of the half-precision prefilter (derivation in the header / DESIGN.md 4.2).
+//   prefilter_bounds_kernel: (max ||e||, max ||e~||, max ||e~ - e||) over the rows of the f32 table and its half copy,
+//   prefilter_band_kernel  : per query row  ||dq|| E~max + ||q|| dEmax + g (||q~|| E~max + ||q|| Emax), rounded UP to float.
+// Norms in float64 (their own roundoff, ~k 2^-53 relative, is far inside the 1e-6 the band is inflated by); a wave per row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_double(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void atomic_max_nonneg(double* dst, double v) {   // v >= 0: the bit patterns order like the values
+    atomicMax(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ __launch_bounds__(256) void prefilter_bounds_kernel(const float* __restrict__ ent, int64_t n_rows, int64_t ld,
+                                                               const _Float16* __restrict__ enth, int64_t ldh, int k_int,
+                                                               double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double m_e = 0.0, m_h = 0.0, m_d = 0.0;   // this wave's maxima of the SQUARED norms
+    for (int64_t r = wave; r < n_rows; r += n_waves) {
+        double se = 0.0, sh = 0.0, sd = 0.0;
+        for (int c = lane; c < k_int; c += 64) {
+            const double e = (double)ent[r * ld + c], h = (double)(float)enth[r * ldh + c], d = h - e;
+            se = fma(e, e, se); sh = fma(h, h, sh); sd = fma(d, d, sd);
+        }
+        m_e = fmax(m_e, wave_sum_double(se)); m_h = fmax(m_h, wave_sum_double(sh)); m_d = fmax(m_d, wave_sum_double(sd));
+    }
+    if (lane == 0) {   // (sqrt is monotonic: the maximum of the norms is the root of the maximum of the squares)
+        atomic_max_nonneg(out + 0, sqrt(m_e)); atomic_max_nonneg(out + 1, sqrt(m_h)); atomic_max_nonneg(out + 2, sqrt(m_d));
+    }
+}
+
+__global__ __launch_bounds__(256) void prefilter_band_kernel(const float* __restrict__ Q, int64_t n_rows, int64_t ldq,
+                                                             const _Float16* __restrict__ Qh, int64_t ldqh, int k_int,
+                                                             const double* __restrict__ bounds, float* __restrict__ band) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    double sq = 0.0, sh = 0.0, sd = 0.0;
+    for (int c = lane; c < k_int; c += 64) {
+        const double q = (double)Q[r * ldq + c], h = (double)(float)Qh[r * ldqh + c], d = h - q;
+        sq = fma(q, q, sq); sh = fma(h, h, sh); sd = fma(d, d, sd);
+    }
+    const double nq = sqrt(wave_sum_double(sq)), nh = sqrt(wave_sum_double(sh)), nd = sqrt(wave_sum_double(sd));
+    if (lane != 0) return;
+    const double e_max = bounds[0], h_max = bounds[1], d_max = bounds[2];
+    const double g = 2.0 * (double)(k_int + 32) * 5.9604644775390625e-08;   // 2 (k + 32) 2^-24
+    const double b = (nd * h_max + nq * d_max + g * (nh * h_max + nq * e_max)) * (1.0 + 1e-6);
+    band[r] = __double2float_ru(b) + 1e-37f;
+}
+
 __global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
                                uint16_t* __restrict__ dst, int64_t ld_dst) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -827,6 +881,30 @@ extern "C" int emg_to_f16(const float* src, int64_t n_rows, int64_t ld_src, int3
     if (n_rows == 0) return EMG_OK;
     hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)cdiv(n_rows * ld_dst, 256)), dim3(256), 0, (hipStream_t)stream, src,
                        n_rows, ld_src, (int)k_int, (_Float16*)dst_f16, ld_dst);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_eval_prefilter_bounds(const float* ent, int64_t n_rows, int64_t ld_ent, const void* ent_f16,
+                                         int64_t ld_f16, int32_t k_int, double* bounds3, void* stream) {
+    EMG_REQUIRE(ent && ent_f16 && bounds3 && n_rows >= 0 && ld_ent >= k_int && ld_f16 >= k_int && k_int > 0,
+                "emg_eval_prefilter_bounds: bad arguments");
+    EMG_HIP(hipMemsetAsync(bounds3, 0, 3 * sizeof(double), (hipStream_t)stream));
+    if (n_rows == 0) return EMG_OK;
+    const int64_t waves = n_rows < 16384 ? n_rows : 16384;   // a few rows per wave, one atomic triple per wave
+    hipLaunchKernelGGL(prefilter_bounds_kernel, dim3((unsigned)cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, ent,
+                       n_rows, ld_ent, (const _Float16*)ent_f16, ld_f16, (int)k_int, bounds3);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t ldq, const void* q_f16, int64_t ldq_f16,
+                                       int32_t k_int, const double* bounds3, float* band, void* stream) {
+    EMG_REQUIRE(n_rows >= 0 && k_int > 0 && ldq >= k_int && ldq_f16 >= k_int, "emg_eval_prefilter_band: bad sizes");
+    if (n_rows == 0) return EMG_OK;
+    EMG_REQUIRE(q && q_f16 && bounds3 && band, "emg_eval_prefilter_band: null pointer");
+    hipLaunchKernelGGL(prefilter_band_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, q,
+                       n_rows, ldq, (const _Float16*)q_f16, ldq_f16, (int)k_int, bounds3, band);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

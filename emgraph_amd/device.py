@@ -480,6 +480,32 @@ def _chk_f16(t, name):
     return t.data_ptr(), t.shape[0], t.stride(0)
 
 
+def eval_prefilter_bounds(ent, ent_f16, k_int):
+    """(max ||e||, max ||e~||, max ||e~ - e||) over the rows of an f32 table (slab) and its half copy: 3 float64 ON THE
+    DEVICE (no host round trip), what ``eval_prefilter_band`` needs of the table"""
+    lib = L.load()
+    pe, n, ld = _chk_table(ent, "ent")
+    ph, nh, ldh = _chk_f16(ent_f16, "ent_f16")
+    if nh != n:
+        raise ValueError("ent_f16 must have the rows of ent")
+    out = torch.empty(3, dtype=torch.float64, device=ent.device)
+    L.check(lib.emg_eval_prefilter_bounds(pe, n, ld, ph, ldh, k_int, out.data_ptr(), _stream()), "emg_eval_prefilter_bounds")
+    return out
+
+
+def eval_prefilter_band(Q, Q_f16, k_int, bounds):
+    """per query row the rigorous bound on |half-precision MFMA accumulator - exact f32 chain| (include/emgraph_hip.h)"""
+    lib = L.load()
+    pq, n, ldq = _chk_table(Q, "Q")
+    ph, nh, ldh = _chk_f16(Q_f16, "Q_f16")
+    if nh != n:
+        raise ValueError("Q_f16 must have the rows of Q")
+    band = torch.empty(n, dtype=torch.float32, device=Q.device)
+    L.check(lib.emg_eval_prefilter_band(pq, n, ldq, ph, ldh, k_int, _chk_vec(bounds, torch.float64, "bounds", 3),
+                                        band.data_ptr(), _stream()), "emg_eval_prefilter_band")
+    return band
+
+
 def eval_prefilter_segments(n_rows, n_cand):
     """number of segments (= waves of the prefilter kernel) the pair buffer is cut into; pair_count has one more entry"""
     return int(L.load().emg_eval_prefilter_segments(n_rows, n_cand))

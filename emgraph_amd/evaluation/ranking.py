@@ -155,17 +155,11 @@ def _ev_collect(stats):
 _U32 = 2.0 ** -24   # unit roundoff of fp32
 
 
-def table_norm_bounds(ent, ent_bf16, k_int, rows=1 << 16):
-    """(max ||e||, max ||e~||, max ||e~ - e||) over the rows of the fp32 table and of its bf16 copy, in float64 —
-    computed from the tensors as they are NOW (a stale bf16 copy only widens the band, it never breaks it)."""
-    e_max = eb_max = de_max = 0.0
-    for r0 in range(0, ent.shape[0], rows):
-        e = ent[r0:r0 + rows, :k_int].double()
-        eb = ent_bf16[r0:r0 + rows, :k_int].double()
-        e_max = max(e_max, float(e.norm(dim=1).max()))
-        eb_max = max(eb_max, float(eb.norm(dim=1).max()))
-        de_max = max(de_max, float((eb - e).norm(dim=1).max()))
-    return e_max, eb_max, de_max
+def table_norm_bounds(ent, ent_f16, k_int):
+    """(max ||e||, max ||e~||, max ||e~ - e||) over the rows of the fp32 table and of its half copy, float64 on the
+    device (emg_eval_prefilter_bounds) — computed from the tensors as they are NOW (a stale copy only widens the
+    band, it never breaks it)."""
+    return D.eval_prefilter_bounds(ent, ent_f16, k_int)
 
 
 def prefilter_band(Q, Qb, k_int, bounds):
@@ -175,14 +169,19 @@ def prefilter_band(Q, Qb, k_int, bounds):
     With q~ = q + dq, e~ = e + de:   sum q~e~ - sum qe = dq.e~ + q.de,  so by Cauchy-Schwarz
         |a - s| <= ||dq|| ||e~|| + ||q|| ||de||  +  g (||q~|| ||e~|| + ||q|| ||e||),
     g = 2 (k + 32) 2^-24 bounding the accumulation error of either sum (standard gamma_k, doubled).  The norms of the
-    residuals are the ACTUAL ones of this query tile / this table, not worst-case roundoff: ~0.4 x 2^-11 relative."""
-    e_max, eb_max, de_max = bounds
+    residuals are the ACTUAL ones of this query tile / this table, not worst-case roundoff: ~0.4 x 2^-11 relative.
+    Evaluated in float64 by emg_eval_prefilter_band (csrc/emg_rank.hip), inflated by 1e-6 and rounded up to float."""
+    return D.eval_prefilter_band(Q, Qb, k_int, bounds)
+
+
+def prefilter_band_reference(Q, Qb, k_int, bounds):
+    """the same bound with torch float64 operations (tests compare the kernel against it)"""
+    e_max, eb_max, de_max = (float(x) for x in bounds)
     q = Q[:, :k_int].double()
     qb = Qb[:, :k_int].double()
     nq, nqb, ndq = q.norm(dim=1), qb.norm(dim=1), (qb - q).norm(dim=1)
     g = 2.0 * (k_int + 32) * _U32
-    band = ndq * eb_max + nq * de_max + g * (nqb * eb_max + nq * e_max)
-    return (band * (1.0 + 1e-6)).float().contiguous() + 1e-37   # rounded outwards
+    return (ndq * eb_max + nq * de_max + g * (nqb * eb_max + nq * e_max)) * (1.0 + 1e-6)
 
 
 class PrefilterTables:

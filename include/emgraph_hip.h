@@ -334,6 +334,16 @@ int emg_eval_filter_count_bf16(int model, const void* q_bf16, int64_t ldq, const
 /* f32 -> IEEE half (round-to-nearest-even) copy of a table / query matrix for precision mode 2; same layout rules
  * as emg_to_bf16 (rows zero-padded to ld_dst >= round_up(k_int, 64)) */
 int emg_to_f16(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, void* dst_f16, int64_t ld_dst, void* stream);
+/* The prefilter's error band.  With q~ = q + dq, e~ = e + de the half-rounded operands:
+ *   |MFMA(q~, e~) - chain(q, e)| <= ||dq|| max||e~|| + ||q|| max||de|| + g (||q~|| max||e~|| + ||q|| max||e||),  g = 2 (k + 32) 2^-24
+ * (Cauchy-Schwarz on dq.e~ + q.de, plus the accumulation error of either sum).  emg_eval_prefilter_bounds writes
+ * bounds3 = (max||e||, max||e~||, max||e~ - e||) over the rows of a table (slab) and its half copy — float64, DEVICE memory;
+ * emg_eval_prefilter_band evaluates the bound per query row from the ACTUAL residual norms of this query tile, inflated
+ * by 1e-6 and rounded up to float: the `band` input of emg_eval_prefilter_f16. */
+int emg_eval_prefilter_bounds(const float* ent, int64_t n_rows, int64_t ld_ent, const void* ent_f16, int64_t ld_f16,
+                              int32_t k_int, double* bounds3, void* stream);
+int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t ldq, const void* q_f16, int64_t ldq_f16,
+                            int32_t k_int, const double* bounds3, float* band, void* stream);
 
 /* ---- exact ranks at MFMA speed (precision mode 2): half-precision MFMA prefilter (v_mfma_f32_32x32x16_f16: 11
  * significant bits, an 8x narrower error band than bf16 at the same rate) + exact re-scoring of the undecided.

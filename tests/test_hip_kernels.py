@@ -700,6 +700,39 @@ def test_bf16_filter_counts_are_what_the_count_kernel_counted(model, k, n_ent):
     np.testing.assert_array_equal(slab.cpu().numpy(), exp2)
 
 
+@pytest.mark.parametrize("k_int,n_ent,nq", [(400, 5000, 300), (200, 777, 65), (37, 100, 3)])
+def test_prefilter_band_kernels_match_float64_math(k_int, n_ent, nq):
+    """emg_eval_prefilter_bounds / emg_eval_prefilter_band (the error band of precision mode 2) against numpy float64:
+    table maxima to 1e-12 relative, every row's band >= the float64 value (rounded UP) and within 1e-6 of it; a row of
+    exact half values has dq = 0, a huge row dominates the maxima."""
+    d = dev()
+    rs = np.random.RandomState(k_int)
+    E = (rs.randn(n_ent, k_int) * 0.3).astype(F32)
+    E[7] *= 50.0                                   # one dominant row
+    E[9] = E[9].astype(np.float16).astype(F32)     # exactly representable: no residual
+    Q = (rs.randn(nq, k_int) * 0.8).astype(F32)
+    Q[1] = Q[1].astype(np.float16).astype(F32)
+    Et, Qt = cu(E), cu(Q)
+    ld = d.bf16_ld(k_int)
+    Eh, Qh = d.to_f16(Et, k_int, ld_dst=ld), d.to_f16(Qt, k_int, ld_dst=ld)
+    b = d.eval_prefilter_bounds(Et, Eh, k_int).cpu().numpy()
+    E64, Eh64 = E.astype(np.float64), E.astype(np.float16).astype(np.float64)
+    exp_b = np.array([np.linalg.norm(E64, axis=1).max(), np.linalg.norm(Eh64, axis=1).max(),
+                      np.linalg.norm(Eh64 - E64, axis=1).max()])
+    np.testing.assert_allclose(b, exp_b, rtol=1e-12)
+    band = d.eval_prefilter_band(Qt, Qh, k_int, cu(b)).cpu().numpy().astype(np.float64)
+    Q64, Qh64 = Q.astype(np.float64), Q.astype(np.float16).astype(np.float64)
+    g = 2.0 * (k_int + 32) * 2.0 ** -24
+    exp = (np.linalg.norm(Qh64 - Q64, axis=1) * exp_b[1] + np.linalg.norm(Q64, axis=1) * exp_b[2]
+           + g * (np.linalg.norm(Qh64, axis=1) * exp_b[1] + np.linalg.norm(Q64, axis=1) * exp_b[0])) * (1.0 + 1e-6)
+    assert np.all(band >= exp * (1.0 - 1e-12))
+    np.testing.assert_allclose(band, exp, rtol=1e-6)
+    # a slab's maxima are its own
+    bs = d.eval_prefilter_bounds(Et[100:], Eh[100:], k_int).cpu().numpy() if n_ent > 200 else None
+    if bs is not None:
+        assert bs[0] < b[0] and abs(bs[0] - np.linalg.norm(E64[100:], axis=1).max()) <= 1e-12 * bs[0]
+
+
 def test_bf16_rank_agreement_with_exact_path():
     """random trained-scale embeddings: bf16 ranks track the exact f32 ranks (statistical contract)"""
     from emgraph_amd.evaluation import rank_triples_device
