@@ -67,9 +67,12 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
                                int32_t* rank_out, void* stream) {
     EMG_REQUIRE(side_mode >= EMG_EVAL_S && side_mode <= EMG_EVAL_S_O, "emg_rank_1vsall: bad side_mode %d", side_mode);
     EMG_REQUIRE(strategy >= 0 && strategy <= 2, "emg_rank_1vsall: strategy must be 0 worst, 1 best, 2 middle");
-    EMG_REQUIRE(precision_mode == 0 || precision_mode == 1, "emg_rank_1vsall: precision_mode %d is not built", precision_mode);
-    EMG_REQUIRE(precision_mode == 0 || (model >= EMG_DISTMULT && model <= EMG_HOLE),
+    EMG_REQUIRE(precision_mode >= 0 && precision_mode <= 2, "emg_rank_1vsall: precision_mode %d is not built", precision_mode);
+    EMG_REQUIRE(precision_mode != 1 || (model >= EMG_DISTMULT && model <= EMG_HOLE),
                 "emg_rank_1vsall: the bf16 mode needs a contraction model (DistMult, ComplEx, HolE)");
+    // mode 2 = the SAME ranks as mode 0 through the half-precision prefilter: where its kernel does not apply (TransE, a
+    // candidate list, an uncovered width, few rows) the exact kernel runs instead — same result either way
+    if (precision_mode == 2 && (!(model >= EMG_DISTMULT && model <= EMG_HOLE) || cand != nullptr)) precision_mode = 0;
     if (n_q == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && test_spo && rank_out, "emg_rank_1vsall: null pointer");
     EMG_REQUIRE((filt_ptr == nullptr) == (filt_idx == nullptr) || filt_ptr, "emg_rank_1vsall: filter CSR needs both arrays");
@@ -87,6 +90,21 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
         se_off = total; total += p_bytes;
         eb_off = total; total += up256((size_t)n_ent * ldb * 2);
     }
+    // precision 2: half copies of Q and the table, the band, the pair buffer (one segment per prefilter wave)
+    size_t band_off = 0, bounds_off = 0, pairs_off = 0, pcount_off = 0;
+    int64_t n_seg = 0, pair_cap = 0;
+    if (precision_mode == 2) {
+        n_seg = emg_eval_prefilter_segments(n_rows, nc);
+        int64_t per = ((int64_t)1 << 27) / (n_seg > 0 ? n_seg : 1);   // <= 1 GiB of pairs in total
+        per = per < 64 ? 64 : (per > 2048 ? 2048 : per);
+        pair_cap = n_seg * per;
+        qb_off = total; total += up256((size_t)n_rows * ldb * 2);
+        eb_off = total; total += up256((size_t)n_ent * ldb * 2);
+        band_off = total; total += p_bytes;
+        bounds_off = total; total += 256;
+        pcount_off = total; total += up256((size_t)(n_seg + 1) * 4);
+        pairs_off = total; total += up256((size_t)pair_cap * 8);
+    }
     char* ws = nullptr;
     EMG_HIP(hipMallocAsync((void**)&ws, total, st));
     float* Q = (float*)ws;
@@ -97,7 +115,42 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     if (hipMemsetAsync(cnt, 0, (size_t)4 * n_rows * 4, st) != hipSuccess) rc = fail(EMG_EHIP, "emg_rank_1vsall: memset failed");
     step(emg_eval_build_queries(model, ent, n_ent, ld_ent, rel, n_rel, ld_rel, k_int, scale, test_spo, n_q, side_mode, Q,
                                 ldq, pos_int, stream));
-    if (precision_mode == 0) {
+    if (precision_mode == 2 && nc > 0) {
+        void* Qh = ws + qb_off;
+        void* Eh = ws + eb_off;
+        float* band = (float*)(ws + band_off);
+        double* bounds = (double*)(ws + bounds_off);
+        uint64_t* pairs = (uint64_t*)(ws + pairs_off);
+        uint32_t* pcount = (uint32_t*)(ws + pcount_off);
+        step(emg_to_f16(ent, n_ent, ld_ent, k_int, Eh, ldb, stream));
+        step(emg_to_f16(Q, n_rows, ldq, k_int, Qh, ldb, stream));
+        step(emg_eval_prefilter_bounds(ent, n_ent, ld_ent, Eh, ldb, k_int, bounds, stream));
+        step(emg_eval_prefilter_band(Q, n_rows, ldq, Qh, ldb, k_int, bounds, band, stream));
+        bool exact = rc != EMG_OK;
+        if (rc == EMG_OK) {
+            const int r = emg_eval_prefilter_f16(model, Qh, ldb, pos_int, band, n_rows, Eh, n_ent, ldb, 0, (k_int + 15) / 16 * 16,
+                                                 scale, cnt, pairs, pcount, pair_cap, stream);
+            if (r == EMG_ENOSUP) exact = true;   // a shape the register-stationary kernel does not cover
+            else step(r);
+        }
+        if (rc == EMG_OK && !exact) {
+            step(emg_eval_rescore_pairs(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg, cnt,
+                                        cnt + n_rows, stream));
+            uint32_t over = 0;   // some wave ran out of pair room: these counters are void, the exact kernel redoes them
+            if (rc == EMG_OK && (hipMemcpyAsync(&over, pcount + n_seg, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                 hipStreamSynchronize(st) != hipSuccess))
+                rc = fail(EMG_EHIP, "emg_rank_1vsall: reading the prefilter's overflow flag failed");
+            exact = over != 0;
+        }
+        if (rc == EMG_OK && exact) {
+            if (hipMemsetAsync(cnt, 0, (size_t)2 * n_rows * 4, st) != hipSuccess) rc = fail(EMG_EHIP, "emg_rank_1vsall: memset failed");
+            step(emg_eval_count(model, Q, ldq, pos_int, n_rows, ent, nc, ld_ent, cand, k_int, scale, 0, nullptr, 0, cnt,
+                                cnt + n_rows, stream));
+        }
+        if (filt_ptr)
+            step(emg_eval_filter_count(model, Q, ldq, pos_int, n_rows, ent, n_ent, ld_ent, 0, k_int, scale, 0, filt_ptr,
+                                       filt_idx, cnt + 2 * n_rows, cnt + 3 * n_rows, stream));
+    } else if (precision_mode == 0 || precision_mode == 2) {
         if (nc > 0)
             step(emg_eval_count(model, Q, ldq, pos_int, n_rows, ent, nc, ld_ent, cand, k_int, scale, 0, nullptr, 0, cnt,
                                 cnt + n_rows, stream));

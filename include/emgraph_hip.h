@@ -388,7 +388,11 @@ int emg_corrupt_fit(const int32_t* pos, int64_t B, int32_t eta, int side, int64_
  * emg_eval_build_queries -> emg_eval_count[_bf16] -> emg_eval_filter_count[_bf16] -> rank assembly
  * (EmbeddingModel.py:1845-2033).  filt_ptr/filt_idx: optional CSR over the n_rows query rows in the row order
  * documented above (object-side rows first), GLOBAL entity ids, each list containing the row's true entity.
- * strategy: 0 worst | 1 best | 2 middle.  precision_mode: 0 exact f32 | 1 bf16 MFMA (statistical agreement).
+ * strategy: 0 worst | 1 best | 2 middle.  precision_mode: 0 exact f32 | 1 bf16 MFMA (statistical agreement) |
+ * 2 the ranks of mode 0, bit for bit, through the half-precision MFMA prefilter + exact re-scoring (emg_to_f16,
+ * emg_eval_prefilter_bounds / _band, emg_eval_prefilter_f16, emg_eval_rescore_pairs; one host synchronisation to read the
+ * overflow flag; the exact kernel takes over for TransE, candidate lists, shapes the prefilter kernel does not cover
+ * and overflowing pair buffers).
  * rank_out int32: [n_q] for side_mode 0,1,2; [n_q,2] = [subject_rank, object_rank] for side_mode 3. */
 int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel,
                     int64_t ld_rel, int32_t k_int, float scale, const int32_t* test_spo, int64_t n_q, int side_mode,

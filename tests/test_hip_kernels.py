@@ -797,6 +797,38 @@ def test_rank_1vsall_one_call_matches_python_path(model):
         np.testing.assert_array_equal(got.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 30000, 300), ("DistMult", 200, 9000, 200), ("HolE", 100, 5000, 150),
+                                              ("DistMult", 24, 700, 60), ("TransE_L1", 40, 900, 40), ("ComplEx", 200, 4000, 50)])
+def test_rank_1vsall_one_call_precision_2_equals_precision_0(model, k, n_ent, nq):
+    """emg_rank_1vsall(precision_mode = 2) == precision_mode 0 for every side and strategy, filtered, with planted exact
+    ties: through the half-precision prefilter where its kernel applies (the first three shapes), through the exact
+    kernel where it does not (an uncovered width, TransE, fewer than 129 query rows, a candidate list)"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex
+    d = dev()
+    E, R, ki = make_tables(model, k, n_ent, 5, seed=k + nq, scale=0.15)
+    rs = np.random.RandomState(nq)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 5, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 5):
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+    Fl = np.concatenate([T, np.stack([rs.randint(0, n_ent, 3000), rs.randint(0, 5, 3000), rs.randint(0, n_ent, 3000)], 1)]).astype(np.int32)
+    F = FilterIndex(Fl)
+    sc = scale_of(model, k)
+    Et, Rt = cu(E), cu(R)
+    for sm in (L.EVAL_S, L.EVAL_O, L.EVAL_SPO, L.EVAL_S_O):
+        ptr, idx = F.csr(T, sm, n_ent, None)
+        for si in range(3):
+            exp = d.rank_1vsall(MID[model], Et, Rt, ki, sc, cu(T), sm, strategy=si, filt_ptr=cu(ptr), filt_idx=cu(idx))
+            got = d.rank_1vsall(MID[model], Et, Rt, ki, sc, cu(T), sm, strategy=si, filt_ptr=cu(ptr), filt_idx=cu(idx),
+                                precision_mode=2)
+            np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy(), err_msg=str((sm, si)))
+    sub = cu(np.arange(0, n_ent, 3).astype(np.int32))
+    ptr, idx = F.csr(T, L.EVAL_S_O, n_ent, np.arange(0, n_ent, 3).astype(np.int32))
+    np.testing.assert_array_equal(
+        d.rank_1vsall(MID[model], Et, Rt, ki, sc, cu(T), L.EVAL_S_O, cand=sub, filt_ptr=cu(ptr), filt_idx=cu(idx), precision_mode=2).cpu().numpy(),
+        d.rank_1vsall(MID[model], Et, Rt, ki, sc, cu(T), L.EVAL_S_O, cand=sub, filt_ptr=cu(ptr), filt_idx=cu(idx)).cpu().numpy())
+
+
 @pytest.mark.parametrize("model,loss,opt,sides", [("ComplEx", "nll", "adam", ("s,o",)), ("TransE_L2", "pairwise", "sgd", ("s", "o")),
                                                   ("DistMult", "self_adversarial", "adagrad", ("s,o",)),
                                                   ("HolE", "multiclass_nll", "momentum", ("s,o",))])
