@@ -151,6 +151,23 @@ SIGNATURES.update({
     "emg_train_step": (_int, [C.POINTER(StepArgs), _p]),
 })
 
+class ApplyArgs(C.Structure):
+    """mirror of `emg_apply_args`"""
+    _fields_ = [
+        ("opt", _i32), ("k_int", _i32), ("table", _p), ("n_rows", _i64), ("ld", _i64),
+        ("state0", _p), ("state1", _p), ("tag", _p), ("step", _i32), ("skip_single", _i32),
+        ("contrib", _p), ("ldc", _i64), ("n_contrib", _i64),
+        ("hyper", _f32 * 8), ("lp_accum", _p), ("workspace", _p), ("workspace_bytes", _i64),
+        ("factored", _i32), ("reserved0", _i32),
+    ]
+
+
+SIGNATURES.update({
+    "emg_apply_grouped_ex": (_int, [C.POINTER(ApplyArgs), _p]),
+    "emg_apply_grouped_pair": (_int, [C.POINTER(ApplyArgs), C.POINTER(ApplyArgs), _p]),
+})
+
+
 class PlanSlot(C.Structure):
     """mirror of `emg_plan_slot`"""
     _fields_ = [("codes", _p), ("dest_ent", _p), ("dest_rel", _p), ("single", _p),

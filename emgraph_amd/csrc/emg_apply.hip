@@ -211,9 +211,9 @@ __device__ __forceinline__ int64_t segment_end_search(const ApplyParams& P, int6
 }
 
 template <int W, int DEPTH>
-__global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
+__device__ __forceinline__ void apply_rows_body(const ApplyParams& P, int64_t block) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave = (block * blockDim.x + threadIdx.x) >> 6;
     const int64_t w0 = wave * P.win;
     const int64_t t0 = w0 + lane;
     const bool in = lane < P.win && t0 < P.n;
@@ -266,6 +266,19 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
+template <int W, int DEPTH>
+__global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyParams P) {
+    apply_rows_body<W, DEPTH>(P, (int64_t)blockIdx.x);
+}
+
+// the entity and the relation table of one training step in ONE launch: blocks [0, blocks0) work on P0, the rest on
+// P1.  (On separate streams the two launches only slowed each other down; one after the other they pay two launches.)
+template <int W, int DEPTH>
+__global__ __launch_bounds__(256) void apply_rows_pair_kernel(const ApplyParams P0, const ApplyParams P1, unsigned blocks0) {
+    if (blockIdx.x < blocks0) apply_rows_body<W, DEPTH>(P0, (int64_t)blockIdx.x);
+    else apply_rows_body<W, DEPTH>(P1, (int64_t)(blockIdx.x - blocks0));
+}
+
 // Deferred segments arrive here as BLOCK TASKS (P.long_list): block b = rows [64 b, 64 b + 64) of its segment.
 //   one block (33..64 rows): the task's wave sums the rows left to right, 16 in flight per trip, and updates the table row;
 //   more blocks            : each task's wave — any wave of the launch, so a hub row's thousands of contributions spread
@@ -316,12 +329,13 @@ __device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, 
 }
 
 template <int W>
-__global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, float* __restrict__ partial, int64_t ldp) {
+__device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, unsigned block,
+                                                unsigned n_blocks) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const unsigned n_tasks = min(*P.long_count, P.long_cap);
     const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
-    for (unsigned i = blockIdx.x * nwv + wv; i < n_tasks; i += gridDim.x * nwv) {   // one task per wave at a time
+    for (unsigned i = block * nwv + wv; i < n_tasks; i += n_blocks * nwv) {   // one task per wave at a time
         const LongTask tk = P.long_list[i];                                         // (wave-uniform)
         if (tk.len == 0) continue;
         const int64_t t = tk.head, end = t + tk.len;
@@ -422,8 +436,21 @@ __global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, f
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(P.long_count + 1, 1u) == gridDim.x - 1) { P.long_count[0] = 0u; P.long_count[1] = 0u; }
+        if (atomicAdd(P.long_count + 1, 1u) == n_blocks - 1) { P.long_count[0] = 0u; P.long_count[1] = 0u; }
     }
+}
+
+template <int W>
+__global__ __launch_bounds__(1024) void apply_long_kernel(const ApplyParams P, float* __restrict__ partial, int64_t ldp) {
+    apply_long_body<W>(P, partial, ldp, blockIdx.x, gridDim.x);
+}
+
+template <int W>
+__global__ __launch_bounds__(1024) void apply_long_pair_kernel(const ApplyParams P0, float* __restrict__ partial0, int64_t ldp0,
+                                                               unsigned blocks0, const ApplyParams P1,
+                                                               float* __restrict__ partial1, int64_t ldp1) {
+    if (blockIdx.x < blocks0) apply_long_body<W>(P0, partial0, ldp0, blockIdx.x, blocks0);
+    else apply_long_body<W>(P1, partial1, ldp1, blockIdx.x - blocks0, gridDim.x - blocks0);
 }
 
 // Variant of apply_rows_kernel for SKINNY rows (<= 16 sixteen-byte chunks: a column slab of an 8-GPU job, TransE
@@ -843,10 +870,17 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     return group_dest_impl(a->dest_rel, n_cr, a->n_rel, a->ws_rel, a->ws_rel_bytes, nullptr, st);
 }
 
-static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
-                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
-                              int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
-                              void* workspace, int64_t workspace_bytes, bool factored, void* stream) {
+// launch geometry of one table's apply, decided once so that two tables can share their launches
+struct ApplyLaunch {
+    bool any = false, vec = false, skinny = false, dense = false;
+    unsigned grid = 0, nb = 0;   // window-kernel workgroups; task-kernel workgroups (0: no task list)
+    float* partial = nullptr; int64_t ldp = 0;
+};
+
+static int apply_setup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                       int32_t* tag, int32_t step, const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
+                       const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, bool factored,
+                       ApplyParams& P, ApplyLaunch& A) {
     EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
     EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
@@ -856,64 +890,128 @@ static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld,
                 "emg_apply_grouped: adam needs state0 and state1");
     EMG_REQUIRE(opt != EMG_OPT_ADAM || tag, "emg_apply_grouped: dense-equivalent adam needs the tag array");
     EMG_REQUIRE(hyper[6] == 0.f || (tag && hyper[7] >= 1.f), "emg_apply_grouped: a folded LP regulariser needs the tag array and p >= 1");
-    hipStream_t st = (hipStream_t)stream;
-    ApplyParams P{};
+    P = ApplyParams{};
+    A = ApplyLaunch{};
     P.table = table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
     P.state0 = state0; P.state1 = state1; P.tag = tag; P.step = step;
     P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = lp_accum;
-    if (n_contrib > 0) {
-        const bool vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
-                         (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
-        const int64_t ldp = (k_int + 3) / 4 * 4;
-        WsLayout w;
-        int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w, ldp);
-        if (rc != EMG_OK) return rc;
-        P.keys = w.keys;
-        P.vals = w.vals;
-        P.srcrow = factored ? w.srcrow : w.vals;
-        P.coef = factored ? w.coef : nullptr;
-        // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
-        int win = 64;
-        while (win > 1 && n_contrib / win < 16384) win >>= 1;
-        if (const char* e = getenv("EMG_APPLY_WIN")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) win = v; }  // A/B aid
-        P.win = win;
-        const dim3 grid((unsigned)cdiv(cdiv(n_contrib, win) * 64, 256)), block(256);
-        const int nch = vec ? k_int / 4 : k_int;
-        const bool skinny = nch <= 16;
-        static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aids
-        static const int defer_env = getenv("EMG_DEFER") ? atoi(getenv("EMG_DEFER")) : 0;
-        P.defer = defer_env >= 8 ? defer_env : kDeferSegment;   // (>= 8: the task list has room for n / 8 tasks)
-        if (w.partial && !skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
-            P.long_list = w.long_list; P.long_count = w.long_count; P.arrive = w.arrive;
-            P.long_cap = (uint32_t)(n_contrib / (P.defer < kDeferSegment ? P.defer : kDeferSegment) + 1);
-        }
+    A.dense = opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f;
+    if (n_contrib <= 0) return EMG_OK;
+    A.any = true;
+    A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
+            (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
+    A.ldp = (k_int + 3) / 4 * 4;
+    WsLayout w;
+    int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w, A.ldp);
+    if (rc != EMG_OK) return rc;
+    P.keys = w.keys;
+    P.vals = w.vals;
+    P.srcrow = factored ? w.srcrow : w.vals;
+    P.coef = factored ? w.coef : nullptr;
+    // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
+    int win = 64;
+    while (win > 1 && n_contrib / win < 16384) win >>= 1;
+    if (const char* e = getenv("EMG_APPLY_WIN")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) win = v; }  // A/B aid
+    P.win = win;
+    A.grid = (unsigned)cdiv(cdiv(n_contrib, win) * 64, 256);
+    const int nch = A.vec ? k_int / 4 : k_int;
+    A.skinny = nch <= 16;
+    static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aids
+    static const int defer_env = getenv("EMG_DEFER") ? atoi(getenv("EMG_DEFER")) : 0;
+    P.defer = defer_env >= 8 ? defer_env : kDeferSegment;   // (>= 8: the task list has room for n / 8 tasks)
+    if (w.partial && !A.skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
+        P.long_list = w.long_list; P.long_count = w.long_count; P.arrive = w.arrive;
+        P.long_cap = (uint32_t)(n_contrib / (P.defer < kDeferSegment ? P.defer : kDeferSegment) + 1);
+        A.partial = w.partial;
+        // one wave per block task, 16 waves per workgroup.  Tables with few rows (relations) defer most of their
+        // segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller grid,
+        // whose cost when the list is empty is a few microseconds
+        const int64_t possible = n_contrib / (kDeferSegment + 1) < n_rows ? n_contrib / (kDeferSegment + 1) : n_rows;
+        const int64_t most = n_rows <= 4096 ? 256 : 64;
+        A.nb = (unsigned)(possible < 1 ? 1 : (possible < most ? possible : most));
+    }
+    return EMG_OK;
+}
+
+static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t st) {
+    if (A.any) {
+        const dim3 grid(A.grid), block(256);
         // DEPTH 2 everywhere (measured, C3: relation table 0.121 ms vs 0.148 ms with 16 rows in flight at 2 waves/SIMD,
-        // entity table 0.112 vs 0.22): segments of up to 64 rows gain more from 7 waves/SIMD than from deeper trips
-        if (skinny) {  // skinny rows: four segments per wave
-            if (vec) hipLaunchKernelGGL((apply_rows_sub_kernel<4, 16>), grid, block, 0, st, P);
+        // entity table 0.112 vs 0.22; alone on the chip the relation apply takes 0.047 / 0.054 / 0.064 ms at 2 / 8 / 16):
+        // segments of up to 64 rows gain more from 7 waves/SIMD than from deeper trips
+        if (A.skinny) {  // skinny rows: four segments per wave
+            if (A.vec) hipLaunchKernelGGL((apply_rows_sub_kernel<4, 16>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((apply_rows_sub_kernel<1, 16>), grid, block, 0, st, P);
-        } else if (vec) hipLaunchKernelGGL((apply_rows_kernel<4, 2>), grid, block, 0, st, P);
+        } else if (A.vec) hipLaunchKernelGGL((apply_rows_kernel<4, 2>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((apply_rows_kernel<1, 2>), grid, block, 0, st, P);
         EMG_LAUNCH_CHECK();
-        if (P.long_list) {
-            // one wave per block task, 16 waves per workgroup.  Tables with few rows (relations) defer most of their
-            // segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller grid,
-            // whose cost when the list is empty is a few microseconds
-            const int64_t possible = n_contrib / (kDeferSegment + 1) < n_rows ? n_contrib / (kDeferSegment + 1) : n_rows;
-            const int64_t most = n_rows <= 4096 ? 256 : 64;
-            const unsigned nb = (unsigned)(possible < 1 ? 1 : (possible < most ? possible : most));
-            if (vec) hipLaunchKernelGGL((apply_long_kernel<4>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
-            else hipLaunchKernelGGL((apply_long_kernel<1>), dim3(nb), dim3(1024), 0, st, P, w.partial, ldp);
+        if (A.nb) {
+            if (A.vec) hipLaunchKernelGGL((apply_long_kernel<4>), dim3(A.nb), dim3(1024), 0, st, P, A.partial, A.ldp);
+            else hipLaunchKernelGGL((apply_long_kernel<1>), dim3(A.nb), dim3(1024), 0, st, P, A.partial, A.ldp);
             EMG_LAUNCH_CHECK();
         }
     }
-    if (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) {
-        hipLaunchKernelGGL(untouched_rows_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, st, P);
+    if (A.dense) {
+        hipLaunchKernelGGL(untouched_rows_kernel, dim3((unsigned)cdiv(P.n_rows * 64, 256)), dim3(256), 0, st, P);
         EMG_LAUNCH_CHECK();
     }
     return EMG_OK;
+}
+
+static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                              int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                              void* workspace, int64_t workspace_bytes, bool factored, void* stream) {
+    ApplyParams P;
+    ApplyLaunch A;
+    int rc = apply_setup(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single, hyper,
+                         lp_accum, workspace, workspace_bytes, factored, P, A);
+    if (rc != EMG_OK) return rc;
+    return apply_launch(P, A, (hipStream_t)stream);
+}
+
+static int setup_from_args(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) {
+    return apply_setup(a->opt, a->table, a->n_rows, a->ld, a->k_int, a->state0, a->state1, a->tag, a->step, a->contrib, a->ldc,
+                       a->n_contrib, a->skip_single, a->hyper, a->lp_accum, a->workspace, a->workspace_bytes, a->factored != 0, P, A);
+}
+
+extern "C" int emg_apply_grouped_ex(const emg_apply_args* a, void* stream) {
+    EMG_REQUIRE(a, "emg_apply_grouped_ex: null args");
+    ApplyParams P;
+    ApplyLaunch A;
+    int rc = setup_from_args(a, P, A);
+    if (rc != EMG_OK) return rc;
+    return apply_launch(P, A, (hipStream_t)stream);
+}
+
+// Two tables (the entity and the relation table of a training step) through SHARED launches: one window kernel, one
+// task kernel.  Same results as two emg_apply_grouped_ex calls; falls back to exactly those where the shapes differ.
+extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream) {
+    EMG_REQUIRE(a && b, "emg_apply_grouped_pair: null args");
+    ApplyParams P0, P1;
+    ApplyLaunch A0, A1;
+    int rc = setup_from_args(a, P0, A0);
+    if (rc == EMG_OK) rc = setup_from_args(b, P1, A1);
+    if (rc != EMG_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool share = A0.any && A1.any && A0.vec && A1.vec && !A0.skinny && !A1.skinny && (A0.nb != 0) == (A1.nb != 0);
+    if (!share) {
+        rc = apply_launch(P0, A0, st);
+        return rc != EMG_OK ? rc : apply_launch(P1, A1, st);
+    }
+    hipLaunchKernelGGL((apply_rows_pair_kernel<4, 2>), dim3(A0.grid + A1.grid), dim3(256), 0, st, P0, P1, A0.grid);
+    EMG_LAUNCH_CHECK();
+    if (A0.nb) {
+        hipLaunchKernelGGL((apply_long_pair_kernel<4>), dim3(A0.nb + A1.nb), dim3(1024), 0, st, P0, A0.partial, A0.ldp, A0.nb, P1,
+                           A1.partial, A1.ldp);
+        EMG_LAUNCH_CHECK();
+    }
+    ApplyLaunch D0 = A0, D1 = A1;   // the dense passes (Keras Adam, folded LP), if any, stay per table
+    D0.any = D1.any = false;
+    rc = apply_launch(P0, D0, st);
+    return rc != EMG_OK ? rc : apply_launch(P1, D1, st);
 }
 
 extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,

@@ -137,41 +137,63 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         rc = emg_train_backward_ex(&ba, main);
         if (rc != EMG_OK) return rc;
     }
-    // the relation table's apply is independent of the entity table's: on its own stream underneath it, when the
-    // batch is large enough for the overlap to pay for the fork / join
-    const bool use_aux = P->aux != nullptr && n_ce >= c.aux_min_rows;
-    hipStream_t rst = main;
-    if (use_aux) {
-        EMG_HIP(hipEventRecord(P->fork, main));
-        EMG_HIP(hipStreamWaitEvent(P->aux, P->fork, 0));
-        rst = P->aux;
-    }
-    auto apply_rel = [&]() {
-        Timed t(P, ST_APPLY_REL, rst);
-        return emg_apply_grouped(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, step,
-                                 c.contrib_rel, c.ldc, B, 0, hr, lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, rst);
+    // The two tables' applies are independent.  Large batches: ONE pair of launches over both groupings
+    // (emg_apply_grouped_pair).  On separate streams the relation apply ran underneath the entity apply but slowed it
+    // down by as much as it saved (C3: entity apply alone 0.10 ms, beside the relation apply 0.12; relation apply alone
+    // 0.047 ms, nearly all of it launch + window preamble) — the aux stream remains as the EMG_PAIR_APPLY=0 A/B path.
+    auto fill = [&](emg_apply_args& aa, bool ent_table) {
+        aa = emg_apply_args{};
+        aa.opt = c.opt; aa.k_int = c.k_int; aa.step = step;
+        const float* h = ent_table ? he : hr;
+        for (int i = 0; i < 8; ++i) aa.hyper[i] = h[i];
+        if (ent_table) {
+            aa.table = c.ent; aa.n_rows = c.n_ent; aa.ld = c.ld_ent; aa.state0 = c.ent_state0; aa.state1 = c.ent_state1;
+            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? 1 : 0; aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
+            aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
+            aa.factored = c.factored;
+        } else {
+            aa.table = c.rel; aa.n_rows = c.n_rel; aa.ld = c.ld_rel; aa.state0 = c.rel_state0; aa.state1 = c.rel_state1;
+            aa.tag = c.tag_rel; aa.skip_single = 0; aa.contrib = c.contrib_rel; aa.n_contrib = B;
+            aa.lp_accum = lp ? c.lp_sum + 1 : nullptr; aa.workspace = sl.buf.ws_rel; aa.workspace_bytes = sl.buf.ws_rel_bytes;
+        }
+        aa.ldc = c.ldc;
     };
-    if (use_aux) {
-        rc = apply_rel();
-        if (rc != EMG_OK) return rc;
-        EMG_HIP(hipEventRecord(P->join, P->aux));
-    }
-    {
+    emg_apply_args ae, ar;
+    fill(ae, true);
+    fill(ar, false);
+    static const bool pair = getenv("EMG_PAIR_APPLY") == nullptr || atoi(getenv("EMG_PAIR_APPLY")) != 0;
+    const bool big = n_ce >= c.aux_min_rows;
+    if (big && pair) {
         Timed t(P, ST_APPLY_ENT, main);
-        if (c.factored)
-            rc = emg_apply_grouped_factored(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent,
-                                            step, c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr,
-                                            sl.buf.ws_ent, sl.buf.ws_ent_bytes, main);
-        else
-            rc = emg_apply_grouped(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, step,
-                                   c.contrib_ent, c.ldc, n_ce, c.inplace ? 1 : 0, he, lp ? c.lp_sum : nullptr, sl.buf.ws_ent,
-                                   sl.buf.ws_ent_bytes, main);
+        rc = emg_apply_grouped_pair(&ae, &ar, main);
         if (rc != EMG_OK) return rc;
-    }
-    if (use_aux) EMG_HIP(hipStreamWaitEvent(main, P->join, 0));
-    else {
-        rc = apply_rel();
-        if (rc != EMG_OK) return rc;
+    } else {
+        const bool use_aux = P->aux != nullptr && big;
+        hipStream_t rst = main;
+        if (use_aux) {
+            EMG_HIP(hipEventRecord(P->fork, main));
+            EMG_HIP(hipStreamWaitEvent(P->aux, P->fork, 0));
+            rst = P->aux;
+        }
+        auto apply_rel = [&]() {
+            Timed t(P, ST_APPLY_REL, rst);
+            return emg_apply_grouped_ex(&ar, rst);
+        };
+        if (use_aux) {
+            rc = apply_rel();
+            if (rc != EMG_OK) return rc;
+            EMG_HIP(hipEventRecord(P->join, P->aux));
+        }
+        {
+            Timed t(P, ST_APPLY_ENT, main);
+            rc = emg_apply_grouped_ex(&ae, main);
+            if (rc != EMG_OK) return rc;
+        }
+        if (use_aux) EMG_HIP(hipStreamWaitEvent(main, P->join, 0));
+        else {
+            rc = apply_rel();
+            if (rc != EMG_OK) return rc;
+        }
     }
     if (c.normalize) {  // EmbeddingModel.py:1434-1440: tf.clip_by_norm(ent_emb, clip_norm=1, axes=1) after each batch
         Timed t(P, ST_CLIP, main);

@@ -280,6 +280,31 @@ def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_co
             "emg_apply_grouped_factored" if factored else "emg_apply_grouped")
 
 
+def _apply_args(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace,
+                lp_accum=None, factored=False):
+    a = L.ApplyArgs()
+    a.opt, a.k_int = opt_id, k_int
+    a.table, a.n_rows, a.ld = _chk_table(table, "table")
+    a.state0 = _chk_table(state0, "state0")[0] if state0 is not None else None
+    a.state1 = _chk_table(state1, "state1")[0] if state1 is not None else None
+    a.tag = _chk_vec(tag, torch.int32, "tag")
+    a.step, a.skip_single = step, int(skip_single)
+    pc, _, ldc = _chk_table(contrib, "contrib")
+    a.contrib, a.ldc, a.n_contrib = pc, ldc, n_contrib
+    for i, v in enumerate(_hyper8(hyper)):
+        a.hyper[i] = v
+    a.lp_accum = _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    a.factored = 1 if factored else 0
+    return a
+
+
+def apply_grouped_pair(first, second):
+    """two tables' applies (each a dict of apply_grouped's arguments) through shared launches (emg_apply_grouped_pair)"""
+    a, b = _apply_args(**first), _apply_args(**second)
+    L.check(L.load().emg_apply_grouped_pair(C.byref(a), C.byref(b), _stream()), "emg_apply_grouped_pair")
+
+
 def apply_workspace_views(workspace, n_contrib):
     """(sorted destination ids, contribution indices) int32 views of a grouping workspace filled by group_dest /
     prepare_batch (layout of emg_apply.hip::ws_layout: keys at byte 0, values at 2 * align256(4 n))"""

@@ -85,7 +85,7 @@ def alloc_table(rows, k_int, device, init=None, fill=None):
 # Two, not more: main + apply_rel stream + 2 side streams = 4 = the HIP runtime's hardware queues per device;
 # a fifth stream is multiplexed onto them and the step got SLOWER (measured 0.47 -> 0.67 ms at 3, 0.73 at 4).
 LOOKAHEAD = int(os.environ.get("EMG_LOOKAHEAD", "2"))
-AUX_MIN_ROWS = 100_000  # entity contribution rows per batch above which apply_rel gets its own stream
+AUX_MIN_ROWS = int(os.environ.get("EMG_AUX_MIN_ROWS", "100000"))  # (env: A/B aid) entity contribution rows per batch above which apply_rel gets its own stream
 
 
 class Trainer:

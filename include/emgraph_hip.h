@@ -211,6 +211,19 @@ int emg_apply_grouped_factored(int opt, float* table, int64_t n_rows, int64_t ld
                                float* state0, float* state1, int32_t* tag, int32_t step,
                                const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
                                const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, void* stream);
+/* emg_apply_grouped[_factored] with every argument in a struct, and the PAIR form: two tables (a training step's entity
+ * and relation table) through shared launches — one window kernel over both groupings, one task kernel over both task
+ * lists.  Same results as two calls; where the two shapes cannot share a launch (scalar or <= 16-chunk rows, only one of
+ * the workspaces sized for tasks) it IS two calls. */
+typedef struct emg_apply_args {
+    int32_t opt; int32_t k_int; float* table; int64_t n_rows; int64_t ld;
+    float* state0; float* state1; int32_t* tag; int32_t step; int32_t skip_single;
+    const float* contrib; int64_t ldc; int64_t n_contrib;
+    float hyper[8]; double* lp_accum; void* workspace; int64_t workspace_bytes;
+    int32_t factored; int32_t reserved0;
+} emg_apply_args;
+int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
+int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);
 /* LP regulariser folded into the optimizer step (hyper[6] = lambda != 0, hyper[7] = p): the penalty covers the FULL
  * table (regularizers/lp.py:107-113, EmbeddingModel.py:818-820), so its gradient lambda*p*|w|^(p-1)*sign(w) reaches
  * every row.  Rows with contributions (and rows the backward kernel updates in place) add it to their summed

@@ -190,7 +190,7 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
 # ------------------------------------------------------------------------------------------------
 # factored entity contributions: a negative's gradient row is (one float) x (a query row of its triple group)
 # ------------------------------------------------------------------------------------------------
-def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kind, steps=3, seed=5):
+def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kind, steps=3, seed=5, pair=False):
     """the C-ABI sequence of fit(): emg_prepare_batch -> emg_train_backward_ex -> emg_apply_grouped[_factored] (entities)
     -> emg_apply_grouped (relations); returns tables, optimizer state, tags and the loss after `steps` batches"""
     from emgraph_amd import _lib as L
@@ -231,9 +231,16 @@ def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kin
         d.train_backward_ex(MID[model], Et, Rt, ki, sc, pos, eta, codes, ce, cr, fused_loss=L.LOSS_IDS[loss], margin=1.0,
                             loss_accum=acc, single_ent=single if inplace else None, opt_id=L.OPT_IDS[opt], step=step,
                             hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, fac_ws_ent=we if factored else None)
-        d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, inplace, hyper, we,
-                        factored=factored)
-        d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, 0, hyper, wr)
+        if pair:   # both tables through shared launches (what emg_plan_step does for large batches)
+            d.apply_grouped_pair(
+                dict(opt_id=L.OPT_IDS[opt], table=Et, k_int=ki, state0=se[0], state1=se[1], tag=tag_e, step=step, contrib=ce,
+                     n_contrib=n_ce, skip_single=inplace, hyper=hyper, workspace=we, factored=factored),
+                dict(opt_id=L.OPT_IDS[opt], table=Rt, k_int=ki, state0=sr[0], state1=sr[1], tag=tag_r, step=step, contrib=cr,
+                     n_contrib=B, skip_single=0, hyper=hyper, workspace=wr))
+        else:
+            d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, inplace, hyper, we,
+                            factored=factored)
+            d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, 0, hyper, wr)
         if inplace:
             n_single += int(single.sum().item())
     torch.cuda.synchronize()
@@ -285,3 +292,16 @@ def test_factored_contributions_refused_for_transe():
     with pytest.raises(RuntimeError, match="bilinear"):
         d.train_backward_ex(MID["TransE_L1"], Et, Rt, 8, 1.0, pos, 2, codes, ce, cr, fused_loss=L.LOSS_IDS["pairwise"],
                             loss_accum=torch.zeros(1, dtype=torch.float64, device=dev), fac_ws_ent=ws)
+
+
+@pytest.mark.parametrize("case", list(FACTORED_CASES))
+def test_pair_apply_is_bit_identical(case):
+    """emg_apply_grouped_pair (entity and relation table through one window launch and one task launch) == the two
+    separate calls, BIT for BIT over three steps — incl. Keras Adam's dense pass, scalar (k % 4 != 0) and <= 16-chunk rows,
+    where the pair call falls back to two launches"""
+    from emgraph_amd import device as d
+    d.require_gpu()
+    one, _ = _run_steps(True, 1, *FACTORED_CASES[case])
+    two, _ = _run_steps(True, 1, *FACTORED_CASES[case], pair=True)
+    for a, b in zip(one, two):
+        np.testing.assert_array_equal(a, b)
