@@ -106,7 +106,7 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r2_d_pmc_traffic.json", "r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
+    for fn in ("r2_e_pmc_traffic.json", "r2_d_pmc_traffic.json", "r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
@@ -217,7 +217,11 @@ class StepRunner:
                              "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
             for name, v in ms.items():
                 ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single)
+                if name == "apply_ent" and "apply_rel" not in ms:   # pair apply: both tables in the same launches
+                    ab += algorithmic_bytes("apply_rel", B, eta, self.k_local, n_ue, n_ur, n_single)
                 out[name] = {"ms": round(v, 4), "alg_bytes": ab, "GBps": round(ab / (v * 1e-3) / 1e9, 1) if ab else None}
+                if name == "apply_ent" and "apply_rel" not in ms:
+                    out[name]["note"] = "entity + relation table through shared launches (emg_apply_grouped_pair)"
                 if getattr(tr, "factored", False) and tr.inplace and name in ("fused", "apply_ent"):
                     flags = sl["single"][:n_ce]
                     n_s_so, n_s_neg = int(flags[:2 * B].sum().item()), int(flags[2 * B:].sum().item())
