@@ -153,3 +153,32 @@ def test_sharded_fit_and_eval_two_ranks_match_single_process(tmp_path, name, los
     np.testing.assert_array_equal(evaluate_performance(X[800:], m, filter_triples=X, corrupt_side="s,o"), res[0]["ranks"])
     np.testing.assert_array_equal(evaluate_performance(X[800:840], m, filter_triples=X, corrupt_side="s+o",
                                                        entities_subset=list(range(0, 80, 3))), res[0]["ranks_sub"])
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_collectives_run(tmp_path):
+    """RCCL itself (backend "nccl" on ROCm) on this box: a one-rank process group is all a single GPU allows — two
+    ranks cannot share a device under RCCL, which is why the two-rank GPU tests above stage their collectives through
+    gloo.  Creates the communicator on cuda:0 and runs the three collectives the sharded paths use (all_reduce of
+    scores / counters, all_gather of slabs, all_to_all_single of gradient rows) in a subprocess of its own."""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+t = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+dist.all_reduce(t)
+g = [torch.empty_like(t)]
+dist.all_gather(g, t)
+o = torch.empty_like(t)
+dist.all_to_all_single(o, t)
+torch.cuda.synchronize()
+assert torch.equal(g[0], t) and torch.equal(o, t) and float(t[12345]) == 12345.0
+dist.destroy_process_group()
+print("rccl ok")
+''' % _free_port()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
