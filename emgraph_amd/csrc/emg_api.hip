@@ -253,6 +253,13 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     pa.dest_rel = dest_rel; pa.n_extra_rel = 0; pa.n_rel = a->n_rel;
     pa.ws_ent = ws + L.ws_ent; pa.ws_ent_bytes = L.ws_ent_bytes; pa.ws_rel = ws + L.ws_rel; pa.ws_rel_bytes = L.ws_rel_bytes;
     pa.single_flags = inplace ? single : nullptr;
+    // bilinear models: a negative's gradient row stays factored (one float x a query row of its group) between the
+    // backward pass and the apply, as in emg_plan_step; rows wider than the register-tiled kernels take the separate
+    // forward / loss / backward path (column blocks)
+    const bool factored = !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2);
+    const bool cplx = a->model == EMG_COMPLEX || a->model == EMG_HOLE;
+    const bool wide = (cplx ? a->k_int / 2 : a->k_int) > 512;
+    pa.factored = factored;
     rc = emg_prepare_batch(&pa, stream);
     if (rc != EMG_OK) return rc;
 
@@ -264,8 +271,9 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     ba.single_ent = inplace ? single : nullptr; ba.opt = a->opt; ba.step = a->step;
     for (int i = 0; i < 8; ++i) ba.hyper[i] = a->hyper[i];
     ba.ent_state0 = a->ent_state0; ba.ent_state1 = a->ent_state1; ba.tag_ent = a->tag_ent;
+    if (factored) { ba.fac_ws_ent = ws + L.ws_ent; ba.fac_ws_ent_bytes = L.ws_ent_bytes; }
     const bool pair_local = a->loss == EMG_LOSS_PAIRWISE || a->loss == EMG_LOSS_NLL || a->loss == EMG_LOSS_ABSOLUTE_MARGIN;
-    if (pair_local) {
+    if (pair_local && !wide) {
         ba.fused_loss = a->loss;
     } else {  // softmax-coupled losses: scores, then the loss kernel, then backward with external dL/dscore
         rc = emg_train_forward(a->model, a->ent, a->n_ent, a->ld_ent, a->rel, a->n_rel, a->ld_rel, a->k_int, a->scale, a->pos,
@@ -274,12 +282,17 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
         rc = emg_loss(a->loss, sp, sn, a->B, a->eta, a->n_sides, a->margin, a->alpha, a->loss_accum, gp, gn, stream);
         if (rc != EMG_OK) return rc;
         ba.fused_loss = -1; ba.g_pos = gp; ba.g_neg = gn;
+        if (wide && a->model == EMG_TRANSE_L2) { ba.bw_scores_pos = sp; ba.bw_scores_neg = sn; }   // column blocks need the full norms
     }
     rc = emg_train_backward_ex(&ba, stream);
     if (rc != EMG_OK) return rc;
-    rc = emg_apply_grouped(a->opt, a->ent, a->n_ent, a->ld_ent, a->k_int, a->ent_state0, a->ent_state1, a->tag_ent, a->step,
-                           ce, L.ldc, L.n_ce, inplace ? 1 : 0, a->hyper, nullptr, ws + L.ws_ent, L.ws_ent_bytes, stream);
-    if (rc != EMG_OK) return rc;
-    return emg_apply_grouped(a->opt, a->rel, a->n_rel, a->ld_rel, a->k_int, a->rel_state0, a->rel_state1, a->tag_rel, a->step,
-                             cr, L.ldc, a->B, 0, a->hyper, nullptr, ws + L.ws_rel, L.ws_rel_bytes, stream);
+    emg_apply_args ae{}, ar{};   // both tables through shared launches
+    ae.opt = ar.opt = a->opt; ae.k_int = ar.k_int = a->k_int; ae.step = ar.step = a->step; ae.ldc = ar.ldc = L.ldc;
+    for (int i = 0; i < 8; ++i) ae.hyper[i] = ar.hyper[i] = a->hyper[i];
+    ae.table = a->ent; ae.n_rows = a->n_ent; ae.ld = a->ld_ent; ae.state0 = a->ent_state0; ae.state1 = a->ent_state1;
+    ae.tag = a->tag_ent; ae.skip_single = inplace ? 1 : 0; ae.contrib = ce; ae.n_contrib = L.n_ce;
+    ae.workspace = ws + L.ws_ent; ae.workspace_bytes = L.ws_ent_bytes; ae.factored = factored;
+    ar.table = a->rel; ar.n_rows = a->n_rel; ar.ld = a->ld_rel; ar.state0 = a->rel_state0; ar.state1 = a->rel_state1;
+    ar.tag = a->tag_rel; ar.contrib = cr; ar.n_contrib = a->B; ar.workspace = ws + L.ws_rel; ar.workspace_bytes = L.ws_rel_bytes;
+    return emg_apply_grouped_pair(&ae, &ar, stream);
 }
