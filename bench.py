@@ -410,7 +410,7 @@ def run_eval(r, args):
         dtt = time.perf_counter() - t0
         lane_ops = 2.0 * kt_ * w["n_ent"] * 2 * len(Tt) / world   # one subtract + one |.|-accumulate per (row, entity, k)
         out["transe_l1"] = {"value": round(2 * len(Tt) / dtt, 1), "unit": "ranks/s", "test_triples": len(Tt), "k": kt_,
-                            "kernel": "count_transe_kernel (f32 VALU)", "kernel_ms": round(stt["count_ms"], 3),
+                            "kernel": "count_transe_big_kernel (f32 VALU, 128x128 tiles, 8x8 per thread)", "kernel_ms": round(stt["count_ms"], 3),
                             "roofline": {"bound": "valu", "achieved": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12, 2),
                                          "peak": MFMA_F32_PEAK_TF / 2, "unit": "T lane-op/s (f32 VALU: 157.3 TFLOP/s counts an FMA as 2)",
                                          "frac": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12 / (MFMA_F32_PEAK_TF / 2), 4)}}

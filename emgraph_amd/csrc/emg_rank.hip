@@ -13,6 +13,8 @@
 // acc + |q_k - e_k|; L2: fmaf(d,d,acc)).  The MFMA kernel, the positive scorer and the filter
 // scorer all produce exactly that chain, so the test entity and every filter entity compare
 // identically wherever they are scored.
+#include <stdlib.h>
+
 #include "emg_common.hpp"
 
 // The canonical order below is only canonical if the compiler never fuses a*b+c on its own:
@@ -376,6 +378,138 @@ __global__ __launch_bounds__(256) void count_transe_kernel(const CountParams P) 
                 if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
                 if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransE count kernel, large form: 128 queries x 128 entities per block, 8 x 8 per thread, 16-wide k tiles double-
+// buffered in LDS with the next tile's 16-byte global loads in flight under the arithmetic.  Per k-step a thread
+// reads 4 x 16 bytes from LDS for 64 (query, entity) pairs x 2 VALU instructions (the 4 x 4 form above: 2 reads per
+// 16 pairs, single-buffered, scalar global loads: 33 % of the VALU peak).  Every pair still accumulates |q_k - e_k|
+// (or (q_k - e_k)^2) in ascending k in one register: same bits.  Needs 16-byte aligned rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int UQ = 128, UE = 128, UK = 16;
+
+template <bool L2>
+__global__ __launch_bounds__(256) void count_transe_big_kernel(const CountParams P) {
+    __shared__ __attribute__((aligned(16))) float Qs[2][UK * UQ];
+    __shared__ __attribute__((aligned(16))) float Es[2][UK * UE];
+    __shared__ int pos_s[UQ];
+    __shared__ unsigned cnt_s[UQ];
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot = id >> 3;
+    const int64_t qb = slot % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x;
+    const int tq = tid & 15, te = tid >> 4;
+    const int lrow = tid & 127, lk = tid >> 7;   // loader: row lrow, 16-byte slots lk and lk + 2 of the 16-wide k tile
+
+    if (tid < UQ) {
+        const int64_t qr = qb * UQ + tid;
+        pos_s[tid] = qr < P.n_rows ? P.pos_int[qr] : 0x7fffffff;
+        cnt_s[tid] = 0u;
+    }
+    const int64_t qrow_g = min(qb * UQ + lrow, P.n_rows - 1);   // clamped: rows past the end count nothing (pos = INT_MAX)
+    const float* qptr = P.Q + qrow_g * P.ldq;
+    const int nkt = (P.k_int + UK - 1) / UK;
+
+    unsigned cnt[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) cnt[a] = 0u;
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int64_t tile1 = min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles);
+    for (int64_t tile = tile0; tile < tile1; ++tile) {
+        const int64_t el = min(tile * UE + lrow, P.n_cand - 1);
+        const float* eptr = P.ent + (P.cand ? (int64_t)P.cand[el] : el) * P.ld_ent;
+        float4 gq[2], ge[2];
+        auto fetch = [&](int kt) {   // k-tile kt of this thread's query row and entity row -> registers (zeros past k_int)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kb = kt * UK + 4 * (lk + 2 * h);
+                gq[h] = ge[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kb + 4 <= P.k_int) {
+                    gq[h] = *reinterpret_cast<const float4*>(qptr + kb);
+                    ge[h] = *reinterpret_cast<const float4*>(eptr + kb);
+                } else if (kb < P.k_int) {
+                    float tq4[4] = {0.f, 0.f, 0.f, 0.f}, te4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < 4; ++c)
+                        if (kb + c < P.k_int) { tq4[c] = qptr[kb + c]; te4[c] = eptr[kb + c]; }
+                    gq[h] = make_float4(tq4[0], tq4[1], tq4[2], tq4[3]);
+                    ge[h] = make_float4(te4[0], te4[1], te4[2], te4[3]);
+                }
+            }
+        };
+        auto stage = [&](int buf) {   // registers -> LDS, k-major
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kl = 4 * (lk + 2 * h);
+                Qs[buf][(kl + 0) * UQ + lrow] = gq[h].x; Qs[buf][(kl + 1) * UQ + lrow] = gq[h].y;
+                Qs[buf][(kl + 2) * UQ + lrow] = gq[h].z; Qs[buf][(kl + 3) * UQ + lrow] = gq[h].w;
+                Es[buf][(kl + 0) * UE + lrow] = ge[h].x; Es[buf][(kl + 1) * UE + lrow] = ge[h].y;
+                Es[buf][(kl + 2) * UE + lrow] = ge[h].z; Es[buf][(kl + 3) * UE + lrow] = ge[h].w;
+            }
+        };
+        float acc[8][8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
+        fetch(0);
+        __syncthreads();       // (the previous tile's readers are done with buffer 0)
+        stage(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) fetch(kt + 1);   // in flight under the arithmetic below
+            __syncthreads();                   // buffer `buf` is staged; buffer 1 - buf is free again
+#pragma unroll 4
+            for (int k = 0; k < UK; ++k) {
+                const float4 q0 = *reinterpret_cast<const float4*>(&Qs[buf][k * UQ + 4 * tq]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&Qs[buf][k * UQ + 64 + 4 * tq]);
+                const float4 e0 = *reinterpret_cast<const float4*>(&Es[buf][k * UE + 4 * te]);
+                const float4 e1 = *reinterpret_cast<const float4*>(&Es[buf][k * UE + 64 + 4 * te]);
+                const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const float d = q[a] - e[b];   // (nothing here can contract: one rounding per operation, as __f*_rn)
+                        if constexpr (L2) acc[a][b] = __builtin_fmaf(d, d, acc[a][b]);
+                        else asm("v_add_f32 %0, %0, |%1|" : "+v"(acc[a][b]) : "v"(d));   // |d| as a source modifier of the add: hipcc emits
+                                                                                             // v_and + v_pk_add otherwise (2.5 VALU per pair)
+                    }
+            }
+            if (kt + 1 < nkt) stage(1 - buf);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int ql = (a < 4 ? 0 : 64) + 4 * tq + (a & 3);
+            const int p = pos_s[ql];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int64_t ecol = tile * UE + (b < 4 ? 0 : 64) + 4 * te + (b & 3);
+                const bool cok = ecol < P.n_cand;
+                const float v = L2 ? -sqrtf(acc[a][b]) : -acc[a][b];
+                const int ci = cmp_int(v);
+                cnt[a] += (unsigned)(cok && ci > p) + ((unsigned)(cok && ci == p) << 16);
+            }
+        }
+    }
+    // per thread <= 8 * tiles_per_chunk per field; 16 threads share a query row
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (cnt[a]) atomicAdd(&cnt_s[(a < 4 ? 0 : 64) + 4 * tq + (a & 3)], cnt[a]);
+    __syncthreads();
+    if (tid < UQ) {
+        const int64_t qr = qb * UQ + tid;
+        const unsigned c = cnt_s[tid];
+        if (qr < P.n_rows) {
+            if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+            if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
         }
     }
 }
@@ -754,7 +888,17 @@ static int launch_count(bool dense, int model, CountParams& P, int precision, hi
     const int64_t blocks = 8 * P.n_qb * cdiv(P.n_cb, 8);
     EMG_REQUIRE(blocks < ((int64_t)1 << 31), "emg_eval_count: grid too large");
     const dim3 grid((unsigned)blocks), block(256);
-    if (transe) {
+    static const bool transe_big = getenv("EMG_TRANSE_BIG") == nullptr || atoi(getenv("EMG_TRANSE_BIG")) != 0;   // A/B aid
+    if (transe && !dense && transe_big && (P.ldq % 4 == 0) && (P.ld_ent % 4 == 0) && aligned16(P.Q) && aligned16(P.ent)) {
+        P.n_qb = cdiv(P.n_rows, UQ);
+        P.n_tiles = cdiv(P.n_cand, UE);
+        P.tiles_per_chunk = 32;   // 4096 entities per chunk; 8 x 32 counts per thread and field stay far below 16 bits
+        P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
+        const int64_t blocksb = 8 * P.n_qb * cdiv(P.n_cb, 8);
+        EMG_REQUIRE(blocksb < ((int64_t)1 << 31), "emg_eval_count: grid too large");
+        if (model == EMG_TRANSE_L1) hipLaunchKernelGGL((count_transe_big_kernel<false>), dim3((unsigned)blocksb), block, 0, st, P);
+        else hipLaunchKernelGGL((count_transe_big_kernel<true>), dim3((unsigned)blocksb), block, 0, st, P);
+    } else if (transe) {
         if (model == EMG_TRANSE_L1) {
             if (dense) hipLaunchKernelGGL((count_transe_kernel<false, true>), grid, block, 0, st, P);
             else hipLaunchKernelGGL((count_transe_kernel<false, false>), grid, block, 0, st, P);
