@@ -48,23 +48,49 @@ def create_mappings_and_index(X):
     return rel_to_idx, ent_to_idx, X_idx
 
 
+_LOOKUP_CACHE = []   # [(mapping, len, sorted keys, their ids, direct table or None)]: the last few dictionaries looked up
+
+
+def _lookup_tables(mapping):
+    """sorted key / id arrays of a label dictionary (+ a direct label -> id table for dense non-negative integer labels),
+    remembered for the dictionaries most recently used: evaluate_performance maps the test set and the (large) filter
+    set through the same two dictionaries every call."""
+    for ent in _LOOKUP_CACHE:
+        if ent[0] is mapping and ent[1] == len(mapping):
+            return ent[2], ent[3], ent[4]
+    keys = np.array(list(mapping.keys()))
+    vals = np.fromiter(mapping.values(), dtype=np.int64, count=len(mapping))
+    order = np.argsort(keys, kind="stable")
+    skeys, svals = keys[order], vals[order]
+    table = None
+    if skeys.dtype.kind in "iu" and len(skeys) and int(skeys[0]) >= 0 and int(skeys[-1]) < 8 * len(skeys) + 1024:
+        table = np.full(int(skeys[-1]) + 1, -1, dtype=np.int64)
+        table[skeys] = svals
+    _LOOKUP_CACHE.insert(0, (mapping, len(mapping), skeys, svals, table))
+    del _LOOKUP_CACHE[4:]
+    return skeys, svals, table
+
+
 def _lookup(col, mapping):
     """vectorised dict lookup; returns (ids, ok_mask)."""
     if len(mapping) == 0:
         return np.zeros(len(col), np.int64), np.zeros(len(col), bool)
-    keys = np.array(list(mapping.keys()))
-    vals = np.fromiter(mapping.values(), dtype=np.int64, count=len(mapping))
+    skeys, svals, table = _lookup_tables(mapping)
     col = np.asarray(col)
-    if keys.dtype.kind != col.dtype.kind and not (keys.dtype.kind in "US" and col.dtype.kind in "US"):
+    if skeys.dtype.kind != col.dtype.kind and not (skeys.dtype.kind in "US" and col.dtype.kind in "US") \
+            and not (skeys.dtype.kind in "iu" and col.dtype.kind in "iu"):
         got = [mapping.get(v) for v in col.tolist()]
         ok = np.array([g is not None for g in got], dtype=bool)
         return np.array([g if g is not None else 0 for g in got], dtype=np.int64), ok
-    order = np.argsort(keys, kind="stable")
-    skeys = keys[order]
+    if table is not None and col.dtype.kind in "iu":   # dense integer labels: one gather
+        inside = (col >= 0) & (col < len(table))
+        ids = table[np.where(inside, col, 0)]
+        ok = inside & (ids >= 0)
+        return np.where(ok, ids, 0), ok
     pos = np.searchsorted(skeys, col)
     pos_c = np.minimum(pos, len(skeys) - 1)
     ok = skeys[pos_c] == col
-    return vals[order][pos_c], ok
+    return svals[pos_c], ok
 
 
 def to_idx(X, ent_to_idx, rel_to_idx):

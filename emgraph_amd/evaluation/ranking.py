@@ -30,6 +30,21 @@ def _expand_ranges(lo, hi):
     return idx, owner
 
 
+def _stable_argsort(key):
+    """stable argsort of non-negative int64 keys.  Large key sets that fit 31 bits go through the library's stable radix
+    sort on the GPU (emg_group_dest: the grouping the training step uses; 1M keys in well under a millisecond + two 4 MB
+    copies, against ~75 ms for numpy's merge sort); anything else — small sets, wide keys, a GPU-less host — through numpy.
+    Both orders are THE stable order, so the index is the same either way."""
+    n = len(key)
+    if n >= 100_000 and torch.cuda.is_available() and int(key.max()) < (1 << 31) - 1 and int(key.min()) >= 0:
+        dev = torch.device("cuda")
+        kd = torch.from_numpy(key.astype(np.int32)).to(dev)
+        ws = torch.empty(D.apply_workspace_bytes(n, int(key.max()) + 1), dtype=torch.uint8, device=dev)
+        D.group_dest(kd, n, int(key.max()) + 1, ws)
+        return D.apply_workspace_views(ws, n)[1].cpu().numpy().astype(np.int64)
+    return np.argsort(key, kind="stable")
+
+
 class FilterIndex:
     """One-off index of the filter triples: (s,p)-sorted objects and (o,p)-sorted subjects.  Built once
     per evaluate_performance call (two argsorts); each query chunk then costs two searchsorted calls.
@@ -43,7 +58,7 @@ class FilterIndex:
         self._sides = {}
         for name, kcol, vcol in (("obj", 0, 2), ("sub", 2, 0)):
             key = F[:, kcol] * self.n_rel + F[:, 1]
-            order = np.argsort(key, kind="stable")
+            order = _stable_argsort(key)
             self._sides[name] = (key[order], F[order, vcol])
 
     def _pairs(self, name, q_ent, q_rel, q_self):

@@ -1026,3 +1026,30 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
     kint_ok = (ki + 15) // 16 in (8, 13, 25)
     if kint_ok and 2 * nq > 128:
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
+
+
+def test_filter_index_gpu_sort_equals_numpy_sort():
+    """FilterIndex built through the library's radix sort (large filter sets on a GPU host) == the numpy merge-sort build:
+    same stable order, same CSR for every side"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import ranking as RK
+    dev()
+    rs = np.random.RandomState(3)
+    n_ent, n_rel, n = 50000, 37, 250000
+    F = np.stack([rs.randint(0, n_ent, n), rs.randint(0, n_rel, n), rs.randint(0, n_ent, n)], 1).astype(np.int64)
+    key = F[:, 0] * n_rel + F[:, 1]
+    np.testing.assert_array_equal(RK._stable_argsort(key), np.argsort(key, kind="stable"))
+    fast = RK.FilterIndex(F)
+    slow = RK.FilterIndex(F[:90000])      # below the size threshold: numpy path
+    ref = RK.FilterIndex.__new__(RK.FilterIndex)
+    ref.n_rel, ref.max_entity, ref._sides = fast.n_rel, fast.max_entity, {}
+    for name, kcol, vcol in (("obj", 0, 2), ("sub", 2, 0)):
+        k2 = F[:, kcol] * fast.n_rel + F[:, 1]
+        o2 = np.argsort(k2, kind="stable")
+        ref._sides[name] = (k2[o2], F[o2, vcol])
+    T = F[:500].astype(np.int32)
+    for sm in (L.EVAL_S, L.EVAL_O, L.EVAL_SPO, L.EVAL_S_O):
+        a, b = fast.csr(T, sm, n_ent), ref.csr(T, sm, n_ent)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    assert slow._sides["obj"][0].shape[0] == 90000
