@@ -618,4 +618,4 @@ class Trainer:
         return v
 
     def tables_numpy(self):
-        return self.ent.cpu().numpy().copy(), self.rel.cpu().numpy().copy()
+        return self.ent.cpu().numpy(), self.rel.cpu().numpy()   # (.cpu() of a device tensor is a fresh host copy already)
