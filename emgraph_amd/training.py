@@ -618,4 +618,5 @@ class Trainer:
         return v
 
     def tables_numpy(self):
-        return self.ent.cpu().numpy(), self.rel.cpu().numpy()   # (.cpu() of a device tensor is a fresh host copy already)
+        # (.cpu() of a device tensor is a fresh host copy already; only padded rows need compacting)
+        return np.ascontiguousarray(self.ent.cpu().numpy()), np.ascontiguousarray(self.rel.cpu().numpy())
