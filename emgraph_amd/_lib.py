@@ -206,6 +206,7 @@ SIGNATURES.update({
     "emg_plan_timing": (_int, [_p, _i32]),
     "emg_plan_stage_ms": (_int, [_p, C.POINTER(_f32), C.POINTER(_i32)]),
     "emg_plan_destroy": (_int, [_p]),
+    "emg_init_table": (_int, [_int, _p, _i64, _i64, _i32, _f32, _f32, _u64, _u64, _p]),
 })
 
 _lib = None

@@ -249,6 +249,54 @@ extern "C" int emg_lp_grad_rows(const float* table, int64_t n_rows, int64_t ld, 
     return EMG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Table initialisers on the device (initializers/{glorot_uniform,uniform,normal}.py: the reference's draws come from
+// TensorFlow's generators and cannot be reproduced — parity-unpinned — so the contract is the distribution):
+// element (r, c) of the table takes word (c & 3) of Philox4x32-10(counter = (r * k_int + c) / 4, stream, seed).
+// ---------------------------------------------------------------------------------------------
+__global__ void init_table_kernel(int kind, float* __restrict__ table, int64_t n_rows, int64_t ld, int k_int, float a, float b,
+                                  uint64_t seed, uint64_t stream_id) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 consecutive elements of the flat [n_rows, k_int] table
+    const int64_t total = n_rows * (int64_t)k_int;
+    if (4 * q >= total) return;
+    const Philox4 o = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t w[4] = {o.v[0], o.v[1], o.v[2], o.v[3]};
+    float v[4];
+    if (kind == 0) {   // U[a, b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = a + (b - a) * ((float)(w[i] >> 8) * 5.9604644775390625e-08f);
+    } else {           // N(a, b^2): Box-Muller on the two pairs of words
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const float u1 = ((float)(w[i] >> 8) + 0.5f) * 5.9604644775390625e-08f;   // (0, 1)
+            const float u2 = (float)(w[i + 1] >> 8) * 5.9604644775390625e-08f;
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            v[i] = a + b * rad * cs;
+            v[i + 1] = a + b * rad * sn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t e = 4 * q + i;
+        if (e < total) table[(e / k_int) * ld + (e % k_int)] = v[i];
+    }
+}
+
+extern "C" int emg_init_table(int kind, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float a, float b,
+                              uint64_t seed, uint64_t stream_id, void* stream) {
+    EMG_REQUIRE(kind == 0 || kind == 1, "emg_init_table: kind must be 0 (uniform [a, b)) or 1 (normal mean a, std b)");
+    EMG_REQUIRE(table && n_rows >= 0 && ld >= k_int && k_int > 0, "emg_init_table: bad arguments");
+    if (n_rows == 0) return EMG_OK;
+    const int64_t groups = (n_rows * (int64_t)k_int + 3) / 4;
+    hipLaunchKernelGGL(init_table_kernel, dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream, kind, table, n_rows,
+                       ld, (int)k_int, a, b, seed, stream_id);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
 extern "C" int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream) {
     EMG_REQUIRE(table && n_rows >= 0 && ld >= k_int && k_int > 0, "emg_clip_rows: bad arguments");
     if (n_rows == 0) return EMG_OK;

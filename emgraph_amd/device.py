@@ -224,6 +224,15 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     L.check(lib.emg_train_backward_ex(C.byref(a), _stream()), "emg_train_backward_ex")
 
 
+def init_table(table, k_int, kind, a, b, seed, stream_id):
+    """fill ``table[:, :k_int]`` in place: kind 'uniform' = U[a, b), 'normal' = N(mean a, std b) (emg_init_table)"""
+    lib = L.load()
+    pt, n, ld = _chk_table(table, "table")
+    L.check(lib.emg_init_table({"uniform": 0, "normal": 1}[kind], pt, n, ld, k_int, float(a), float(b),
+                               int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id), _stream()), "emg_init_table")
+    return table
+
+
 def group_dest(dest, n, n_rows, workspace, single_flags=None):
     lib = L.load()
     L.check(lib.emg_group_dest(_chk_vec(dest, torch.int32, "dest"), n, n_rows, workspace.data_ptr(),

@@ -108,6 +108,25 @@ def _initial_table(kind, params, rnd, rows, cols, concept):
     raise ValueError("Unsupported initializer: {}".format(kind))
 
 
+def _initial_table_device(kind, params, seed, rows, cols, concept, device):
+    """the same initialisers drawn on the device (emg_init_table, Philox keyed by (seed, table)): no 1M x 400 float64
+    array on the host.  Returns a float32 device tensor [rows, cols] (row stride padded to 16 bytes), or None for
+    initialisers that have no device form ('constant')."""
+    from ..training import alloc_table
+    stream_id = 1 if concept == "e" else 2
+    if kind == "glorot_uniform":
+        limit = float(np.sqrt(6 / (rows + cols)))
+        spec = ("uniform", -limit, limit)
+    elif kind == "uniform":
+        spec = ("uniform", params.get("low", DEFAULT_UNIFORM_LOW), params.get("high", DEFAULT_UNIFORM_HIGH))
+    elif kind == "normal":
+        spec = ("normal", params.get("mean", DEFAULT_NORMAL_MEAN), params.get("std", DEFAULT_NORMAL_STD))
+    else:
+        return None
+    t = alloc_table(rows, cols, device)
+    return D.init_table(t, cols, spec[0], spec[1], spec[2], seed, stream_id)
+
+
 class EmbeddingModel(abc.ABC):  # noqa: B024
     """Abstract base of the embedding models (EmbeddingModel.py:96-336)."""
 
@@ -316,8 +335,14 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         self.batch_size = batch_size
         rnd = np.random.RandomState(self.seed)  # refit -> same seed -> same run (EmbeddingModel.py:1286-1290)
         n_ent, n_rel = len(self.ent_to_idx), len(self.rel_to_idx)
-        ent0 = _initial_table(self.initializer, self.initializer_params, rnd, n_ent, self.internal_k, "e")
-        rel0 = _initial_table(self.initializer, self.initializer_params, rnd, n_rel, self.internal_k, "r")
+        # drawn on the device where the initialiser has a device form (a pure function of (seed, table, shape): the same
+        # table for any number of GPUs); 'constant' comes from the caller's arrays
+        dev = torch.device("cuda")
+        ent0 = _initial_table_device(self.initializer, self.initializer_params, self.seed, n_ent, self.internal_k, "e", dev)
+        rel0 = _initial_table_device(self.initializer, self.initializer_params, self.seed, n_rel, self.internal_k, "r", dev)
+        if ent0 is None:
+            ent0 = _initial_table(self.initializer, self.initializer_params, rnd, n_ent, self.internal_k, "e")
+            rel0 = _initial_table(self.initializer, self.initializer_params, rnd, n_rel, self.internal_k, "r")
         normalize = self.embedding_model_params.get("normalize_ent_emb", DEFAULT_NORMALIZE_EMBEDDINGS)
         rank, world = parallel.rank_world()
         # multi-GPU plan (one process per GPU): "k" = column slabs + all-reduce of partial scores (default);

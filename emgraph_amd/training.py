@@ -74,8 +74,8 @@ def alloc_table(rows, k_int, device, init=None, fill=None):
     ld = _padded_ld(k_int)
     buf = torch.zeros((rows, ld), dtype=torch.float32, device=device)
     view = buf[:, :k_int]
-    if init is not None:
-        view.copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)))
+    if init is not None:   # a host array, or a device tensor (tables initialised on the device)
+        view.copy_(init if torch.is_tensor(init) else torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)))
     elif fill is not None:
         view.fill_(fill)
     return view  # 2-D view with stride(0) = ld

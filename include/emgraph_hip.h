@@ -263,6 +263,12 @@ int emg_lp_grad_rows(const float* table, int64_t n_rows, int64_t ld, int32_t k_i
 
 /* ---- K9: optional row-norm clip after a batch (EmbeddingModel.py:1371-1380, clip_by_norm axes=1) */
 int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream);
+/* initializers/{glorot_uniform,uniform,normal}.py on the device: kind 0 = U[a, b), 1 = N(mean a, std b); element (r, c)
+ * takes word (c & 3) of Philox4x32-10(counter (r * k_int + c) / 4, stream_id, seed), so a table is a pure function of
+ * (seed, stream_id, shape) — the same on any number of GPUs.  The reference draws from TensorFlow's generators (cannot
+ * be reproduced: parity-unpinned); Glorot-uniform is U(+-sqrt(6 / (rows + cols))) (glorot_uniform.py:59-74). */
+int emg_init_table(int kind, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float a, float b,
+                   uint64_t seed, uint64_t stream_id, void* stream);
 
 /* ====================== filtered 1-vs-all ranking (K10-K13) ======================
  * side_mode: 0 's' | 1 'o' | 2 's+o' | 3 's,o'.  Query rows: for modes 2,3 rows [0,n_q) are the

@@ -1053,3 +1053,29 @@ def test_filter_index_gpu_sort_equals_numpy_sort():
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
     assert slow._sides["obj"][0].shape[0] == 90000
+
+
+def test_device_initialisers_distribution_and_determinism():
+    """emg_init_table: U[a, b) and N(mean, std) moments, bounds, determinism in (seed, stream), independence of the two
+    tables, untouched row padding (initializers/*.py: the reference's TF draws are unpinned, the distribution is the contract)"""
+    from emgraph_amd.training import alloc_table
+    d = dev()
+    rows, k = 20000, 50            # 50 floats per row: stride padded to 52
+    t = alloc_table(rows, k, torch.device("cuda"), fill=7.0)
+    base = t.as_strided((rows, 52), (52, 1))
+    base.fill_(7.0)
+    d.init_table(t, k, "uniform", -0.25, 0.75, 11, 1)
+    u = t.cpu().numpy().astype(np.float64)
+    assert u.min() >= -0.25 and u.max() < 0.75
+    assert abs(u.mean() - 0.25) < 2e-3 and abs(u.var() - 1.0 / 12) < 2e-3
+    assert float(base[:, 50:].min()) == 7.0 and float(base[:, 50:].max()) == 7.0      # padding untouched
+    t2 = alloc_table(rows, k, torch.device("cuda"))
+    d.init_table(t2, k, "uniform", -0.25, 0.75, 11, 1)
+    assert torch.equal(t, t2)                                                          # same (seed, stream) -> same table
+    d.init_table(t2, k, "uniform", -0.25, 0.75, 11, 2)
+    assert not torch.equal(t, t2) and abs(np.corrcoef(u.ravel(), t2.cpu().numpy().ravel())[0, 1]) < 5e-3
+    d.init_table(t2, k, "normal", 0.5, 0.1, 3, 1)
+    g = t2.cpu().numpy().astype(np.float64)
+    assert abs(g.mean() - 0.5) < 1e-3 and abs(g.std() - 0.1) < 1e-3
+    z = (g - 0.5) / 0.1
+    assert abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3.0) < 5e-2          # skewness, kurtosis of a normal
