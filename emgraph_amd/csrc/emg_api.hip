@@ -72,7 +72,8 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
                 "emg_rank_1vsall: the bf16 mode needs a contraction model (DistMult, ComplEx, HolE)");
     // mode 2 = the SAME ranks as mode 0 through the half-precision prefilter: where its kernel does not apply (TransE, a
     // candidate list, an uncovered width, few rows) the exact kernel runs instead — same result either way
-    if (precision_mode == 2 && (!(model >= EMG_DISTMULT && model <= EMG_HOLE) || cand != nullptr)) precision_mode = 0;
+    const bool sad = precision_mode == 2 && model == EMG_TRANSE_L1 && cand == nullptr;   // TransE-L1: the fixed-point prefilter
+    if (precision_mode == 2 && !sad && (!(model >= EMG_DISTMULT && model <= EMG_HOLE) || cand != nullptr)) precision_mode = 0;
     if (n_q == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && test_spo && rank_out, "emg_rank_1vsall: null pointer");
     EMG_REQUIRE((filt_ptr == nullptr) == (filt_idx == nullptr) || filt_ptr, "emg_rank_1vsall: filter CSR needs both arrays");
@@ -80,7 +81,7 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     const int64_t n_rows = side_mode >= EMG_EVAL_SPO ? 2 * n_q : n_q;
     const int64_t ldq = (k_int + 3) / 4 * 4;
     const int64_t nc = cand ? n_cand : n_ent;
-    const int64_t ldb = (k_int + 63) / 64 * 64;  // bf16 row stride
+    const int64_t ldb = sad ? emg_eval_sad_ld(k_int) : (k_int + 63) / 64 * 64;  // row stride of the 16-bit images
     const size_t q_bytes = up256((size_t)n_rows * ldq * 4), p_bytes = up256((size_t)n_rows * 4);
     const size_t c_bytes = up256((size_t)4 * n_rows * 4);
     size_t total = q_bytes + p_bytes + c_bytes;
@@ -94,13 +95,13 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     size_t band_off = 0, bounds_off = 0, pairs_off = 0, pcount_off = 0;
     int64_t n_seg = 0, pair_cap = 0;
     if (precision_mode == 2) {
-        n_seg = emg_eval_prefilter_segments(n_rows, nc);
+        n_seg = sad ? emg_eval_sad_segments(n_rows, nc) : emg_eval_prefilter_segments(n_rows, nc);
         int64_t per = ((int64_t)1 << 27) / (n_seg > 0 ? n_seg : 1);   // <= 1 GiB of pairs in total
         per = per < 64 ? 64 : (per > 2048 ? 2048 : per);
         pair_cap = n_seg * per;
         qb_off = total; total += up256((size_t)n_rows * ldb * 2);
         eb_off = total; total += up256((size_t)n_ent * ldb * 2);
-        band_off = total; total += p_bytes;
+        band_off = total; total += 2 * p_bytes;   // (the fixed-point prefilter keeps two thresholds per row here)
         bounds_off = total; total += 256;
         pcount_off = total; total += up256((size_t)(n_seg + 1) * 4);
         pairs_off = total; total += up256((size_t)pair_cap * 8);
@@ -122,12 +123,23 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
         double* bounds = (double*)(ws + bounds_off);
         uint64_t* pairs = (uint64_t*)(ws + pairs_off);
         uint32_t* pcount = (uint32_t*)(ws + pcount_off);
-        step(emg_to_f16(ent, n_ent, ld_ent, k_int, Eh, ldb, stream));
-        step(emg_to_f16(Q, n_rows, ldq, k_int, Qh, ldb, stream));
-        step(emg_eval_prefilter_bounds(ent, n_ent, ld_ent, Eh, ldb, k_int, bounds, stream));
-        step(emg_eval_prefilter_band(Q, n_rows, ldq, Qh, ldb, k_int, bounds, band, stream));
+        if (sad) {
+            step(emg_eval_sad_range(ent, n_ent, ld_ent, rel, n_rel, ld_rel, k_int, bounds, stream));
+            step(emg_eval_sad_quantize(ent, n_ent, ld_ent, k_int, bounds, Eh, ldb, stream));
+            step(emg_eval_sad_quantize(Q, n_rows, ldq, k_int, bounds, Qh, ldb, stream));
+            step(emg_eval_sad_thresholds(pos_int, n_rows, k_int, bounds, (uint32_t*)band, (uint32_t*)((char*)band + p_bytes), stream));
+        } else {
+            step(emg_to_f16(ent, n_ent, ld_ent, k_int, Eh, ldb, stream));
+            step(emg_to_f16(Q, n_rows, ldq, k_int, Qh, ldb, stream));
+            step(emg_eval_prefilter_bounds(ent, n_ent, ld_ent, Eh, ldb, k_int, bounds, stream));
+            step(emg_eval_prefilter_band(Q, n_rows, ldq, Qh, ldb, k_int, bounds, band, stream));
+        }
         bool exact = rc != EMG_OK;
-        if (rc == EMG_OK) {
+        if (sad && rc == EMG_OK) {
+            uint32_t* lo = (uint32_t*)band;
+            uint32_t* hi = (uint32_t*)((char*)band + p_bytes);
+            step(emg_eval_prefilter_sad(Qh, ldb, lo, hi, n_rows, Eh, n_ent, ldb, 0, k_int, cnt, pairs, pcount, pair_cap, stream));
+        } else if (rc == EMG_OK) {
             const int r = emg_eval_prefilter_f16(model, Qh, ldb, pos_int, band, n_rows, Eh, n_ent, ldb, 0, (k_int + 15) / 16 * 16,
                                                  scale, cnt, pairs, pcount, pair_cap, stream);
             if (r == EMG_ENOSUP) exact = true;   // a shape the register-stationary kernel does not cover

@@ -559,7 +559,8 @@ struct RescoreParams {
 };
 
 __device__ __forceinline__ void rescore_finish(const RescoreParams& P, int64_t row, float acc) {
-    const float score = P.model == EMG_HOLE ? __fmul_rn(acc, P.scale) : acc;
+    const float score = P.model == EMG_HOLE ? __fmul_rn(acc, P.scale)
+                      : (P.model == EMG_TRANSE_L1 ? -acc : (P.model == EMG_TRANSE_L2 ? -sqrtf(acc) : acc));
     const int ci = cmp_int(score), p = P.pos_int[row];
     if (ci > p) atomicAdd(&P.cnt_gt[row], 1);
     else if (ci == p) atomicAdd(&P.cnt_eq[row], 1);
@@ -579,7 +580,15 @@ __device__ __forceinline__ void wave_lds_sync() {   // this wave's LDS writes ar
     asm volatile("" ::: "memory");
 }
 
-template <bool VEC>
+// KIND: the chain step of chain_score — 0: fmaf(q, e, acc); 1: acc + |q - e|; 2: fmaf(d, d, acc), d = q - e
+template <int KIND>
+__device__ __forceinline__ float chain_step(float q, float e, float acc) {
+    if constexpr (KIND == 0) return __fmaf_rn(q, e, acc);
+    else if constexpr (KIND == 1) return __fadd_rn(acc, fabsf(__fsub_rn(q, e)));
+    else { const float d = __fsub_rn(q, e); return __fmaf_rn(d, d, acc); }
+}
+
+template <bool VEC, int KIND>
 __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams P) {
     __shared__ __attribute__((aligned(16))) float qs[4][64 * RS_LD];
     __shared__ __attribute__((aligned(16))) float es[4][64 * RS_LD];
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
             if constexpr (!VEC) {
                 const float* q = P.Q + row * P.ldq;
                 const float* er = P.ent + e * P.ld_ent;
-                for (int k = 0; k < P.k_int; ++k) acc = __fmaf_rn(q[k], er[k], acc);
+                for (int k = 0; k < P.k_int; ++k) acc = chain_step<KIND>(q[k], er[k], acc);
             } else {
                 const float* qp[4];
                 const float* ep[4];
@@ -636,8 +645,8 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
                         if (4 * c < kn) {
                             const float4 a = *reinterpret_cast<const float4*>(myq + lane * RS_LD + 4 * c);
                             const float4 b2 = *reinterpret_cast<const float4*>(mye + lane * RS_LD + 4 * c);
-                            acc = __fmaf_rn(a.x, b2.x, acc); acc = __fmaf_rn(a.y, b2.y, acc);
-                            acc = __fmaf_rn(a.z, b2.z, acc); acc = __fmaf_rn(a.w, b2.w, acc);
+                            acc = chain_step<KIND>(a.x, b2.x, acc); acc = chain_step<KIND>(a.y, b2.y, acc);
+                            acc = chain_step<KIND>(a.z, b2.z, acc); acc = chain_step<KIND>(a.w, b2.w, acc);
                         }
                     }
                 }
@@ -1001,7 +1010,7 @@ extern "C" int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, co
                                       int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
                                       const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
                                       int64_t n_segments, int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
-    EMG_REQUIRE(model >= EMG_DISTMULT && model <= EMG_HOLE, "emg_eval_rescore_pairs: contraction models only");
+    EMG_REQUIRE(model >= EMG_TRANSE_L1 && model <= EMG_HOLE, "emg_eval_rescore_pairs: unknown model id %d", model);
     EMG_REQUIRE(Q && pos_int && ent && pairs && pair_count && cnt_gt && cnt_eq, "emg_eval_rescore_pairs: null pointer");
     if (n_segments <= 0) return EMG_OK;
     EMG_REQUIRE(pairs_capacity >= n_segments, "emg_eval_rescore_pairs: pair buffer smaller than one entry per segment");
@@ -1013,8 +1022,17 @@ extern "C" int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, co
     const bool vec = (k_int % 4 == 0) && (ldq % 4 == 0) && (ld_ent % 4 == 0) && aligned16(Q) && aligned16(ent);
     const int64_t blocks = cdiv(n_segments, 4);
     const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384)), block(256);
-    if (vec) hipLaunchKernelGGL(rescore_pairs_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(rescore_pairs_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
+    hipStream_t st = (hipStream_t)stream;
+    if (model == EMG_TRANSE_L1) {
+        if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 1>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((rescore_pairs_kernel<false, 1>), grid, block, 0, st, P);
+    } else if (model == EMG_TRANSE_L2) {
+        if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 2>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((rescore_pairs_kernel<false, 2>), grid, block, 0, st, P);
+    } else {
+        if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 0>), grid, block, 0, st, P);
+        else hipLaunchKernelGGL((rescore_pairs_kernel<false, 0>), grid, block, 0, st, P);
+    }
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

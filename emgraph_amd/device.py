@@ -573,6 +573,71 @@ def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pair
                                        _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs")
 
 
+def _chk_u16(t, name):
+    if not (t.is_cuda and t.dtype == torch.int16 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError("%s must be a 2-D int16 CUDA tensor (u16 image rows) with unit column stride" % name)
+    return t.data_ptr(), t.shape[0], t.stride(0)
+
+
+def eval_sad_range(ent, rel, k_int):
+    """(max|ent|, max|rel|) as 2 float64 ON THE DEVICE: the range of the 16-bit fixed-point images of the TransE-L1
+    prefilter (csrc/emg_rank_sad.hip)"""
+    lib = L.load()
+    pe, ne, lde = _chk_table(ent, "ent")
+    pr, nr, ldr = _chk_table(rel, "rel")
+    out = torch.empty(2, dtype=torch.float64, device=ent.device)
+    L.check(lib.emg_eval_sad_range(pe, ne, lde, pr, nr, ldr, k_int, out.data_ptr(), _stream()), "emg_eval_sad_range")
+    return out
+
+
+def eval_sad_ld(k_int):
+    return int(L.load().emg_eval_sad_ld(k_int))
+
+
+def eval_sad_quantize(src, k_int, rng):
+    """u16 image (stored in an int16 tensor) of the f32 rows over the range ``rng`` (eval_sad_range)"""
+    lib = L.load()
+    ps, n, ld = _chk_table(src, "src")
+    ldd = eval_sad_ld(k_int)
+    out = torch.empty((n, ldd), dtype=torch.int16, device=src.device)
+    L.check(lib.emg_eval_sad_quantize(ps, n, ld, k_int, _chk_vec(rng, torch.float64, "range", 2), out.data_ptr(), ldd,
+                                      _stream()), "emg_eval_sad_quantize")
+    return out
+
+
+def eval_sad_thresholds(pos_int, k_int, rng):
+    """int32 [2, n_rows] holding the uint32 sums (lo, hi) between which a candidate is undecided"""
+    lib = L.load()
+    n = pos_int.numel()
+    out = torch.empty((2, n), dtype=torch.int32, device=pos_int.device)
+    L.check(lib.emg_eval_sad_thresholds(_chk_vec(pos_int, torch.int32, "pos_int", n), n, k_int,
+                                        _chk_vec(rng, torch.float64, "range", 2), out[0].data_ptr(), out[1].data_ptr(),
+                                        _stream()), "emg_eval_sad_thresholds")
+    return out
+
+
+def eval_sad_segments(n_rows, n_cand):
+    return int(L.load().emg_eval_sad_segments(n_rows, n_cand))
+
+
+def eval_prefilter_sad(q_u16, thresholds, ent_u16, ent_offset, k_int, cnt_gt, pairs, pair_count):
+    """fixed-point prefilter of the TransE-L1 exact-fast mode: definite `>` counts into cnt_gt, undecided (row, entity)
+    pairs into ``pairs`` in the layout eval_rescore_pairs reads"""
+    lib = L.load()
+    pq, n_rows, ldq = _chk_u16(q_u16, "q_u16")
+    pe, ne, lde = _chk_u16(ent_u16, "ent_u16")
+    n_seg = eval_sad_segments(n_rows, ne)
+    if not (thresholds.is_cuda and thresholds.dtype == torch.int32 and tuple(thresholds.shape) == (2, n_rows)
+            and thresholds.is_contiguous()):
+        raise ValueError("thresholds must be the int32 [2, n_rows] tensor of eval_sad_thresholds")
+    L.check(lib.emg_eval_prefilter_sad(pq, ldq, thresholds[0].data_ptr(), thresholds[1].data_ptr(), n_rows, pe, ne, lde,
+                                       ent_offset, k_int, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                       _chk_vec(pairs, torch.int64, "pairs"),
+                                       _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), pairs.numel(), _stream()),
+            "emg_eval_prefilter_sad")
+    return n_seg
+
+
 def eval_scores_dense_bf16(model_id, q_bf16, ent_bf16, k_int, scale, cand=None):
     lib = L.load()
     pq, n_rows, ldq = _chk_bf16(q_bf16, "q_bf16")

@@ -215,6 +215,16 @@ class PrefilterTables:
         return self._bounds[(e0, n)]
 
 
+class SadTables:
+    """what the TransE-L1 exact-fast mode derives from the tables, built once per evaluation run: the range of the
+    fixed-point map and the 16-bit image of the entity table.  Valid while the tables do not change."""
+
+    def __init__(self, ent, rel, k_int):
+        self.range = D.eval_sad_range(ent, rel, k_int)
+        self.ent_u16 = D.eval_sad_quantize(ent, k_int, self.range)
+        self.k_int = k_int
+
+
 _pair_buffers = {}
 
 
@@ -249,8 +259,12 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     (prefilter_band), the others — typically 0.1-3 % — are re-scored with the exact f32 chain; shapes the prefilter
     kernel does not cover, and query tiles with too many undecided candidates, take the exact kernel (stats['fallback']).
 
-    ``precision='auto'``: 2 where it applies and pays (contraction model, no candidate list, k_int the prefilter kernel covers, at
-    least 128 test triples against at least 32768 entities), else 0 — the ranks are the same either way.
+    ``precision=2`` with TransE-L1: the same contract through a different prefilter — sums of absolute differences of
+    16-bit fixed-point images of the rows (``v_sad_u16``, csrc/emg_rank_sad.hip) bound every candidate's score from both
+    sides; the undecided ones are re-scored with the exact chain.  TransE-L2 always takes the exact kernel.
+
+    ``precision='auto'``: 2 where it applies and pays (contraction model at a k_int the prefilter kernel covers, or TransE-L1; no
+    candidate list, at least 128 test triples against at least 32768 entities), else 0 — the ranks are the same either way.
 
     ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
     (HIP events on the launch stream) and ``count_launches``."""
@@ -259,12 +273,13 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
         n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
         wide_enough = any(lo < k_int <= hi for lo, hi in ((112, 128), (192, 208), (384, 400)))
-        precision = 2 if (model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and entities_subset is None and wide_enough
-                          and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
+        applies = (model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and wide_enough) or (model_id == L.TRANSE_L1 and k_int >= 16)
+        precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
     if precision not in (0, 1, 2):
         raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA), 2 (exact via half-precision prefilter) or 'auto' (0 or 2)")
-    if precision == 2 and (model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE) or entities_subset is not None):
-        precision = 0   # TransE is not a contraction; candidate lists go through the exact kernel: same ranks
+    if precision == 2 and (model_id not in (L.TRANSE_L1, L.DISTMULT, L.COMPLEX, L.HOLE) or entities_subset is not None):
+        precision = 0   # TransE-L2 has no prefilter; candidate lists go through the exact kernel: same ranks
+    sad = precision == 2 and model_id == L.TRANSE_L1   # fixed-point prefilter instead of the half-precision MFMA one
     if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):
         raise ValueError("the bf16 MFMA mode needs a contraction model (DistMult, ComplEx, HolE)")
     if corrupt_side not in L.EVAL_SIDE_IDS:
@@ -294,7 +309,13 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     if filter_triples is not None:
         findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
     bounds = None
-    if precision == 2:
+    if sad:
+        if isinstance(ent_f16, SadTables):
+            sad_range, ent_u16 = ent_f16.range, ent_f16.ent_u16
+        else:
+            sad_range = D.eval_sad_range(ent, rel, k_int)
+            ent_u16 = D.eval_sad_quantize(ent, k_int, sad_range)
+    elif precision == 2:
         if isinstance(ent_f16, PrefilterTables):   # built once per evaluation run by the caller
             bounds, ent_f16 = ent_f16.bounds(e0, slab.shape[0]), ent_f16.ent_f16
         else:
@@ -332,7 +353,17 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             fcount = lambda fp_, fi_: D.eval_filter_count(model_id, Q, pos_int, tab, off, k_int, scale, fp_, fi_,  # noqa: E731
                                                           cnt[2], cnt[3])
         pre = None    # (overflow flag, undecided pairs) of this tile on the device + what an exact re-run needs
-        if precision == 2 and have_cands:
+        if sad and have_cands:
+            Qu = D.eval_sad_quantize(Q, k_int, sad_range)
+            thr = D.eval_sad_thresholds(pos_int, k_int, sad_range)
+            n_seg = D.eval_sad_segments(n_rows, slab.shape[0])
+            pairs, pcount = _pair_buffer(ent.device, n_seg)
+            ev = _ev_start(stats)
+            D.eval_prefilter_sad(Qu, thr, ent_u16[e0:e0 + slab.shape[0]], e0, k_int, cnt[0], pairs, pcount)
+            D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+            _ev_stop(stats, ev)
+            pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
+        elif precision == 2 and have_cands:
             # half-precision MFMA prefilter, then exact re-scoring of the undecided pairs: both asynchronous; whether a
             # wave ran out of pair room (-> this tile is redone by the exact kernel) is read with the counters at the end
             kp = D.bf16_ld(k_int)

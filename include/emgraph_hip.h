@@ -391,6 +391,34 @@ int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);
 
+/* TransE-L1: the ranks of emg_eval_count, bit for bit, at integer speed (csrc/emg_rank_sad.hip).  The score of the
+ * reference, -sum_k |q_k - e_k| (TransE.py:208-216 with norm 1, compared as int(score * 1e5), EmbeddingModel.py:
+ * 2010-2033), is bounded from both sides by a sum of absolute differences of 16-bit fixed-point images of the rows
+ * (v_sad_u16: two coordinates per instruction); candidates the bound decides are counted, the rest re-scored by
+ * emg_eval_rescore_pairs (which takes TransE model ids for this purpose).
+ *   emg_eval_sad_range      range[0] = max|ent|, range[1] = max|rel| (device doubles, written by the call): the image
+ *                           maps [-R, R], R = (range[0] + range[1])(1 + 1e-6), onto 0..65535 — every query row
+ *                           emg_eval_build_queries makes from these tables (s+p, o-p) lies inside
+ *   emg_eval_sad_ld         columns of an image row for k_int coordinates (k_int rounded up to 16)
+ *   emg_eval_sad_quantize   f32 rows -> u16 image rows (ld_dst u16 columns, padding columns 0)
+ *   emg_eval_sad_thresholds per query row the integer sums below which a candidate certainly compares greater (lo)
+ *                           and above which certainly less (hi) than pos_int
+ *   emg_eval_prefilter_sad  cnt_gt[row] += #(candidates with sum < lo); (row << 32 | ent_offset + column) of the
+ *                           candidates with lo <= sum <= hi into `pairs`, cut into emg_eval_sad_segments(n_rows,
+ *                           n_cand) segments exactly as emg_eval_prefilter_f16 does (pair_count zeroed by the call;
+ *                           pair_count[segments] != 0: some wave ran out of room, use emg_eval_count for these rows) */
+int emg_eval_sad_range(const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel, int64_t ld_rel,
+                       int32_t k_int, double* range, void* stream);
+int64_t emg_eval_sad_ld(int32_t k_int);
+int emg_eval_sad_quantize(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, const double* range,
+                          void* dst_u16, int64_t ld_dst, void* stream);
+int emg_eval_sad_thresholds(const int32_t* pos_int, int64_t n_rows, int32_t k_int, const double* range, uint32_t* lo,
+                            uint32_t* hi, void* stream);
+int64_t emg_eval_sad_segments(int64_t n_rows, int64_t n_cand);
+int emg_eval_prefilter_sad(const void* q_u16, int64_t ldq, const uint32_t* lo, const uint32_t* hi, int64_t n_rows,
+                           const void* ent_u16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset, int32_t k_int,
+                           int32_t* cnt_gt, uint64_t* pairs, uint32_t* pair_count, int64_t pairs_capacity, void* stream);
+
 /* ====================== one-call forms (compositions of the entry points above, one stream) ==============
  * The C-ABI sketched in SURVEY.md 8b.  A maintainer binding the library from the reference calls these once per
  * batch / per test set; the finer-grained entry points exist so that a host can overlap stages on several
@@ -410,8 +438,9 @@ int emg_corrupt_fit(const int32_t* pos, int64_t B, int32_t eta, int side, int64_
  * strategy: 0 worst | 1 best | 2 middle.  precision_mode: 0 exact f32 | 1 bf16 MFMA (statistical agreement) |
  * 2 the ranks of mode 0, bit for bit, through the half-precision MFMA prefilter + exact re-scoring (emg_to_f16,
  * emg_eval_prefilter_bounds / _band, emg_eval_prefilter_f16, emg_eval_rescore_pairs; one host synchronisation to read the
- * overflow flag; the exact kernel takes over for TransE, candidate lists, shapes the prefilter kernel does not cover
- * and overflowing pair buffers).
+ * overflow flag; TransE-L1 goes through the 16-bit fixed-point prefilter emg_eval_prefilter_sad instead; the exact
+ * kernel takes over for TransE-L2, candidate lists, shapes the prefilter kernels do not cover and overflowing pair
+ * buffers).
  * rank_out int32: [n_q] for side_mode 0,1,2; [n_q,2] = [subject_rank, object_rank] for side_mode 3. */
 int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel,
                     int64_t ld_rel, int32_t k_int, float scale, const int32_t* test_spo, int64_t n_q, int side_mode,

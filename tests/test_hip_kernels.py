@@ -798,11 +798,13 @@ def test_rank_1vsall_one_call_matches_python_path(model):
 
 
 @pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 30000, 300), ("DistMult", 200, 9000, 200), ("HolE", 100, 5000, 150),
-                                              ("DistMult", 24, 700, 60), ("TransE_L1", 40, 900, 40), ("ComplEx", 200, 4000, 50)])
+                                              ("DistMult", 24, 700, 60), ("TransE_L1", 40, 900, 40), ("ComplEx", 200, 4000, 50),
+                                              ("TransE_L1", 200, 20000, 300), ("TransE_L1", 37, 3000, 70), ("TransE_L2", 64, 2000, 90)])
 def test_rank_1vsall_one_call_precision_2_equals_precision_0(model, k, n_ent, nq):
     """emg_rank_1vsall(precision_mode = 2) == precision_mode 0 for every side and strategy, filtered, with planted exact
-    ties: through the half-precision prefilter where its kernel applies (the first three shapes), through the exact
-    kernel where it does not (an uncovered width, TransE, fewer than 129 query rows, a candidate list)"""
+    ties: through the half-precision prefilter where its kernel applies (the first three shapes), through the fixed-point
+    prefilter for TransE-L1 (any width), through the exact kernel where neither does (an uncovered width, TransE-L2,
+    fewer than 129 query rows of a contraction model, a candidate list)"""
     from emgraph_amd import _lib as L
     from emgraph_amd.evaluation import FilterIndex
     d = dev()
@@ -1026,6 +1028,84 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
     kint_ok = (ki + 15) // 16 in (8, 13, 25)
     if kint_ok and 2 * nq > 128:
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
+
+
+@pytest.mark.parametrize("k,n_ent,nq,scale", [(200, 30000, 300, 0.1), (100, 9000, 200, 1.0), (50, 20000, 150, 0.002),
+                                              (37, 5000, 140, 0.3), (16, 40000, 130, 0.05), (200, 5000, 40, 0.1)])
+def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
+    """TransE-L1, precision=2 (v_sad_u16 sums over 16-bit fixed-point images bound every score from both sides; the
+    undecided candidates are re-scored with the canonical f32 chain) == precision=0 for every side, strategy and filter
+    setting.  Planted: exact ties (copies of the true entity's row), near ties (copies perturbed in the last bits and
+    by about one comparison quantum, 1e-5), one entity far outside the bulk (stretches the fixed-point range), a tiny
+    scale (scores below the quantum: every comparison integer ties at 0), an odd width (unaligned rows) and widths that
+    are not a multiple of the image's 16-column tile."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import SadTables, rank_triples_device
+    d = dev()
+    E, R, ki = make_tables("TransE_L1", k, n_ent, 5, seed=k + n_ent, scale=scale)
+    rs = np.random.RandomState(n_ent + k)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 5, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 4):
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+        E[rs.randint(0, n_ent, 1)] = E[T[j, 0]]
+        near = E[T[j, 2]].copy()
+        near[rs.randint(0, ki)] += F32(1e-5) * F32(rs.choice([-1.5, -1.0, -0.5, 0.5, 1.0, 1.5]))   # about one quantum of the comparison
+        E[rs.randint(0, n_ent)] = near
+        E[rs.randint(0, n_ent)] = np.nextafter(E[T[j, 0]], F32(np.inf))                               # last-bit neighbours
+    far = rs.randint(0, n_ent)
+    if far not in T[:, [0, 2]]:
+        E[far] *= F32(6.0)
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 5000), rs.randint(0, 5, 5000), rs.randint(0, n_ent, 5000)], 1)]).astype(np.int32)
+    Et, Rt = cu(E), cu(R)
+    tabs = SadTables(Et, Rt, ki)
+    used = 0
+    for side in ("s,o", "s+o", "o", "s"):
+        for strategy in ("worst", "best", "middle"):
+            for filt in (None, F):
+                st = {}
+                exact = rank_triples_device(L.TRANSE_L1, Et, Rt, ki, 1.0, T, side, strategy, filter_triples=filt)
+                fast = rank_triples_device(L.TRANSE_L1, Et, Rt, ki, 1.0, T, side, strategy, filter_triples=filt, precision=2,
+                                           stats=st, ent_f16=tabs if side != "o" else None, query_chunk=200 if side == "s" else 4096)
+                np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
+                used += st.get("pairs", 0) + st.get("fallback", 0)
+    assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
+
+
+def test_sad_images_and_thresholds_bound_the_exact_chain():
+    """the pieces of the fixed-point prefilter against float64 math: the image is rint((x + R) / delta) over the range
+    emg_eval_sad_range reports, and for every (query, entity) pair the exact comparison integer lies on the side the
+    thresholds promise: S < lo => int(score 1e5) > pos_int, S > hi => int(score 1e5) < pos_int"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    rs = np.random.RandomState(5)
+    n_ent, nq, k = 3000, 96, 72
+    E = (rs.randn(n_ent, k) * 0.2).astype(F32)
+    R = (rs.randn(4, k) * 0.2).astype(F32)
+    Et, Rt = cu(E), cu(R)
+    rng = d.eval_sad_range(Et, Rt, k)
+    r = rng.cpu().numpy()
+    assert r[0] == np.abs(E).max() and r[1] == np.abs(R).max()
+    Rh = (r[0] + r[1]) * (1.0 + 1e-6)
+    delta = 2.0 * Rh / 65535.0
+    img = d.eval_sad_quantize(Et, k, rng).cpu().numpy().view(np.uint16)
+    assert img.shape[1] == d.eval_sad_ld(k) == 80 and not img[:, k:].any()
+    np.testing.assert_array_equal(img[:, :k], np.rint((E.astype(np.float64) + Rh) * (65535.0 / (2.0 * Rh))).astype(np.uint16))
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    Q, pos_int = d.eval_build_queries(L.TRANSE_L1, Et, Rt, k, 1.0, cu(T), L.EVAL_O)
+    thr = d.eval_sad_thresholds(pos_int, k, rng).cpu().numpy().view(np.uint32).astype(np.int64)
+    qimg = d.eval_sad_quantize(Q, k, rng).cpu().numpy().view(np.uint16).astype(np.int64)
+    S = np.abs(qimg[:, None, :] - img[None, :, :].astype(np.int64)).sum(-1)                      # [nq, n_ent]
+    Qh = Q.cpu().numpy()
+    acc = np.zeros((nq, n_ent), F32)
+    for c in range(k):                                                                           # the canonical f32 chain
+        acc = acc + np.abs(Qh[:, c:c + 1] - E[None, :, c])
+    ci = (-(acc) * F32(100000.0)).astype(np.int32)                                               # truncation toward zero
+    p = pos_int.cpu().numpy()[:, None]
+    assert np.all(np.abs(acc.astype(np.float64) - delta * S) <= k * delta * 1.001 + 1e-5 * acc)
+    assert np.all(ci[S < thr[0][:, None]] > np.broadcast_to(p, S.shape)[S < thr[0][:, None]])
+    assert np.all(ci[S > thr[1][:, None]] < np.broadcast_to(p, S.shape)[S > thr[1][:, None]])
+    undecided = ((S >= thr[0][:, None]) & (S <= thr[1][:, None])).mean()
+    assert undecided < 0.05, undecided
 
 
 def test_filter_index_gpu_sort_equals_numpy_sort():
