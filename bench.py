@@ -106,7 +106,7 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r2_f_pmc_traffic.json", "r2_e_pmc_traffic.json", "r2_d_pmc_traffic.json", "r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
+    for fn in ("r2_g_pmc_traffic.json", "r2_f_pmc_traffic.json", "r2_e_pmc_traffic.json", "r2_d_pmc_traffic.json", "r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
@@ -293,7 +293,7 @@ def score_kernel_alone(r, reps=50):
     return {"kernel": "train_forward_kernel (gather + score of %d x %d triples)" % (B, 1 + eta), "bound": "hbm",
             "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": ab, "achieved": round(ab / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": "static: profiles/r2_f_pmc_traffic.json" if traffic else None,
+            "traffic": traffic, "traffic_source": "static: profiles/r2_g_pmc_traffic.json" if traffic else None,
             "triples_per_s": round(B * (1 + eta) / (ms * 1e-3), 1)}
 
 
@@ -384,8 +384,8 @@ def run_eval(r, args):
                      "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
     out["exact_fast"] = ex
     out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
-                              "DistMult / ComplEx / HolE at k_int in {113..128, 193..208, 385..400}, >= 128 test triples, >= 32768 "
-                              "entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
+                              "DistMult / ComplEx / HolE at k_int in {113..128, 193..208, 385..400} and (transe_l1.exact_fast) for TransE-L1, "
+                              ">= 128 test triples, >= 32768 entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
     if not args.quick:
         # query-tile sweep (B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode
         sweep = {}
@@ -414,6 +414,28 @@ def run_eval(r, args):
                             "roofline": {"bound": "valu", "achieved": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12, 2),
                                          "peak": MFMA_F32_PEAK_TF / 2, "unit": "T lane-op/s (f32 VALU: 157.3 TFLOP/s counts an FMA as 2)",
                                          "frac": round(lane_ops / (stt["count_ms"] * 1e-3) / 1e12 / (MFMA_F32_PEAK_TF / 2), 4)}}
+        # the same ranks through the fixed-point prefilter (v_sad_u16: two coordinates per instruction) + exact re-scoring
+        from emgraph_amd.evaluation import SadTables
+        exact_t = rank_triples_device(0, ent_t, rel_t, kt_, 1.0, Tt, "s+o", "worst", filter_triples=F, shard=shard)
+        tabs = SadTables(ent_t, rel_t, kt_)
+        rank_triples_device(0, ent_t, rel_t, kt_, 1.0, Tt[:32], "s+o", "worst", filter_triples=F, shard=shard, precision=2, ent_f16=tabs)
+        torch.cuda.synchronize()
+        sts = {}
+        t0 = time.perf_counter()
+        fast_t = rank_triples_device(0, ent_t, rel_t, kt_, 1.0, Tt, "s+o", "worst", filter_triples=F, shard=shard, precision=2,
+                                     ent_f16=tabs, stats=sts)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        sad_ops = ((kt_ + 15) // 16 * 8) * float(w["n_ent"]) * 2 * len(Tt) / world    # v_sad_u16 lane-instructions (k padded to 16)
+        valu_issue_peak = 256 * 4 * 16 * 2.4e9 / 1e12                                  # one VALU instruction per SIMD and 4 clocks
+        out["transe_l1"]["exact_fast"] = {
+            "value": round(2 * len(Tt) / dts, 1), "unit": "ranks/s", "equal_to_exact_f32_ranks": bool(np.array_equal(fast_t, exact_t)),
+            "undecided_pairs": int(sts.get("pairs", 0)), "undecided_fraction": round(sts.get("pairs", 0) / (2.0 * len(Tt) * w["n_ent"] / world), 6),
+            "tiles_redone_by_exact_kernel": int(sts.get("fallback", 0)), "kernel_ms": round(sts["count_ms"], 3),
+            "kernels": "count_sad_kernel (v_sad_u16 over 16-bit fixed-point images) + rescore_pairs_kernel",
+            "roofline": {"bound": "valu", "achieved": round(sad_ops / (sts["count_ms"] * 1e-3) / 1e12, 2), "peak": round(valu_issue_peak, 2),
+                         "unit": "T lane-instr/s (VALU issue rate; kernel_ms includes the re-scoring)",
+                         "frac": round(sad_ops / (sts["count_ms"] * 1e-3) / 1e12 / valu_issue_peak, 4)}}
     return out
 
 
