@@ -204,6 +204,24 @@ def test_mappings_and_to_idx_match_oracle():
     np.testing.assert_array_equal(to_idx(Xn, en, rn), [[0, 0, 1], [1, 1, 2]])
 
 
+def test_filter_unseen_entities_matches_isin_semantics():
+    """protocol.py:1014-1041: keep exactly the triples whose subject AND object are keys of ent_to_idx — string labels,
+    dense and sparse integer labels (the cached gather table and the sorted-key search), nothing to remove -> same array"""
+    from types import SimpleNamespace
+    from emgraph_amd.evaluation.protocol import filter_unseen_entities
+    rs = np.random.RandomState(0)
+    for labels in (np.array(["e%d" % i for i in range(50)]), np.arange(100, 150), np.arange(0, 50) * 100003):
+        model = SimpleNamespace(ent_to_idx={(v.item() if hasattr(v, "item") else v): i for i, v in enumerate(labels)})
+        extra = np.array(["zz", "e999"]) if labels.dtype.kind in "US" else np.array([-5, 7, 10 ** 9])
+        pool = np.concatenate([labels, extra])
+        X = np.stack([rs.choice(pool, 400), rs.choice(labels, 400), rs.choice(pool, 400)], 1)
+        seen = np.array(list(model.ent_to_idx.keys()))
+        keep = np.isin(X[:, 0], seen) & np.isin(X[:, 2], seen)
+        assert 0 < keep.sum() < len(X)
+        np.testing.assert_array_equal(filter_unseen_entities(X, model), X[keep])
+        assert filter_unseen_entities(X[keep], model) is not None and len(filter_unseen_entities(X[keep], model)) == keep.sum()
+
+
 def test_metrics_match_reference_goldens(golden):
     from emgraph_amd.evaluation import hits_at_n_score, mr_score, mrr_score, rank_score
     g = golden("misc")
