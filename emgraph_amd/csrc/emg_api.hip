@@ -73,7 +73,8 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     // mode 2 = the SAME ranks as mode 0 through the half-precision prefilter: where its kernel does not apply (TransE, a
     // candidate list, an uncovered width, few rows) the exact kernel runs instead — same result either way
     const bool sad = precision_mode == 2 && model == EMG_TRANSE_L1 && cand == nullptr;   // TransE-L1: the fixed-point prefilter
-    if (precision_mode == 2 && !sad && (!(model >= EMG_DISTMULT && model <= EMG_HOLE) || cand != nullptr)) precision_mode = 0;
+    const bool l2 = precision_mode == 2 && model == EMG_TRANSE_L2 && cand == nullptr;    // TransE-L2: MFMA prefilter on augmented rows
+    if (precision_mode == 2 && !sad && !l2 && (!(model >= EMG_DISTMULT && model <= EMG_HOLE) || cand != nullptr)) precision_mode = 0;
     if (n_q == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && test_spo && rank_out, "emg_rank_1vsall: null pointer");
     EMG_REQUIRE((filt_ptr == nullptr) == (filt_idx == nullptr) || filt_ptr, "emg_rank_1vsall: filter CSR needs both arrays");
@@ -81,7 +82,7 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     const int64_t n_rows = side_mode >= EMG_EVAL_SPO ? 2 * n_q : n_q;
     const int64_t ldq = (k_int + 3) / 4 * 4;
     const int64_t nc = cand ? n_cand : n_ent;
-    const int64_t ldb = sad ? emg_eval_sad_ld(k_int) : (k_int + 63) / 64 * 64;  // row stride of the 16-bit images
+    const int64_t ldb = sad ? emg_eval_sad_ld(k_int) : (k_int + (l2 ? 2 : 0) + 63) / 64 * 64;  // row stride of the 16-bit images
     const size_t q_bytes = up256((size_t)n_rows * ldq * 4), p_bytes = up256((size_t)n_rows * 4);
     const size_t c_bytes = up256((size_t)4 * n_rows * 4);
     size_t total = q_bytes + p_bytes + c_bytes;
@@ -92,7 +93,7 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
         eb_off = total; total += up256((size_t)n_ent * ldb * 2);
     }
     // precision 2: half copies of Q and the table, the band, the pair buffer (one segment per prefilter wave)
-    size_t band_off = 0, bounds_off = 0, pairs_off = 0, pcount_off = 0;
+    size_t band_off = 0, bounds_off = 0, pairs_off = 0, pcount_off = 0, q2_off = 0, thr_off = 0;
     int64_t n_seg = 0, pair_cap = 0;
     if (precision_mode == 2) {
         n_seg = sad ? emg_eval_sad_segments(n_rows, nc) : emg_eval_prefilter_segments(n_rows, nc);
@@ -105,6 +106,10 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
         bounds_off = total; total += 256;
         pcount_off = total; total += up256((size_t)(n_seg + 1) * 4);
         pairs_off = total; total += up256((size_t)pair_cap * 8);
+        if (l2) {
+            q2_off = total; total += q_bytes;
+            thr_off = total; total += up256((size_t)2 * n_rows * 4);
+        }
     }
     char* ws = nullptr;
     EMG_HIP(hipMallocAsync((void**)&ws, total, st));
@@ -123,7 +128,14 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
         double* bounds = (double*)(ws + bounds_off);
         uint64_t* pairs = (uint64_t*)(ws + pairs_off);
         uint32_t* pcount = (uint32_t*)(ws + pcount_off);
-        if (sad) {
+        if (l2) {
+            float* Q2 = (float*)(ws + q2_off);
+            step(emg_to_f16_l2(ent, n_ent, ld_ent, k_int, 0, Eh, ldb, nullptr, bounds + 3, stream));
+            step(emg_to_f16_l2(Q, n_rows, ldq, k_int, 1, Qh, ldb, Q2, nullptr, stream));
+            step(emg_eval_prefilter_bounds(ent, n_ent, ld_ent, Eh, ldb, k_int, bounds, stream));
+            step(emg_eval_prefilter_band(Q2, n_rows, ldq, Qh, ldb, k_int, bounds, band, stream));
+            step(emg_eval_l2_thresholds(Q, n_rows, ldq, pos_int, band, bounds, k_int, (float*)(ws + thr_off), stream));
+        } else if (sad) {
             step(emg_eval_sad_range(ent, n_ent, ld_ent, rel, n_rel, ld_rel, k_int, bounds, stream));
             step(emg_eval_sad_quantize(ent, n_ent, ld_ent, k_int, bounds, Eh, ldb, stream));
             step(emg_eval_sad_quantize(Q, n_rows, ldq, k_int, bounds, Qh, ldb, stream));
@@ -135,7 +147,12 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
             step(emg_eval_prefilter_band(Q, n_rows, ldq, Qh, ldb, k_int, bounds, band, stream));
         }
         bool exact = rc != EMG_OK;
-        if (sad && rc == EMG_OK) {
+        if (l2 && rc == EMG_OK) {
+            const int r = emg_eval_prefilter_f16_thr(Qh, ldb, (const float*)(ws + thr_off), n_rows, Eh, n_ent, ldb, 0,
+                                                     (k_int + 2 + 15) / 16 * 16, cnt, pairs, pcount, pair_cap, stream);
+            if (r == EMG_ENOSUP) exact = true;   // a width the register-stationary kernel does not cover
+            else step(r);
+        } else if (sad && rc == EMG_OK) {
             uint32_t* lo = (uint32_t*)band;
             uint32_t* hi = (uint32_t*)((char*)band + p_bytes);
             step(emg_eval_prefilter_sad(Qh, ldb, lo, hi, n_rows, Eh, n_ent, ldb, 0, k_int, cnt, pairs, pcount, pair_cap, stream));

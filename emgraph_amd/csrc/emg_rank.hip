@@ -719,6 +719,77 @@ __global__ __launch_bounds__(256) void prefilter_band_kernel(const float* __rest
     band[r] = __double2float_ru(b) + 1e-37f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// TransE-L2 through the half-precision MFMA prefilter: ||q - e||^2 = |q|^2 - (2 q.e - |e|^2) is a contraction over
+// k + 2 coordinates, q' = [2q | -1 | -1], e' = [e | n_hi | n_lo] with n_hi + n_lo ~ |e|^2 split over two halves.
+// to_f16_l2_kernel writes these rows (one wave per row); for entity rows the largest |(n_hi + n_lo) - |e|^2| goes to
+// *n_res (its actual value enters the error band, so a clamped or badly split norm only widens the band), for query
+// rows the doubled f32 row goes to `doubled` (what emg_eval_prefilter_band measures the rounding residual against).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void to_f16_l2_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
+                                                        int is_query, _Float16* __restrict__ dst, int64_t ld_dst,
+                                                        float* __restrict__ doubled, double* __restrict__ n_res) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    double worst = 0.0;
+    for (int64_t r = wave; r < n_rows; r += n_waves) {
+        const float* x = src + r * ld_src;
+        _Float16* out = dst + r * ld_dst;
+        double n = 0.0;
+        for (int c = lane; c < (int)ld_dst; c += 64) {
+            float v = 0.f;
+            if (c < k_int) {
+                v = x[c];
+                n = fma((double)v, (double)v, n);
+                if (is_query) {
+                    v = __fmul_rn(v, 2.0f);
+                    if (doubled) doubled[r * ld_src + c] = v;
+                }
+                v = fminf(fmaxf(v, -65000.f), 65000.f);   // (no infinities in the MFMA operands; the residual norms see the clamp)
+            } else if (is_query && c < k_int + 2) {
+                v = -1.f;
+            }
+            if (is_query || c < k_int || c >= k_int + 2) out[c] = (_Float16)v;
+        }
+        if (!is_query) {
+            n = wave_sum_double(n);
+            const _Float16 hi = (_Float16)fminf((float)n, 60000.f);
+            const double rest = n - (double)(float)hi;
+            const _Float16 lo = (_Float16)fminf(fmaxf((float)rest, -60000.f), 60000.f);
+            if (lane == 0) { out[k_int] = hi; out[k_int + 1] = lo; }
+            worst = fmax(worst, fabs(rest - (double)(float)lo));
+        }
+    }
+    if (!is_query && n_res && lane == 0 && worst > 0.0) atomic_max_nonneg(n_res, worst);
+}
+
+// accumulator thresholds of the TransE-L2 prefilter (derivation: DESIGN.md 4.2).  thr[r]: counted when acc >= it,
+// thr[n_rows + r]: emitted for exact re-scoring when acc >= it (and not counted).
+__global__ void l2_thresholds_kernel(const float* __restrict__ Q, int64_t n_rows, int64_t ldq, const int32_t* __restrict__ pos_int,
+                                     const float* __restrict__ band, const double* __restrict__ bounds, int k_int,
+                                     float* __restrict__ thr) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    double nq2 = 0.0;
+    for (int c = 0; c < k_int; ++c) { const double q = (double)Q[r * ldq + c]; nq2 = fma(q, q, nq2); }
+    const double u = 5.9604644775390625e-08;                               // 2^-24
+    const double n_max = bounds[0] * bounds[0] * (1.0 + 1e-6);             // largest |e|^2
+    const double g_mfma = 2.0 * (double)(k_int + 34) * u;                  // the two norm coordinates join the k products
+    const double E = ((double)band[r] + g_mfma * n_max + bounds[3]) * (1.0 + 1e-6) + 1e-30;
+    const double gamma = (double)(k_int + 2) * u * 1.01;                   // the exact kernel's chain of k fused squares
+    const double m = -(double)pos_int[r];
+    const double tg = m > 0.0 ? (m * 1e-5) * (m * 1e-5) * (1.0 - 8.0 * u) : 0.0;
+    const double tl = (m + 1.0) > 0.0 ? ((m + 1.0) * 1e-5) * ((m + 1.0) * 1e-5) * (1.0 + 8.0 * u) : 0.0;
+    float g = INFINITY, e = -INFINITY;
+    if (E == E && E < 1e30) {
+        if (m > 0.0) g = nextafterf(__double2float_ru(nq2 * (1.0 + 1e-12) + E - tg / (1.0 + gamma)), INFINITY);
+        e = nextafterf(__double2float_rd(nq2 * (1.0 - 1e-12) - E - tl / (1.0 - gamma)), -INFINITY);
+    }
+    thr[r] = g;
+    thr[n_rows + r] = e;
+}
+
 __global__ void to_bf16_kernel(const float* __restrict__ src, int64_t n_rows, int64_t ld_src, int k_int,
                                uint16_t* __restrict__ dst, int64_t ld_dst) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1067,6 +1138,30 @@ extern "C" int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t l
     EMG_REQUIRE(q && q_f16 && bounds3 && band, "emg_eval_prefilter_band: null pointer");
     hipLaunchKernelGGL(prefilter_band_kernel, dim3((unsigned)cdiv(n_rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, q,
                        n_rows, ldq, (const _Float16*)q_f16, ldq_f16, (int)k_int, bounds3, band);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_to_f16_l2(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, int is_query, void* dst_f16,
+                             int64_t ld_dst, float* doubled, double* n_residual_max, void* stream) {
+    EMG_REQUIRE(n_rows >= 0 && k_int > 0 && ld_src >= k_int && ld_dst >= k_int + 2, "emg_to_f16_l2: bad sizes");
+    if (n_rows == 0) return EMG_OK;
+    EMG_REQUIRE(src && dst_f16, "emg_to_f16_l2: null pointer");
+    if (!is_query && n_residual_max) EMG_HIP(hipMemsetAsync(n_residual_max, 0, sizeof(double), (hipStream_t)stream));
+    const int64_t b = cdiv(n_rows, 4 * 4);
+    hipLaunchKernelGGL(to_f16_l2_kernel, dim3((unsigned)(b > 65536 ? 65536 : b)), dim3(256), 0, (hipStream_t)stream, src, n_rows,
+                       ld_src, k_int, is_query, (_Float16*)dst_f16, ld_dst, doubled, n_residual_max);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_eval_l2_thresholds(const float* Q, int64_t n_rows, int64_t ldq, const int32_t* pos_int, const float* band,
+                                      const double* bounds4, int32_t k_int, float* thr, void* stream) {
+    EMG_REQUIRE(n_rows >= 0 && k_int > 0 && ldq >= k_int, "emg_eval_l2_thresholds: bad sizes");
+    if (n_rows == 0) return EMG_OK;
+    EMG_REQUIRE(Q && pos_int && band && bounds4 && thr, "emg_eval_l2_thresholds: null pointer");
+    hipLaunchKernelGGL(l2_thresholds_kernel, dim3((unsigned)cdiv(n_rows, 128)), dim3(128), 0, (hipStream_t)stream, Q, n_rows, ldq,
+                       pos_int, band, bounds4, k_int, thr);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

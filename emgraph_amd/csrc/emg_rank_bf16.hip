@@ -45,6 +45,8 @@ struct CountBf16Params {
     int64_t n_qb; int64_t n_cb; int64_t n_tiles; int32_t tiles_per_chunk;
     // prefilter mode (exact ranks at MFMA speed, see count_mfma_bf16_v3_kernel MODE 2)
     const float* band;         // per query row: rigorous bound on |bf16 accumulator - exact f32 chain| over all candidates
+    const float* thr_direct;   // or (TransE-L2 through the augmented contraction): the two accumulator thresholds themselves,
+                               //   [0, n_rows): counted when acc >= it; [n_rows, 2 n_rows): emitted when acc >= it (and not counted)
     uint64_t* pairs;           // (row << 32 | global entity id) of the candidates the bound cannot decide:
     uint32_t* pair_count;      //   wave w of the grid owns pairs[w * pair_cap ...), pair_count[w] = how many it wrote
     uint32_t pair_cap;         //   (no atomics: a returning atomic per emission cost more than the MFMAs of the tile);
@@ -564,7 +566,9 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
         const int row = tid & (V3_BM - 1);
         const int64_t qr = qb * V3_BM + row;
         float t = INFINITY;  // rows past the end count nothing
-        if (qr < P.n_rows) {
+        if (PRE && P.thr_direct != nullptr) {
+            if (qr < P.n_rows) t = P.thr_direct[(tid < V3_BM ? 0 : P.n_rows) + qr];
+        } else if (qr < P.n_rows) {
             const int p = P.pos_int[qr];
             const bool want_gt = ONE ? P.need == 2 : tid < V3_BM;
             t = acc_threshold(want_gt ? gt_threshold(p) : ge_threshold(p), P.cmul);
@@ -1037,6 +1041,24 @@ extern "C" int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq,
     P.ent = (const uint16_t*)ent_f16; P.n_cand = n_cand; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
     P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_gt; P.need = 0;
     P.band = band; P.pairs = pairs; P.pair_count = pair_count; P.pair_cap = (uint32_t)(pairs_capacity / n_seg);
+    P.n_segments = (uint32_t)n_seg;
+    EMG_HIP(hipMemsetAsync(pair_count, 0, (size_t)(n_seg + 1) * sizeof(uint32_t), (hipStream_t)stream));
+    return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
+}
+
+extern "C" int emg_eval_prefilter_f16_thr(const void* q_f16, int64_t ldq, const float* thr, int64_t n_rows, const void* ent_f16,
+                                          int64_t n_cand, int64_t ld_ent, int64_t ent_offset, int32_t k_pad, int32_t* cnt_gt,
+                                          uint64_t* pairs, uint32_t* pair_count, int64_t pairs_capacity, void* stream) {
+    EMG_REQUIRE(q_f16 && thr && ent_f16 && cnt_gt && pairs && pair_count, "emg_eval_prefilter_f16_thr: null pointer");
+    EMG_REQUIRE(n_rows < ((int64_t)1 << 31) && ent_offset + n_cand < ((int64_t)1 << 31), "emg_eval_prefilter_f16_thr: ids must fit 31 bits");
+    if (n_rows == 0 || n_cand == 0) return EMG_OK;
+    const int64_t n_seg = emg_eval_prefilter_segments(n_rows, n_cand);
+    EMG_REQUIRE(pairs_capacity >= n_seg && pairs_capacity / n_seg < ((int64_t)1 << 31), "emg_eval_prefilter_f16_thr: pair buffer smaller than one entry per wave (%lld)", (long long)n_seg);
+    CountBf16Params P{};
+    P.Q = (const uint16_t*)q_f16; P.ldq = ldq; P.pos_int = nullptr; P.n_rows = n_rows;
+    P.ent = (const uint16_t*)ent_f16; P.n_cand = n_cand; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
+    P.k_pad = k_pad; P.scale = 1.0f; P.model = EMG_DISTMULT; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_gt; P.need = 0;
+    P.band = nullptr; P.thr_direct = thr; P.pairs = pairs; P.pair_count = pair_count; P.pair_cap = (uint32_t)(pairs_capacity / n_seg);
     P.n_segments = (uint32_t)n_seg;
     EMG_HIP(hipMemsetAsync(pair_count, 0, (size_t)(n_seg + 1) * sizeof(uint32_t), (hipStream_t)stream));
     return launch_bf16(BF_COUNT, P, (hipStream_t)stream);

@@ -573,6 +573,47 @@ def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pair
                                        _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs")
 
 
+def to_f16_l2(src, k_int, is_query, ld_dst=None):
+    """half rows of the TransE-L2 contraction (include/emgraph_hip.h): entity rows [e | n_hi | n_lo] -> (rows, residual
+    max as 1 float64 on the device); query rows [2q | -1 | -1] -> (rows, the f32 rows 2q)"""
+    lib = L.load()
+    ps, n, ld = _chk_table(src, "src")
+    ldd = ld_dst or bf16_ld(k_int + 2)
+    out = torch.empty((n, ldd), dtype=torch.float16, device=src.device)
+    if is_query:
+        dbl = torch.zeros_like(src)
+        L.check(lib.emg_to_f16_l2(ps, n, ld, k_int, 1, out.data_ptr(), ldd, dbl.data_ptr(), None, _stream()), "emg_to_f16_l2")
+        return out, dbl
+    res = torch.zeros(1, dtype=torch.float64, device=src.device)
+    L.check(lib.emg_to_f16_l2(ps, n, ld, k_int, 0, out.data_ptr(), ldd, None, res.data_ptr(), _stream()), "emg_to_f16_l2")
+    return out, res
+
+
+def eval_l2_thresholds(Q, pos_int, band, bounds4, k_int):
+    lib = L.load()
+    pq, n, ldq = _chk_table(Q, "Q")
+    thr = torch.empty(2 * n, dtype=torch.float32, device=Q.device)
+    L.check(lib.emg_eval_l2_thresholds(pq, n, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n),
+                                       _chk_vec(band, torch.float32, "band", n), _chk_vec(bounds4, torch.float64, "bounds4", 4),
+                                       k_int, thr.data_ptr(), _stream()), "emg_eval_l2_thresholds")
+    return thr
+
+
+def eval_prefilter_f16_thr(q_f16, thr, ent_f16, ent_offset, k_cols, cnt_gt, pairs, pair_count):
+    """the half-precision MFMA prefilter with given accumulator thresholds (TransE-L2); k_cols = contraction width
+    (k_int + 2).  Raises EmgError(EMG_ENOSUP) for shapes the register-stationary kernel does not cover."""
+    lib = L.load()
+    pq, n_rows, ldq = _chk_f16(q_f16, "q_f16")
+    pe, ne, lde = _chk_f16(ent_f16, "ent_f16")
+    n_seg = eval_prefilter_segments(n_rows, ne)
+    L.check(lib.emg_eval_prefilter_f16_thr(pq, ldq, _chk_vec(thr, torch.float32, "thr", 2 * n_rows), n_rows, pe, ne, lde, ent_offset,
+                                           bf16_pad(k_cols), _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                           _chk_vec(pairs, torch.int64, "pairs"),
+                                           _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), pairs.numel(), _stream()),
+            "emg_eval_prefilter_f16_thr")
+    return n_seg
+
+
 def _chk_u16(t, name):
     if not (t.is_cuda and t.dtype == torch.int16 and t.dim() == 2 and t.stride(1) == 1):
         raise ValueError("%s must be a 2-D int16 CUDA tensor (u16 image rows) with unit column stride" % name)

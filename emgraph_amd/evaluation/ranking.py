@@ -215,6 +215,23 @@ class PrefilterTables:
         return self._bounds[(e0, n)]
 
 
+class L2Tables:
+    """what the TransE-L2 exact-fast mode derives from the entity table, built once per evaluation run: the half rows
+    [e | n_hi | n_lo] of the augmented contraction, the residual of the norm split and the norm bounds of the band."""
+
+    def __init__(self, ent, k_int):
+        self.ent_f16, self._res = D.to_f16_l2(ent, k_int, False)
+        self.k_int = k_int
+        self._bounds = {}
+        self._ent = ent
+
+    def bounds(self, e0, n):
+        if (e0, n) not in self._bounds:
+            b3 = D.eval_prefilter_bounds(self._ent[e0:e0 + n], self.ent_f16[e0:e0 + n], self.k_int)
+            self._bounds[(e0, n)] = torch.cat([b3, self._res])
+        return self._bounds[(e0, n)]
+
+
 class SadTables:
     """what the TransE-L1 exact-fast mode derives from the tables, built once per evaluation run: the range of the
     fixed-point map and the 16-bit image of the entity table.  Valid while the tables do not change."""
@@ -261,10 +278,12 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
 
     ``precision=2`` with TransE-L1: the same contract through a different prefilter — sums of absolute differences of
     16-bit fixed-point images of the rows (``v_sad_u16``, csrc/emg_rank_sad.hip) bound every candidate's score from both
-    sides; the undecided ones are re-scored with the exact chain.  TransE-L2 always takes the exact kernel.
+    sides; the undecided ones are re-scored with the exact chain.  TransE-L2: ||q-e||^2 = |q|^2 - (2q.e - |e|^2) is a
+    contraction over k+2 coordinates and goes through the half-precision MFMA prefilter with thresholds derived for the
+    squared distance (``L2Tables``), at the widths that kernel covers.
 
-    ``precision='auto'``: 2 where it applies and pays (contraction model at a k_int the prefilter kernel covers, or TransE-L1; no
-    candidate list, at least 128 test triples against at least 32768 entities), else 0 — the ranks are the same either way.
+    ``precision='auto'``: 2 where it applies and pays (contraction model, or TransE-L2 with k+2, at a width the prefilter kernel
+    covers, or TransE-L1; no candidate list, at least 128 test triples against at least 32768 entities), else 0 — the ranks are the same either way.
 
     ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
     (HIP events on the launch stream) and ``count_launches``."""
@@ -272,14 +291,16 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         # the exact-fast mode returns the SAME ranks as precision 0 (bit for bit) and pays off once the 1-vs-all
         # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
         n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
-        wide_enough = any(lo < k_int <= hi for lo, hi in ((112, 128), (192, 208), (384, 400)))
-        applies = (model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and wide_enough) or (model_id == L.TRANSE_L1 and k_int >= 16)
+        covered = lambda w: any(lo < w <= hi for lo, hi in ((112, 128), (192, 208), (384, 400)))  # noqa: E731
+        applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
+                   or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
         precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
     if precision not in (0, 1, 2):
         raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA), 2 (exact via half-precision prefilter) or 'auto' (0 or 2)")
-    if precision == 2 and (model_id not in (L.TRANSE_L1, L.DISTMULT, L.COMPLEX, L.HOLE) or entities_subset is not None):
-        precision = 0   # TransE-L2 has no prefilter; candidate lists go through the exact kernel: same ranks
+    if precision == 2 and entities_subset is not None:
+        precision = 0   # candidate lists go through the exact kernel: same ranks
     sad = precision == 2 and model_id == L.TRANSE_L1   # fixed-point prefilter instead of the half-precision MFMA one
+    l2 = precision == 2 and model_id == L.TRANSE_L2    # MFMA prefilter on the augmented rows
     if precision == 1 and model_id not in (L.DISTMULT, L.COMPLEX, L.HOLE):
         raise ValueError("the bf16 MFMA mode needs a contraction model (DistMult, ComplEx, HolE)")
     if corrupt_side not in L.EVAL_SIDE_IDS:
@@ -315,6 +336,9 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         else:
             sad_range = D.eval_sad_range(ent, rel, k_int)
             ent_u16 = D.eval_sad_quantize(ent, k_int, sad_range)
+    elif l2:
+        tabs = ent_f16 if isinstance(ent_f16, L2Tables) else L2Tables(ent, k_int)
+        ent_f16, bounds = tabs.ent_f16, tabs.bounds(e0, slab.shape[0])
     elif precision == 2:
         if isinstance(ent_f16, PrefilterTables):   # built once per evaluation run by the caller
             bounds, ent_f16 = ent_f16.bounds(e0, slab.shape[0]), ent_f16.ent_f16
@@ -363,6 +387,21 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
             _ev_stop(stats, ev)
             pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
+        elif l2 and have_cands:
+            Qh, Q2 = D.to_f16_l2(Q, k_int, True)
+            band = D.eval_prefilter_band(Q2, Qh, k_int, bounds[:3])
+            thr = D.eval_l2_thresholds(Q, pos_int, band, bounds, k_int)
+            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0])
+            pairs, pcount = _pair_buffer(ent.device, n_seg)
+            ev = _ev_start(stats)
+            try:
+                D.eval_prefilter_f16_thr(Qh, thr, ent_f16[e0:e0 + slab.shape[0]], e0, k_int + 2, cnt[0], pairs, pcount)
+            except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
+                pre = None
+            else:
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+                _ev_stop(stats, ev)
+                pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         elif precision == 2 and have_cands:
             # half-precision MFMA prefilter, then exact re-scoring of the undecided pairs: both asynchronous; whether a
             # wave ran out of pair room (-> this tile is redone by the exact kernel) is read with the counters at the end

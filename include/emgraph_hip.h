@@ -391,6 +391,26 @@ int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);
 
+/* TransE-L2 through the same half-precision MFMA prefilter: ||q - e||^2 = |q|^2 - (2 q.e - |e|^2) is a contraction over
+ * k_int + 2 coordinates, q' = [2q | -1 | -1], e' = [e | n_hi | n_lo], n_hi + n_lo ~ |e|^2 (TransE.py:208-216 with norm 2:
+ * score = -sqrt(sum_k (q_k - e_k)^2), compared as int(score * 1e5), EmbeddingModel.py:2010-2033).
+ *   emg_to_f16_l2            f32 rows -> half rows of ld_dst >= k_int + 2 columns.  is_query = 0: [e | n_hi | n_lo | 0..],
+ *                            *n_residual_max (device double, optional, written by the call) = max |n_hi + n_lo - |e|^2|;
+ *                            is_query = 1: [2q | -1 | -1 | 0..] and, if `doubled` is given, the f32 rows 2q (ld_src stride)
+ *   emg_eval_l2_thresholds   per query row the two accumulator thresholds (thr float [2 * n_rows]) from pos_int, the
+ *                            band of emg_eval_prefilter_band(2q, half(2q)) and bounds4 = the three norms of
+ *                            emg_eval_prefilter_bounds followed by *n_residual_max
+ *   emg_eval_prefilter_f16_thr  emg_eval_prefilter_f16 with the thresholds given instead of derived from pos_int / band:
+ *                            cnt_gt[row] += #(acc >= thr[row]); pairs with thr[n_rows + row] <= acc < thr[row] are emitted
+ * followed by emg_eval_rescore_pairs(EMG_TRANSE_L2, ...): the counters equal emg_eval_count's bit for bit. */
+int emg_to_f16_l2(const float* src, int64_t n_rows, int64_t ld_src, int32_t k_int, int is_query, void* dst_f16,
+                  int64_t ld_dst, float* doubled, double* n_residual_max, void* stream);
+int emg_eval_l2_thresholds(const float* Q, int64_t n_rows, int64_t ldq, const int32_t* pos_int, const float* band,
+                           const double* bounds4, int32_t k_int, float* thr, void* stream);
+int emg_eval_prefilter_f16_thr(const void* q_f16, int64_t ldq, const float* thr, int64_t n_rows, const void* ent_f16,
+                               int64_t n_cand, int64_t ld_ent, int64_t ent_offset, int32_t k_pad, int32_t* cnt_gt,
+                               uint64_t* pairs, uint32_t* pair_count, int64_t pairs_capacity, void* stream);
+
 /* TransE-L1: the ranks of emg_eval_count, bit for bit, at integer speed (csrc/emg_rank_sad.hip).  The score of the
  * reference, -sum_k |q_k - e_k| (TransE.py:208-216 with norm 1, compared as int(score * 1e5), EmbeddingModel.py:
  * 2010-2033), is bounded from both sides by a sum of absolute differences of 16-bit fixed-point images of the rows
@@ -438,9 +458,9 @@ int emg_corrupt_fit(const int32_t* pos, int64_t B, int32_t eta, int side, int64_
  * strategy: 0 worst | 1 best | 2 middle.  precision_mode: 0 exact f32 | 1 bf16 MFMA (statistical agreement) |
  * 2 the ranks of mode 0, bit for bit, through the half-precision MFMA prefilter + exact re-scoring (emg_to_f16,
  * emg_eval_prefilter_bounds / _band, emg_eval_prefilter_f16, emg_eval_rescore_pairs; one host synchronisation to read the
- * overflow flag; TransE-L1 goes through the 16-bit fixed-point prefilter emg_eval_prefilter_sad instead; the exact
- * kernel takes over for TransE-L2, candidate lists, shapes the prefilter kernels do not cover and overflowing pair
- * buffers).
+ * overflow flag; TransE-L1 goes through the 16-bit fixed-point prefilter emg_eval_prefilter_sad instead, TransE-L2
+ * through the MFMA prefilter on the augmented rows of emg_to_f16_l2; the exact kernel takes over for candidate lists,
+ * shapes the prefilter kernels do not cover and overflowing pair buffers).
  * rank_out int32: [n_q] for side_mode 0,1,2; [n_q,2] = [subject_rank, object_rank] for side_mode 3. */
 int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel,
                     int64_t ld_rel, int32_t k_int, float scale, const int32_t* test_spo, int64_t n_q, int side_mode,

@@ -300,3 +300,36 @@ def test_transe_l1_exact_fast_ranking_full_size_equals_exact(world):
     auto = rank_triples_device(L.TRANSE_L1, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F, precision="auto", stats=st)
     np.testing.assert_array_equal(auto, rank_triples_device(L.TRANSE_L1, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F))
     assert st.get("pairs", 0) > 0
+
+
+def test_transe_l2_exact_fast_ranking_full_size_equals_exact(world):
+    """TransE-L2 at |E| = 1M, k = 200 through the MFMA prefilter on the augmented rows: ranks BIT-equal to the exact f32
+    kernel, filtered and raw, all three strategies; precision 'auto' takes this path (k + 2 = 202 is a covered width)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex, L2Tables, rank_triples_device
+    from emgraph_amd.training import alloc_table
+    _, rel, _, pos = world
+    T = pos[:384]
+    F = FilterIndex(pos[:200000])
+    rs = np.random.RandomState(12)
+    k = 200
+    E = (rs.randn(N_ENT, k) * 0.1).astype(np.float32)
+    for j in range(0, len(T), 3):
+        E[rs.randint(0, N_ENT, 2)] = E[T[j, 2]]
+        E[rs.randint(0, N_ENT)] = np.nextafter(E[T[j, 0]], np.float32(np.inf))
+    dev_ = torch.device("cuda")
+    ent_t = alloc_table(N_ENT, k, dev_, init=E)
+    rel_t = alloc_table(rel.shape[0], k, dev_, init=(rs.randn(rel.shape[0], k) * 0.1).astype(np.float32))
+    tabs = L2Tables(ent_t, k)
+    for strategy in ("worst", "best", "middle"):
+        for filt in (F, None):
+            st = {}
+            exact = rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", strategy, filter_triples=filt)
+            fast = rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", strategy, filter_triples=filt, precision=2,
+                                       ent_f16=tabs, stats=st)
+            np.testing.assert_array_equal(fast, exact, err_msg=str((strategy, filt is not None, st)))
+            assert st.get("pairs", 0) > 0 and st.get("fallback", 0) == 0
+    st = {}
+    auto = rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F, precision="auto", stats=st)
+    np.testing.assert_array_equal(auto, rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F))
+    assert st.get("pairs", 0) > 0

@@ -799,12 +799,14 @@ def test_rank_1vsall_one_call_matches_python_path(model):
 
 @pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 30000, 300), ("DistMult", 200, 9000, 200), ("HolE", 100, 5000, 150),
                                               ("DistMult", 24, 700, 60), ("TransE_L1", 40, 900, 40), ("ComplEx", 200, 4000, 50),
-                                              ("TransE_L1", 200, 20000, 300), ("TransE_L1", 37, 3000, 70), ("TransE_L2", 64, 2000, 90)])
+                                              ("TransE_L1", 200, 20000, 300), ("TransE_L1", 37, 3000, 70), ("TransE_L2", 64, 2000, 90),
+                                              ("TransE_L2", 200, 20000, 300), ("TransE_L2", 126, 6000, 140)])
 def test_rank_1vsall_one_call_precision_2_equals_precision_0(model, k, n_ent, nq):
     """emg_rank_1vsall(precision_mode = 2) == precision_mode 0 for every side and strategy, filtered, with planted exact
     ties: through the half-precision prefilter where its kernel applies (the first three shapes), through the fixed-point
-    prefilter for TransE-L1 (any width), through the exact kernel where neither does (an uncovered width, TransE-L2,
-    fewer than 129 query rows of a contraction model, a candidate list)"""
+    prefilter for TransE-L1 (any width), through the MFMA prefilter on the augmented rows for TransE-L2 (k + 2 in a covered
+    width), through the exact kernel where none does (an uncovered width, fewer than 129 query rows of a contraction
+    model, a candidate list)"""
     from emgraph_amd import _lib as L
     from emgraph_amd.evaluation import FilterIndex
     d = dev()
@@ -1069,6 +1071,51 @@ def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
     assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
+
+
+@pytest.mark.parametrize("k,n_ent,nq,scale,huge", [(200, 30000, 300, 0.1, False), (126, 9000, 200, 1.0, False), (398, 6000, 150, 0.05, False),
+                                                   (200, 20000, 150, 0.0005, False), (100, 5000, 140, 0.3, False), (200, 5000, 40, 0.1, False),
+                                                   (200, 8000, 160, 0.1, True)])
+def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, huge):
+    """TransE-L2, precision=2 (||q-e||^2 as a contraction over k+2 coordinates through the half-precision MFMA prefilter,
+    thresholds derived for the squared distance, undecided candidates re-scored with the canonical f32 chain) ==
+    precision=0 for every side, strategy and filter setting.  Planted: exact ties, last-bit and one-quantum neighbours,
+    identical query/entity rows (distance exactly 0), a tiny scale (all comparison integers tie -> everything undecided
+    -> overflow -> exact kernel), widths the kernel does not cover (k+2 = 102; <= 128 query rows) and an entity whose
+    squared norm does not fit a half (the clamped split shows up in the band, never in the ranks)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import L2Tables, rank_triples_device
+    dev()
+    E, R, ki = make_tables("TransE_L2", k, n_ent, 5, seed=k + n_ent, scale=scale)
+    rs = np.random.RandomState(n_ent + k)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 5, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 4):
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+        E[rs.randint(0, n_ent, 1)] = E[T[j, 0]]
+        near = E[T[j, 2]].copy()
+        near[rs.randint(0, ki)] += F32(1e-5) * F32(rs.choice([-1.5, -1.0, -0.5, 0.5, 1.0, 1.5]))
+        E[rs.randint(0, n_ent)] = near
+        E[rs.randint(0, n_ent)] = np.nextafter(E[T[j, 0]], F32(np.inf))
+    R[4] = 0                                            # relation 4: q = s, so the subject itself sits at distance exactly 0
+    if huge:
+        far = rs.randint(0, n_ent)
+        if far not in T[:, [0, 2]]:
+            E[far] = F32(30.0)                          # |e|^2 = 180000 > the largest half
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 5000), rs.randint(0, 5, 5000), rs.randint(0, n_ent, 5000)], 1)]).astype(np.int32)
+    Et, Rt = cu(E), cu(R)
+    tabs = L2Tables(Et, ki)
+    used = 0
+    for side in ("s,o", "s+o", "o", "s"):
+        for strategy in ("worst", "best", "middle"):
+            for filt in (None, F):
+                st = {}
+                exact = rank_triples_device(L.TRANSE_L2, Et, Rt, ki, 1.0, T, side, strategy, filter_triples=filt)
+                fast = rank_triples_device(L.TRANSE_L2, Et, Rt, ki, 1.0, T, side, strategy, filter_triples=filt, precision=2,
+                                           stats=st, ent_f16=tabs if side != "o" else None, query_chunk=200 if side == "s" else 4096)
+                np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
+                used += st.get("pairs", 0) + st.get("fallback", 0)
+    if k + 2 in (128, 202, 400) and nq > 128:
+        assert used > 0        # the prefilter ran
 
 
 def test_sad_images_and_thresholds_bound_the_exact_chain():
