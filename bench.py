@@ -384,7 +384,7 @@ def run_eval(r, args):
                      "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
     out["exact_fast"] = ex
     out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
-                              "DistMult / ComplEx / HolE at k_int in {113..128, 193..208, 385..400} and (transe_l1.exact_fast) for TransE-L1, "
+                              "DistMult / ComplEx / HolE at k_int in {113..128, 193..208, 385..400} and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 and TransE-L2 (k + 2 in those widths), "
                               ">= 128 test triples, >= 32768 entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
     if not args.quick:
         # query-tile sweep (B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode
@@ -436,6 +436,37 @@ def run_eval(r, args):
             "roofline": {"bound": "valu", "achieved": round(sad_ops / (sts["count_ms"] * 1e-3) / 1e12, 2), "peak": round(valu_issue_peak, 2),
                          "unit": "T lane-instr/s (VALU issue rate; kernel_ms includes the re-scoring)",
                          "frac": round(sad_ops / (sts["count_ms"] * 1e-3) / 1e12 / valu_issue_peak, 4)}}
+        # TransE-L2: exact f32 VALU kernel, and the same ranks through the MFMA prefilter on the augmented rows
+        from emgraph_amd.evaluation import L2Tables
+        T2 = T[:1024]
+        rank_triples_device(1, ent_t, rel_t, kt_, 1.0, T2[:32], "s+o", "worst", filter_triples=F, shard=shard)
+        torch.cuda.synchronize()
+        st2 = {}
+        t0 = time.perf_counter()
+        exact_2 = rank_triples_device(1, ent_t, rel_t, kt_, 1.0, T2, "s+o", "worst", filter_triples=F, shard=shard, stats=st2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        tabs2 = L2Tables(ent_t, kt_)
+        rank_triples_device(1, ent_t, rel_t, kt_, 1.0, T2[:160], "s+o", "worst", filter_triples=F, shard=shard, precision=2, ent_f16=tabs2)
+        torch.cuda.synchronize()
+        st3 = {}
+        t0 = time.perf_counter()
+        fast_2 = rank_triples_device(1, ent_t, rel_t, kt_, 1.0, T2, "s+o", "worst", filter_triples=F, shard=shard, precision=2,
+                                     ent_f16=tabs2, stats=st3)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        mfma_flops = 2.0 * 208 * w["n_ent"] * 2 * len(T2) / world     # k + 2 = 202 coordinates in 13 k-steps of 16
+        out["transe_l2"] = {
+            "value": round(2 * len(T2) / dt2, 1), "unit": "ranks/s", "test_triples": len(T2), "k": kt_,
+            "kernel": "count_transe_big_kernel<L2> (f32 VALU)", "kernel_ms": round(st2["count_ms"], 3),
+            "exact_fast": {
+                "value": round(2 * len(T2) / dt3, 1), "unit": "ranks/s", "equal_to_exact_f32_ranks": bool(np.array_equal(fast_2, exact_2)),
+                "undecided_pairs": int(st3.get("pairs", 0)), "undecided_fraction": round(st3.get("pairs", 0) / (2.0 * len(T2) * w["n_ent"] / world), 6),
+                "tiles_redone_by_exact_kernel": int(st3.get("fallback", 0)), "kernel_ms": round(st3["count_ms"], 3),
+                "kernels": "count_mfma_bf16_v3_kernel<13,4,2> (v_mfma_f32_32x32x16_f16 over [2q|-1|-1].[e|n_hi|n_lo]) + rescore_pairs_kernel",
+                "roofline": {"bound": "mfma", "achieved": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
+                             "unit": "TFLOP/s (kernel_ms includes the re-scoring)",
+                             "frac": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}}}
     return out
 
 
