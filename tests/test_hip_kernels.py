@@ -1000,7 +1000,9 @@ def test_apply_rows_long_segments_block_tree(k, opt):
 @pytest.mark.parametrize("model,k,n_ent,nq,scale", [("ComplEx", 200, 30000, 300, 0.1), ("HolE", 200, 9000, 200, 0.3),
                                                      ("DistMult", 200, 20000, 150, 0.1), ("DistMult", 128, 5000, 140, 0.05),
                                                      ("ComplEx", 64, 12000, 260, 1.0), ("ComplEx", 100, 7000, 80, 0.1),
-                                                     ("ComplEx", 200, 5000, 40, 0.1)])
+                                                     ("ComplEx", 200, 5000, 40, 0.1), ("ComplEx", 50, 15000, 200, 0.2),
+                                                     ("DistMult", 150, 9000, 180, 0.1), ("DistMult", 300, 6000, 150, 0.1),
+                                                     ("HolE", 30, 20000, 170, 0.3), ("DistMult", 100, 4000, 130, 0.02)])
 def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
     """precision=2 (bf16 MFMA prefilter with a rigorous per-row error band + exact f32 re-scoring of the undecided
     candidates) == precision=0 (exact f32 MFMA chain) for every side, strategy and filter setting; exact ties are
@@ -1026,8 +1028,8 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
                 exact = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt)
                 fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, stats=st)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None)))
-                used += st.get("pairs", 0)
-    kint_ok = (ki + 15) // 16 in (8, 13, 25)
+                used += st.get("pairs", 0) + st.get("fallback", 0)
+    kint_ok = (ki + 15) // 16 in (4, 7, 8, 10, 13, 19, 25)
     if kint_ok and 2 * nq > 128:
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
 
@@ -1075,13 +1077,13 @@ def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
 
 @pytest.mark.parametrize("k,n_ent,nq,scale,huge", [(200, 30000, 300, 0.1, False), (126, 9000, 200, 1.0, False), (398, 6000, 150, 0.05, False),
                                                    (200, 20000, 150, 0.0005, False), (100, 5000, 140, 0.3, False), (200, 5000, 40, 0.1, False),
-                                                   (200, 8000, 160, 0.1, True)])
+                                                   (200, 8000, 160, 0.1, True), (150, 7000, 150, 0.1, False), (50, 30000, 200, 0.2, False)])
 def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, huge):
     """TransE-L2, precision=2 (||q-e||^2 as a contraction over k+2 coordinates through the half-precision MFMA prefilter,
     thresholds derived for the squared distance, undecided candidates re-scored with the canonical f32 chain) ==
     precision=0 for every side, strategy and filter setting.  Planted: exact ties, last-bit and one-quantum neighbours,
     identical query/entity rows (distance exactly 0), a tiny scale (all comparison integers tie -> everything undecided
-    -> overflow -> exact kernel), widths the kernel does not cover (k+2 = 102; <= 128 query rows) and an entity whose
+    -> overflow -> exact kernel), <= 128 query rows (exact kernel) and an entity whose
     squared norm does not fit a half (the clamped split shows up in the band, never in the ranks)."""
     from emgraph_amd import _lib as L
     from emgraph_amd.evaluation import L2Tables, rank_triples_device
@@ -1114,7 +1116,7 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
                                            stats=st, ent_f16=tabs if side != "o" else None, query_chunk=200 if side == "s" else 4096)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
-    if k + 2 in (128, 202, 400) and nq > 128:
+    if k + 2 in (52, 102, 128, 152, 202, 400) and nq > 128:
         assert used > 0        # the prefilter ran
 
 
