@@ -490,14 +490,18 @@ def test_reference_written_checkpoint_predicts_reference_scores(name, golden):
     assert np.all(np.abs(got - exp) <= 1e-4 * np.maximum(np.abs(exp), 1.0))
 
 
-@pytest.mark.parametrize("name,k", [("DistMult", 200), ("ComplEx", 100), ("HolE", 200)])
-def test_default_eval_precision_returns_the_exact_ranks(name, k):
-    """evaluate_performance's default ('auto') takes the half-precision prefilter + exact re-scoring path on large
-    tables: the ranks must equal the exact f32 kernel's (eval_precision=0) for every triple, side and strategy"""
+@pytest.mark.parametrize("name,k,params", [("DistMult", 200, {}), ("ComplEx", 100, {}), ("HolE", 200, {}), ("DistMult", 100, {}),
+                                           ("TransE", 200, {}), ("TransE", 75, {"norm": 1}), ("TransE", 200, {"norm": 2}),
+                                           ("TransE", 100, {"norm": 2})])
+def test_default_eval_precision_returns_the_exact_ranks(name, k, params):
+    """evaluate_performance's default ('auto') takes a prefilter + exact re-scoring path on large tables (half-precision
+    MFMA for DistMult / ComplEx / HolE and TransE-L2, 16-bit fixed-point sums for TransE-L1): the ranks must equal the
+    exact f32 kernel's (eval_precision=0) for every triple, side and strategy"""
     import emgraph_amd.models as M
     from emgraph_amd.evaluation import evaluate_performance
     X = synth_graph(n_ent=40000, n_rel=7, n=60000, seed=5)
-    m = getattr(M, name)(k=k, eta=2, epochs=2, batches_count=4, seed=1, optimizer="adam", optimizer_params={"lr": 0.05})
+    m = getattr(M, name)(k=k, eta=2, epochs=2, batches_count=4, seed=1, optimizer="adam", optimizer_params={"lr": 0.05},
+                         embedding_model_params=dict(params))
     m.fit(X)
     Xte = X[:300]
     for strategy in ("worst", "best", "middle"):
