@@ -163,8 +163,8 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
             else step(r);
         }
         if (rc == EMG_OK && !exact) {
-            step(emg_eval_rescore_pairs(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg, cnt,
-                                        cnt + n_rows, stream));
+            step(emg_eval_rescore_pairs_ex(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg,
+                                           sad ? 4 : 8, cnt, cnt + n_rows, stream));
             uint32_t over = 0;   // some wave ran out of pair room: these counters are void, the exact kernel redoes them
             if (rc == EMG_OK && (hipMemcpyAsync(&over, pcount + n_seg, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                                  hipStreamSynchronize(st) != hipSuccess))

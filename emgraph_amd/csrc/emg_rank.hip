@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void filter_count_kernel(int model, const floa
 struct RescoreParams {
     int model; const float* Q; int64_t ldq; const int32_t* pos_int; const float* ent; int64_t ld_ent; int64_t ent_offset;
     int k_int; float scale; const uint64_t* pairs; uint32_t cap; const uint32_t* seg_count; uint32_t n_seg;  // segment s: pairs[s*cap ..+min(count, cap))
+    uint32_t groups_per_block;   // 4-segment groups per workgroup of the prefilter that wrote the pairs (see the kernel)
     int32_t* cnt_gt; int32_t* cnt_eq;
 };
 
@@ -596,7 +597,12 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
     float* myq = qs[wave];
     float* mye = es[wave];
     const int sub = lane >> 2, part = lane & 3;   // loader role: pair (16 it + sub) of the wave's 64, 16-byte piece `part`
-    for (uint32_t seg = blockIdx.x * 4u + wave; seg < P.n_seg; seg += gridDim.x * 4u) {
+    // Workgroup b of the prefilter ran on XCD b & 7 and walked the query blocks of one entity chunk after another; its
+    // segments are re-scored on the SAME XCD in the same order, so the chunk's entity rows (3-6 MB) are still in that XCD's
+    // L2 when the next query block's pairs ask for them (a row is wanted by ~10 query rows of a 2048-row tile).
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, r = P.groups_per_block;
+    const uint32_t group = r * (8u * (j / r) + xcd) + (j % r);
+    for (uint32_t seg = group * 4u + wave; seg < P.n_seg; seg = P.n_seg) {
         const uint32_t n = min(P.seg_count[seg], P.cap);
         const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
         for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
@@ -1081,6 +1087,17 @@ extern "C" int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, co
                                       int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
                                       const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
                                       int64_t n_segments, int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
+    return emg_eval_rescore_pairs_ex(model, Q, ldq, pos_int, ent, ld_ent, ent_offset, k_int, scale, pairs, pairs_capacity, pair_count,
+                                     n_segments, 4, cnt_gt, cnt_eq, stream);
+}
+
+extern "C" int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                         int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
+                                         const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
+                                         int64_t n_segments, int32_t segments_per_block, int32_t* cnt_gt, int32_t* cnt_eq,
+                                         void* stream) {
+    EMG_REQUIRE(segments_per_block >= 4 && segments_per_block % 4 == 0 && segments_per_block <= 64,
+                "emg_eval_rescore_pairs_ex: segments_per_block must be a multiple of 4 (4 = emg_eval_prefilter_sad, 8 = emg_eval_prefilter_f16)");
     EMG_REQUIRE(model >= EMG_TRANSE_L1 && model <= EMG_HOLE, "emg_eval_rescore_pairs: unknown model id %d", model);
     EMG_REQUIRE(Q && pos_int && ent && pairs && pair_count && cnt_gt && cnt_eq, "emg_eval_rescore_pairs: null pointer");
     if (n_segments <= 0) return EMG_OK;
@@ -1091,8 +1108,11 @@ extern "C" int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, co
     P.seg_count = pair_count; P.n_seg = (uint32_t)n_segments;
     P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
     const bool vec = (k_int % 4 == 0) && (ldq % 4 == 0) && (ld_ent % 4 == 0) && aligned16(Q) && aligned16(ent);
-    const int64_t blocks = cdiv(n_segments, 4);
-    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384)), block(256);
+    P.groups_per_block = (uint32_t)(segments_per_block / 4);
+    const int64_t per = 8 * (int64_t)P.groups_per_block;                    // one workgroup per 4-segment group, XCD-aligned
+    const int64_t blocks = cdiv(cdiv(n_segments, 4), per) * per;
+    EMG_REQUIRE(blocks < ((int64_t)1 << 31), "emg_eval_rescore_pairs: too many segments");
+    const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (model == EMG_TRANSE_L1) {
         if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 1>), grid, block, 0, st, P);

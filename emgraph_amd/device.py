@@ -561,16 +561,18 @@ def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_in
     return n_seg
 
 
-def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pairs, pair_count, n_seg, cnt_gt, cnt_eq):
-    """exact re-scoring of the prefilter's undecided pairs (counts read on the device)"""
+def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pairs, pair_count, n_seg, cnt_gt, cnt_eq,
+                       segments_per_block=4):
+    """exact re-scoring of the prefilter's undecided pairs (counts read on the device); ``segments_per_block``: 8 after the
+    half-precision MFMA prefilter, 4 after the fixed-point one (XCD affinity of the re-scoring, include/emgraph_hip.h)"""
     lib = L.load()
     pq, n_rows, ldq = _chk_table(Q, "Q")
     pe, ne, lde = _chk_table(ent, "ent")
-    L.check(lib.emg_eval_rescore_pairs(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset,
-                                       k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
-                                       _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg,
-                                       _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
-                                       _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs")
+    L.check(lib.emg_eval_rescore_pairs_ex(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset,
+                                          k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
+                                          _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg, segments_per_block,
+                                          _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                          _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs_ex")
 
 
 def to_f16_l2(src, k_int, is_query, ld_dst=None):

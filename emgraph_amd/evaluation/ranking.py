@@ -11,6 +11,8 @@ Everything numeric runs in libemgraph_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -243,6 +245,7 @@ class SadTables:
 
 
 _pair_buffers = {}
+_RESCORE_SPB = int(os.environ.get('EMG_RESCORE_SPB', '8'))   # A/B aid: 4 = segments in index order
 
 
 def _pair_buffer(device, n_seg):
@@ -384,7 +387,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             pairs, pcount = _pair_buffer(ent.device, n_seg)
             ev = _ev_start(stats)
             D.eval_prefilter_sad(Qu, thr, ent_u16[e0:e0 + slab.shape[0]], e0, k_int, cnt[0], pairs, pcount)
-            D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+            D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], 4)
             _ev_stop(stats, ev)
             pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         elif l2 and have_cands:
@@ -399,7 +402,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], _RESCORE_SPB)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         elif precision == 2 and have_cands:
@@ -417,7 +420,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1])
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], _RESCORE_SPB)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         if have_cands and pre is None:

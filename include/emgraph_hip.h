@@ -387,6 +387,13 @@ int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, const int32_t
                            int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
                            int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments, int32_t* cnt_gt,
                            int32_t* cnt_eq, void* stream);
+/* the same with the number of segments each workgroup of the prefilter wrote (8: emg_eval_prefilter_f16[_thr], 4:
+ * emg_eval_prefilter_sad and the plain call): the re-scoring then runs each workgroup's segments on the XCD that produced
+ * them, in the same order, so the entity rows of a chunk are re-read from that XCD's L2 instead of HBM */
+int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                              int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
+                              int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments,
+                              int32_t segments_per_block, int32_t* cnt_gt, int32_t* cnt_eq, void* stream);
 int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64_t n_rows, const void* ent_bf16,
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);
