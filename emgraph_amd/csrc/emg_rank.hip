@@ -602,7 +602,8 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
     // L2 when the next query block's pairs ask for them (a row is wanted by ~10 query rows of a 2048-row tile).
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, r = P.groups_per_block;
     const uint32_t group = r * (8u * (j / r) + xcd) + (j % r);
-    for (uint32_t seg = group * 4u + wave; seg < P.n_seg; seg = P.n_seg) {
+    const uint32_t seg = group * 4u + wave;   // one wave per segment (the grid is padded: groups past the end do nothing)
+    if (seg < P.n_seg) {
         const uint32_t n = min(P.seg_count[seg], P.cap);
         const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
         for (uint32_t c0 = 0; c0 < n; c0 += 64u) {

@@ -1035,7 +1035,8 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
 
 
 @pytest.mark.parametrize("k,n_ent,nq,scale", [(200, 30000, 300, 0.1), (100, 9000, 200, 1.0), (50, 20000, 150, 0.002),
-                                              (37, 5000, 140, 0.3), (16, 40000, 130, 0.05), (200, 5000, 40, 0.1)])
+                                              (37, 5000, 140, 0.3), (16, 40000, 130, 0.05), (200, 5000, 40, 0.1), (3, 9, 6, 0.5),
+                                              (1, 130, 3, 0.5), (520, 1500, 70, 0.05)])
 def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
     """TransE-L1, precision=2 (v_sad_u16 sums over 16-bit fixed-point images bound every score from both sides; the
     undecided candidates are re-scored with the canonical f32 chain) == precision=0 for every side, strategy and filter
@@ -1061,6 +1062,7 @@ def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
         E[far] *= F32(6.0)
     F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 5000), rs.randint(0, 5, 5000), rs.randint(0, n_ent, 5000)], 1)]).astype(np.int32)
     Et, Rt = cu(E), cu(R)
+    assert rank_triples_device(L.TRANSE_L1, Et, Rt, ki, 1.0, T[:0], "s,o", "worst", precision=2).shape == (0, 2)
     tabs = SadTables(Et, Rt, ki)
     used = 0
     for side in ("s,o", "s+o", "o", "s"):
