@@ -1,6 +1,8 @@
 """GPU parity tests, kernel level: every C-ABI entry point against the oracle on seeded inputs.
 Bar: bit-exact for integer/index work (corruptions, ranks, counts); fp32 scores/gradients within
 1e-4 relative (north_star), tolerance written at each assert."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1120,6 +1122,33 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
                 used += st.get("pairs", 0) + st.get("fallback", 0)
     if k + 2 in (52, 102, 128, 152, 202, 400) and nq > 128:
         assert used > 0        # the prefilter ran
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+def test_transe_prefilters_random_shapes_equal_exact(seed):
+    """soak of both TransE prefilters: random widths, table scales over four decades, heavy-tailed tables, relation scales
+    far from the entity scale, query sets with many repeated entities — precision 2 must return the ranks of precision 0"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import rank_triples_device
+    dev()
+    rs = np.random.RandomState(1000 + seed)
+    for _ in range(5):
+        l2 = bool(rs.randint(0, 2))
+        k = int(rs.choice([50, 98, 100, 126, 150, 198, 200, 300, 398])) if l2 else int(rs.randint(1, 261))
+        n_ent, nq = int(rs.randint(1500, 20000)), int(rs.randint(130, 300))
+        scale = 10.0 ** rs.uniform(-3, 1)
+        E = (rs.standard_t(3, (n_ent, k)) if rs.randint(0, 2) else rs.randn(n_ent, k)).astype(F32) * F32(scale)
+        R = (rs.randn(6, k) * scale * 10.0 ** rs.uniform(-2, 1)).astype(F32)
+        pool = rs.randint(0, n_ent, 40)                                   # few distinct entities: many equal scores
+        T = np.stack([rs.choice(pool, nq), rs.randint(0, 6, nq), rs.choice(pool, nq)], 1).astype(np.int32)
+        E[rs.randint(0, n_ent, 30)] = E[rs.choice(pool, 30)]             # copies of query entities elsewhere in the table
+        mid = L.TRANSE_L2 if l2 else L.TRANSE_L1
+        Et, Rt = cu(E), cu(R)
+        side, strategy = str(rs.choice(["s,o", "s+o", "s", "o"])), str(rs.choice(["worst", "best", "middle"]))
+        filt = T if rs.randint(0, 2) else None
+        exact = rank_triples_device(mid, Et, Rt, k, 1.0, T, side, strategy, filter_triples=filt)
+        fast = rank_triples_device(mid, Et, Rt, k, 1.0, T, side, strategy, filter_triples=filt, precision=2)
+        np.testing.assert_array_equal(fast, exact, err_msg=str((seed, l2, k, n_ent, nq, scale, side, strategy)))
 
 
 def test_sad_images_and_thresholds_bound_the_exact_chain():
