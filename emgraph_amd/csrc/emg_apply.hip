@@ -287,25 +287,31 @@ __global__ __launch_bounds__(256) void apply_rows_pair_kernel(const ApplyParams 
 //       optimizer.  The reduction tree is defined by the segment alone, so the bits do not depend on which wave, window
 //       or GPU did what (a one-block segment is the same tree: plain left to right, like the window kernel's).
 template <int W>
-__device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, float (&out)[W]) {
+__device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, uint32_t my_row, float my_coef,
+                                          float (&out)[W]) {
+    // (my_row, my_coef): source row and factor of position u0 + lane, loaded by the WHOLE wave in one instruction before
+    // the column loop (block_sources) and handed out with v_readlane — one load round trip per block instead of one per
+    // 16 rows in front of the row loads that depend on it
     if constexpr (W == 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int64_t u = u0;
-        for (; u + 16 <= u1; u += 16) {
+        const int n = (int)(u1 - u0);
+        int j0 = 0;
+        for (; j0 + 16 <= n; j0 += 16) {
             float4 v[16];
             float cf[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const Src sj = contrib_src(P, u + j);
-                cf[j] = sj.coef;
-                v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)sj.row * P.ldc + 4 * c);
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0 + j);
+                cf[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), j0 + j));
+                v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c);
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) add_scaled(acc, v[j], cf[j]);
         }
-        for (; u < u1; ++u) {
-            const Src su = contrib_src(P, u);
-            add_scaled(acc, *reinterpret_cast<const float4*>(P.contrib + (int64_t)su.row * P.ldc + 4 * c), su.coef);
+        for (; j0 < n; ++j0) {
+            const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0);
+            const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), j0));
+            add_scaled(acc, *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c), cf);
         }
         out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
     } else {
@@ -316,6 +322,11 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
         }
         out[0] = acc;
     }
+}
+
+// sources of the (at most 64) positions [u0, u1): lane j holds position u0 + j — call with all 64 lanes active
+__device__ __forceinline__ Src block_sources(const ApplyParams& P, int64_t u0, int64_t u1, int lane) {
+    return u0 + lane < u1 ? contrib_src(P, u0 + lane) : Src{0u, 0.f};
 }
 
 __device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, uint32_t key, int lane) {
@@ -335,7 +346,13 @@ __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __r
     const unsigned n_tasks = min(*P.long_count, P.long_cap);
     const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
-    for (unsigned i = block * nwv + wv; i < n_tasks; i += n_blocks * nwv) {   // one task per wave at a time
+    // Rows wider than 64 column chunks: TWO waves per task, each with every other group of 64 chunks — a task is a chain
+    // of dependent loads (source row index, then 16 rows at a time), so the second wave halves its length instead of
+    // walking the rows a second time (measured on the Zipf batch: see DESIGN.md 4.1).  Column sums are unchanged.
+    const unsigned per = (nchunks > 64 && P.n < ((int64_t)1 << 22)) ? 2u : 1u;   // (block counts stay below 2^16: see the arrival fields)
+    for (unsigned i2 = block * nwv + wv; i2 < n_tasks * per; i2 += n_blocks * nwv) {   // one (task, column half) per wave at a time
+        const unsigned i = i2 / per, half = i2 % per;
+        const int col0 = 64 * (int)half, cstep = 64 * (int)per;
         const LongTask tk = P.long_list[i];                                         // (wave-uniform)
         if (tk.len == 0) continue;
         const int64_t t = tk.head, end = t + tk.len;
@@ -356,12 +373,13 @@ __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __r
         };
         const int64_t nblk = (tk.len + kLongSegment - 1) / kLongSegment;
         if (nblk == 1) {
-            for (int c = lane; c < nchunks; c += 64) {
+            const Src mine = block_sources(P, t, end, lane);
+            for (int c = lane + col0; c < nchunks; c += cstep) {
                 float g[W];
-                sum_block<W>(P, t, end, c, g);
+                sum_block<W>(P, t, end, c, mine.row, mine.coef, g);
                 update(c, g);
             }
-            if (P.tag && lane == 0) P.tag[key] = P.step;
+            if (P.tag && lane == 0 && half == 0) P.tag[key] = P.step;
             continue;
         }
         // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
@@ -370,25 +388,29 @@ __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __r
         // segment's arrival counter.
         const int64_t u0 = t + (int64_t)tk.block * kLongSegment, u1 = min(u0 + kLongSegment, end);
         float* prow = partial + (2 * (u0 / kLongSegment) + (tk.block == 0 ? 1 : 0)) * ldp;
-        for (int c = lane; c < nchunks; c += 64) {
+        const Src mine = block_sources(P, u0, u1, lane);
+        for (int c = lane + col0; c < nchunks; c += cstep) {
             float g[W];
-            sum_block<W>(P, u0, u1, c, g);
+            sum_block<W>(P, u0, u1, c, mine.row, mine.coef, g);
             if constexpr (W == 4) store4_through(prow + 4 * c, g[0], g[1], g[2], g[3]);
             else __hip_atomic_store(prow + c, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         wait_memory();   // this wave's block sum has left for memory
+        // arrivals of the two column halves are counted in the two 16-bit fields of the segment's counter
+        // (split only below 2^22 contributions: a segment then has fewer than 65536 blocks)
+        const int shift = 16 * (int)half;
         int before = 0;
-        if (lane == 0) before = atomicAdd(P.arrive + t / kLongSegment, 1);
-        before = __builtin_amdgcn_readfirstlane(before);
+        if (lane == 0) before = atomicAdd(P.arrive + t / kLongSegment, 1 << shift);
+        before = (__builtin_amdgcn_readfirstlane(before) >> shift) & 0xffff;
         if (before != (int)nblk - 1) continue;
-        // the segment's last block: every block sum is in memory
-        if (lane == 0) P.arrive[t / kLongSegment] = 0;   // ready for the next apply on this workspace
+        // the segment's last block (of this column half): every block sum is in memory
+        if (lane == 0) atomicSub(P.arrive + t / kLongSegment, (int)nblk << shift);   // ready for the next apply on this workspace
         const int64_t m0 = t / kLongSegment;             // (t + 64 b) / 64 = t / 64 + b
         if constexpr (W == 4) {
             // two chunks per lane x 8 block sums per trip in flight, added left to right: 0 + first block sum + ...
             for (int c0 = 0; c0 < nchunks; c0 += 128) {
                 const int ca = c0 + lane, cb = c0 + 64 + lane;
-                const bool oa = ca < nchunks, ob = cb < nchunks;
+                const bool oa = ca < nchunks && (per == 1u || half == 0u), ob = cb < nchunks && (per == 1u || half == 1u);
                 vfloat4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
                 const float* first = partial + (2 * m0 + 1) * ldp;
                 if (oa) a = load4_through(first + 4 * ca);
@@ -419,7 +441,7 @@ __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __r
                 if (ob) update(cb, gb);
             }
         } else {
-            for (int c = lane; c < nchunks; c += 64) {
+            for (int c = lane + col0; c < nchunks; c += cstep) {
                 float acc[W];
                 float a = __hip_atomic_load(partial + (2 * m0 + 1) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int64_t bq = 1; bq < nblk; ++bq)
@@ -428,7 +450,7 @@ __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __r
                 update(c, acc);
             }
         }
-        if (P.tag && lane == 0) P.tag[key] = P.step;
+        if (P.tag && lane == 0 && half == 0) P.tag[key] = P.step;
     }
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
     // the last workgroup to finish empties the list, so that a second emg_apply_grouped on the same grouping (or the
