@@ -285,7 +285,7 @@ def score_kernel_alone(r, reps=50):
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
     traffic = None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_f_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_i_pmc_traffic.json")))
         k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
         traffic = k[0]["hbm_bytes_per_launch"] if k else None
     except (OSError, ValueError, KeyError):
