@@ -942,7 +942,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
     else if (mode == BF_DIAG) hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_DIAG>, dim3((unsigned)blocks), dim3(256), 0, st, P);
     else if (P.cand == nullptr && P.cmul > 0.f && P.cmul < INFINITY && P.n_rows > V2_BM &&
              (P.k16 == 25 || P.k16 == 13 || P.k16 == 8 ||
-              (P.pairs != nullptr && (P.k16 == 4 || P.k16 == 7 || P.k16 == 10 || P.k16 == 19)))) {
+              (P.pairs != nullptr && (P.k16 == 4 || P.k16 == 7 || P.k16 == 10 || P.k16 == 16 || P.k16 == 19 || P.k16 == 22)))) {
         // register-stationary query fragments + deep LDS-DMA ring (see its header); common k only
         P.n_qb = cdiv(P.n_rows, V3_BM);
         P.n_tiles = cdiv(P.n_cand, V3_BN);
@@ -957,15 +957,18 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         else if (P.k16 == 13) rc = EMG_V3(13);
         else if (P.k16 == 8) rc = EMG_V3(8);
         // the prefilter (exact-fast mode, what evaluate_performance uses by default) also at the other common widths:
-        // k_int 49..64, 97..112, 145..160, 289..304 (k = 50 / 100 / 150 / 300, or half of it for ComplEx / HolE)
+        // k_int 49..64, 97..112, 145..160, 241..256, 289..304, 337..352 (k = 50 / 100 / 150 / 256 / 300 / 350, or half of it
+        // for ComplEx / HolE)
         else if (P.k16 == 4) rc = launch_v3<4, 4, 2>(P, nblk, st);
         else if (P.k16 == 7) rc = launch_v3<7, 4, 2>(P, nblk, st);
         else if (P.k16 == 10) rc = launch_v3<10, 4, 2>(P, nblk, st);
-        else rc = launch_v3<19, 4, 2>(P, nblk, st);
+        else if (P.k16 == 16) rc = launch_v3<16, 4, 2>(P, nblk, st);
+        else if (P.k16 == 19) rc = launch_v3<19, 4, 2>(P, nblk, st);
+        else rc = launch_v3<22, 4, 2>(P, nblk, st);
 #undef EMG_V3
         if (rc != EMG_OK) return rc;
     } else if (P.pairs) {
-        return fail(EMG_ENOSUP, "bf16 prefilter: only k_int in (48..64], (96..128], (144..160], (192..208], (288..304], (384..400], more than 128 query rows, no candidate list");
+        return fail(EMG_ENOSUP, "bf16 prefilter: only k_int in (48..64], (96..128], (144..160], (192..208], (240..256], (288..304], (336..352], (384..400], more than 128 query rows, no candidate list");
     } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
         // query-stationary LDS-DMA kernel (see its header); anything else takes the v1 tile kernel above
         const int m = P.k_pad / 32;

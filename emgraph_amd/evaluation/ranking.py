@@ -294,7 +294,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         # the exact-fast mode returns the SAME ranks as precision 0 (bit for bit) and pays off once the 1-vs-all
         # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
         n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
-        covered = lambda w: any(lo < w <= hi for lo, hi in ((48, 64), (96, 128), (144, 160), (192, 208), (288, 304), (384, 400)))  # noqa: E731
+        covered = lambda w: any(lo < w <= hi for lo, hi in ((48, 64), (96, 128), (144, 160), (192, 208), (240, 256), (288, 304), (336, 352), (384, 400)))  # noqa: E731
         applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
                    or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
         precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
