@@ -384,7 +384,7 @@ def run_eval(r, args):
                      "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
     out["exact_fast"] = ex
     out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
-                              "DistMult / ComplEx / HolE at k_int in {49..64, 97..128, 145..160, 193..208, 241..256, 289..304, 337..352, 385..400} and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 and TransE-L2 (k + 2 in those widths), "
+                              "DistMult / ComplEx / HolE at k_int in 33..400 and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 (any k) and TransE-L2 (k + 2 <= 400), "
                               ">= 128 test triples, >= 32768 entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
     if not args.quick:
         # query-tile sweep (B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode

@@ -82,7 +82,8 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     const int64_t n_rows = side_mode >= EMG_EVAL_SPO ? 2 * n_q : n_q;
     const int64_t ldq = (k_int + 3) / 4 * 4;
     const int64_t nc = cand ? n_cand : n_ent;
-    const int64_t ldb = sad ? emg_eval_sad_ld(k_int) : (k_int + (l2 ? 2 : 0) + 63) / 64 * 64;  // row stride of the 16-bit images
+    const int64_t ldb = sad ? emg_eval_sad_ld(k_int)   // row stride of the 16-bit images
+                            : (precision_mode == 2 ? emg_eval_prefilter_ld(k_int + (l2 ? 2 : 0)) : (k_int + 63) / 64 * 64);
     const size_t q_bytes = up256((size_t)n_rows * ldq * 4), p_bytes = up256((size_t)n_rows * 4);
     const size_t c_bytes = up256((size_t)4 * n_rows * 4);
     size_t total = q_bytes + p_bytes + c_bytes;

@@ -921,6 +921,18 @@ __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const
     }
 }
 
+// k-steps of 16 the prefilter kernel is instantiated for, and what they ask of the operand rows
+static int v3_prefilter_steps(int k16) {
+    static const int have[] = {4, 7, 8, 10, 13, 16, 19, 22, 25};
+    for (int nq : have)
+        if (k16 <= nq) return nq;
+    return 0;
+}
+static int64_t v3_prefilter_ld(int k16) {   // the entity slices are fetched 64 columns at a time
+    const int nq = v3_prefilter_steps(k16);
+    return nq ? 64 * (int64_t)((nq + 3) / 4) : 0;
+}
+
 static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
     EMG_REQUIRE(P.model >= EMG_DISTMULT && P.model <= EMG_HOLE, "bf16 eval: model %d is not a contraction (TransE stays f32 VALU)", P.model);
     const int64_t ld_min = (P.k_pad + HBK_ - 1) / HBK_ * HBK_;
@@ -942,7 +954,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
     else if (mode == BF_DIAG) hipLaunchKernelGGL(count_mfma_bf16_kernel<BF_DIAG>, dim3((unsigned)blocks), dim3(256), 0, st, P);
     else if (P.cand == nullptr && P.cmul > 0.f && P.cmul < INFINITY && P.n_rows > V2_BM &&
              (P.k16 == 25 || P.k16 == 13 || P.k16 == 8 ||
-              (P.pairs != nullptr && (P.k16 == 4 || P.k16 == 7 || P.k16 == 10 || P.k16 == 16 || P.k16 == 19 || P.k16 == 22)))) {
+              (P.pairs != nullptr && v3_prefilter_steps(P.k16) != 0 && P.ldq >= v3_prefilter_ld(P.k16) && P.ld_ent >= v3_prefilter_ld(P.k16)))) {
         // register-stationary query fragments + deep LDS-DMA ring (see its header); common k only
         P.n_qb = cdiv(P.n_rows, V3_BM);
         P.n_tiles = cdiv(P.n_cand, V3_BN);
@@ -953,22 +965,22 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
         const int md = P.pairs ? 2 : (P.need != 0 ? 1 : 0);
 #define EMG_V3(NQ_) (md == 2 ? launch_v3<NQ_, 4, 2>(P, nblk, st) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
-        if (P.k16 == 25) rc = EMG_V3(25);
-        else if (P.k16 == 13) rc = EMG_V3(13);
-        else if (P.k16 == 8) rc = EMG_V3(8);
-        // the prefilter (exact-fast mode, what evaluate_performance uses by default) also at the other common widths:
-        // k_int 49..64, 97..112, 145..160, 241..256, 289..304, 337..352 (k = 50 / 100 / 150 / 256 / 300 / 350, or half of it
-        // for ComplEx / HolE)
-        else if (P.k16 == 4) rc = launch_v3<4, 4, 2>(P, nblk, st);
-        else if (P.k16 == 7) rc = launch_v3<7, 4, 2>(P, nblk, st);
-        else if (P.k16 == 10) rc = launch_v3<10, 4, 2>(P, nblk, st);
-        else if (P.k16 == 16) rc = launch_v3<16, 4, 2>(P, nblk, st);
-        else if (P.k16 == 19) rc = launch_v3<19, 4, 2>(P, nblk, st);
+        // the prefilter (exact-fast mode, what evaluate_performance uses by default) at EVERY width up to 400: the next
+        // instantiated step count, the extra k-steps multiply the rows' zero padding (exact zeros: nothing changes)
+        const int nq = P.pairs != nullptr ? v3_prefilter_steps(P.k16) : P.k16;
+        if (nq == 25) rc = EMG_V3(25);
+        else if (nq == 13) rc = EMG_V3(13);
+        else if (nq == 8) rc = EMG_V3(8);
+        else if (nq == 4) rc = launch_v3<4, 4, 2>(P, nblk, st);
+        else if (nq == 7) rc = launch_v3<7, 4, 2>(P, nblk, st);
+        else if (nq == 10) rc = launch_v3<10, 4, 2>(P, nblk, st);
+        else if (nq == 16) rc = launch_v3<16, 4, 2>(P, nblk, st);
+        else if (nq == 19) rc = launch_v3<19, 4, 2>(P, nblk, st);
         else rc = launch_v3<22, 4, 2>(P, nblk, st);
 #undef EMG_V3
         if (rc != EMG_OK) return rc;
     } else if (P.pairs) {
-        return fail(EMG_ENOSUP, "bf16 prefilter: only k_int in (48..64], (96..128], (144..160], (192..208], (240..256], (288..304], (336..352], (384..400], more than 128 query rows, no candidate list");
+        return fail(EMG_ENOSUP, "bf16 prefilter: contraction widths up to 400 on rows of at least emg_eval_prefilter_ld columns, more than 128 query rows, no candidate list");
     } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
         // query-stationary LDS-DMA kernel (see its header); anything else takes the v1 tile kernel above
         const int m = P.k_pad / 32;
@@ -1031,6 +1043,13 @@ extern "C" int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, c
 static int64_t v3_blocks(int64_t n_rows, int64_t n_cand) {
     const int64_t n_qb = cdiv(n_rows, V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), 32);
     return 8 * n_qb * cdiv(n_cb, 8);
+}
+
+extern "C" int64_t emg_eval_prefilter_ld(int32_t k_cols) {
+    const int64_t plain = ((int64_t)k_cols + 63) / 64 * 64;
+    if (k_cols <= 0) return 0;
+    const int64_t need = v3_prefilter_ld((k_cols + 15) / 16);
+    return need > plain ? need : plain;
 }
 
 extern "C" int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand) {

@@ -540,6 +540,11 @@ def eval_prefilter_band(Q, Q_f16, k_int, bounds):
     return band
 
 
+def prefilter_ld(k_cols):
+    """row stride (elements) of the half-precision prefilter's operands for a contraction over k_cols columns"""
+    return int(L.load().emg_eval_prefilter_ld(k_cols))
+
+
 def eval_prefilter_segments(n_rows, n_cand):
     """number of segments (= waves of the prefilter kernel) the pair buffer is cut into; pair_count has one more entry"""
     return int(L.load().emg_eval_prefilter_segments(n_rows, n_cand))
@@ -580,7 +585,7 @@ def to_f16_l2(src, k_int, is_query, ld_dst=None):
     max as 1 float64 on the device); query rows [2q | -1 | -1] -> (rows, the f32 rows 2q)"""
     lib = L.load()
     ps, n, ld = _chk_table(src, "src")
-    ldd = ld_dst or bf16_ld(k_int + 2)
+    ldd = ld_dst or prefilter_ld(k_int + 2)
     out = torch.empty((n, ldd), dtype=torch.float16, device=src.device)
     if is_query:
         dbl = torch.zeros_like(src)

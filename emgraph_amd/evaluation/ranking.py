@@ -206,7 +206,7 @@ class PrefilterTables:
     half-precision copy and the norm bounds of prefilter_band.  Valid while the table does not change."""
 
     def __init__(self, ent, k_int):
-        self.ent_f16 = D.to_f16(ent, k_int, ld_dst=D.bf16_ld(k_int))
+        self.ent_f16 = D.to_f16(ent, k_int, ld_dst=D.prefilter_ld(k_int))
         self.k_int = k_int
         self._bounds = {}
         self._ent = ent
@@ -294,7 +294,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         # the exact-fast mode returns the SAME ranks as precision 0 (bit for bit) and pays off once the 1-vs-all
         # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
         n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
-        covered = lambda w: any(lo < w <= hi for lo, hi in ((48, 64), (96, 128), (144, 160), (192, 208), (240, 256), (288, 304), (336, 352), (384, 400)))  # noqa: E731
+        covered = lambda w: 32 < w <= 400   # noqa: E731  (the prefilter kernel pads a width up to its next instantiation)
         applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
                    or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
         precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
@@ -347,7 +347,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             bounds, ent_f16 = ent_f16.bounds(e0, slab.shape[0]), ent_f16.ent_f16
         else:
             if ent_f16 is None:   # half-precision copy of the table for the prefilter
-                ent_f16 = D.to_f16(ent, k_int, ld_dst=D.bf16_ld(k_int))
+                ent_f16 = D.to_f16(ent, k_int, ld_dst=D.prefilter_ld(k_int))
             bounds = table_norm_bounds(slab, ent_f16[e0:e0 + slab.shape[0]], k_int)
     pending = []  # (counters on the device, nq) per chunk: every launch is asynchronous, ONE D2H at the end
     for c0 in range(0, n, query_chunk):
@@ -408,7 +408,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         elif precision == 2 and have_cands:
             # half-precision MFMA prefilter, then exact re-scoring of the undecided pairs: both asynchronous; whether a
             # wave ran out of pair room (-> this tile is redone by the exact kernel) is read with the counters at the end
-            kp = D.bf16_ld(k_int)
+            kp = D.prefilter_ld(k_int)
             Qb = D.to_f16(Q, k_int, ld_dst=kp)
             band = prefilter_band(Q, Qb, k_int, bounds)
             n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0])

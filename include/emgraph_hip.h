@@ -379,6 +379,10 @@ int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t ldq, const v
  * on the device (no host round trip between the two calls).  The resulting counters equal
  * emg_eval_count(precision 0) bit for bit. */
 int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand);
+/* row stride (elements, zero padded) the half-precision prefilter wants of BOTH operands for a contraction over k_cols
+ * columns: the kernel is instantiated for 4, 7, 8, 10, 13, 16, 19, 22 and 25 k-steps of 16 and fetches entity rows 64
+ * columns at a time; a width in between runs the next instantiation over the zero padding (k_cols <= 400) */
+int64_t emg_eval_prefilter_ld(int32_t k_cols);
 int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
                            int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset,
                            int32_t k_pad, float scale, int32_t* cnt_gt, uint64_t* pairs, uint32_t* pair_count,

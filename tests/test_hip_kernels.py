@@ -1005,7 +1005,10 @@ def test_apply_rows_long_segments_block_tree(k, opt):
                                                      ("ComplEx", 200, 5000, 40, 0.1), ("ComplEx", 50, 15000, 200, 0.2),
                                                      ("DistMult", 150, 9000, 180, 0.1), ("DistMult", 300, 6000, 150, 0.1),
                                                      ("HolE", 30, 20000, 170, 0.3), ("DistMult", 100, 4000, 130, 0.02),
-                                                     ("ComplEx", 128, 8000, 150, 0.1), ("DistMult", 350, 5000, 140, 0.1)])
+                                                     ("ComplEx", 128, 8000, 150, 0.1), ("DistMult", 350, 5000, 140, 0.1),
+                                                     ("DistMult", 130, 6000, 140, 0.1), ("ComplEx", 85, 5000, 150, 0.2),
+                                                     ("DistMult", 353, 4000, 130, 0.1), ("HolE", 9, 30000, 140, 0.5),
+                                                     ("DistMult", 401, 3000, 130, 0.1)])
 def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
     """precision=2 (bf16 MFMA prefilter with a rigorous per-row error band + exact f32 re-scoring of the undecided
     candidates) == precision=0 (exact f32 MFMA chain) for every side, strategy and filter setting; exact ties are
@@ -1032,7 +1035,7 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
                 fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, stats=st)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
-    kint_ok = (ki + 15) // 16 in (4, 7, 8, 10, 13, 16, 19, 22, 25)
+    kint_ok = ki <= 400      # every width up to 400 runs the prefilter (padded to its next instantiation); 401 takes the exact kernel
     if kint_ok and 2 * nq > 128:
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
 
@@ -1082,7 +1085,8 @@ def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
 
 @pytest.mark.parametrize("k,n_ent,nq,scale,huge", [(200, 30000, 300, 0.1, False), (126, 9000, 200, 1.0, False), (398, 6000, 150, 0.05, False),
                                                    (200, 20000, 150, 0.0005, False), (100, 5000, 140, 0.3, False), (200, 5000, 40, 0.1, False),
-                                                   (200, 8000, 160, 0.1, True), (150, 7000, 150, 0.1, False), (50, 30000, 200, 0.2, False)])
+                                                   (200, 8000, 160, 0.1, True), (150, 7000, 150, 0.1, False), (50, 30000, 200, 0.2, False),
+                                                   (75, 9000, 140, 0.1, False), (351, 3000, 130, 0.1, False), (7, 20000, 150, 0.5, False)])
 def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, huge):
     """TransE-L2, precision=2 (||q-e||^2 as a contraction over k+2 coordinates through the half-precision MFMA prefilter,
     thresholds derived for the squared distance, undecided candidates re-scored with the canonical f32 chain) ==
@@ -1121,7 +1125,7 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
                                            stats=st, ent_f16=tabs if side != "o" else None, query_chunk=200 if side == "s" else 4096)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
-    if k + 2 in (52, 102, 128, 152, 202, 400) and nq > 128:
+    if k + 2 <= 400 and nq > 128:
         assert used > 0        # the prefilter ran
 
 
@@ -1135,7 +1139,7 @@ def test_transe_prefilters_random_shapes_equal_exact(seed):
     rs = np.random.RandomState(1000 + seed)
     for _ in range(5):
         l2 = bool(rs.randint(0, 2))
-        k = int(rs.choice([50, 98, 100, 126, 150, 198, 200, 300, 398])) if l2 else int(rs.randint(1, 261))
+        k = int(rs.randint(1, 420)) if l2 else int(rs.randint(1, 261))
         n_ent, nq = int(rs.randint(1500, 20000)), int(rs.randint(130, 300))
         scale = 10.0 ** rs.uniform(-3, 1)
         E = (rs.standard_t(3, (n_ent, k)) if rs.randint(0, 2) else rs.randn(n_ent, k)).astype(F32) * F32(scale)
