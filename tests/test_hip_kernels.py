@@ -835,6 +835,24 @@ def test_rank_1vsall_one_call_precision_2_equals_precision_0(model, k, n_ent, nq
         d.rank_1vsall(MID[model], Et, Rt, ki, sc, cu(T), L.EVAL_S_O, cand=sub, filt_ptr=cu(ptr), filt_idx=cu(idx)).cpu().numpy())
 
 
+@pytest.mark.parametrize("model,k", [("TransE_L1", 200), ("TransE_L2", 198), ("DistMult", 200)])
+def test_rank_1vsall_one_call_precision_2_overflow_falls_back_to_the_exact_kernel(model, k):
+    """tables so small that every comparison integer is 0: every candidate is undecided, the pair buffer overflows and
+    emg_rank_1vsall(precision_mode = 2) must redo the tile with the exact kernel — same ranks as precision_mode 0"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    n_ent, nq = 12000, 200
+    E, R, ki = make_tables(model, k, n_ent, 5, seed=3, scale=2e-5)
+    rs = np.random.RandomState(9)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 5, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    Et, Rt = cu(E), cu(R)
+    for si in range(3):
+        exp = d.rank_1vsall(MID[model], Et, Rt, ki, scale_of(model, k), cu(T), L.EVAL_S_O, strategy=si).cpu().numpy()
+        got = d.rank_1vsall(MID[model], Et, Rt, ki, scale_of(model, k), cu(T), L.EVAL_S_O, strategy=si, precision_mode=2).cpu().numpy()
+        np.testing.assert_array_equal(got, exp)
+    assert exp.max() > 1000      # (ties everywhere: 'worst' ranks are large)
+
+
 @pytest.mark.parametrize("model,loss,opt,sides", [("ComplEx", "nll", "adam", ("s,o",)), ("TransE_L2", "pairwise", "sgd", ("s", "o")),
                                                   ("DistMult", "self_adversarial", "adagrad", ("s,o",)),
                                                   ("HolE", "multiclass_nll", "momentum", ("s,o",))])
