@@ -471,7 +471,9 @@ int emg_corrupt_fit(const int32_t* pos, int64_t B, int32_t eta, int side, int64_
  * emg_eval_prefilter_bounds / _band, emg_eval_prefilter_f16, emg_eval_rescore_pairs; one host synchronisation to read the
  * overflow flag; TransE-L1 goes through the 16-bit fixed-point prefilter emg_eval_prefilter_sad instead, TransE-L2
  * through the MFMA prefilter on the augmented rows of emg_to_f16_l2; the exact kernel takes over for candidate lists,
- * shapes the prefilter kernels do not cover and overflowing pair buffers).
+ * shapes the prefilter kernels do not cover and overflowing pair buffers — the pair buffer of a call is capped at
+ * 1 GiB, so hand mode 2 a few thousand test triples per call (emgraph_amd/evaluation/ranking.py uses 4096): a much larger
+ * call still returns the exact ranks, but through the exact kernel).
  * rank_out int32: [n_q] for side_mode 0,1,2; [n_q,2] = [subject_rank, object_rank] for side_mode 3. */
 int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel, int64_t n_rel,
                     int64_t ld_rel, int32_t k_int, float scale, const int32_t* test_spo, int64_t n_q, int side_mode,
