@@ -39,12 +39,22 @@ def _stable_argsort(key):
     Both orders are THE stable order, so the index is the same either way."""
     n = len(key)
     if n >= 100_000 and torch.cuda.is_available() and int(key.max()) < (1 << 31) - 1 and int(key.min()) >= 0:
-        dev = torch.device("cuda")
-        kd = torch.from_numpy(key.astype(np.int32)).to(dev)
-        ws = torch.empty(D.apply_workspace_bytes(n, int(key.max()) + 1), dtype=torch.uint8, device=dev)
-        D.group_dest(kd, n, int(key.max()) + 1, ws)
-        return D.apply_workspace_views(ws, n)[1].cpu().numpy().astype(np.int64)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # on its own stream: the index is built lazily, i.e. usually while the big count kernel of the first query tile
+        # runs on the caller's stream — the sort must not queue behind it
+        side = _sort_streams.get(dev.index)
+        if side is None:
+            side = _sort_streams[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
+        with torch.cuda.stream(side):
+            kd = torch.from_numpy(key.astype(np.int32)).to(dev)
+            ws = torch.empty(D.apply_workspace_bytes(n, int(key.max()) + 1), dtype=torch.uint8, device=dev)
+            D.group_dest(kd, n, int(key.max()) + 1, ws)
+            order = D.apply_workspace_views(ws, n)[1].cpu().numpy().astype(np.int64)   # (synchronises the side stream only)
+        return order
     return np.argsort(key, kind="stable")
+
+
+_sort_streams = {}
 
 
 class FilterIndex:
@@ -57,16 +67,25 @@ class FilterIndex:
         F = np.asarray(filter_triples, dtype=np.int64).reshape(-1, 3)
         self.n_rel = int(F[:, 1].max()) + 1 if len(F) else 1
         self.max_entity = int(max(F[:, 0].max(), F[:, 2].max())) if len(F) else -1
-        self._sides = {}
-        for name, kcol, vcol in (("obj", 0, 2), ("sub", 2, 0)):
+        self._F = F
+        self._sides = {}     # built on first use (_side): rank_triples_device asks for the CSR of a query tile AFTER it has
+                             # launched the tile's count kernel, so the two sorts run underneath that kernel
+
+    def _side(self, name):
+        """(sorted keys, values in that order) of one side: 'obj' = objects by (subject, relation), 'sub' = subjects by
+        (object, relation)"""
+        if name not in self._sides:
+            kcol, vcol = {"obj": (0, 2), "sub": (2, 0)}[name]
+            F = self._F
             key = F[:, kcol] * self.n_rel + F[:, 1]
             order = _stable_argsort(key)
             self._sides[name] = (key[order], F[order, vcol])
+        return self._sides[name]
 
     def _pairs(self, name, q_ent, q_rel, q_self):
         """(row, entity) pairs: filter entities matching the row's (entity, relation) key, plus the row's
         own entity ('select <id> union select distinct ...', sqlite_adapter.py:472-495)."""
-        skey, sval = self._sides[name]
+        skey, sval = self._side(name)
         qk = np.where(q_rel < self.n_rel, q_ent * self.n_rel + q_rel, -1)
         lo = np.searchsorted(skey, qk, side="left")
         hi = np.searchsorted(skey, qk, side="right")

@@ -1235,7 +1235,7 @@ def test_filter_index_gpu_sort_equals_numpy_sort():
         a, b = fast.csr(T, sm, n_ent), ref.csr(T, sm, n_ent)
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
-    assert slow._sides["obj"][0].shape[0] == 90000
+    assert slow._side("obj")[0].shape[0] == 90000
 
 
 def test_device_initialisers_distribution_and_determinism():
