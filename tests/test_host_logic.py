@@ -30,6 +30,26 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert handle.emg_target() == b"gfx950"
 
 
+def test_prefilter_layout_queries_are_host_arithmetic():
+    """the row strides / segment counts the ranking prefilters ask of their callers (include/emgraph_hip.h): pure host
+    functions of the sizes, answered without a GPU"""
+    from emgraph_amd import _lib as L
+    lib = L.load()
+    # half-precision MFMA prefilter: instantiated for 4, 7, 8, 10, 13, 16, 19, 22, 25 k-steps of 16, rows fetched 64 columns at a time
+    for k_cols, ld in ((8, 64), (64, 64), (65, 128), (100, 128), (128, 128), (130, 192), (200, 256), (202, 256), (256, 256),
+                       (257, 320), (300, 320), (353, 448), (400, 448), (401, 448), (800, 832)):
+        assert lib.emg_eval_prefilter_ld(k_cols) == ld, (k_cols, lib.emg_eval_prefilter_ld(k_cols))
+        assert lib.emg_eval_prefilter_ld(k_cols) >= k_cols and lib.emg_eval_prefilter_ld(k_cols) % 64 == 0
+    assert lib.emg_eval_prefilter_ld(0) == 0
+    # fixed-point (v_sad_u16) prefilter: u16 image rows padded to whole 8-dword k tiles
+    for k, ld in ((1, 16), (16, 16), (17, 32), (200, 208), (208, 208)):
+        assert lib.emg_eval_sad_ld(k) == ld
+    # one pair-buffer segment per wave of the prefilter grids (8 waves per 256 rows x 4096 entities; 4 waves per 128 x 4096)
+    assert lib.emg_eval_prefilter_segments(0, 10) == 0 and lib.emg_eval_sad_segments(5, 0) == 0
+    assert lib.emg_eval_prefilter_segments(8192, 1_000_000) == 8 * 8 * 32 * 31
+    assert lib.emg_eval_sad_segments(4096, 1_000_000) == 4 * 8 * 32 * 31
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "emgraph_amd")
     for dirpath, _, files in os.walk(pkg):
