@@ -171,6 +171,69 @@ def test_folded_lp_regulariser_reaches_untouched_rows(opt, p):
     np.testing.assert_allclose(sum(m.epoch_losses), total, rtol=1e-4)                   # data term + lambda * sum |w|^p
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_FUZZ_SEEDS", "10"))))
+def test_fit_random_configurations_match_oracle_training_loop(seed):
+    """soak over the configuration space of fit(): a random model / width / eta / loss / optimizer / corruption-side list /
+    graph shape (uniform or hub-heavy) per seed, trained for a few batches and compared with the oracle loop driven by the
+    same Philox draws (same tolerances as the hand-picked cases above).  EMG_FUZZ_SEEDS widens it."""
+    rs = np.random.RandomState(7000 + seed)
+    name = str(rs.choice(["TransE", "TransE", "DistMult", "ComplEx", "HolE"]))
+    norm = int(rs.choice([1, 2]))
+    k = int(rs.choice([3, 5, 8, 13, 16, 24, 33, 50, 64, 100, 130]))
+    eta = int(rs.choice([1, 2, 3, 5, 10, 20]))
+    loss = str(rs.choice(["pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll"]))
+    opt = str(rs.choice(["sgd", "momentum", "adagrad", "adam"]))
+    sides = [("s,o",), ("s", "o"), ("o",), ("s",), ("s+o",)][rs.randint(0, 5)]
+    n_ent, n_rel = int(rs.randint(20, 1500)), int(rs.randint(1, 9))
+    n, bc, epochs, lr = int(rs.randint(60, 900)), int(rs.randint(1, 5)), int(rs.randint(1, 3)), float(rs.choice([0.01, 0.05]))
+    if rs.randint(0, 2):   # hub-heavy subjects / objects: long segments in the apply
+        w = 1.0 / np.arange(1, n_ent + 1)
+        w /= w.sum()
+        X = np.stack([rs.choice(n_ent, n, p=w), rs.randint(0, n_rel, n), rs.choice(n_ent, n, p=w)], 1)
+    else:
+        X = np.stack([rs.randint(0, n_ent, n), rs.randint(0, n_rel, n), rs.randint(0, n_ent, n)], 1)
+    ids = np.unique(np.concatenate([X[:, 0], X[:, 2]]))                       # labels == ids after the np.unique mapping
+    remap = np.full(n_ent, -1, np.int64)
+    remap[ids] = np.arange(len(ids))
+    X = np.stack([remap[X[:, 0]], X[:, 1], remap[X[:, 2]]], 1).astype(np.int64)
+    rels = np.unique(X[:, 1])
+    X[:, 1] = np.searchsorted(rels, X[:, 1])
+    n_ent, n_rel = len(ids), len(rels)
+    ki = 2 * k if name in ("ComplEx", "HolE") else k
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    emp = {"corrupt_side": list(sides) if len(sides) > 1 else sides[0]}
+    if name == "TransE":
+        emp["norm"] = norm
+    m = _models()[name](k=k, eta=eta, epochs=epochs, batches_count=bc, seed=seed, loss=loss, optimizer=opt,
+                        optimizer_params={"lr": lr}, embedding_model_params=emp, initializer="constant",
+                        initializer_params={"entity": ent0, "relation": rel0})
+    omodel = ("TransE_L%d" % norm) if name == "TransE" else name
+    E, R, losses = oracle_fit(omodel, k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, loss, None, opt, lr, sides=sides)
+    what = str((name, norm, k, eta, loss, opt, sides, n_ent, n_rel, n, bc, epochs, lr))
+    if not np.all(np.isfinite(losses)):                      # the reference stops with this message (EmbeddingModel.py:1340-1345)
+        with pytest.raises(ValueError, match="Loss is nan"):
+            m.fit(X)
+        return
+    m.fit(X)
+    if max(np.abs(E).max(), np.abs(R).max()) > 20.0:         # a diverging run amplifies the last bit of every sum: nothing to compare
+        assert np.all(np.isfinite(m.trained_model_params[0]))
+        return
+    if opt != "adam":
+        np.testing.assert_allclose(m.trained_model_params[0], E, rtol=2e-3, atol=2e-5, err_msg=what)
+        np.testing.assert_allclose(m.trained_model_params[1], R, rtol=2e-3, atol=2e-5, err_msg=what)
+        np.testing.assert_allclose(m.epoch_losses, losses, rtol=2e-4, atol=1e-6, err_msg=what)
+    else:
+        # Keras Adam moves a weight by ~lr * g / (|g| + 1e-7): where the true gradient is exactly zero (equal and opposite
+        # contributions, e.g. a subject shared by a positive and its corruption under a softmax loss) the last-bit noise
+        # of the sum decides a step of up to lr — in the oracle's arithmetic as much as here.  Those elements cannot agree;
+        # all the others must, and a wrong gradient would move most of them.
+        for got, exp in ((m.trained_model_params[0], E), (m.trained_model_params[1], R)):
+            err = np.abs(got - exp)
+            bad = err > 2e-5 + 2e-3 * np.abs(exp)
+            assert np.median(err) < 2e-4 and err.max() <= 2.5 * lr * epochs * bc, (what, bad.mean(), np.median(err), err.max())
+
+
 # ------------------------------------------------------------------------------------------------
 # the reference's own toy-graph tests (test_models.py:218-335,338-367,389-409,967-992)
 # ------------------------------------------------------------------------------------------------
