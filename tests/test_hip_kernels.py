@@ -539,6 +539,36 @@ def test_bf16_ranks_exact_on_bf16_representable_data(model):
                 np.testing.assert_array_equal(got, exp, err_msg=str((side, strategy, filt is not None, subset is not None)))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+def test_ranks_random_protocols_equal_literal_oracle(seed):
+    """soak of the ranking protocol against the oracle's literal per-triple evaluation (generate_corruptions_for_eval +
+    score + perform_comparison + filter lookups): random model, width, side, strategy, filter set, candidate
+    subset and precision mode (0 exact, 2 exact-fast where a prefilter applies) on tables of small dyadic values — every
+    score is exact in f32 whatever the summation order, so the ranks must be EQUAL, with all the ties such tables have"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import rank_triples_device
+    dev()
+    rs = np.random.RandomState(4000 + seed)
+    for _ in range(4):
+        model = str(rs.choice(["TransE_L1", "TransE_L2", "DistMult", "ComplEx", "HolE"]))
+        k = int(rs.choice([1, 2, 3, 4, 6, 8])) if model != "HolE" else int(rs.choice([1, 2, 4, 8]))   # HolE: 2/k exact in binary
+        n_ent, n_rel, nq = int(rs.randint(5, 400)), int(rs.randint(1, 6)), int(rs.randint(1, 150))
+        ki = kint_of(model, k)
+        E = (rs.randint(-4, 5, (n_ent, ki)) / 4.0).astype(F32)
+        R = (rs.randint(-4, 5, (n_rel, ki)) / 4.0).astype(F32)
+        T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, n_rel, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+        nf = int(rs.randint(0, 3000))
+        filt = None if nf < 300 else np.concatenate([T, np.stack([rs.randint(0, n_ent, nf), rs.randint(0, n_rel, nf),
+                                                                  rs.randint(0, n_ent, nf)], 1)]).astype(np.int32)
+        subset = None if rs.randint(0, 3) else np.unique(rs.randint(0, n_ent, max(2, n_ent // 2)))
+        side, strategy = str(rs.choice(["s,o", "s+o", "s", "o"])), str(rs.choice(["worst", "best", "middle"]))
+        precision = int(rs.choice([0, 2]))
+        got = rank_triples_device(MID[model], cu(E), cu(R), ki, scale_of(model, k), T, side, strategy, filter_triples=filt,
+                                  entities_subset=subset, precision=precision, query_chunk=int(rs.choice([7, 64, 4096])))
+        exp = orc.get_ranks(model, E, R, T, corrupt_side=side, strategy=strategy, filter_triples=filt, corruption_entities=subset, k=k)
+        np.testing.assert_array_equal(got, exp, err_msg=str((seed, model, k, n_ent, n_rel, nq, side, strategy, nf, subset is not None, precision)))
+
+
 @pytest.mark.parametrize("B,eta,sides,n_ent,n_rel,xe", [(1000, 5, (2,), 50000, 37, 0), (16384, 3, (0, 1), 300000, 1000, 0),
                                                          (257, 2, (2,), 90, 70000, 90), (40, 1, (1,), 12, 3, 0)])
 def test_prepare_batch_equals_separate_calls(B, eta, sides, n_ent, n_rel, xe):
