@@ -219,6 +219,9 @@ def test_fit_random_configurations_match_oracle_training_loop(seed):
     if max(np.abs(E).max(), np.abs(R).max()) > 20.0:         # a diverging run amplifies the last bit of every sum: nothing to compare
         assert np.all(np.isfinite(m.trained_model_params[0]))
         return
+    Xt = X[:40]                                             # predict() on the fitted tables == the oracle's score of the same tables
+    np.testing.assert_allclose(m.predict(Xt), orc.score_triples(omodel, m.trained_model_params[0], m.trained_model_params[1],
+                                                                Xt.astype(np.int32), k=k), rtol=1e-4, atol=1e-5, err_msg=what)
     if opt != "adam":
         np.testing.assert_allclose(m.trained_model_params[0], E, rtol=2e-3, atol=2e-5, err_msg=what)
         np.testing.assert_allclose(m.trained_model_params[1], R, rtol=2e-3, atol=2e-5, err_msg=what)
