@@ -205,12 +205,16 @@ def test_fit_random_configurations_match_oracle_training_loop(seed):
     emp = {"corrupt_side": list(sides) if len(sides) > 1 else sides[0]}
     if name == "TransE":
         emp["norm"] = norm
+    reg, reg_kw = None, {}
+    if rs.randint(0, 3) == 0:                                # LP regulariser over the FULL tables (regularizers/lp.py:81-113)
+        reg = {"lam": float(rs.choice([0.001, 0.01])), "p": int(rs.choice([1, 2, 3]))}
+        reg_kw = dict(regularizer="LP", regularizer_params={"lambda": reg["lam"], "p": reg["p"]})
     m = _models()[name](k=k, eta=eta, epochs=epochs, batches_count=bc, seed=seed, loss=loss, optimizer=opt,
                         optimizer_params={"lr": lr}, embedding_model_params=emp, initializer="constant",
-                        initializer_params={"entity": ent0, "relation": rel0})
+                        initializer_params={"entity": ent0, "relation": rel0}, **reg_kw)
     omodel = ("TransE_L%d" % norm) if name == "TransE" else name
-    E, R, losses = oracle_fit(omodel, k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, loss, None, opt, lr, sides=sides)
-    what = str((name, norm, k, eta, loss, opt, sides, n_ent, n_rel, n, bc, epochs, lr))
+    E, R, losses = oracle_fit(omodel, k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, loss, None, opt, lr, sides=sides, reg=reg)
+    what = str((name, norm, k, eta, loss, opt, sides, n_ent, n_rel, n, bc, epochs, lr, reg))
     if not np.all(np.isfinite(losses)):                      # the reference stops with this message (EmbeddingModel.py:1340-1345)
         with pytest.raises(ValueError, match="Loss is nan"):
             m.fit(X)
