@@ -179,7 +179,7 @@ def test_fit_random_configurations_match_oracle_training_loop(seed):
     rs = np.random.RandomState(7000 + seed)
     name = str(rs.choice(["TransE", "TransE", "DistMult", "ComplEx", "HolE"]))
     norm = int(rs.choice([1, 2]))
-    k = int(rs.choice([3, 5, 8, 13, 16, 24, 33, 50, 64, 100, 130]))
+    k = int(rs.choice([3, 5, 8, 13, 16, 24, 33, 50, 64, 100, 130, 200, 260]))
     eta = int(rs.choice([1, 2, 3, 5, 10, 20]))
     loss = str(rs.choice(["pairwise", "nll", "absolute_margin", "self_adversarial", "multiclass_nll"]))
     opt = str(rs.choice(["sgd", "momentum", "adagrad", "adam"]))
