@@ -68,6 +68,7 @@ class FilterIndex:
         self.n_rel = int(F[:, 1].max()) + 1 if len(F) else 1
         self.max_entity = int(max(F[:, 0].max(), F[:, 2].max())) if len(F) else -1
         self._F = F
+        self._Fd = None
         self._cols = None
         self._sides = {}     # built on first use (_side): rank_triples_device asks for the CSR of a query tile AFTER it has
                              # launched the tile's count kernel, so the two sorts run underneath that kernel
@@ -77,6 +78,26 @@ class FilterIndex:
         (object, relation)"""
         if name not in self._sides:
             kcol, vcol = {"obj": (0, 2), "sub": (2, 0)}[name]
+            n, kmax = len(self._F), (self.max_entity + 1) * self.n_rel
+            if n >= 100_000 and torch.cuda.is_available() and 0 <= kmax < (1 << 31) - 1 and int(self._F.min()) >= 0:
+                # large filter sets on a GPU host: keys, the stable sort (the library's grouping) and the two gathers on the
+                # device, on a stream of their own (usually underneath the count kernel of the first query tile)
+                dev = torch.device("cuda", torch.cuda.current_device())
+                side = _sort_streams.get(dev.index)
+                if side is None:
+                    side = _sort_streams[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
+                with torch.cuda.stream(side):
+                    if self._Fd is None:
+                        self._Fd = torch.from_numpy(self._F).to(dev)
+                    key = self._Fd[:, kcol] * self.n_rel + self._Fd[:, 1]
+                    ws = torch.empty(D.apply_workspace_bytes(n, kmax + 1), dtype=torch.uint8, device=dev)
+                    D.group_dest(key.to(torch.int32), n, kmax + 1, ws)
+                    order = D.apply_workspace_views(ws, n)[1].long()
+                    self._sides[name] = (key.index_select(0, order).cpu().numpy(),
+                                         self._Fd[:, vcol].index_select(0, order).cpu().numpy())
+                if len(self._sides) == 2:
+                    self._Fd = None
+                return self._sides[name]
             if self._cols is None:   # contiguous columns: the strided [n, 3] views cost 3-4x in every pass below
                 self._cols = [np.ascontiguousarray(self._F[:, c]) for c in range(3)]
             key = self._cols[kcol] * self.n_rel + self._cols[1]
