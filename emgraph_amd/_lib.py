@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE = range(5)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
@@ -82,6 +82,7 @@ class BackwardArgs(C.Structure):
         ("single_ent", _p), ("opt", _i32), ("step", _i32), ("hyper", _f32 * 8),
         ("ent_state0", _p), ("ent_state1", _p), ("tag_ent", _p),
         ("fac_ws_ent", _p), ("fac_ws_ent_bytes", _i64),
+        ("layout_B", _i64), ("ctl", _p),
     ]
 
 
@@ -107,7 +108,8 @@ class PrepareArgs(C.Structure):
         ("ws_ent", _p), ("ws_ent_bytes", _i64), ("ws_rel", _p), ("ws_rel_bytes", _i64),
         ("single_flags", _p),
         ("B_global", _i64), ("row_offset", _i64),
-        ("factored", _i32), ("reserved0", _i32),
+        ("factored", _i32), ("ws_clean", _i32),
+        ("layout_B", _i64), ("ctl", _p),
     ]
 
 
@@ -169,7 +171,8 @@ class ApplyArgs(C.Structure):
         ("state0", _p), ("state1", _p), ("tag", _p), ("step", _i32), ("skip_single", _i32),
         ("contrib", _p), ("ldc", _i64), ("n_contrib", _i64),
         ("hyper", _f32 * 8), ("lp_accum", _p), ("workspace", _p), ("workspace_bytes", _i64),
-        ("factored", _i32), ("reserved0", _i32),
+        ("factored", _i32), ("table_index", _i32),
+        ("layout_n", _i64), ("ctl", _p),
     ]
 
 

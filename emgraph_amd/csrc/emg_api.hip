@@ -324,5 +324,6 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     ae.workspace = ws + L.ws_ent; ae.workspace_bytes = L.ws_ent_bytes; ae.factored = factored;
     ar.table = a->rel; ar.n_rows = a->n_rel; ar.ld = a->ld_rel; ar.state0 = a->rel_state0; ar.state1 = a->rel_state1;
     ar.tag = a->tag_rel; ar.contrib = cr; ar.n_contrib = a->B; ar.workspace = ws + L.ws_rel; ar.workspace_bytes = L.ws_rel_bytes;
+    ar.table_index = 1;
     return emg_apply_grouped_pair(&ae, &ar, stream);
 }

@@ -2,30 +2,23 @@
 //
 // The reference hands TF IndexedSlices (row ids + gradient rows) to Keras optimizers
 // (training/sgd.py:97, momentum.py:63, adagrad.py:42, adam.py:45).  Here the backward pass writes one
-// gradient row per (positive group, role) without atomics; this file
-//   1. emg_group_dest: stable radix sort of (destination row, contribution index) — equal destinations
-//      keep index order, so the float sum order is fixed => bit-reproducible training (the reference's
-//      refit-determinism test, tests/emgraph/models/test_models.py:338-367) — and a per-contribution
-//      SINGLETON flag (destination hit exactly once in this batch).  Depends only on the batch's
-//      ids, not on the tables, so it can run ahead of / beside the scoring kernels.
-//   2. emg_apply_grouped: one wave per segment head sums the segment's rows (16-byte coalesced loads)
-//      and performs the optimizer update of that table row exactly once.  Singletons can be skipped:
-//      the backward kernel already updated them in place from registers (no contribution round trip).
+// gradient row per (positive group, role) without atomics; emg_group.hip groups them by destination (stable:
+// equal destinations keep slot order, so the float sum order is fixed => bit-reproducible training, the reference's
+// refit-determinism test tests/emgraph/models/test_models.py:338-367) and this file sums each destination's rows in
+// that order and performs the optimizer update of the table row exactly once:
+//   apply_segments_kernel   the training path (counting grouping): a persistent grid works from the SEGMENT
+//                           DESCRIPTORS the grouping's scan emitted — destinations with 2..32 contributions,
+//                           singletons (unless the backward kernel already updated them in place), 64-row block
+//                           tasks of longer segments — both tables of a step in ONE launch
+//   apply_rows_*_kernel     window kernels that find their segments in the sorted keys themselves: the sort
+//                           backend (wide keys), rows of <= 16 chunks (four segments per wave) and scalar rows
 #include <stdlib.h>
 #include <string.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
-#include "emg_common.hpp"
-#include <mutex>
+#include "emg_group.hpp"
 
 namespace emg {
-
-constexpr int kLongSegment = 64;   // rows; the block size of the long-segment reduction tree
-constexpr int kDeferSegment = 32;  // segments longer than this leave the window kernel (2 rows in flight per trip: a
-                                   // 60-row segment would keep ONE wave busy for 30 dependent trips, ~0.1 ms)
-struct LongTask { uint32_t head, block, len; };   // sorted position of the segment's head, block index, rows of the segment (0 = void)
 
 struct ApplyParams {
     float* table; int64_t n_rows; int64_t ld; int32_t k_int;
@@ -49,6 +42,10 @@ struct ApplyParams {
     //   grouping (mark_single_kernel: the codes are known there), coef[t] is written by the backward kernel straight
     //   into sorted order (pos_of_slot) — so a window's sources are ONE coalesced load each, like its keys.
     const uint32_t* srcrow; const float* coef;
+    // segment descriptors of the counting grouping (apply_segments_kernel): see emg_group.hpp
+    const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* counters; uint32_t task_cap;
+    int32_t which;             // 0: entity table, 1: relation table (which hyper-parameters of a StepCtl apply)
+    const StepCtl* ctl;        // graph node: step number and learning rates from the device record
 };
 
 struct Src { uint32_t row; float coef; };
@@ -64,38 +61,6 @@ __device__ __forceinline__ void add_scaled(float4& acc, const float4& v, float c
 __device__ __forceinline__ void add_scaled(float& acc, float v, float coef) {
 #pragma clang fp contract(off)
     acc += coef * v;
-}
-
-// flags[original index] = 1 iff its destination occurs exactly once in the batch (flags may be null).
-// fac_codes != null (factored contributions): srcrow[t] = the row of the 4B-row contribution buffer the slot at sorted
-// position t points at, pos_of_slot[slot - 2B] = t for the negatives' slots (where the backward kernel puts their factor),
-// coef[t] = 1 for the subject / object slots.
-__global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
-                                   uint8_t* __restrict__ flags, uint32_t* __restrict__ long_count,
-                                   const int32_t* __restrict__ fac_codes, uint32_t fac_B, uint32_t* __restrict__ srcrow,
-                                   uint32_t* __restrict__ pos_of_slot, float* __restrict__ coef,
-                                   int32_t* __restrict__ arrive) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) { long_count[0] = 0u; long_count[1] = 0u; }  // task list of the apply that follows (saves a memset launch)
-    if (t <= n / kLongSegment) arrive[t] = 0;                 // and its per-segment block counters
-    if (t >= n) return;
-    const uint32_t key = keys[t];
-    const uint32_t slot = vals[t];
-    if (flags) {
-        const bool head = (t == 0) || keys[t - 1] != key;
-        const bool last = (t + 1 == n) || keys[t + 1] != key;
-        flags[slot] = (head && last) ? 1 : 0;
-    }
-    if (fac_codes) {
-        if (slot < 2u * fac_B) {
-            srcrow[t] = slot;
-            coef[t] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
-        } else {
-            const uint32_t i = slot - 2u * fac_B;
-            srcrow[t] = (fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
-            pos_of_slot[i] = (uint32_t)t;
-        }
-    }
 }
 
 // One wave per WIN (a power of two <= 64) consecutive SORTED positions: the wave finds the segment heads inside its window with
@@ -288,12 +253,12 @@ __global__ __launch_bounds__(256) void apply_rows_pair_kernel(const ApplyParams 
 //       or GPU did what (a one-block segment is the same tree: plain left to right, like the window kernel's).
 template <int W>
 __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, uint32_t my_row, float my_coef,
-                                          float (&out)[W]) {
+                                          float (&out)[W], bool carry = false) {
     // (my_row, my_coef): source row and factor of position u0 + lane, loaded by the WHOLE wave in one instruction before
     // the column loop (block_sources) and handed out with v_readlane — one load round trip per block instead of one per
     // 16 rows in front of the row loads that depend on it
     if constexpr (W == 4) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = carry ? make_float4(out[0], out[1], out[2], out[3]) : make_float4(0.f, 0.f, 0.f, 0.f);   // carry: continue a running sum
         const int n = (int)(u1 - u0);
         int j0 = 0;
         for (; j0 + 16 <= n; j0 += 16) {
@@ -315,7 +280,7 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
         }
         out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
     } else {
-        float acc = 0.f;
+        float acc = carry ? out[0] : 0.f;
         for (int64_t u = u0; u < u1; ++u) {
             const Src su = contrib_src(P, u);
             add_scaled(acc, P.contrib[(int64_t)su.row * P.ldc + c], su.coef);
@@ -339,119 +304,129 @@ __device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, 
     }
 }
 
+// one (block task, column half) — the work of ONE wave.  per = 1: the wave walks every column chunk; per = 2: every other
+// group of 64 chunks (half = which), arrivals counted in the two 16-bit fields of the segment's counter.
+template <int W>
+__device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptParams& opt, int32_t step, float* __restrict__ partial,
+                                               int64_t ldp, const LongTask tk, unsigned half, unsigned per, int lane,
+                                               float& lp_acc) {
+    const int nchunks = P.k_int / W;
+    const int col0 = 64 * (int)half, cstep = 64 * (int)per;
+    if (tk.len == 0) return;
+    const int64_t t = tk.head, end = t + tk.len;
+    const uint32_t key = P.keys[t];
+    if ((int64_t)key >= P.n_rows) return;  // defensive: never write outside the table
+    float* wrow = P.table + (int64_t)key * P.ld;
+    float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+    float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+    auto update = [&](int c, float (&g)[W]) {   // optimizer step of columns [W c, W c + W) with summed gradient g
+        float w[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            w[j] = wrow[W * c + j];
+            lp_fold(opt, w[j], g[j], lp_acc);
+            opt_update_elem(opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
+            wrow[W * c + j] = w[j];
+        }
+    };
+    const int64_t nblk = (tk.len + kLongSegment - 1) / kLongSegment;
+    if (nblk == 1) {
+        const Src mine = block_sources(P, t, end, lane);
+        for (int c = lane + col0; c < nchunks; c += cstep) {
+            float g[W];
+            sum_block<W>(P, t, end, c, mine.row, mine.coef, g);
+            update(c, g);
+        }
+        if (P.tag && lane == 0 && half == 0) P.tag[key] = step;
+        return;
+    }
+    // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
+    // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one
+    // first-block start (a long segment spans more than 64 positions) — and for the same reason t / 64 names the
+    // segment's arrival counter.
+    const int64_t u0 = t + (int64_t)tk.block * kLongSegment, u1 = min(u0 + kLongSegment, end);
+    float* prow = partial + (2 * (u0 / kLongSegment) + (tk.block == 0 ? 1 : 0)) * ldp;
+    const Src mine = block_sources(P, u0, u1, lane);
+    for (int c = lane + col0; c < nchunks; c += cstep) {
+        float g[W];
+        sum_block<W>(P, u0, u1, c, mine.row, mine.coef, g);
+        if constexpr (W == 4) store4_through(prow + 4 * c, g[0], g[1], g[2], g[3]);
+        else __hip_atomic_store(prow + c, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wait_memory();   // this wave's block sum has left for memory
+    // arrivals of the two column halves are counted in the two 16-bit fields of the segment's counter
+    // (split only below 2^22 contributions: a segment then has fewer than 65536 blocks)
+    const int shift = 16 * (int)half;
+    int before = 0;
+    if (lane == 0) before = atomicAdd(P.arrive + t / kLongSegment, 1 << shift);
+    before = (__builtin_amdgcn_readfirstlane(before) >> shift) & 0xffff;
+    if (before != (int)nblk - 1) return;
+    // the segment's last block (of this column half): every block sum is in memory
+    if (lane == 0) atomicSub(P.arrive + t / kLongSegment, (int)nblk << shift);   // ready for the next apply on this workspace
+    const int64_t m0 = t / kLongSegment;             // (t + 64 b) / 64 = t / 64 + b
+    if constexpr (W == 4) {
+        // two chunks per lane x 8 block sums per trip in flight, added left to right: 0 + first block sum + ...
+        for (int c0 = 0; c0 < nchunks; c0 += 128) {
+            const int ca = c0 + lane, cb = c0 + 64 + lane;
+            const bool oa = ca < nchunks && (per == 1u || half == 0u), ob = cb < nchunks && (per == 1u || half == 1u);
+            vfloat4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+            const float* first = partial + (2 * m0 + 1) * ldp;
+            if (oa) a = load4_through(first + 4 * ca);
+            if (ob) b = load4_through(first + 4 * cb);
+            wait_memory();
+            landed(a); landed(b);
+            for (int64_t bq = 1; bq < nblk; bq += 8) {
+                const int cnt = (int)min((int64_t)8, nblk - bq);
+                vfloat4 va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    va[j] = vfloat4{0.f, 0.f, 0.f, 0.f}; vb[j] = va[j];
+                    if (j < cnt) {
+                        const float* r = partial + 2 * (m0 + bq + j) * ldp;
+                        if (oa) va[j] = load4_through(r + 4 * ca);
+                        if (ob) vb[j] = load4_through(r + 4 * cb);
+                    }
+                }
+                wait_memory();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    landed(va[j]); landed(vb[j]);
+                    if (j < cnt) { a += va[j]; b += vb[j]; }
+                }
+            }
+            float ga[4] = {a.x, a.y, a.z, a.w}, gb[4] = {b.x, b.y, b.z, b.w};
+            if (oa) update(ca, ga);
+            if (ob) update(cb, gb);
+        }
+    } else {
+        for (int c = lane + col0; c < nchunks; c += cstep) {
+            float acc[W];
+            float a = __hip_atomic_load(partial + (2 * m0 + 1) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t bq = 1; bq < nblk; ++bq)
+                a += __hip_atomic_load(partial + 2 * (m0 + bq) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[0] = a;
+            update(c, acc);
+        }
+    }
+    if (P.tag && lane == 0 && half == 0) P.tag[key] = step;
+}
+
+// Rows wider than 64 column chunks: TWO waves per task, each with every other group of 64 chunks — a task is a chain
+// of dependent loads (source row index, then 16 rows at a time), so the second wave halves its length instead of
+// walking the rows a second time (measured on the Zipf batch: see DESIGN.md 4.1).  Column sums are unchanged.
+__device__ __forceinline__ unsigned waves_per_task(const ApplyParams& P, int nchunks) {
+    return (nchunks > 64 && P.n < ((int64_t)1 << 22)) ? 2u : 1u;   // (block counts stay below 2^16: see the arrival fields)
+}
+
 template <int W>
 __device__ __forceinline__ void apply_long_body(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, unsigned block,
                                                 unsigned n_blocks) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const unsigned n_tasks = min(*P.long_count, P.long_cap);
-    const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
-    // Rows wider than 64 column chunks: TWO waves per task, each with every other group of 64 chunks — a task is a chain
-    // of dependent loads (source row index, then 16 rows at a time), so the second wave halves its length instead of
-    // walking the rows a second time (measured on the Zipf batch: see DESIGN.md 4.1).  Column sums are unchanged.
-    const unsigned per = (nchunks > 64 && P.n < ((int64_t)1 << 22)) ? 2u : 1u;   // (block counts stay below 2^16: see the arrival fields)
-    for (unsigned i2 = block * nwv + wv; i2 < n_tasks * per; i2 += n_blocks * nwv) {   // one (task, column half) per wave at a time
-        const unsigned i = i2 / per, half = i2 % per;
-        const int col0 = 64 * (int)half, cstep = 64 * (int)per;
-        const LongTask tk = P.long_list[i];                                         // (wave-uniform)
-        if (tk.len == 0) continue;
-        const int64_t t = tk.head, end = t + tk.len;
-        const uint32_t key = P.keys[t];
-        if ((int64_t)key >= P.n_rows) continue;  // defensive: never write outside the table
-        float* wrow = P.table + (int64_t)key * P.ld;
-        float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
-        float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
-        auto update = [&](int c, float (&g)[W]) {   // optimizer step of columns [W c, W c + W) with summed gradient g
-            float w[W];
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                w[j] = wrow[W * c + j];
-                lp_fold(P.opt, w[j], g[j], lp_acc);
-                opt_update_elem(P.opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
-                wrow[W * c + j] = w[j];
-            }
-        };
-        const int64_t nblk = (tk.len + kLongSegment - 1) / kLongSegment;
-        if (nblk == 1) {
-            const Src mine = block_sources(P, t, end, lane);
-            for (int c = lane + col0; c < nchunks; c += cstep) {
-                float g[W];
-                sum_block<W>(P, t, end, c, mine.row, mine.coef, g);
-                update(c, g);
-            }
-            if (P.tag && lane == 0 && half == 0) P.tag[key] = P.step;
-            continue;
-        }
-        // partial row of the block that starts at sorted position u0: 2 * (u0 / 64) + (first block of its segment).
-        // Collision-free: a 64-aligned bucket of positions holds at most one non-first block start and one
-        // first-block start (a long segment spans more than 64 positions) — and for the same reason t / 64 names the
-        // segment's arrival counter.
-        const int64_t u0 = t + (int64_t)tk.block * kLongSegment, u1 = min(u0 + kLongSegment, end);
-        float* prow = partial + (2 * (u0 / kLongSegment) + (tk.block == 0 ? 1 : 0)) * ldp;
-        const Src mine = block_sources(P, u0, u1, lane);
-        for (int c = lane + col0; c < nchunks; c += cstep) {
-            float g[W];
-            sum_block<W>(P, u0, u1, c, mine.row, mine.coef, g);
-            if constexpr (W == 4) store4_through(prow + 4 * c, g[0], g[1], g[2], g[3]);
-            else __hip_atomic_store(prow + c, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        wait_memory();   // this wave's block sum has left for memory
-        // arrivals of the two column halves are counted in the two 16-bit fields of the segment's counter
-        // (split only below 2^22 contributions: a segment then has fewer than 65536 blocks)
-        const int shift = 16 * (int)half;
-        int before = 0;
-        if (lane == 0) before = atomicAdd(P.arrive + t / kLongSegment, 1 << shift);
-        before = (__builtin_amdgcn_readfirstlane(before) >> shift) & 0xffff;
-        if (before != (int)nblk - 1) continue;
-        // the segment's last block (of this column half): every block sum is in memory
-        if (lane == 0) atomicSub(P.arrive + t / kLongSegment, (int)nblk << shift);   // ready for the next apply on this workspace
-        const int64_t m0 = t / kLongSegment;             // (t + 64 b) / 64 = t / 64 + b
-        if constexpr (W == 4) {
-            // two chunks per lane x 8 block sums per trip in flight, added left to right: 0 + first block sum + ...
-            for (int c0 = 0; c0 < nchunks; c0 += 128) {
-                const int ca = c0 + lane, cb = c0 + 64 + lane;
-                const bool oa = ca < nchunks && (per == 1u || half == 0u), ob = cb < nchunks && (per == 1u || half == 1u);
-                vfloat4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-                const float* first = partial + (2 * m0 + 1) * ldp;
-                if (oa) a = load4_through(first + 4 * ca);
-                if (ob) b = load4_through(first + 4 * cb);
-                wait_memory();
-                landed(a); landed(b);
-                for (int64_t bq = 1; bq < nblk; bq += 8) {
-                    const int cnt = (int)min((int64_t)8, nblk - bq);
-                    vfloat4 va[8], vb[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        va[j] = vfloat4{0.f, 0.f, 0.f, 0.f}; vb[j] = va[j];
-                        if (j < cnt) {
-                            const float* r = partial + 2 * (m0 + bq + j) * ldp;
-                            if (oa) va[j] = load4_through(r + 4 * ca);
-                            if (ob) vb[j] = load4_through(r + 4 * cb);
-                        }
-                    }
-                    wait_memory();
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        landed(va[j]); landed(vb[j]);
-                        if (j < cnt) { a += va[j]; b += vb[j]; }
-                    }
-                }
-                float ga[4] = {a.x, a.y, a.z, a.w}, gb[4] = {b.x, b.y, b.z, b.w};
-                if (oa) update(ca, ga);
-                if (ob) update(cb, gb);
-            }
-        } else {
-            for (int c = lane + col0; c < nchunks; c += cstep) {
-                float acc[W];
-                float a = __hip_atomic_load(partial + (2 * m0 + 1) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int64_t bq = 1; bq < nblk; ++bq)
-                    a += __hip_atomic_load(partial + 2 * (m0 + bq) * ldp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc[0] = a;
-                update(c, acc);
-            }
-        }
-        if (P.tag && lane == 0 && half == 0) P.tag[key] = P.step;
-    }
+    const unsigned per = waves_per_task(P, P.k_int / W);
+    for (unsigned i2 = block * nwv + wv; i2 < n_tasks * per; i2 += n_blocks * nwv)   // one (task, column half) per wave at a time
+        long_task_wave<W>(P, P.opt, P.step, partial, ldp, P.long_list[i2 / per], i2 % per, per, lane, lp_acc);
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
     // the last workgroup to finish empties the list, so that a second emg_apply_grouped on the same grouping (or the
     // next batch that reuses the workspace) starts from zero; every workgroup has read the count by then
@@ -629,10 +604,15 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
 //     EmbeddingModel.py:818-820): an untouched row still has g = lambda * p * |w|^(p-1) * sign(w), and its |w|^p
 //     belongs to the loss.  Touched rows got the same term folded into their update (lp_fold), so the regulariser
 //     costs ONE pass over the rows nothing else visited instead of n_rows extra contribution rows.
-__device__ __forceinline__ void untouched_rows_body(const ApplyParams& P, int64_t block) {
+__device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64_t block) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (block * blockDim.x + threadIdx.x) >> 6;
     float lp_acc = 0.f;
+    ApplyParams P = P0;
+    if (P0.ctl) {   // graph node: step number and learning rates from the device record
+        const float* h = P0.which ? P0.ctl->hyper_rel : P0.ctl->hyper_ent;
+        P.opt.lr = h[0]; P.opt.lr_t = h[5]; P.step = P0.ctl->step;
+    }
     if (r < P.n_rows && P.tag[r] != P.step) {
         float* w = P.table + r * P.ld;
         float* s0 = P.state0 ? P.state0 + r * P.ld : nullptr;
@@ -655,305 +635,246 @@ __global__ __launch_bounds__(256) void untouched_rows_pair_kernel(const ApplyPar
     else untouched_rows_body(P1, (int64_t)(blockIdx.x - blocks0));
 }
 
-static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// force Onesweep (histogram + scan + one pass per 8-bit digit) above 4096 items: the default picks a
-// block sort + ~13 merge launches below 1M items, which is launch-bound at our sizes (3e5 keys)
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 4096>;
-
-// the size query walks rocPRIM's host-side config selection (device lookup included): remember the last few
-// answers — a training run asks for the same two sizes four times per step
-static int sort_temp_bytes(int64_t n, size_t* bytes) {
-    *bytes = 0;
-    if (n <= 0) return EMG_OK;
-    static std::mutex mu;
-    static int64_t cached_n[8] = {0};
-    static size_t cached_b[8] = {0};
-    static int next = 0;
-    {
-        std::lock_guard<std::mutex> g(mu);
-        for (int i = 0; i < 8; ++i)
-            if (cached_n[i] == n) { *bytes = cached_b[i]; return EMG_OK; }
-    }
-    EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(nullptr, *bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
-                                                  (hipStream_t)0, false));
-    std::lock_guard<std::mutex> g(mu);
-    cached_n[next] = n; cached_b[next] = *bytes; next = (next + 1) & 7;
-    return EMG_OK;
+// ---------------------------------------------------------------------------------------------------------------
+// The training path: descriptor-driven apply (counting grouping).  A persistent grid; every wave
+//   1. takes its share of the BLOCK TASKS (round robin: they are the heavy items), as apply_long_kernel does;
+//   2. takes a CONTIGUOUS stretch of the segment list (destinations with 2..32 contributions, then — unless the backward
+//      kernel updated them in place — the singletons): its descriptors arrive in ONE coalesced load (lane k = item k),
+//      the source rows / factors of item k + 1 are fetched while item k's rows are in flight, and a segment is
+//      table row + up to 4 contribution rows in flight per trip, summed in contribution order (same bits as ever).
+// Nothing is searched: no key loads, no ballots, no window preamble (DESIGN.md 4.1 has the before / after).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Src segment_sources(const ApplyParams& P, uint32_t start, uint32_t len, int lane) {
+    return (uint32_t)lane < len ? contrib_src(P, (int64_t)start + lane) : Src{0u, 0.f};
 }
 
-// workspace layout: [keys_sorted | long-segment list | vals_sorted | (unused) | 256 B: long-segment count | rocprim temp
-//                    | partial rows of the long-segment reduction (only in workspaces sized by emg_apply_workspace_bytes_ex)]
-struct WsLayout {
-    size_t kb, temp;
-    uint32_t *keys, *vals;
-    void* tmp;
-    LongTask* long_list;  // first half of the 2nd key-sized region (room for n / 6 tasks; at most n / 8 are ever needed)
-    int32_t* arrive;      // second half of it: n / 64 + 1 per-segment block counters
-    uint32_t* long_count;
-    float* partial;       // nullptr when the workspace has no room for it (then long segments are summed by one wave)
-    // factored contributions: srcrow in the 4th key-sized region; pos_of_slot | coef in the radix sort's temporary
-    // storage (sized >= 2 key regions), which is free once the sort has run
-    uint32_t *srcrow, *pos_of_slot;
-    float* coef;
-};
-
-static inline size_t partial_rows(int64_t n) { return 2 * ((size_t)n / kLongSegment + 2); }
-
-static int ws_layout(void* workspace, int64_t workspace_bytes, int64_t n, WsLayout* o, int64_t ldp = 0) {
-    size_t tmp = 0;
-    int rc = sort_temp_bytes(n, &tmp);
-    if (rc != EMG_OK) return rc;
-    o->kb = align256((size_t)n * 4);
-    o->temp = tmp;
-    const size_t tmp_region = align256(tmp) > 2 * o->kb ? align256(tmp) : 2 * o->kb;   // also holds pos_of_slot | coef
-    EMG_REQUIRE((int64_t)(4 * o->kb + 256 + tmp_region) <= workspace_bytes,
-                "apply workspace too small (%lld < %lld)", (long long)workspace_bytes,
-                (long long)(4 * o->kb + 256 + tmp_region));
-    char* ws = (char*)workspace;
-    o->keys = (uint32_t*)ws;
-    o->vals = (uint32_t*)(ws + 2 * o->kb);
-    o->tmp = ws + 4 * o->kb + 256;
-    o->long_list = (LongTask*)(ws + o->kb);
-    o->arrive = (int32_t*)(ws + o->kb + o->kb / 2);
-    o->long_count = (uint32_t*)(ws + 4 * o->kb);
-    o->srcrow = (uint32_t*)(ws + 3 * o->kb);
-    o->pos_of_slot = (uint32_t*)o->tmp;
-    o->coef = (float*)((char*)o->tmp + o->kb);
-    const size_t base = 4 * o->kb + 256 + tmp_region;
-    const size_t need = partial_rows(n) * (size_t)ldp * sizeof(float);
-    o->partial = (ldp > 0 && n > kLongSegment && (int64_t)(base + need) <= workspace_bytes) ? (float*)(ws + base) : nullptr;
-    return EMG_OK;
-}
-
-int factor_view(void* workspace, int64_t workspace_bytes, int64_t n, FactorView* out) {
-    WsLayout w;
-    int rc = ws_layout(workspace, workspace_bytes, n, &w);
-    if (rc != EMG_OK) return rc;
-    out->pos_of_slot = w.pos_of_slot; out->coef = w.coef;
-    return EMG_OK;
-}
-
-// Small grouping problems (the relation table: n <= 16384 contributions, keys < 65536) are sorted by ONE
-// workgroup: 16-bit keys and 16-bit positions through rocprim::block_radix_sort (stable), instead of the
-// device-wide sort's histogram + one launch per digit.
-constexpr int BS_THREADS = 1024, BS_ITEMS = 16, BS_MAX = BS_THREADS * BS_ITEMS;
-
-__global__ __launch_bounds__(BS_THREADS) void block_group_kernel(const int32_t* __restrict__ dest, int n, int end_bit,
-                                                                 uint32_t* __restrict__ keys_out,
-                                                                 uint32_t* __restrict__ vals_out,
-                                                                 uint32_t* __restrict__ long_count,
-                                                                 int32_t* __restrict__ arrive) {
-    if (threadIdx.x == 0) { long_count[0] = 0u; long_count[1] = 0u; }
-    for (int i = threadIdx.x; i <= n / kLongSegment; i += BS_THREADS) arrive[i] = 0;
-    using sort_t = rocprim::block_radix_sort<uint16_t, BS_THREADS, BS_ITEMS, uint16_t>;
-    __shared__ typename sort_t::storage_type storage;
-    uint16_t k[BS_ITEMS], v[BS_ITEMS];
-    const int base = threadIdx.x * BS_ITEMS;  // blocked arrangement: thread t holds positions [16t, 16t+16)
+__device__ __forceinline__ void segment_update(const ApplyParams& P, const OptParams& opt, int32_t step, uint32_t dest, int len,
+                                               const Src mine, int lane, int nchunks, float& lp_acc) {
+    float* wrow = P.table + (int64_t)dest * P.ld;
+    float* s0row = P.state0 ? P.state0 + (int64_t)dest * P.ld : nullptr;
+    float* s1row = P.state1 ? P.state1 + (int64_t)dest * P.ld : nullptr;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < nchunks; c0 += 128) {
+        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        const bool oa = ca < nchunks, ob = cb < nchunks;
+        float4 accA = zero, accB = zero, wA = zero, wB = zero;
+        if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
+        if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
+        for (int u = 0; u < len; u += 4) {
+            float4 va[4], vb[4];
+            float cf[4];
 #pragma unroll
-    for (int i = 0; i < BS_ITEMS; ++i) {
-        const int idx = base + i;
-        k[i] = idx < n ? (uint16_t)dest[idx] : (uint16_t)0xffffu;  // padding sorts to the back (real keys < 2^end_bit)
-        v[i] = (uint16_t)idx;
-    }
-    sort_t().sort(k, v, storage, 0, end_bit < 16 ? end_bit + 1 : 16);  // +1 bit: keeps the 0xffff padding behind
+            for (int j = 0; j < 4; ++j) {
+                va[j] = zero; vb[j] = zero; cf[j] = 0.f;
+                if (u + j < len) {
+                    const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)mine.row, u + j);
+                    cf[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.coef), u + j));
+                    const float* rj = P.contrib + (int64_t)row * P.ldc;
+                    if (oa) va[j] = *reinterpret_cast<const float4*>(rj + 4 * ca);
+                    if (ob) vb[j] = *reinterpret_cast<const float4*>(rj + 4 * cb);
+                }
+            }
 #pragma unroll
-    for (int i = 0; i < BS_ITEMS; ++i) {
-        const int idx = base + i;
-        if (idx < n) { keys_out[idx] = k[i]; vals_out[idx] = v[i]; }
+            for (int j = 0; j < 4; ++j) {   // added in contribution order
+                if (u + j < len) {
+                    if (oa) add_scaled(accA, va[j], cf[j]);
+                    if (ob) add_scaled(accB, vb[j], cf[j]);
+                }
+            }
+        }
+        auto finish = [&](int c, float4 wv, const float4& g) {
+            const int64_t off = 4 * (int64_t)c;
+            float w[4] = {wv.x, wv.y, wv.z, wv.w};
+            float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lp_fold(opt, w[j], gg[j], lp_acc);
+                opt_update_elem(opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+            }
+            *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
+        };
+        if (oa) finish(ca, wA, accA);
+        if (ob) finish(cb, wB, accB);
     }
+    if (P.tag && lane == 0) P.tag[dest] = step;
 }
 
-// stable grouping of n destination ids: sorted keys + original positions into the workspace
-static int group_dest_impl(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
-                           uint8_t* single_flags, hipStream_t st, const int32_t* fac_codes = nullptr, int64_t fac_B = 0) {
-    WsLayout w;
-    int rc = ws_layout(workspace, workspace_bytes, n, &w);
-    if (rc != EMG_OK) return rc;
-    int end_bit = 1;
-    while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
-    bool counted = false;  // the long-segment counters have been zeroed by one of the kernels below
-    if (n <= BS_MAX && end_bit <= 15) {
-        hipLaunchKernelGGL(block_group_kernel, dim3(1), dim3(BS_THREADS), 0, st, dest, (int)n, end_bit, w.keys, w.vals,
-                           w.long_count, w.arrive);
-        EMG_LAUNCH_CHECK();
-        counted = true;
-    } else {
-        size_t tmp = w.temp;
-        // values = original positions, generated on the fly (no iota array)
-        EMG_HIP(rocprim::radix_sort_pairs<SortConfig>(w.tmp, tmp, (const uint32_t*)dest, w.keys,
-                                                      rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
-                                                      end_bit, st, false));
+// a segment of more than kDeferSegment rows in a workspace WITHOUT partial rows (sized by emg_apply_workspace_bytes):
+// one wave sums all of it left to right (slow for hub rows; the documented small-workspace behaviour)
+__device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const OptParams& opt, int32_t step, const LongTask tk,
+                                                    int lane, int nchunks, float& lp_acc) {
+    const int64_t t = tk.head, end = t + tk.len;
+    const uint32_t key = P.keys[t];
+    if ((int64_t)key >= P.n_rows) return;
+    float* wrow = P.table + (int64_t)key * P.ld;
+    float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
+    float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+    for (int c0 = 0; c0 < nchunks; c0 += 64) {   // (uniform loop: block_sources needs every lane)
+        const int c = c0 + lane;
+        const bool ok = c < nchunks;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t u0 = t; u0 < end; u0 += kLongSegment) {
+            const int64_t u1 = min(u0 + kLongSegment, end);
+            const Src mine = block_sources(P, u0, u1, lane);
+            sum_block<4>(P, u0, u1, ok ? c : 0, mine.row, mine.coef, g, true);
+        }
+        if (ok) {
+            float w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[j] = wrow[4 * c + j];
+                lp_fold(opt, w[j], g[j], lp_acc);
+                opt_update_elem(opt, w[j], g[j], s0row ? s0row + 4 * c + j : nullptr, s1row ? s1row + 4 * c + j : nullptr);
+                wrow[4 * c + j] = w[j];
+            }
+        }
     }
-    if (single_flags || fac_codes) {
-        hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                           single_flags, w.long_count, fac_codes, (uint32_t)fac_B, w.srcrow, w.pos_of_slot, w.coef, w.arrive);
-        EMG_LAUNCH_CHECK();
-        counted = true;
-    }
-    if (!counted) {  // task list / block counters of the apply that follows
-        EMG_HIP(hipMemsetAsync(w.long_count, 0, 2 * sizeof(uint32_t), st));
-        EMG_HIP(hipMemsetAsync(w.arrive, 0, (size_t)(n / kLongSegment + 1) * sizeof(int32_t), st));
-    }
-    return EMG_OK;
+    if (P.tag && lane == 0) P.tag[key] = step;
 }
 
-// corruption codes (Philox / injected) + the destination ids they imply, for every corruption side, ONE launch
-struct PrepParams {
-    const int32_t* pos; int64_t B; int32_t eta; int32_t n_sides; int32_t sides[4];
-    uint64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t counter0;
-    const int32_t* inj_mask; const int32_t* inj_repl;
-    int32_t* codes; int32_t* dest_ent; int32_t* dest_rel;
-    int64_t B_global; int64_t row_offset;  // draw index of (negative je, local row i) = je * B_global + row_offset + i
-};
+__device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
+                                                     int64_t nw, int lane) {
+    OptParams opt = P.opt;
+    int32_t step = P.step;
+    if (P.ctl) {   // the step's number and learning rates from the device record (a captured graph cannot bake them)
+        const float* h = P.which ? P.ctl->hyper_rel : P.ctl->hyper_ent;
+        opt.lr = h[0]; opt.lr_t = h[5];
+        step = P.ctl->step;
+    }
+    const int nchunks = P.k_int / 4;
+    const uint32_t n_multi = P.counters[GC_MULTI];
+    const uint32_t n_single = P.skip_single ? 0u : P.counters[GC_SINGLE];
+    const uint32_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
+    float lp_acc = 0.f;
+    if (n_tasks && partial) {
+        const unsigned per = waves_per_task(P, nchunks);
+        for (int64_t i2 = gw; i2 < (int64_t)n_tasks * per; i2 += nw)
+            long_task_wave<4>(P, opt, step, partial, ldp, P.tasks[i2 / per], (unsigned)(i2 % per), per, lane, lp_acc);
+    } else if (n_tasks) {
+        for (int64_t i = gw; i < (int64_t)n_tasks; i += nw) {
+            const LongTask tk = P.tasks[i];
+            if (tk.block == 0u && tk.len != 0u) long_segment_serial(P, opt, step, tk, lane, nchunks, lp_acc);
+        }
+    }
+    const int64_t total = (int64_t)n_multi + n_single;
+    const int64_t share = (total + nw - 1) / nw;
+    const int64_t i0 = gw * share, i1 = min(total, i0 + share);
+    for (int64_t base = i0; base < i1; base += 64) {
+        const int64_t it = base + lane;
+        Seg sg{0u, 0u, 0u};
+        if (it < i1) {
+            if (it < (int64_t)n_multi) sg = P.multi[it];
+            else { const uint32_t at = P.single[it - n_multi]; sg = Seg{at, 1u, P.keys[at]}; }
+        }
+        const int cnt = (int)min((int64_t)64, i1 - base);
+        Src nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, 0), (uint32_t)__builtin_amdgcn_readlane((int)sg.len, 0), lane);
+        for (int k = 0; k < cnt; ++k) {
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k);
+            const uint32_t dest = (uint32_t)__builtin_amdgcn_readlane((int)sg.dest, k);
+            const Src mine = nxt;
+            if (k + 1 < cnt)
+                nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, k + 1),
+                                      (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
+            if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
+            segment_update(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
+        }
+    }
+    if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
+}
 
-__global__ void prepare_ids_kernel(const PrepParams P) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t per_side = (int64_t)P.eta * P.B;
-    if (j < P.B) {
-        P.dest_ent[j] = P.pos[3 * j + 0];
-        P.dest_ent[P.B + j] = P.pos[3 * j + 2];
-        P.dest_rel[j] = P.pos[3 * j + 1];
-    }
-    if (j >= per_side * P.n_sides) return;
-    const int sd = (int)(j / per_side);
-    int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
-    if (P.B_global != P.B) {          // this batch is rows [row_offset, row_offset + B) of a larger one: draw what IT would
-        const int64_t je = jj / P.B;
-        jj = je * P.B_global + P.row_offset + (jj - je * P.B);
-    }
-    const int side = P.sides[sd];
-    uint32_t keep, idx;
-    if (P.inj_repl) {
-        idx = (uint32_t)P.inj_repl[j];
-        keep = P.inj_mask ? (uint32_t)(P.inj_mask[j] != 0) : 0u;
-    } else {
-        corruption_draw(P.seed, P.counter0 + (uint64_t)sd, (uint64_t)jj, P.n_choices, &keep, &idx);
-    }
-    if (side == EMG_SIDE_O) keep = 1u;
-    else if (side == EMG_SIDE_S) keep = 0u;
-    const uint32_t repl = P.entities_list ? (uint32_t)P.entities_list[idx] : idx;
-    P.codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
-    P.dest_ent[2 * P.B + j] = (int32_t)(repl & 0x7fffffffu);
+__global__ __launch_bounds__(256) void apply_segments_kernel(const ApplyParams P0, float* __restrict__ partial0, int64_t ldp0,
+                                                             const ApplyParams P1, float* __restrict__ partial1, int64_t ldp1,
+                                                             int n_tables) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    apply_segments_table(P0, partial0, ldp0, gw, nw, lane);
+    if (n_tables > 1) apply_segments_table(P1, partial1, ldp1, nw - 1 - gw, nw, lane);   // (the other end first: the relation table's few items meet idle waves)
 }
 
 }  // namespace emg
 
 using namespace emg;
 
-extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) {
-    (void)n_rows;
-    if (n_contrib <= 0) return 256;
-    size_t tmp = 0;
-    if (sort_temp_bytes(n_contrib, &tmp) != EMG_OK) return -1;
-    const size_t kb = align256((size_t)n_contrib * 4);
-    return (int64_t)(4 * kb + 256 + (align256(tmp) > 2 * kb ? align256(tmp) : 2 * kb) + 256);
-}
-
-extern "C" int64_t emg_apply_workspace_bytes_ex(int64_t n_contrib, int64_t n_rows, int32_t k_int) {
-    const int64_t base = emg_apply_workspace_bytes(n_contrib, n_rows);
-    if (base < 0 || n_contrib <= kLongSegment || k_int <= 0) return base;
-    const int64_t ldp = (k_int + 3) / 4 * 4;
-    return base + (int64_t)(partial_rows(n_contrib) * (size_t)ldp * sizeof(float));
-}
-
-extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace,
-                              int64_t workspace_bytes, uint8_t* single_flags, void* stream) {
-    EMG_REQUIRE(n >= 0 && n_rows > 0 && n_rows < ((int64_t)1 << 31), "emg_group_dest: bad sizes");
-    if (n == 0) return EMG_OK;
-    EMG_REQUIRE(dest && workspace, "emg_group_dest: null pointer");
-    return group_dest_impl(dest, n, n_rows, workspace, workspace_bytes, single_flags, (hipStream_t)stream);
-}
-
-extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
-    EMG_REQUIRE(a, "emg_prepare_batch: null args");
-    EMG_REQUIRE(a->B >= 0 && a->eta >= 1 && a->n_sides >= 1 && a->n_sides <= 4, "emg_prepare_batch: bad sizes");
-    if (a->B == 0) return EMG_OK;
-    EMG_REQUIRE(a->pos && a->codes && a->dest_ent && a->dest_rel && a->ws_ent && a->ws_rel, "emg_prepare_batch: null pointer");
-    EMG_REQUIRE(a->inj_repl || a->n_choices > 0, "emg_prepare_batch: n_choices must be positive");
-    EMG_REQUIRE(a->n_extra_ent >= 0 && a->n_extra_rel >= 0 && a->n_ent > 0 && a->n_rel > 0, "emg_prepare_batch: bad table sizes");
-    hipStream_t st = (hipStream_t)stream;
-    PrepParams P{};
-    P.pos = a->pos; P.B = a->B; P.eta = a->eta; P.n_sides = a->n_sides;
-    for (int i = 0; i < a->n_sides; ++i) {
-        EMG_REQUIRE(a->sides[i] >= EMG_SIDE_S && a->sides[i] <= EMG_SIDE_SO, "emg_prepare_batch: bad side %d", a->sides[i]);
-        P.sides[i] = a->sides[i];
-    }
-    P.n_choices = (uint64_t)a->n_choices; P.entities_list = a->entities_list; P.seed = a->seed; P.counter0 = a->draw_counter0;
-    P.inj_mask = a->inj_mask; P.inj_repl = a->inj_repl; P.codes = a->codes;
-    EMG_REQUIRE(a->B_global == 0 || (a->row_offset >= 0 && a->row_offset + a->B <= a->B_global),
-                "emg_prepare_batch: rows [row_offset, row_offset + B) must lie inside the global batch");
-    P.B_global = a->B_global > 0 ? a->B_global : a->B;
-    P.row_offset = a->B_global > 0 ? a->row_offset : 0;
-    P.dest_ent = a->dest_ent + a->n_extra_ent; P.dest_rel = a->dest_rel + a->n_extra_rel;
-    const int64_t n_neg = a->B * (int64_t)a->eta * a->n_sides;
-    hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)cdiv(n_neg > a->B ? n_neg : a->B, 256)), dim3(256), 0, st, P);
-    EMG_LAUNCH_CHECK();
-    const int64_t n_ce = a->n_extra_ent + 2 * a->B + n_neg, n_cr = a->n_extra_rel + a->B;
-    EMG_REQUIRE(!a->factored || (a->n_extra_ent == 0 && n_ce < ((int64_t)1 << 31)),
-                "emg_prepare_batch: factored contributions exclude caller-filled extra entity rows");
-    int rc = group_dest_impl(a->dest_ent, n_ce, a->n_ent, a->ws_ent, a->ws_ent_bytes, a->single_flags, st,
-                             a->factored ? a->codes : nullptr, a->B);
-    if (rc != EMG_OK) return rc;
-    return group_dest_impl(a->dest_rel, n_cr, a->n_rel, a->ws_rel, a->ws_rel_bytes, nullptr, st);
-}
-
 // launch geometry of one table's apply, decided once so that two tables can share their launches
 struct ApplyLaunch {
     bool any = false, vec = false, skinny = false, dense = false;
-    unsigned grid = 0, nb = 0;   // window-kernel workgroups; task-kernel workgroups (0: no task list)
+    bool segs = false;           // descriptor-driven kernel (counting grouping, 16-byte rows of more than 16 chunks)
+    unsigned grid = 0, nb = 0;   // window-kernel workgroups (segs: persistent workgroups); task-kernel workgroups (0: no task list)
     float* partial = nullptr; int64_t ldp = 0;
 };
 
-static int apply_setup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
-                       int32_t* tag, int32_t step, const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
-                       const float* hyper, double* lp_accum, void* workspace, int64_t workspace_bytes, bool factored,
-                       ApplyParams& P, ApplyLaunch& A) {
+static bool segments_path_enabled() {
+    static const bool on = [] { const char* e = getenv("EMG_APPLY"); return !(e && strcmp(e, "window") == 0); }();   // A/B aid
+    return on;
+}
+
+static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) {
+    const int opt = a->opt;
+    const int32_t k_int = a->k_int;
+    const int64_t n_rows = a->n_rows, ld = a->ld, ldc = a->ldc, n_contrib = a->n_contrib;
+    const float* hyper = a->hyper;
     EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM_LAZY, "emg_apply_grouped: unknown optimizer %d", opt);
-    EMG_REQUIRE(table && hyper && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
+    EMG_REQUIRE(a->table && n_rows > 0 && ld >= k_int && k_int > 0, "emg_apply_grouped: bad table arguments");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31), "emg_apply_grouped: too many rows");
-    EMG_REQUIRE(n_contrib == 0 || (contrib && workspace && ldc >= k_int), "emg_apply_grouped: bad contribution arguments");
-    EMG_REQUIRE(!(opt == EMG_OPT_MOMENTUM || opt == EMG_OPT_ADAGRAD) || state0, "emg_apply_grouped: optimizer needs state0");
-    EMG_REQUIRE(!(opt == EMG_OPT_ADAM || opt == EMG_OPT_ADAM_LAZY) || (state0 && state1),
+    EMG_REQUIRE(n_contrib == 0 || (a->contrib && a->workspace && ldc >= k_int), "emg_apply_grouped: bad contribution arguments");
+    EMG_REQUIRE(!(opt == EMG_OPT_MOMENTUM || opt == EMG_OPT_ADAGRAD) || a->state0, "emg_apply_grouped: optimizer needs state0");
+    EMG_REQUIRE(!(opt == EMG_OPT_ADAM || opt == EMG_OPT_ADAM_LAZY) || (a->state0 && a->state1),
                 "emg_apply_grouped: adam needs state0 and state1");
-    EMG_REQUIRE(opt != EMG_OPT_ADAM || tag, "emg_apply_grouped: dense-equivalent adam needs the tag array");
-    EMG_REQUIRE(hyper[6] == 0.f || (tag && hyper[7] >= 1.f), "emg_apply_grouped: a folded LP regulariser needs the tag array and p >= 1");
+    EMG_REQUIRE(opt != EMG_OPT_ADAM || a->tag, "emg_apply_grouped: dense-equivalent adam needs the tag array");
+    EMG_REQUIRE(hyper[6] == 0.f || (a->tag && hyper[7] >= 1.f), "emg_apply_grouped: a folded LP regulariser needs the tag array and p >= 1");
+    EMG_REQUIRE(a->layout_n == 0 || a->layout_n >= n_contrib, "emg_apply_grouped: layout_n < n_contrib");
     P = ApplyParams{};
     A = ApplyLaunch{};
-    P.table = table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
-    P.state0 = state0; P.state1 = state1; P.tag = tag; P.step = step;
-    P.contrib = contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = skip_single;
+    P.table = a->table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
+    P.state0 = a->state0; P.state1 = a->state1; P.tag = a->tag; P.step = a->step;
+    P.contrib = a->contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = a->skip_single;
     P.opt = make_opt_params(opt, hyper);
-    P.lp_accum = lp_accum;
+    P.lp_accum = a->lp_accum;
+    P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
     A.dense = opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f;
     if (n_contrib <= 0) return EMG_OK;
     A.any = true;
-    A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(table) && aligned16(contrib) &&
-            (!state0 || aligned16(state0)) && (!state1 || aligned16(state1));
+    A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(a->table) && aligned16(a->contrib) &&
+            (!a->state0 || aligned16(a->state0)) && (!a->state1 || aligned16(a->state1));
     A.ldp = (k_int + 3) / 4 * 4;
-    WsLayout w;
-    int rc = ws_layout(workspace, workspace_bytes, n_contrib, &w, A.ldp);
+    const int64_t N = a->layout_n > 0 ? a->layout_n : n_contrib;   // what the workspace was laid out for
+    GroupWs w;
+    int rc = group_ws_layout(a->workspace, a->workspace_bytes, N, n_rows, A.ldp, &w);
     if (rc != EMG_OK) return rc;
     P.keys = w.keys;
     P.vals = w.vals;
-    P.srcrow = factored ? w.srcrow : w.vals;
-    P.coef = factored ? w.coef : nullptr;
+    P.srcrow = a->factored ? w.srcrow : w.vals;
+    P.coef = a->factored ? w.coef : nullptr;
+    P.arrive = w.arrive;
+    const int nch = A.vec ? k_int / 4 : k_int;
+    A.skinny = nch <= 16;
+    A.segs = w.counting && A.vec && !A.skinny && segments_path_enabled();
+    EMG_REQUIRE(!P.ctl || A.segs, "emg_apply_grouped: a device-side step record needs the descriptor-driven apply (counting "
+                                  "grouping, 16-byte aligned rows of more than 16 chunks)");
+    if (A.segs) {
+        P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.counters = w.counters; P.task_cap = w.task_cap;
+        A.partial = w.partial;
+        // persistent grid: enough waves to fill the chip at 8 per SIMD, fewer for small batches (every wave of the launch
+        // reads the list counters and its descriptors before it has anything to do)
+        static const int env_blocks = getenv("EMG_SEG_BLOCKS") ? atoi(getenv("EMG_SEG_BLOCKS")) : 0;   // A/B aid
+        int64_t waves = N / 2;
+        waves = waves < 256 ? 256 : (waves > 8192 ? 8192 : waves);
+        A.grid = env_blocks > 0 ? (unsigned)env_blocks : (unsigned)cdiv(waves, 4);
+        return EMG_OK;
+    }
     // window per wave: large enough to amortise wave launches, small enough for >= ~16k waves in flight
     int win = 64;
     while (win > 1 && n_contrib / win < 16384) win >>= 1;
     if (const char* e = getenv("EMG_APPLY_WIN")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) win = v; }  // A/B aid
     P.win = win;
     A.grid = (unsigned)cdiv(cdiv(n_contrib, win) * 64, 256);
-    const int nch = A.vec ? k_int / 4 : k_int;
-    A.skinny = nch <= 16;
     static const bool no_long = getenv("EMG_NO_LONG") != nullptr;     // A/B aids
     static const int defer_env = getenv("EMG_DEFER") ? atoi(getenv("EMG_DEFER")) : 0;
     P.defer = defer_env >= 8 ? defer_env : kDeferSegment;   // (>= 8: the task list has room for n / 8 tasks)
     if (w.partial && !A.skinny && !no_long) {  // long segments go to apply_long_kernel (count zeroed by the grouping)
-        P.long_list = w.long_list; P.long_count = w.long_count; P.arrive = w.arrive;
-        P.long_cap = (uint32_t)(n_contrib / (P.defer < kDeferSegment ? P.defer : kDeferSegment) + 1);
+        P.long_list = w.tasks; P.long_count = w.counters + GC_LONG_COUNT;
+        P.long_cap = w.task_cap;
         A.partial = w.partial;
         // one wave per block task, 16 waves per workgroup.  Tables with few rows (relations) defer most of their
         // segments: a workgroup per CU; tables with many rows (entities) defer hub rows only: a smaller grid,
@@ -966,7 +887,10 @@ static int apply_setup(int opt, float* table, int64_t n_rows, int64_t ld, int32_
 }
 
 static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t st) {
-    if (A.any) {
+    if (A.any && A.segs) {
+        hipLaunchKernelGGL(apply_segments_kernel, dim3(A.grid), dim3(256), 0, st, P, A.partial, A.ldp, P, A.partial, A.ldp, 1);
+        EMG_LAUNCH_CHECK();
+    } else if (A.any) {
         const dim3 grid(A.grid), block(256);
         // DEPTH 2 everywhere (measured, C3: relation table 0.121 ms vs 0.148 ms with 16 rows in flight at 2 waves/SIMD,
         // entity table 0.112 vs 0.22; alone on the chip the relation apply takes 0.047 / 0.054 / 0.064 ms at 2 / 8 / 16):
@@ -990,53 +914,44 @@ static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t 
     return EMG_OK;
 }
 
-static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
-                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
-                              int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
-                              void* workspace, int64_t workspace_bytes, bool factored, void* stream) {
-    ApplyParams P;
-    ApplyLaunch A;
-    int rc = apply_setup(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, skip_single, hyper,
-                         lp_accum, workspace, workspace_bytes, factored, P, A);
-    if (rc != EMG_OK) return rc;
-    return apply_launch(P, A, (hipStream_t)stream);
-}
-
-static int setup_from_args(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) {
-    return apply_setup(a->opt, a->table, a->n_rows, a->ld, a->k_int, a->state0, a->state1, a->tag, a->step, a->contrib, a->ldc,
-                       a->n_contrib, a->skip_single, a->hyper, a->lp_accum, a->workspace, a->workspace_bytes, a->factored != 0, P, A);
-}
-
 extern "C" int emg_apply_grouped_ex(const emg_apply_args* a, void* stream) {
     EMG_REQUIRE(a, "emg_apply_grouped_ex: null args");
     ApplyParams P;
     ApplyLaunch A;
-    int rc = setup_from_args(a, P, A);
+    int rc = apply_setup(a, P, A);
     if (rc != EMG_OK) return rc;
     return apply_launch(P, A, (hipStream_t)stream);
 }
 
-// Two tables (the entity and the relation table of a training step) through SHARED launches: one window kernel, one
-// task kernel.  Same results as two emg_apply_grouped_ex calls; falls back to exactly those where the shapes differ.
+// Two tables (the entity and the relation table of a training step) through SHARED launches: one apply kernel (or one
+// window kernel + one task kernel), one dense pass.  Same results as two emg_apply_grouped_ex calls; falls back to exactly
+// those where the shapes differ.
 extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream) {
     EMG_REQUIRE(a && b, "emg_apply_grouped_pair: null args");
     ApplyParams P0, P1;
     ApplyLaunch A0, A1;
-    int rc = setup_from_args(a, P0, A0);
-    if (rc == EMG_OK) rc = setup_from_args(b, P1, A1);
+    int rc = apply_setup(a, P0, A0);
+    if (rc == EMG_OK) rc = apply_setup(b, P1, A1);
     if (rc != EMG_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const bool share = A0.any && A1.any && A0.vec && A1.vec && !A0.skinny && !A1.skinny && (A0.nb != 0) == (A1.nb != 0);
-    if (!share) {
+    const bool share_segs = A0.any && A1.any && A0.segs && A1.segs;
+    const bool share = A0.any && A1.any && !A0.segs && !A1.segs && A0.vec && A1.vec && !A0.skinny && !A1.skinny && (A0.nb != 0) == (A1.nb != 0);
+    if (!share && !share_segs) {
         rc = apply_launch(P0, A0, st);
         return rc != EMG_OK ? rc : apply_launch(P1, A1, st);
     }
-    hipLaunchKernelGGL((apply_rows_pair_kernel<4, 2>), dim3(A0.grid + A1.grid), dim3(256), 0, st, P0, P1, A0.grid);
-    EMG_LAUNCH_CHECK();
-    if (A0.nb) {
-        hipLaunchKernelGGL((apply_long_pair_kernel<4>), dim3(A0.nb + A1.nb), dim3(1024), 0, st, P0, A0.partial, A0.ldp, A0.nb, P1,
-                           A1.partial, A1.ldp);
+    if (share_segs) {
+        hipLaunchKernelGGL(apply_segments_kernel, dim3(A0.grid > A1.grid ? A0.grid : A1.grid), dim3(256), 0, st, P0, A0.partial, A0.ldp,
+                           P1, A1.partial, A1.ldp, 2);
         EMG_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL((apply_rows_pair_kernel<4, 2>), dim3(A0.grid + A1.grid), dim3(256), 0, st, P0, P1, A0.grid);
+        EMG_LAUNCH_CHECK();
+        if (A0.nb) {
+            hipLaunchKernelGGL((apply_long_pair_kernel<4>), dim3(A0.nb + A1.nb), dim3(1024), 0, st, P0, A0.partial, A0.ldp, A0.nb, P1,
+                               A1.partial, A1.ldp);
+            EMG_LAUNCH_CHECK();
+        }
     }
     if (A0.dense && A1.dense) {   // the dense passes (Keras Adam, folded LP) of both tables: one launch too
         const unsigned b0 = (unsigned)cdiv(P0.n_rows * 64, 256), b1 = (unsigned)cdiv(P1.n_rows * 64, 256);
@@ -1048,6 +963,19 @@ extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_a
     D0.any = D1.any = false;
     rc = apply_launch(P0, D0, st);
     return rc != EMG_OK ? rc : apply_launch(P1, D1, st);
+}
+
+static int apply_grouped_impl(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,
+                              float* state1, int32_t* tag, int32_t step, const float* contrib, int64_t ldc,
+                              int64_t n_contrib, int32_t skip_single, const float* hyper, double* lp_accum,
+                              void* workspace, int64_t workspace_bytes, bool factored, void* stream) {
+    EMG_REQUIRE(hyper, "emg_apply_grouped: null hyper");
+    emg_apply_args a{};
+    a.opt = opt; a.k_int = k_int; a.table = table; a.n_rows = n_rows; a.ld = ld; a.state0 = state0; a.state1 = state1;
+    a.tag = tag; a.step = step; a.skip_single = skip_single; a.contrib = contrib; a.ldc = ldc; a.n_contrib = n_contrib;
+    for (int i = 0; i < 8; ++i) a.hyper[i] = hyper[i];
+    a.lp_accum = lp_accum; a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.factored = factored ? 1 : 0;
+    return emg_apply_grouped_ex(&a, stream);
 }
 
 extern "C" int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0,

@@ -261,11 +261,6 @@ __device__ __forceinline__ vfloat4 load4_through(const float* p) {   // issue on
 __device__ __forceinline__ void wait_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void landed(vfloat4& v) { asm volatile("" : "+v"(v)); }   // orders uses of v behind wait_memory()
 
-// What the backward kernel needs of an entity grouping workspace (emg_apply.hip::ws_layout) when contributions are
-// FACTORED: where each negative's slot landed in the sorted order, and the per-position factor array it fills.
-struct FactorView { const uint32_t* pos_of_slot; float* coef; };
-int factor_view(void* workspace, int64_t workspace_bytes, int64_t n, FactorView* out);   // emg_apply.hip
-
 static inline OptParams make_opt_params(int opt, const float* hyper) {
     OptParams o;
     o.opt = opt == EMG_OPT_ADAM_LAZY ? EMG_OPT_ADAM : opt;

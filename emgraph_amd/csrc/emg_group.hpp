@@ -1,0 +1,59 @@
+// emg_group.hpp — the grouping workspace: what emg_group.hip produces about a batch's gradient contributions and what
+// the backward kernel (emg_score.hip) and the row-sparse apply (emg_apply.hip) consume.
+//
+// Two backends fill it (group_backend()):
+//   COUNTING (the training path: destinations are rows of a table, n_rows <= 16 n + 2^20): histogram over the row ids
+//       (int32 atomics, fused into the id kernel) -> one decoupled-look-back scan over the rows -> scatter -> in-segment
+//       ordering.  Besides the stable order (keys / vals) the scan emits SEGMENT DESCRIPTORS — the list of destinations
+//       with 2..kDeferSegment contributions, the list of singletons, the block tasks of longer segments — so that the
+//       apply kernel starts streaming rows at instruction 0 instead of searching segment ends.
+//   SORT (wide keys: the filter index's (entity, relation) keys, tables far larger than the batch): rocPRIM's
+//       device radix sort; the apply then runs the window kernels, which find their segments themselves.
+#pragma once
+#include "emg_common.hpp"
+
+namespace emg {
+
+constexpr int kLongSegment = 64;   // rows; the block size of the long-segment reduction tree
+constexpr int kDeferSegment = 32;  // segments longer than this leave the per-segment path as block tasks
+struct LongTask { uint32_t head, block, len; };   // sorted position of the segment's head, block index, rows of the segment (0 = void)
+struct Seg { uint32_t start, len, dest; };        // contributions at sorted positions [start, start + len) belong to table row dest
+
+// words of GroupWs::counters
+enum { GC_MULTI = 0, GC_SINGLE = 1, GC_TASKS = 2, GC_VALID = 3,      // written by the scan: list lengths, grouped contributions
+       GC_SCAN_TICKET = 4, GC_SCAN_DONE = 5,                          // scan bookkeeping (zero between launches)
+       GC_LONG_COUNT = 8, GC_LONG_DONE = 9,                           // window path: task list length / finished workgroups
+       GC_WORDS = 64 };
+
+// Per-step values a captured step graph cannot bake into kernel arguments (include/emgraph_hip.h: emg_step_ctl)
+typedef emg_step_ctl StepCtl;
+
+struct GroupWs {
+    bool counting;
+    size_t kb;                                   // bytes of one N-entry uint32 region
+    uint32_t *keys, *vals, *tmpv, *srcrow, *pos_of_slot;
+    float* coef;
+    Seg* multi; uint32_t* single; LongTask* tasks; int32_t* arrive; uint32_t* counters;
+    unsigned long long* status; int scan_blocks;
+    int32_t* cnt; uint32_t* off;                 // counting backend: per-row count / cursor, exclusive offsets [R + 1]
+    void* sort_tmp; size_t sort_tmp_bytes;       // sort backend
+    float* partial;                              // block sums of the long-segment reduction (nullptr: no room)
+    size_t clean_offset, clean_bytes;            // the control region that must be zero before the first grouping
+    uint32_t task_cap;
+};
+
+constexpr int kScanTile = 4096;                  // rows per scan workgroup (256 threads x 16)
+
+bool group_backend_counting(int64_t N, int64_t R);
+int64_t group_ws_bytes(int64_t N, int64_t R, int64_t ldp);
+// N: contribution slots the layout is sized for (a plan: its capacity), R: table rows, ldp: floats per partial row (0: none)
+int group_ws_layout(void* ws, int64_t ws_bytes, int64_t N, int64_t R, int64_t ldp, GroupWs* out);
+
+static inline size_t partial_rows(int64_t n) { return 2 * ((size_t)n / kLongSegment + 2); }
+
+// What the backward kernel needs of an entity grouping workspace when contributions are FACTORED: where each negative's
+// slot landed in the sorted order, and the per-position factor array it fills.
+struct FactorView { const uint32_t* pos_of_slot; float* coef; };
+int factor_view(void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, FactorView* out);
+
+}  // namespace emg

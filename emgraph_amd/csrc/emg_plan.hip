@@ -18,7 +18,7 @@
 
 #include <stdlib.h>
 
-#include "emg_common.hpp"
+#include "emg_group.hpp"
 
 namespace emg {
 
@@ -79,6 +79,8 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     a.ws_ent = sl.buf.ws_ent; a.ws_ent_bytes = sl.buf.ws_ent_bytes; a.ws_rel = sl.buf.ws_rel; a.ws_rel_bytes = sl.buf.ws_rel_bytes;
     a.single_flags = c.inplace ? sl.buf.single : nullptr;
     a.factored = c.factored;
+    a.ws_clean = 1;            // emg_plan_create zeroed the control regions; every grouping leaves them zero
+    a.layout_B = c.cap_B;      // one workspace layout for every batch size of the run
     int rc;
     {
         Timed t(P, ST_PREPARE, st);
@@ -110,6 +112,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
     if (c.factored) { ba.fac_ws_ent = sl.buf.ws_ent; ba.fac_ws_ent_bytes = sl.buf.ws_ent_bytes; }
+    ba.layout_B = c.cap_B;
     int rc;
     if (c.fused) {
         ba.fused_loss = c.loss;
@@ -150,11 +153,12 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             aa.table = c.ent; aa.n_rows = c.n_ent; aa.ld = c.ld_ent; aa.state0 = c.ent_state0; aa.state1 = c.ent_state1;
             aa.tag = c.tag_ent; aa.skip_single = c.inplace ? 1 : 0; aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
             aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
-            aa.factored = c.factored;
+            aa.factored = c.factored; aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
         } else {
             aa.table = c.rel; aa.n_rows = c.n_rel; aa.ld = c.ld_rel; aa.state0 = c.rel_state0; aa.state1 = c.rel_state1;
             aa.tag = c.tag_rel; aa.skip_single = 0; aa.contrib = c.contrib_rel; aa.n_contrib = B;
             aa.lp_accum = lp ? c.lp_sum + 1 : nullptr; aa.workspace = sl.buf.ws_rel; aa.workspace_bytes = sl.buf.ws_rel_bytes;
+            aa.layout_n = c.cap_B; aa.table_index = 1;
         }
         aa.ldc = c.ldc;
     };
@@ -233,6 +237,16 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     }
     for (int i = 0; i < cfg->n_slots; ++i) {
         P->slots[i].buf = cfg->slots[i];
+        // the grouping workspaces' control regions start out zero (emg_prepare_args.ws_clean)
+        const int64_t et = (int64_t)cfg->eta * cfg->n_sides;
+        GroupWs we, wr;
+        if (group_ws_layout(cfg->slots[i].ws_ent, cfg->slots[i].ws_ent_bytes, (2 + et) * cfg->cap_B, cfg->n_ent, 0, &we) != EMG_OK ||
+            group_ws_layout(cfg->slots[i].ws_rel, cfg->slots[i].ws_rel_bytes, cfg->cap_B, cfg->n_rel, 0, &wr) != EMG_OK) {
+            emg_plan_destroy(P);
+            return EMG_EINVAL;
+        }
+        if (hipMemset((char*)cfg->slots[i].ws_ent + we.clean_offset, 0, we.clean_bytes) != hipSuccess ||
+            hipMemset((char*)cfg->slots[i].ws_rel + wr.clean_offset, 0, wr.clean_bytes) != hipSuccess) return bail("hipMemset");
         if (hipEventCreateWithFlags(&P->slots[i].ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&P->slots[i].done, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
     }

@@ -19,7 +19,7 @@
 // definition, read by no other group of this batch.  All other rows go to the contribution buffer and
 // are summed in a fixed order by emg_apply_grouped (no float atomics anywhere).
 // HBM-bound by design: algorithmic bytes per group in DESIGN.md §4.
-#include "emg_common.hpp"
+#include "emg_group.hpp"
 
 namespace emg {
 
@@ -168,6 +168,7 @@ struct GroupParams {
     float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
     OptParams opt;
     FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
+    const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
 };
 
 #ifndef EMG_BW_THREADS
@@ -405,10 +406,16 @@ struct keep_rows {
     static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && IP != 0));
 };
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
-__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P) {
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P0) {
     using R = Row<MODEL, W, NV>;
+    GroupParams P = P0;
+    if (P0.ctl) {   // a node of a captured step graph: which rows, which step, which learning rates come from the device record
+        P.B = P0.ctl->B; P.pos = P0.pos + 3 * P0.ctl->start; P.step = P0.ctl->step;
+        P.opt.lr = P0.ctl->hyper_ent[0]; P.opt.lr_t = P0.ctl->hyper_ent[5];
+    }
     const int lg = threadIdx.x % LPG;
     int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPG;
+    if ((int64_t)blockIdx.x * (kThreads / LPG) >= P.B) return;   // (a launch sized for the plan's capacity: workgroups past the batch)
     const bool active = g < P.B;
     if (!active) g = P.B - 1;
     const int64_t B = P.B;
@@ -805,7 +812,8 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
         EMG_REQUIRE(!(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
                     "emg_train_backward_ex: factored contributions need a bilinear model — a TransE gradient row depends "
                     "on the replacement entity");
-        int rc = factor_view(a->fac_ws_ent, a->fac_ws_ent_bytes, (2 + (int64_t)a->eta) * a->B, &P.fac);
+        const int64_t Bl = a->layout_B > 0 ? a->layout_B : a->B;
+        int rc = factor_view(a->fac_ws_ent, a->fac_ws_ent_bytes, (2 + (int64_t)a->eta) * Bl, a->n_ent, &P.fac);
         if (rc != EMG_OK) return rc;
     }
     P.single_ent = a->single_ent;
@@ -822,6 +830,12 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
         // with an LP regulariser every gradient row goes through emg_apply_grouped, which folds it in
         EMG_REQUIRE(a->hyper[6] == 0.f, "emg_train_backward_ex: in-place singleton updates cannot fold an LP regulariser "
                                         "(pass single_ent = NULL and let emg_apply_grouped apply every row)");
+    }
+    EMG_REQUIRE(a->layout_B == 0 || a->layout_B >= a->B, "emg_train_backward_ex: layout_B < B");
+    P.ctl = (const StepCtl*)a->ctl;
+    if (P.ctl) {   // the launch covers the capacity; the kernel reads the batch's rows and size from the record
+        EMG_REQUIRE(a->layout_B > 0, "emg_train_backward_ex: a device-side step record needs layout_B (the launch size)");
+        P.B = a->layout_B;
     }
     return run_group_pass(fused ? Pass::Fused : Pass::Backward, a->model, P, (hipStream_t)stream);
 }

@@ -311,15 +311,16 @@ def _apply_args(opt_id, table, k_int, state0, state1, tag, step, contrib, n_cont
 def apply_grouped_pair(first, second):
     """two tables' applies (each a dict of apply_grouped's arguments) through shared launches (emg_apply_grouped_pair)"""
     a, b = _apply_args(**first), _apply_args(**second)
+    b.table_index = 1
     L.check(L.load().emg_apply_grouped_pair(C.byref(a), C.byref(b), _stream()), "emg_apply_grouped_pair")
 
 
 def apply_workspace_views(workspace, n_contrib):
     """(sorted destination ids, contribution indices) int32 views of a grouping workspace filled by group_dest /
-    prepare_batch (layout of emg_apply.hip::ws_layout: keys at byte 0, values at 2 * align256(4 n))"""
+    prepare_batch (layout of emg_group.hip::layout_impl: keys at byte 0, values at align256(4 n))"""
     kb = (4 * n_contrib + 255) // 256 * 256
     w32 = workspace.view(torch.int32)
-    return w32[:n_contrib], w32[2 * kb // 4:2 * kb // 4 + n_contrib]
+    return w32[:n_contrib], w32[kb // 4:kb // 4 + n_contrib]
 
 
 def apply_workspace_bytes(n_contrib, n_rows, k_int=0):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 2
+#define EMG_ABI_VERSION 3
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */
@@ -131,6 +131,18 @@ int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_en
 int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const int32_t* codes,
                    int32_t* dest_ent, int32_t* dest_rel, void* stream);
 
+/* Per-step values of a training step that a captured step graph cannot bake into kernel arguments: a DEVICE record
+ * every kernel of the step reads instead (emg_prepare_args.ctl, emg_backward_args.ctl, emg_apply_args.ctl; NULL = the
+ * values of the argument struct).  emg_plan_run fills an array of them per replay.  The batch is rows
+ * [start, start + B) of the resident training set (the `pos` pointer of the call is then the set's row 0). */
+typedef struct emg_step_ctl {
+    int64_t start; int64_t B;
+    uint64_t draw_counter0;                                  /* as emg_prepare_args.draw_counter0 */
+    int64_t n_choices; const int32_t* entities_list;         /* corruption pool (n_choices 0: the call's) */
+    int32_t step; int32_t reserved0;                         /* optimizer step number (>= 1) */
+    float hyper_ent[8]; float hyper_rel[8];                  /* as emg_apply_rows' hyper; entries 0 (lr) and 5 (lr_t) are read */
+} emg_step_ctl;
+
 /* ---- everything about a training batch that does not depend on the tables, in one call (what the step
  * pipeline runs ahead on a side stream): the corruption codes of every corruption side (as emg_corrupt_codes,
  * side sd drawing with counter draw_counter0 + sd, codes side-major then eta-major), the destination ids of
@@ -154,7 +166,13 @@ typedef struct emg_prepare_args {
     /* factored != 0 (bilinear models, n_extra_ent = 0): the entity workspace also receives, per sorted position, the
      * row of the 4*B-row contribution buffer its slot points at, and per negative slot its sorted position — what
      * emg_train_backward_ex (fac_ws_ent) and emg_apply_grouped_factored work from. */
-    int32_t factored; int32_t reserved0;
+    int32_t factored;
+    /* ws_clean != 0: the caller zeroed the workspaces once (hipMemset of the whole buffer) and has used them only through
+     * this library since — the grouping then skips re-zeroing its control region (every grouping leaves it zero) */
+    int32_t ws_clean;
+    /* layout_B > 0: the workspaces are laid out (and the launches sized) for layout_B >= B positives — a plan's capacity,
+     * so that batches of different sizes share one layout; ctl: optional device record (see emg_step_ctl) */
+    int64_t layout_B; const void* ctl;
 } emg_prepare_args;
 int emg_prepare_batch(const emg_prepare_args* args, void* stream);
 
@@ -191,11 +209,14 @@ typedef struct emg_backward_args {
      * side, and the table apply is emg_apply_grouped_factored (same sums, same order, same bits: it adds the rounded
      * product gi * q exactly where the unfactored path adds the stored row). */
     void* fac_ws_ent; int64_t fac_ws_ent_bytes;
+    int64_t layout_B; const void* ctl;   /* as in emg_prepare_args: layout of fac_ws_ent; device record, pos = row 0 of the resident set */
 } emg_backward_args;   /* hyper[6] (folded LP, see emg_apply_grouped) must be 0 when single_ent != NULL */
 int emg_train_backward_ex(const emg_backward_args* args, void* stream);
 
 /* ---- K8 in two halves (emg_apply_rows = both):
- * emg_group_dest: stable sort of (dest, index) into `workspace` (+ optional singleton flags[n]);
+ * emg_group_dest: stable grouping of (dest, index) into `workspace` (+ optional singleton flags[n]) — a counting sort over
+ *   the table rows (histogram, one scan, scatter, in-segment ordering: csrc/emg_group.hip) that also emits the segment
+ *   descriptors emg_apply_grouped works from; keys wider than 16 n + 2^20 go through a device radix sort instead;
  * emg_apply_grouped: segmented sum + optimizer update using that workspace; skip_single != 0 skips
  * length-1 segments (already applied in place by emg_train_backward_ex). */
 int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
@@ -220,7 +241,9 @@ typedef struct emg_apply_args {
     float* state0; float* state1; int32_t* tag; int32_t step; int32_t skip_single;
     const float* contrib; int64_t ldc; int64_t n_contrib;
     float hyper[8]; double* lp_accum; void* workspace; int64_t workspace_bytes;
-    int32_t factored; int32_t reserved0;
+    int32_t factored;
+    int32_t table_index;                 /* 0 entity / 1 relation table: which hyper-parameters of `ctl` apply */
+    int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
 } emg_apply_args;
 int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
 int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);

@@ -573,8 +573,9 @@ def test_ranks_random_protocols_equal_literal_oracle(seed):
                                                          (257, 2, (2,), 90, 70000, 90), (40, 1, (1,), 12, 3, 0)])
 def test_prepare_batch_equals_separate_calls(B, eta, sides, n_ent, n_rel, xe):
     """emg_prepare_batch == emg_corrupt_codes (per side) + emg_build_dest + emg_group_dest: identical codes,
-    destination ids, sorted keys, ORIGINAL positions (stable) and singleton flags; covers the one-workgroup
-    16-bit sort (<= 16384 rows, ids < 32768) and the device-wide sort, and caller-filled leading rows."""
+    destination ids, sorted keys, ORIGINAL positions (stable) and singleton flags; covers the counting grouping with the
+    histogram fused into the id kernel and with caller-filled leading rows (separate histogram), a table much larger than
+    the batch, and (EMG_GROUPING=sort) the radix-sort backend."""
     d = dev()
     rs = np.random.RandomState(B + eta)
     pos = cu(np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32))
@@ -607,10 +608,9 @@ def test_prepare_batch_equals_separate_calls(B, eta, sides, n_ent, n_rel, xe):
     np.testing.assert_array_equal(dr.cpu().numpy(), dr_ref.cpu().numpy())
     np.testing.assert_array_equal(single.cpu().numpy(), single_ref.cpu().numpy())
 
-    def grouped(ws, n):  # workspace layout: keys | (unused) | vals, each 256-byte aligned
-        kb = (4 * n + 255) // 256 * 256
-        raw = ws.cpu().numpy()
-        return raw[:4 * n].view(np.uint32), raw[2 * kb:2 * kb + 4 * n].view(np.uint32)
+    def grouped(ws, n):  # workspace layout: keys | vals | ..., each 256-byte aligned (device.apply_workspace_views)
+        keys, vals = d.apply_workspace_views(ws, n)
+        return keys.cpu().numpy().view(np.uint32), vals.cpu().numpy().view(np.uint32)
     for ws, ws_ref, dest, n in ((we, we_ref, de, n_ce), (wr, wr_ref, dr, n_cr)):
         keys, vals = grouped(ws, n)
         kref, vref = grouped(ws_ref, n)

@@ -14,7 +14,8 @@ while (( "$#" )); do
   REPL[$f]=1
 done
 objs=()
-for f in emg_abi emg_score emg_train emg_apply emg_rank emg_rank_bf16 emg_api emg_plan; do
+for src in "${CS}"/emg_*.hip; do   # every source build.sh links (derived, so a new file cannot be forgotten here)
+  f="$(basename "${src}" .hip)"
   if [[ -n "${REPL[$f]:-}" ]]; then objs+=("${TMP}/${f}.o"); else objs+=("${OBJ}/${f}.o"); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "${OUT}/libemgraph_hip_${NAME}.so" "${objs[@]}"
