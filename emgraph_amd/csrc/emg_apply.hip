@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void apply_rows_pair_kernel(const ApplyParams 
 //       wave that finishes a segment's LAST block (arrival counter) adds the block sums left to right and applies the
 //       optimizer.  The reduction tree is defined by the segment alone, so the bits do not depend on which wave, window
 //       or GPU did what (a one-block segment is the same tree: plain left to right, like the window kernel's).
-template <int W>
+template <int W, int RIF = 16>   // RIF: contribution rows in flight per trip
 __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int64_t u1, int c, uint32_t my_row, float my_coef,
                                           float (&out)[W], bool carry = false) {
     // (my_row, my_coef): source row and factor of position u0 + lane, loaded by the WHOLE wave in one instruction before
@@ -261,17 +261,17 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
         float4 acc = carry ? make_float4(out[0], out[1], out[2], out[3]) : make_float4(0.f, 0.f, 0.f, 0.f);   // carry: continue a running sum
         const int n = (int)(u1 - u0);
         int j0 = 0;
-        for (; j0 + 16 <= n; j0 += 16) {
-            float4 v[16];
-            float cf[16];
+        for (; j0 + RIF <= n; j0 += RIF) {
+            float4 v[RIF];
+            float cf[RIF];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < RIF; ++j) {
                 const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0 + j);
                 cf[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), j0 + j));
                 v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c);
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) add_scaled(acc, v[j], cf[j]);
+            for (int j = 0; j < RIF; ++j) add_scaled(acc, v[j], cf[j]);
         }
         for (; j0 < n; ++j0) {
             const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0);
@@ -306,7 +306,7 @@ __device__ __forceinline__ int64_t segment_end(const ApplyParams& P, int64_t t, 
 
 // one (block task, column half) — the work of ONE wave.  per = 1: the wave walks every column chunk; per = 2: every other
 // group of 64 chunks (half = which), arrivals counted in the two 16-bit fields of the segment's counter.
-template <int W>
+template <int W, int RIF = 16, int CMB = 8, bool PLAIN = false>   // rows in flight per trip of a block sum / block sums in flight of the combine
 __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptParams& opt, int32_t step, float* __restrict__ partial,
                                                int64_t ldp, const LongTask tk, unsigned half, unsigned per, int lane,
                                                float& lp_acc) {
@@ -317,8 +317,8 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
     const uint32_t key = P.keys[t];
     if ((int64_t)key >= P.n_rows) return;  // defensive: never write outside the table
     float* wrow = P.table + (int64_t)key * P.ld;
-    float* s0row = P.state0 ? P.state0 + (int64_t)key * P.ld : nullptr;
-    float* s1row = P.state1 ? P.state1 + (int64_t)key * P.ld : nullptr;
+    float* s0row = (!PLAIN && P.state0) ? P.state0 + (int64_t)key * P.ld : nullptr;
+    float* s1row = (!PLAIN && P.state1) ? P.state1 + (int64_t)key * P.ld : nullptr;
     auto update = [&](int c, float (&g)[W]) {   // optimizer step of columns [W c, W c + W) with summed gradient g
         float w[W];
 #pragma unroll
@@ -334,7 +334,7 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
         const Src mine = block_sources(P, t, end, lane);
         for (int c = lane + col0; c < nchunks; c += cstep) {
             float g[W];
-            sum_block<W>(P, t, end, c, mine.row, mine.coef, g);
+            sum_block<W, RIF>(P, t, end, c, mine.row, mine.coef, g);
             update(c, g);
         }
         if (P.tag && lane == 0 && half == 0) P.tag[key] = step;
@@ -349,7 +349,7 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
     const Src mine = block_sources(P, u0, u1, lane);
     for (int c = lane + col0; c < nchunks; c += cstep) {
         float g[W];
-        sum_block<W>(P, u0, u1, c, mine.row, mine.coef, g);
+        sum_block<W, RIF>(P, u0, u1, c, mine.row, mine.coef, g);
         if constexpr (W == 4) store4_through(prow + 4 * c, g[0], g[1], g[2], g[3]);
         else __hip_atomic_store(prow + c, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -365,7 +365,7 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
     if (lane == 0) atomicSub(P.arrive + t / kLongSegment, (int)nblk << shift);   // ready for the next apply on this workspace
     const int64_t m0 = t / kLongSegment;             // (t + 64 b) / 64 = t / 64 + b
     if constexpr (W == 4) {
-        // two chunks per lane x 8 block sums per trip in flight, added left to right: 0 + first block sum + ...
+        // two chunks per lane x CMB block sums per trip in flight, added left to right: 0 + first block sum + ...
         for (int c0 = 0; c0 < nchunks; c0 += 128) {
             const int ca = c0 + lane, cb = c0 + 64 + lane;
             const bool oa = ca < nchunks && (per == 1u || half == 0u), ob = cb < nchunks && (per == 1u || half == 1u);
@@ -375,11 +375,11 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
             if (ob) b = load4_through(first + 4 * cb);
             wait_memory();
             landed(a); landed(b);
-            for (int64_t bq = 1; bq < nblk; bq += 8) {
-                const int cnt = (int)min((int64_t)8, nblk - bq);
-                vfloat4 va[8], vb[8];
+            for (int64_t bq = 1; bq < nblk; bq += CMB) {
+                const int cnt = (int)min((int64_t)CMB, nblk - bq);
+                vfloat4 va[CMB], vb[CMB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < CMB; ++j) {
                     va[j] = vfloat4{0.f, 0.f, 0.f, 0.f}; vb[j] = va[j];
                     if (j < cnt) {
                         const float* r = partial + 2 * (m0 + bq + j) * ldp;
@@ -389,7 +389,7 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
                 }
                 wait_memory();
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < CMB; ++j) {
                     landed(va[j]); landed(vb[j]);
                     if (j < cnt) { a += va[j]; b += vb[j]; }
                 }
@@ -644,15 +644,19 @@ __global__ __launch_bounds__(256) void untouched_rows_pair_kernel(const ApplyPar
 //      table row + up to 4 contribution rows in flight per trip, summed in contribution order (same bits as ever).
 // Nothing is searched: no key loads, no ballots, no window preamble (DESIGN.md 4.1 has the before / after).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef EMG_SEG_DEPTH
+#define EMG_SEG_DEPTH 4
+#endif
 __device__ __forceinline__ Src segment_sources(const ApplyParams& P, uint32_t start, uint32_t len, int lane) {
     return (uint32_t)lane < len ? contrib_src(P, (int64_t)start + lane) : Src{0u, 0.f};
 }
 
+template <int DEPTH, bool PLAIN>   // contribution rows in flight per trip; PLAIN: SGD without state / regulariser
 __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptParams& opt, int32_t step, uint32_t dest, int len,
                                                const Src mine, int lane, int nchunks, float& lp_acc) {
     float* wrow = P.table + (int64_t)dest * P.ld;
-    float* s0row = P.state0 ? P.state0 + (int64_t)dest * P.ld : nullptr;
-    float* s1row = P.state1 ? P.state1 + (int64_t)dest * P.ld : nullptr;
+    float* s0row = (!PLAIN && P.state0) ? P.state0 + (int64_t)dest * P.ld : nullptr;
+    float* s1row = (!PLAIN && P.state1) ? P.state1 + (int64_t)dest * P.ld : nullptr;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c0 = 0; c0 < nchunks; c0 += 128) {
         const int ca = c0 + lane, cb = c0 + 64 + lane;
@@ -660,11 +664,11 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
         float4 accA = zero, accB = zero, wA = zero, wB = zero;
         if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
         if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
-        for (int u = 0; u < len; u += 4) {
-            float4 va[4], vb[4];
-            float cf[4];
+        for (int u = 0; u < len; u += DEPTH) {
+            float4 va[DEPTH], vb[DEPTH];
+            float cf[DEPTH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < DEPTH; ++j) {
                 va[j] = zero; vb[j] = zero; cf[j] = 0.f;
                 if (u + j < len) {
                     const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)mine.row, u + j);
@@ -675,7 +679,7 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // added in contribution order
+            for (int j = 0; j < DEPTH; ++j) {   // added in contribution order
                 if (u + j < len) {
                     if (oa) add_scaled(accA, va[j], cf[j]);
                     if (ob) add_scaled(accB, vb[j], cf[j]);
@@ -716,7 +720,7 @@ __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const 
         for (int64_t u0 = t; u0 < end; u0 += kLongSegment) {
             const int64_t u1 = min(u0 + kLongSegment, end);
             const Src mine = block_sources(P, u0, u1, lane);
-            sum_block<4>(P, u0, u1, ok ? c : 0, mine.row, mine.coef, g, true);
+            sum_block<4, 8>(P, u0, u1, ok ? c : 0, mine.row, mine.coef, g, true);
         }
         if (ok) {
             float w[4];
@@ -732,9 +736,11 @@ __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const 
     if (P.tag && lane == 0) P.tag[key] = step;
 }
 
+template <bool PLAIN>
 __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
                                                      int64_t nw, int lane) {
     OptParams opt = P.opt;
+    if constexpr (PLAIN) { opt.opt = EMG_OPT_SGD; opt.lp_lambda = 0.f; }   // (known at compile time: the update folds to w - lr g)
     int32_t step = P.step;
     if (P.ctl) {   // the step's number and learning rates from the device record (a captured graph cannot bake them)
         const float* h = P.which ? P.ctl->hyper_rel : P.ctl->hyper_ent;
@@ -749,7 +755,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     if (n_tasks && partial) {
         const unsigned per = waves_per_task(P, nchunks);
         for (int64_t i2 = gw; i2 < (int64_t)n_tasks * per; i2 += nw)
-            long_task_wave<4>(P, opt, step, partial, ldp, P.tasks[i2 / per], (unsigned)(i2 % per), per, lane, lp_acc);
+            long_task_wave<4, 8, 4, PLAIN>(P, opt, step, partial, ldp, P.tasks[i2 / per], (unsigned)(i2 % per), per, lane, lp_acc);
     } else if (n_tasks) {
         for (int64_t i = gw; i < (int64_t)n_tasks; i += nw) {
             const LongTask tk = P.tasks[i];
@@ -776,20 +782,22 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                 nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, k + 1),
                                       (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
             if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
-            segment_update(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
+            segment_update<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
         }
     }
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-__global__ __launch_bounds__(256) void apply_segments_kernel(const ApplyParams P0, float* __restrict__ partial0, int64_t ldp0,
-                                                             const ApplyParams P1, float* __restrict__ partial1, int64_t ldp1,
-                                                             int n_tables) {
+struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; };
+
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    apply_segments_table(P0, partial0, ldp0, gw, nw, lane);
-    if (n_tables > 1) apply_segments_table(P1, partial1, ldp1, nw - 1 - gw, nw, lane);   // (the other end first: the relation table's few items meet idle waves)
+    // (a loop with a run-time index, not two inlined copies: one set of live registers.  The second table's few items go
+    // to the other end of the grid, where waves have less of the first table's work)
+    for (int ti = 0; ti < K.n_tables; ++ti) apply_segments_table<PLAIN>(K.P[ti], K.partial[ti], K.ldp[ti], ti ? nw - 1 - gw : gw, nw, lane);
 }
 
 }  // namespace emg
@@ -803,6 +811,8 @@ struct ApplyLaunch {
     unsigned grid = 0, nb = 0;   // window-kernel workgroups (segs: persistent workgroups); task-kernel workgroups (0: no task list)
     float* partial = nullptr; int64_t ldp = 0;
 };
+
+static bool plain_sgd(const ApplyParams& P) { return P.opt.opt == EMG_OPT_SGD && P.opt.lp_lambda == 0.f; }
 
 static bool segments_path_enabled() {
     static const bool on = [] { const char* e = getenv("EMG_APPLY"); return !(e && strcmp(e, "window") == 0); }();   // A/B aid
@@ -888,7 +898,10 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
 
 static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t st) {
     if (A.any && A.segs) {
-        hipLaunchKernelGGL(apply_segments_kernel, dim3(A.grid), dim3(256), 0, st, P, A.partial, A.ldp, P, A.partial, A.ldp, 1);
+        SegmentsLaunch K{};
+        K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
+        if (plain_sgd(P)) hipLaunchKernelGGL(apply_segments_kernel<true>, dim3(A.grid), dim3(256), 0, st, K);
+        else hipLaunchKernelGGL(apply_segments_kernel<false>, dim3(A.grid), dim3(256), 0, st, K);
         EMG_LAUNCH_CHECK();
     } else if (A.any) {
         const dim3 grid(A.grid), block(256);
@@ -941,8 +954,12 @@ extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_a
         return rc != EMG_OK ? rc : apply_launch(P1, A1, st);
     }
     if (share_segs) {
-        hipLaunchKernelGGL(apply_segments_kernel, dim3(A0.grid > A1.grid ? A0.grid : A1.grid), dim3(256), 0, st, P0, A0.partial, A0.ldp,
-                           P1, A1.partial, A1.ldp, 2);
+        SegmentsLaunch K{};
+        K.P[0] = P0; K.partial[0] = A0.partial; K.ldp[0] = A0.ldp;
+        K.P[1] = P1; K.partial[1] = A1.partial; K.ldp[1] = A1.ldp; K.n_tables = 2;
+        const dim3 grid(A0.grid > A1.grid ? A0.grid : A1.grid);
+        if (plain_sgd(P0) && plain_sgd(P1)) hipLaunchKernelGGL(apply_segments_kernel<true>, grid, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL(apply_segments_kernel<false>, grid, dim3(256), 0, st, K);
         EMG_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL((apply_rows_pair_kernel<4, 2>), dim3(A0.grid + A1.grid), dim3(256), 0, st, P0, P1, A0.grid);

@@ -304,12 +304,16 @@ __global__ __launch_bounds__(256) void group_scatter_kernel(const GroupLaunch G)
     if (i >= table_n(G, ti)) return;
     const int32_t d = T.dest[i];
     const bool ok = d >= 0 && (int64_t)d < T.R;
+    bool single = false;
     if (ok) {
-        const uint32_t pos = (uint32_t)atomicAdd(T.cnt + d, 1);
+        const uint32_t start = T.off[d];
+        single = T.off[d + 1] - start == 1u;
+        // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
+        const uint32_t pos = single ? start : (uint32_t)atomicAdd(T.cnt + d, 1);
         T.tmpv[pos] = (uint32_t)i;
         T.keys[pos] = (uint32_t)d;
     }
-    if (T.flags) T.flags[i] = (ok && T.off[d + 1] - T.off[d] == 1u) ? 1 : 0;
+    if (T.flags) T.flags[i] = single ? 1 : 0;
 }
 
 // 4. order: rank of a contribution among the slots of its segment = its place in the stable order.

@@ -227,9 +227,10 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     auto bail = [&](const char* what) { emg_plan_destroy(P); return fail(EMG_EHIP, "emg_plan_create: %s failed", what); };
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = highest priority
+    static const bool side_normal = getenv("EMG_SIDE_PRIO") && atoi(getenv("EMG_SIDE_PRIO")) == 0;   // A/B aid
     for (int i = 0; i < P->n_side; ++i)
         // high priority: the many small kernels of a preparation chain must not queue behind the big ones
-        if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, hi) != hipSuccess) return bail("hipStreamCreateWithPriority");
+        if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, side_normal ? lo : hi) != hipSuccess) return bail("hipStreamCreateWithPriority");
     if (P->n_side > 0) {
         if (hipStreamCreateWithFlags(&P->aux, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
         if (hipEventCreateWithFlags(&P->fork, hipEventDisableTiming) != hipSuccess ||

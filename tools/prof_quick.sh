@@ -1,0 +1,10 @@
+#!/usr/bin/env bash
+# rocprofv3 kernel trace of one bench configuration -> gpurun_out/TAG_kernel_stats.md.  usage: bash tools/prof_quick.sh TAG [bench args...]
+TAG="$1"; shift
+cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out; rm -rf gpurun_out/prof_$TAG
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o p -- python3 bench.py --no-cpu --no-eval --no-others --sustained-seconds 0 "$@" > gpurun_out/prof_$TAG.log 2>&1
+db=$(ls gpurun_out/prof_$TAG/*/*results.db gpurun_out/prof_$TAG/*results.db 2>/dev/null | head -1)
+python3 profiles/summarize_rocpd.py "$db" gpurun_out/${TAG}_kernel_stats.md > /dev/null
+tail -1 gpurun_out/prof_$TAG.log > gpurun_out/${TAG}_profiled_bench.json
+rm -rf gpurun_out/prof_$TAG
