@@ -171,6 +171,10 @@ class StepRunner:
         return ((i % self.nb) * self.B, self.B, i // self.nb + 1, i % self.nb + 1)
 
     def run(self, n):
+        if getattr(self.tr, "graph", False) and self.tr.stage_events is None:   # small batches: graph replays, one call
+            self.tr.run_batches([self.spec(self.i + j) for j in range(n)])
+            self.i += n
+            return
         for _ in range(n):
             i = self.i
             s = self.spec(i)

@@ -205,6 +205,7 @@ class PlanConfig(C.Structure):
         ("fused", _i32), ("inplace", _i32), ("normalize", _i32),
         ("n_slots", _i32), ("slots", PlanSlot * 4),
         ("aux_min_rows", _i64),
+        ("ctl_buf", _p), ("ctl_bytes", _i64),
     ]
 
 
@@ -217,6 +218,8 @@ class PlanBatch(C.Structure):
 SIGNATURES.update({
     "emg_plan_create": (_int, [C.POINTER(PlanConfig), C.POINTER(_p)]),
     "emg_plan_step": (_int, [_p, C.POINTER(PlanBatch), _i32, C.POINTER(_f32), C.POINTER(PlanBatch), _i32, _p]),
+    "emg_plan_graph_ok": (_int, [_p]),
+    "emg_plan_run": (_int, [_p, C.POINTER(PlanBatch), _i32, _i32, C.POINTER(_f32), _p]),
     "emg_plan_timing": (_int, [_p, _i32]),
     "emg_plan_stage_ms": (_int, [_p, C.POINTER(_f32), C.POINTER(_i32)]),
     "emg_plan_destroy": (_int, [_p]),

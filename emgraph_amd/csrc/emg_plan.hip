@@ -17,6 +17,7 @@
 #include <vector>
 
 #include <stdlib.h>
+#include <string.h>
 
 #include "emg_group.hpp"
 
@@ -28,6 +29,7 @@ struct SlotState {
     emg_plan_slot buf;
     hipEvent_t ready = nullptr, done = nullptr;
     bool has_key = false, ready_recorded = false;
+    bool done_in_capture = false;   // graph capture: `done` was recorded inside this capture (only then may a captured wait name it)
     int64_t key[4] = {0, 0, 0, 0};
 };
 
@@ -40,7 +42,22 @@ struct Plan {
     int n_side = 0, side_rr = 0;
     int timing_max = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ST_COUNT];
+    // captured step graphs (emg_plan_run), by length in steps
+    std::vector<std::pair<int, hipGraphExec_t>> graphs;
+    const StepCtl* ctl = nullptr;   // capture in progress: the record of the step being captured
+    hipStream_t cap = nullptr;              // origin stream of the captures (the caller's may be the null stream, which cannot capture)
+    bool side_joined[2] = {false, false};   // capture in progress: the side stream has been forked into the capture
+    hipEvent_t side_join[2] = {nullptr, nullptr};
 };
+
+constexpr int kGraphSteps = 32;     // steps per graph replay = records per ctl_write_kernel launch (kernel arguments: 4 KB)
+struct CtlBlock { StepCtl rec[kGraphSteps]; };
+__global__ void ctl_write_kernel(const CtlBlock blk, StepCtl* __restrict__ dst, int n) {
+    // (the records travel as kernel arguments: copied at launch, so the host buffer may be reused at once)
+    const int words = n * (int)(sizeof(StepCtl) / 4);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&blk);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t*>(dst)[i] = src[i];
+}
 
 static bool same_key(const SlotState& s, const emg_plan_batch& b) {
     return s.has_key && s.key[0] == b.start && s.key[1] == b.B && s.key[2] == b.epoch && s.key[3] == b.batch;
@@ -63,10 +80,16 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     const emg_plan_config& c = P->cfg;
     hipStream_t st = main;
     if (P->n_side > 0) {
-        st = P->side[P->side_rr];
+        const int si = P->side_rr;
+        st = P->side[si];
         P->side_rr = (P->side_rr + 1) % P->n_side;
-        EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));                           // the compute that last used this slot
-        if (sl.has_key && sl.ready_recorded) EMG_HIP(hipStreamWaitEvent(st, sl.ready, 0));  // evicted, never consumed
+        if (P->ctl) {   // graph capture: a side stream joins the capture by waiting for an event recorded inside it
+            if (!P->side_joined[si]) { EMG_HIP(hipStreamWaitEvent(st, P->fork, 0)); P->side_joined[si] = true; }
+            if (sl.done_in_capture) EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));
+        } else {
+            EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));                           // the compute that last used this slot
+            if (sl.has_key && sl.ready_recorded) EMG_HIP(hipStreamWaitEvent(st, sl.ready, 0));  // evicted, never consumed
+        }
     }
     emg_prepare_args a{};
     a.pos = c.X + 3 * b.start; a.B = b.B; a.eta = c.eta; a.n_sides = c.n_sides;
@@ -81,6 +104,10 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     a.factored = c.factored;
     a.ws_clean = 1;            // emg_plan_create zeroed the control regions; every grouping leaves them zero
     a.layout_B = c.cap_B;      // one workspace layout for every batch size of the run
+    if (P->ctl) {              // graph capture: rows, size and draw counter come from the device record
+        a.pos = c.X; a.B = c.cap_B; a.ctl = P->ctl;
+        a.n_choices = c.n_ent; a.entities_list = nullptr; a.inj_mask = a.inj_repl = nullptr;
+    }
     int rc;
     {
         Timed t(P, ST_PREPARE, st);
@@ -113,6 +140,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
     if (c.factored) { ba.fac_ws_ent = sl.buf.ws_ent; ba.fac_ws_ent_bytes = sl.buf.ws_ent_bytes; }
     ba.layout_B = c.cap_B;
+    if (P->ctl) { ba.pos = c.X; ba.B = c.cap_B; ba.ctl = P->ctl; }
     int rc;
     if (c.fused) {
         ba.fused_loss = c.loss;
@@ -160,12 +188,14 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             aa.lp_accum = lp ? c.lp_sum + 1 : nullptr; aa.workspace = sl.buf.ws_rel; aa.workspace_bytes = sl.buf.ws_rel_bytes;
             aa.layout_n = c.cap_B; aa.table_index = 1;
         }
+        if (P->ctl) { aa.ctl = P->ctl; aa.n_contrib = aa.layout_n; }
         aa.ldc = c.ldc;
     };
     emg_apply_args ae, ar;
     fill(ae, true);
     fill(ar, false);
-    static const bool pair = getenv("EMG_PAIR_APPLY") == nullptr || atoi(getenv("EMG_PAIR_APPLY")) != 0;
+    static const bool pair_env = getenv("EMG_PAIR_APPLY") == nullptr || atoi(getenv("EMG_PAIR_APPLY")) != 0;
+    const bool pair = pair_env || P->ctl != nullptr;   // (a captured step never forks for the relation apply)
     const bool big = n_ce >= c.aux_min_rows;
     if (pair) {   // (any batch size: C1 0.134 -> 0.126 ms/step, C2 0.100 -> 0.089 against two launch pairs in sequence)
         Timed t(P, ST_APPLY_ENT, main);
@@ -236,6 +266,10 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
         if (hipEventCreateWithFlags(&P->fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&P->join, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
     }
+    for (int i = 0; i < P->n_side; ++i)
+        if (hipEventCreateWithFlags(&P->side_join[i], hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    if (!P->fork && hipEventCreateWithFlags(&P->fork, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
+    if (hipStreamCreateWithFlags(&P->cap, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
     for (int i = 0; i < cfg->n_slots; ++i) {
         P->slots[i].buf = cfg->slots[i];
         // the grouping workspaces' control regions start out zero (emg_prepare_args.ws_clean)
@@ -264,11 +298,15 @@ extern "C" int emg_plan_destroy(void* plan) {
         if (P->slots[i].ready) (void)hipEventDestroy(P->slots[i].ready);
         if (P->slots[i].done) (void)hipEventDestroy(P->slots[i].done);
     }
+    for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
+    for (int i = 0; i < 2; ++i)
+        if (P->side_join[i]) (void)hipEventDestroy(P->side_join[i]);
     if (P->fork) (void)hipEventDestroy(P->fork);
     if (P->join) (void)hipEventDestroy(P->join);
     for (int i = 0; i < 2; ++i)
         if (P->side[i]) { (void)hipStreamSynchronize(P->side[i]); (void)hipStreamDestroy(P->side[i]); }
     if (P->aux) { (void)hipStreamSynchronize(P->aux); (void)hipStreamDestroy(P->aux); }
+    if (P->cap) (void)hipStreamDestroy(P->cap);
     delete P;
     return EMG_OK;
 }
@@ -315,6 +353,125 @@ extern "C" int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step
     // a consumed slot stays valid, so stepping the same few batches again skips their preparation
     static const bool keep = getenv("EMG_PLAN_KEEP") != nullptr;
     if (!keep) sl->has_key = false;
+    return EMG_OK;
+}
+
+// ---- the step as a captured graph (small batches: the step is shorter than its dozen launches take to issue) -------------
+// A graph node's arguments are fixed at capture; what changes from step to step — which rows, how many, the Philox draw
+// counter, the optimizer step number and learning rates — lives in a device array of emg_step_ctl records that every kernel
+// of step i reads at ctl + i.  emg_plan_run writes the records of the next <= 32 steps (one tiny kernel whose ARGUMENTS
+// are the records) and replays the graph of that many steps: two launches per 32 steps from the host.
+static bool graph_capable(const Plan* P) {
+    const emg_plan_config& c = P->cfg;
+    const bool cplx = c.model == EMG_COMPLEX || c.model == EMG_HOLE;
+    const int n = cplx ? c.k_int / 2 : c.k_int;
+    const int64_t et = (int64_t)c.eta * c.n_sides;
+    return c.ctl_buf && c.ctl_bytes >= (int64_t)sizeof(CtlBlock) && c.fused && (n % 4 == 0) && c.k_int / 4 > 16 && c.k_int % 4 == 0 &&
+           c.ld_ent % 4 == 0 && c.ld_rel % 4 == 0 && c.ldc % 4 == 0 &&
+           group_backend_counting((2 + et) * c.cap_B, c.n_ent) && group_backend_counting(c.cap_B, c.n_rel) &&
+           !(getenv("EMG_APPLY") && strcmp(getenv("EMG_APPLY"), "window") == 0);
+}
+
+extern "C" int emg_plan_graph_ok(void* plan) { return plan && graph_capable((const Plan*)plan) ? 1 : 0; }
+
+static int capture_steps(Plan* P, int len, const float* hyper6, hipGraphExec_t* out) {
+    hipStream_t main = P->cap;
+    const emg_plan_config& c = P->cfg;
+    StepCtl* ctl = (StepCtl*)c.ctl_buf;
+    for (int i = 0; i < c.n_slots; ++i) { P->slots[i].has_key = false; P->slots[i].ready_recorded = false; P->slots[i].done_in_capture = false; }
+    P->side_joined[0] = P->side_joined[1] = false;
+    P->side_rr = 0;
+    const int saved_timing = P->timing_max;
+    P->timing_max = 0;
+    emg_plan_batch dummy{};
+    dummy.B = c.cap_B;
+    EMG_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
+    int rc = EMG_OK;
+    auto body = [&]() -> int {
+        EMG_HIP(hipEventRecord(P->fork, main));
+        const int ahead = P->n_side;   // batches prepared ahead inside the graph (0: everything on the one stream)
+        int prepared = 0;              // steps [0, prepared) have had their preparation enqueued
+        for (int i = 0; i < len; ++i) {
+            const int want = i + 1 + ahead < len ? i + 1 + ahead : len;
+            for (; prepared < want; ++prepared) {
+                P->ctl = ctl + prepared;
+                int r = prepare(P, P->slots[prepared % c.n_slots], dummy, main);
+                if (r != EMG_OK) return r;
+            }
+            SlotState& sl = P->slots[i % c.n_slots];
+            if (P->n_side > 0) EMG_HIP(hipStreamWaitEvent(main, sl.ready, 0));
+            P->ctl = ctl + i;
+            int r = compute(P, sl, dummy, 1, hyper6, main);
+            if (r != EMG_OK) return r;
+            if (P->n_side > 0) { EMG_HIP(hipEventRecord(sl.done, main)); sl.done_in_capture = true; }
+        }
+        for (int si = 0; si < P->n_side; ++si)   // every forked stream back into the origin stream
+            if (P->side_joined[si]) {
+                EMG_HIP(hipEventRecord(P->side_join[si], P->side[si]));
+                EMG_HIP(hipStreamWaitEvent(main, P->side_join[si], 0));
+            }
+        return EMG_OK;
+    };
+    rc = body();
+    P->ctl = nullptr;
+    P->timing_max = saved_timing;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(main, &graph);
+    for (int i = 0; i < c.n_slots; ++i) { P->slots[i].has_key = false; P->slots[i].ready_recorded = false; P->slots[i].done_in_capture = false; }
+    if (rc != EMG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail(EMG_EHIP, "emg_plan_run: stream capture failed: %s", hipGetErrorString(e));
+    const hipError_t e2 = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e2 != hipSuccess) return fail(EMG_EHIP, "emg_plan_run: hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+    return EMG_OK;
+}
+
+extern "C" int emg_plan_run(void* plan, const emg_plan_batch* batches, int32_t n, int32_t first_step, const float* hyper6s,
+                            void* stream) {
+    EMG_REQUIRE(plan && (n == 0 || (batches && hyper6s)), "emg_plan_run: null pointer");
+    Plan* P = (Plan*)plan;
+    const emg_plan_config& c = P->cfg;
+    EMG_REQUIRE(graph_capable(P), "emg_plan_run: this plan cannot run as a graph (see emg_plan_graph_ok)");
+    hipStream_t main = (hipStream_t)stream;
+    // eager preparations still in flight on the side streams (emg_plan_step's look-ahead) own slot buffers the graph uses
+    for (int i = 0; i < c.n_slots; ++i) {
+        SlotState& sl = P->slots[i];
+        if (sl.has_key && sl.ready_recorded) EMG_HIP(hipStreamWaitEvent(main, sl.ready, 0));
+        sl.has_key = false; sl.ready_recorded = false;
+    }
+    CtlBlock blk;
+    for (int32_t at = 0; at < n;) {
+        int len = 0;
+        memset(&blk, 0, sizeof(blk));
+        for (; at + len < n && len < kGraphSteps; ++len) {
+            const emg_plan_batch& b = batches[at + len];
+            EMG_REQUIRE(b.B > 0 && b.B <= c.cap_B && b.start >= 0 && b.start + b.B <= c.n_triples,
+                        "emg_plan_run: batch [%lld, +%lld) outside the resident training set / scratch capacity", (long long)b.start, (long long)b.B);
+            EMG_REQUIRE(!b.inj_repl && !b.inj_mask, "emg_plan_run: injected draws need emg_plan_step");
+            StepCtl& r = blk.rec[len];
+            r.start = b.start; r.B = b.B;
+            r.draw_counter0 = (uint64_t)(((int64_t)(b.epoch - 1) * c.batches_count + (b.batch - 1)) * c.n_sides);
+            r.n_choices = b.n_choices > 0 ? b.n_choices : 0; r.entities_list = b.n_choices > 0 ? b.entities_list : nullptr;
+            r.step = first_step + at + len;
+            const float* h = hyper6s + 6 * (size_t)(at + len);
+            for (int k = 0; k < 6; ++k) r.hyper_ent[k] = r.hyper_rel[k] = h[k];
+            r.hyper_ent[6] = c.lp_lambda_ent; r.hyper_rel[6] = c.lp_lambda_rel; r.hyper_ent[7] = r.hyper_rel[7] = (float)c.lp_p;
+        }
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : P->graphs) if (g.first == len) exec = g.second;
+        if (!exec) {
+            int rc = capture_steps(P, len, hyper6s + 6 * (size_t)at, &exec);
+            if (rc != EMG_OK) return rc;
+            P->graphs.push_back({len, exec});
+        }
+        hipLaunchKernelGGL(ctl_write_kernel, dim3(1), dim3(256), 0, main, blk, (StepCtl*)c.ctl_buf, len);
+        EMG_LAUNCH_CHECK();
+        EMG_HIP(hipGraphLaunch(exec, main));
+        at += len;
+    }
+    // a later eager step prepares on the side streams: behind everything the graphs did to the slots
+    if (P->n_side > 0)
+        for (int i = 0; i < c.n_slots; ++i) EMG_HIP(hipEventRecord(P->slots[i].done, main));
     return EMG_OK;
 }
 

@@ -51,18 +51,26 @@ __device__ __forceinline__ void load_row(Row<MODEL, W, NV>& r, const float* __re
     }
 }
 
+#ifndef EMG_INPLACE_NT
+#define EMG_INPLACE_NT 0
+#endif
+#ifndef EMG_STREAM_STORES
+#define EMG_STREAM_STORES 1
+#endif
+// (rows of the contribution buffers: written here, read once by the apply — streamed past the caches)
 template <int MODEL, int W, int NV, int LPG>
 __device__ __forceinline__ void store_row(const Row<MODEL, W, NV>& r, float* __restrict__ base, int lg, int nchunks,
                                           int khalf) {
     constexpr int E = W * NV;
+    constexpr bool STREAM = EMG_STREAM_STORES != 0;
     RowTile<W, NV> t;
 #pragma unroll
     for (int e = 0; e < E; ++e) t.x[e] = r.x[e];
-    store_tile<W, NV, LPG>(t, base, lg, nchunks);
+    store_tile<W, NV, LPG, STREAM>(t, base, lg, nchunks);
     if constexpr (is_complex<MODEL>::value) {
 #pragma unroll
         for (int e = 0; e < E; ++e) t.x[e] = r.x[E + e];
-        store_tile<W, NV, LPG>(t, base + khalf, lg, nchunks);
+        store_tile<W, NV, LPG, STREAM>(t, base + khalf, lg, nchunks);
     }
 }
 
@@ -271,7 +279,13 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
                     }
                 }
                 if constexpr (W == 4) {
+#if EMG_INPLACE_NT
+                    typedef float nt_float4 __attribute__((ext_vector_type(4)));
+                    const nt_float4 nv = {wv[0], wv[1], wv[2], wv[3]};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<nt_float4*>(wrow + off));
+#else
                     *reinterpret_cast<float4*>(wrow + off) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+#endif
                     if (s0row) *reinterpret_cast<float4*>(s0row + off) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
                     if (s1row) *reinterpret_cast<float4*>(s1row + off) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
                 } else {

@@ -400,12 +400,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             return (start, B, epoch, batch, n_choices, fixed_list)
 
         for epoch in epochs_iter:
-            for batch in range(1, self.batches_count + 1):
-                start, B, _, _, nc, el = batch_args(epoch, batch)
-                if B == 0:
-                    continue
-                tr.step(start, B, epoch, batch, n_choices=nc, entities_list=el,
-                        prefetch=[batch_args(epoch, batch + j) for j in (1, 2, 3)])
+            tr.run_batches([batch_args(epoch, batch) for batch in range(1, self.batches_count + 1)])
             loss_epoch = tr.read_loss()
             self.epoch_losses.append(loss_epoch)
             if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)

@@ -85,6 +85,7 @@ def alloc_table(rows, k_int, device, init=None, fill=None):
 # Two, not more: main + apply_rel stream + 2 side streams = 4 = the HIP runtime's hardware queues per device;
 # a fifth stream is multiplexed onto them and the step got SLOWER (measured 0.47 -> 0.67 ms at 3, 0.73 at 4).
 LOOKAHEAD = int(os.environ.get("EMG_LOOKAHEAD", "2"))
+GRAPH_MAX_ROWS = int(os.environ.get("EMG_GRAPH_MAX_ROWS", "200000"))   # entity contribution rows per batch up to which steps run as graph replays
 AUX_MIN_ROWS = int(os.environ.get("EMG_AUX_MIN_ROWS", "100000"))  # (env: A/B aid) entity contribution rows per batch above which apply_rel gets its own stream
 
 
@@ -161,6 +162,7 @@ class Trainer:
         self.reg_rows = False
 
         self.plan = None
+        self.graph = False
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.reg_accum = torch.zeros(1, dtype=torch.float64, device=self.device)  # LP term (column-local when sharded)
         # sum |w|^p per table, accumulated by the kernels that fold the regulariser (scaled by lambda in read_loss)
@@ -291,10 +293,17 @@ class Trainer:
             ps.ws_ent, ps.ws_ent_bytes = sl["ws_ent"].data_ptr(), sl["ws_ent"].numel()
             ps.ws_rel, ps.ws_rel_bytes = sl["ws_rel"].data_ptr(), sl["ws_rel"].numel()
         c.aux_min_rows = AUX_MIN_ROWS
+        self._ctl_buf = torch.zeros(4096, dtype=torch.uint8, device=self.device)   # emg_step_ctl records of a graph replay
+        c.ctl_buf, c.ctl_bytes = self._ctl_buf.data_ptr(), self._ctl_buf.numel()
         h = C.c_void_p()
         L.check(L.load().emg_plan_create(C.byref(c), C.byref(h)), "emg_plan_create")
         self.plan = h
         self._plan_cfg = c   # keeps nothing alive the tensors do not, but documents what the plan points at
+        # Steps as graph replays (emg_plan_run) where a step is shorter than its launches take to issue: small batches.
+        # EMG_GRAPH=1 / 0 forces it on (where the plan can) / off.
+        n_ce = (2 + self.eta_total) * self._cap
+        env = os.environ.get("EMG_GRAPH")
+        self.graph = bool(L.load().emg_plan_graph_ok(self.plan)) and (env == "1" or (env != "0" and n_ce <= GRAPH_MAX_ROWS))
 
     def __del__(self):
         try:
@@ -450,6 +459,34 @@ class Trainer:
         if self.pipeline:
             sl["done"].record(main)
         sl["key"] = None
+
+    def run_batches(self, specs):
+        """Train on a sequence of batches: ``specs`` = [(start, B, epoch, batch[, n_choices, entities_list]), ...] (empty
+        batches allowed).  Small batches run as graph replays — one library call for the whole sequence
+        (emg_plan_run: two launches per 32 steps from the host); otherwise one ``step`` per batch with the next batches
+        prepared ahead."""
+        specs = [s for s in specs if s is not None and s[1] > 0]
+        if not specs:
+            return
+        if not (self.plan is not None and self.graph and self.stage_events is None):
+            for i, s in enumerate(specs):
+                self.step(s[0], s[1], epoch=s[2], batch=s[3], n_choices=s[4] if len(s) > 4 else None,
+                          entities_list=s[5] if len(s) > 5 else None, prefetch=specs[i + 1:i + 4])
+            return
+        import ctypes as C
+        self._alloc_scratch(max(s[1] for s in specs))
+        n = len(specs)
+        arr = (L.PlanBatch * n)()
+        hyp = (C.c_float * (6 * n))()
+        keep = []
+        first = self.step_count + 1
+        for i, s in enumerate(specs):
+            keep.append(self._plan_batch(arr[i], s))
+            self.step_count += 1
+            lr = (sgd_learning_rate(self.sgd_params, self.batches_count, s[2], s[3]) if self.sgd_params is not None else self.lr)
+            hyp[6 * i:6 * i + 6] = self._hyper(lr)
+        L.check(L.load().emg_plan_run(self.plan, arr, n, first, hyp, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "emg_plan_run")
 
     def _compute(self, sl, start, B, epoch, batch, main):
         pos = self.X[start:start + B]

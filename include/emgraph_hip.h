@@ -553,6 +553,7 @@ typedef struct emg_plan_config {
     int32_t fused; int32_t inplace; int32_t normalize;
     int32_t n_slots; emg_plan_slot slots[4];
     int64_t aux_min_rows;                            /* entity contribution rows above which apply_rel gets its stream */
+    void* ctl_buf; int64_t ctl_bytes;                /* optional device scratch (>= 32 * sizeof(emg_step_ctl)) for emg_plan_run */
 } emg_plan_config;
 typedef struct emg_plan_batch {
     int64_t start; int64_t B; int32_t epoch; int32_t batch;   /* rows [start, start + B) of X; 1-based epoch / batch */
@@ -564,6 +565,15 @@ int emg_plan_create(const emg_plan_config* cfg, void** plan);
  * step >= 1 is the optimizer step number, hyper6 = {lr, momentum, beta1, beta2, eps, lr_t} for it. */
 int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step, const float* hyper6,
                   const emg_plan_batch* next, int32_t n_next, void* stream);
+/* The same steps as GRAPH replays (small batches: a step is shorter than its launches take to issue).  The step's
+ * kernels are captured once per graph length (<= 32 steps) with their per-step values read from device records
+ * (emg_step_ctl) that each call writes before the replay: two launches per 32 steps from the host.  batches[i] trains as
+ * optimizer step first_step + i with hyper6s[6 i .. 6 i + 5]; results are those of n emg_plan_step calls.
+ * emg_plan_graph_ok: 1 if the plan can (fused pair-local loss, 16-byte rows of more than 16 chunks, counting grouping,
+ * ctl_buf given); injected draws need emg_plan_step. */
+int emg_plan_graph_ok(void* plan);
+int emg_plan_run(void* plan, const emg_plan_batch* batches, int32_t n, int32_t first_step, const float* hyper6s,
+                 void* stream);
 /* HIP-event timing of the next max_samples launches of every stage (0 = off); avg_ms / counts: 9 entries =
  * prepare, fused, forward, loss, backward, apply_ent, apply_rel, clip, (unused) */
 int emg_plan_timing(void* plan, int32_t max_samples);

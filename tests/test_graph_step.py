@@ -1,0 +1,111 @@
+"""GPU tests of the captured step graph (emg_plan_run): the per-batch loop of EmbeddingModel.fit
+(EmbeddingModel.py:1388-1440) replayed as graphs whose per-step values (batch rows, batch size, Philox draw counter,
+optimizer step number, learning rates) are read from device records.  The graph path must produce, bit for bit, the
+tables / optimizer results / epoch losses of the same steps issued one library call at a time (emg_plan_step) — for
+every optimizer (Adam's lr_t and the SGD schedule change per step), a short last batch, several epochs, an LP
+regulariser, several corruption sides, a restricted corruption pool — and both must agree with the oracle loop."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import emgraph_oracle as orc  # noqa: E402
+from tests.test_api import _models, oracle_fit, synth_graph  # noqa: E402
+
+F32 = np.float32
+
+
+def _fit(monkeypatch, graph, name, k, X, ent0, rel0, **kw):
+    monkeypatch.setenv("EMG_GRAPH", "1" if graph else "0")
+    m = _models()[name](k=k, initializer="constant", initializer_params={"entity": ent0, "relation": rel0}, **kw)
+    m.fit(X)
+    assert bool(m._trainer.graph) == bool(graph), "graph mode not selected as requested"
+    E, R = m.trained_model_params
+    return np.array(E), np.array(R), list(m.epoch_losses), m
+
+
+@pytest.mark.parametrize("name,k,loss,opt,extra", [
+    ("TransE", 100, "pairwise", "adam", {}),
+    ("DistMult", 200, "nll", "adam", {}),
+    ("ComplEx", 100, "nll", "sgd", {"optimizer_params": {"lr": 0.05, "decay_cycle": 1, "decay_lr_rate": 2, "end_lr": 1e-4}}),
+    ("HolE", 40, "absolute_margin", "adagrad", {}),
+    ("ComplEx", 36, "nll", "momentum", {"regularizer": "LP", "regularizer_params": {"lambda": 1e-3, "p": 2}}),
+    ("DistMult", 72, "pairwise", "adam", {"embedding_model_params": {"corrupt_sides": ["s", "o"]}}),
+    ("TransE", 68, "nll", "adam", {"embedding_model_params": {"negative_corruption_entities": "batch"}}),
+])
+def test_graph_steps_equal_single_steps_bit_for_bit(monkeypatch, name, k, loss, opt, extra):
+    n_ent, n_rel, n = 300, 7, 2003          # 2003 triples in 6 batches of 334: the last one is short (333)
+    X = synth_graph(n_ent, n_rel, n, seed=3)
+    rs = np.random.RandomState(5)
+    ki = 2 * k if name in ("ComplEx", "HolE") else k
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    kw = dict(eta=5, epochs=3, batches_count=6, seed=11, loss=loss, optimizer=opt, optimizer_params={"lr": 0.02})
+    kw.update(extra)
+    Eg, Rg, Lg, mg = _fit(monkeypatch, True, name, k, X, ent0, rel0, **kw)
+    Es, Rs, Ls, ms = _fit(monkeypatch, False, name, k, X, ent0, rel0, **kw)
+    np.testing.assert_array_equal(Eg, Es)
+    np.testing.assert_array_equal(Rg, Rs)
+    assert Lg == Ls
+    assert mg._trainer.step_count == ms._trainer.step_count == 18
+    # a second fit of the same object (plan re-created) reproduces the first: the refit-determinism the reference tests
+    # (tests/emgraph/models/test_models.py:338-367)
+    monkeypatch.setenv("EMG_GRAPH", "1")
+    mg.fit(X)
+    np.testing.assert_array_equal(np.array(mg.trained_model_params[0]), Eg)
+
+
+def test_graph_fit_matches_oracle_training_loop(monkeypatch):
+    """the graph path against the oracle loop directly (same Philox draws, Keras Adam), at a width the graph path covers"""
+    name, k, eta, epochs, bc, seed, lr = "DistMult", 72, 3, 2, 5, 7, 0.05
+    n_ent, n_rel = 60, 4
+    X = synth_graph(n_ent, n_rel, 611, seed=2)
+    rs = np.random.RandomState(1)
+    ent0 = (rs.randn(n_ent, k) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, k) * 0.3).astype(F32)
+    E, R, L, m = _fit(monkeypatch, True, name, k, X, ent0, rel0, eta=eta, epochs=epochs, batches_count=bc, seed=seed,
+                      loss="nll", optimizer="adam", optimizer_params={"lr": lr})
+    Eo, Ro, Lo = oracle_fit(name, k, X.astype(np.int32), ent0, rel0, eta, epochs, bc, seed, "nll", None, "adam", lr)
+    np.testing.assert_allclose(E, Eo, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(R, Ro, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(L, Lo, rtol=1e-4)
+    np.testing.assert_allclose(m.predict(X[:40]), orc.score_triples(name, E, R, X[:40].astype(np.int32), k=k), rtol=1e-4, atol=1e-5)
+
+
+def test_graph_and_single_steps_interleave(monkeypatch):
+    """emg_plan_run after emg_plan_step (look-ahead preparations in flight on the side streams) and the other way round,
+    through the Trainer: equal to the same sequence of single steps"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    n_ent, n_rel, k, eta, B = 500, 9, 128, 4, 256
+    rs = np.random.RandomState(0)
+    ent0 = (rs.randn(n_ent, k) * 0.2).astype(F32)
+    rel0 = (rs.randn(n_rel, k) * 0.2).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 8 * B), rs.randint(0, n_rel, 8 * B), rs.randint(0, n_ent, 8 * B)], 1).astype(np.int32)
+    specs = [(i * B, B, 1, i + 1) for i in range(8)]
+
+    def run(order):
+        tr = Trainer(L.DISTMULT, k, 1.0, ent0, rel0, eta, loss="nll", optimizer="adam", optimizer_params={"lr": 0.01},
+                     batches_count=8, seed=3)
+        tr.set_training_set(X, B)
+        assert tr.plan is not None
+        for kind, lo, hi in order:
+            tr.graph = kind == "graph"
+            if kind == "graph":
+                tr.run_batches(specs[lo:hi])
+            else:
+                for i in range(lo, hi):
+                    tr.step(*specs[i], prefetch=specs[i + 1:min(hi, i + 3)])
+        torch.cuda.synchronize()
+        return tr.ent.cpu().numpy().copy(), tr.rel.cpu().numpy().copy(), tr.read_loss()
+
+    monkeypatch.setenv("EMG_GRAPH", "1")
+    ref = run([("single", 0, 8)])
+    for order in ([("graph", 0, 8)], [("single", 0, 3), ("graph", 3, 8)], [("graph", 0, 5), ("single", 5, 8)],
+                  [("graph", 0, 2), ("single", 2, 4), ("graph", 4, 7), ("single", 7, 8)]):
+        got = run(order)
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        assert got[2] == ref[2]
