@@ -16,7 +16,7 @@
 #include <string.h>
 #include <cstring>
 
-#include "emg_group.hpp"
+#include "emg_group_kernels.hpp"
 
 namespace emg {
 
@@ -790,11 +790,17 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
 
 struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; };
 
-template <bool PLAIN>
-__global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K) {
+template <bool PLAIN, bool RIDE>
+__global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
+    // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
+    unsigned bx = blockIdx.x, nbx = gridDim.x;
+    if constexpr (RIDE) {
+        if (run_riders(riders, &bx)) return;
+        nbx -= riders.total;
+    }
     const int lane = threadIdx.x & 63;
-    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t gw = ((int64_t)bx * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)nbx * blockDim.x) >> 6;
     // (a loop with a run-time index, not two inlined copies: one set of live registers.  The second table's few items go
     // to the other end of the grid, where waves have less of the first table's work)
     for (int ti = 0; ti < K.n_tables; ++ti) apply_segments_table<PLAIN>(K.P[ti], K.partial[ti], K.ldp[ti], ti ? nw - 1 - gw : gw, nw, lane);
@@ -900,8 +906,9 @@ static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t 
     if (A.any && A.segs) {
         SegmentsLaunch K{};
         K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
-        if (plain_sgd(P)) hipLaunchKernelGGL(apply_segments_kernel<true>, dim3(A.grid), dim3(256), 0, st, K);
-        else hipLaunchKernelGGL(apply_segments_kernel<false>, dim3(A.grid), dim3(256), 0, st, K);
+        static const Riders none{};
+        if (plain_sgd(P)) hipLaunchKernelGGL((apply_segments_kernel<true, false>), dim3(A.grid), dim3(256), 0, st, K, none);
+        else hipLaunchKernelGGL((apply_segments_kernel<false, false>), dim3(A.grid), dim3(256), 0, st, K, none);
         EMG_LAUNCH_CHECK();
     } else if (A.any) {
         const dim3 grid(A.grid), block(256);
@@ -939,7 +946,15 @@ extern "C" int emg_apply_grouped_ex(const emg_apply_args* a, void* stream) {
 // Two tables (the entity and the relation table of a training step) through SHARED launches: one apply kernel (or one
 // window kernel + one task kernel), one dense pass.  Same results as two emg_apply_grouped_ex calls; falls back to exactly
 // those where the shapes differ.
+namespace emg {
+int apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const Riders* riders, void* stream);
+}
 extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream) {
+    return emg::apply_pair_impl(a, b, nullptr, stream);
+}
+// riders (optional): preparation stages of later batches; carried by the shared descriptor-driven launch, launched on
+// their own first where the two tables do not share one
+int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const Riders* riders, void* stream) {
     EMG_REQUIRE(a && b, "emg_apply_grouped_pair: null args");
     ApplyParams P0, P1;
     ApplyLaunch A0, A1;
@@ -949,6 +964,11 @@ extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_a
     hipStream_t st = (hipStream_t)stream;
     const bool share_segs = A0.any && A1.any && A0.segs && A1.segs;
     const bool share = A0.any && A1.any && !A0.segs && !A1.segs && A0.vec && A1.vec && !A0.skinny && !A1.skinny && (A0.nb != 0) == (A1.nb != 0);
+    if (riders && riders->total && !share_segs) {
+        rc = launch_riders_alone(*riders, st);
+        if (rc != EMG_OK) return rc;
+        riders = nullptr;
+    }
     if (!share && !share_segs) {
         rc = apply_launch(P0, A0, st);
         return rc != EMG_OK ? rc : apply_launch(P1, A1, st);
@@ -957,9 +977,17 @@ extern "C" int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_a
         SegmentsLaunch K{};
         K.P[0] = P0; K.partial[0] = A0.partial; K.ldp[0] = A0.ldp;
         K.P[1] = P1; K.partial[1] = A1.partial; K.ldp[1] = A1.ldp; K.n_tables = 2;
-        const dim3 grid(A0.grid > A1.grid ? A0.grid : A1.grid);
-        if (plain_sgd(P0) && plain_sgd(P1)) hipLaunchKernelGGL(apply_segments_kernel<true>, grid, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL(apply_segments_kernel<false>, grid, dim3(256), 0, st, K);
+        const bool plain = plain_sgd(P0) && plain_sgd(P1);
+        if (riders && riders->total) {
+            const dim3 grid((A0.grid > A1.grid ? A0.grid : A1.grid) + riders->total);
+            if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, true>), grid, dim3(256), 0, st, K, *riders);
+            else hipLaunchKernelGGL((apply_segments_kernel<false, true>), grid, dim3(256), 0, st, K, *riders);
+        } else {
+            static const Riders none{};
+            const dim3 grid(A0.grid > A1.grid ? A0.grid : A1.grid);
+            if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, false>), grid, dim3(256), 0, st, K, none);
+            else hipLaunchKernelGGL((apply_segments_kernel<false, false>), grid, dim3(256), 0, st, K, none);
+        }
         EMG_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL((apply_rows_pair_kernel<4, 2>), dim3(A0.grid + A1.grid), dim3(256), 0, st, P0, P1, A0.grid);

@@ -25,7 +25,7 @@
 
 #include <rocprim/rocprim.hpp>
 
-#include "emg_group.hpp"
+#include "emg_group_kernels.hpp"
 
 namespace emg {
 
@@ -135,219 +135,11 @@ int factor_view(void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, 
     return EMG_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// one table's grouping problem, as the kernels see it
-// ---------------------------------------------------------------------------------------------------------------
-struct TableGroup {
-    const int32_t* dest; int64_t n_extra; int32_t per_B; int32_t pad0;   // n = n_extra + per_B * B contributions
-    int64_t R;
-    int32_t* cnt; uint32_t* off;
-    uint32_t *keys, *vals, *tmpv, *srcrow, *pos_of_slot; float* coef;
-    Seg* multi; uint32_t* single; LongTask* tasks; uint32_t task_cap; int32_t scan_blocks;
-    int32_t* arrive; uint32_t* counters; unsigned long long* status;
-    uint8_t* flags; const int32_t* fac_codes;   // optional: per-slot singleton flags; factored contributions (codes of the batch)
-};
-struct GroupLaunch {
-    TableGroup t[2]; int32_t n_tables; int32_t pad0;
-    int64_t B; const StepCtl* ctl;
-    unsigned split_n, split_scan;   // workgroups of table 0 in the per-contribution / the scan launches
-};
-
-__device__ __forceinline__ int64_t table_n(const GroupLaunch& G, int ti) {
-    const int64_t B = G.ctl ? G.ctl->B : G.B;
-    return G.t[ti].n_extra + (int64_t)G.t[ti].per_B * B;
-}
-
-// start of a grouping: list counters, scan ticket and tile status words back to zero (thread i of the launch)
-__device__ __forceinline__ void group_reset(const TableGroup& T, int64_t i) {
-    if (i < 8) T.counters[i] = 0u;
-    if (T.status && i < T.scan_blocks) T.status[i] = 0ull;
-}
-
-__device__ __forceinline__ void hist_add(const TableGroup& T, int32_t d) {
-    if (d >= 0 && (int64_t)d < T.R) atomicAdd(T.cnt + d, 1);   // (an id outside the table is dropped: it has no row to update)
-}
-
-// 1. histogram of an existing id array (emg_group_dest; emg_prepare_batch with caller-filled extra rows)
-__global__ __launch_bounds__(256) void group_hist_kernel(const GroupLaunch G) {
-    const int ti = blockIdx.x < G.split_n ? 0 : 1;
-    const TableGroup& T = G.t[ti];
-    const int64_t i = (int64_t)(blockIdx.x - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
-    group_reset(T, i);
-    if (i < table_n(G, ti)) hist_add(T, T.dest[i]);
-}
-
-// 2. scan over the table rows.  Tile = 4096 rows = 256 threads x 16; tiles are taken in ticket order, so every
-// predecessor of a tile has started and publishes its aggregate without waiting for anybody (decoupled look-back,
-// Merrill & Garland 2016): status word = value << 2 | (1: tile aggregate, 2: inclusive prefix).
-__global__ __launch_bounds__(256) void group_scan_kernel(const GroupLaunch G) {
-    const int ti = blockIdx.x < G.split_scan ? 0 : 1;
-    const TableGroup& T = G.t[ti];
-    __shared__ unsigned s_bid;
-    __shared__ uint32_t s_wave[4][4];
-    __shared__ uint32_t s_base[4];
-    if (threadIdx.x == 0) s_bid = atomicAdd(T.counters + GC_SCAN_TICKET, 1u);
-    __syncthreads();
-    const unsigned bid = s_bid;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)bid * kScanTile + (int64_t)threadIdx.x * 16;
-    const int64_t rows = T.R + 1;   // row R is the sentinel (count 0): off[R] = number of grouped contributions
-    int c[16];
-    if (r0 + 16 <= rows) {
-        const int4* p = reinterpret_cast<const int4*>(T.cnt + r0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int4 v = p[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) c[j] = r0 + j < rows ? T.cnt[r0 + j] : 0;
-    }
-    uint32_t loc[4] = {0u, 0u, 0u, 0u};   // contributions | segments of 2..kDefer rows | singletons | block tasks
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t cj = (uint32_t)c[j];
-        loc[0] += cj;
-        loc[1] += (cj >= 2u && cj <= (uint32_t)kDeferSegment) ? 1u : 0u;
-        loc[2] += cj == 1u ? 1u : 0u;
-        loc[3] += cj > (uint32_t)kDeferSegment ? (cj + kLongSegment - 1) / kLongSegment : 0u;
-    }
-    uint32_t inc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t v = loc[q];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-        inc[q] = v;
-        if (lane == 63) s_wave[wv][q] = v;
-    }
-    __syncthreads();
-    uint32_t wpre[4], tot[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        wpre[q] = 0u; tot[q] = 0u;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { if (w < wv) wpre[q] += s_wave[w][q]; tot[q] += s_wave[w][q]; }
-    }
-    if (wv == 0) {
-        if (lane == 0) {
-            __hip_atomic_store(T.status + bid, ((unsigned long long)tot[0] << 2) | (bid == 0u ? 2ull : 1ull), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            // the lists need no global order (a segment's sum is self-contained): a tile takes its stretch of each with
-            // one atomic; inside the stretch rows stay ascending
-            s_base[1] = tot[1] ? atomicAdd(T.counters + GC_MULTI, tot[1]) : 0u;
-            s_base[2] = tot[2] ? atomicAdd(T.counters + GC_SINGLE, tot[2]) : 0u;
-            s_base[3] = tot[3] ? atomicAdd(T.counters + GC_TASKS, tot[3]) : 0u;
-        }
-        uint32_t excl = 0u;
-        if (bid > 0u) {
-            int64_t look = (int64_t)bid - 1;
-            for (;;) {
-                const int64_t j = look - lane;
-                const unsigned long long sv = j >= 0 ? __hip_atomic_load(T.status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;
-                const unsigned flag = (unsigned)(sv & 3ull);
-                const unsigned long long ready = __ballot(flag != 0u);
-                const unsigned long long pref = __ballot(flag == 2u);
-                const int p = pref ? __ffsll((long long)pref) - 1 : 63;
-                const unsigned long long need = (2ull << p) - 1ull;   // lanes 0..p (p = 63: all)
-                if ((ready & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }
-                uint32_t v = lane <= p ? (uint32_t)(sv >> 2) : 0u;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-                excl += v;
-                if (pref) break;
-                look -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(T.status + bid, ((unsigned long long)(excl + tot[0]) << 2) | 2ull, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) s_base[0] = excl;
-    }
-    __syncthreads();
-    uint32_t run[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) run[q] = s_base[q] + wpre[q] + inc[q] - loc[q];
-    if ((int64_t)bid == (int64_t)T.scan_blocks - 1 && threadIdx.x == 255) T.counters[GC_VALID] = run[0] + loc[0];
-    uint32_t offs[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t cj = (uint32_t)c[j], start = run[0];
-        const int64_t r = r0 + j;
-        offs[j] = start;
-        if (cj != 0u) {
-            T.cnt[r] = (int32_t)start;   // scatter cursor (rows without contributions keep 0)
-            if (cj == 1u) T.single[run[2]++] = start;
-            else if (cj <= (uint32_t)kDeferSegment) T.multi[run[1]++] = Seg{start, cj, (uint32_t)r};
-            else {
-                const uint32_t nb = (cj + kLongSegment - 1) / kLongSegment;
-                const bool room = run[3] + nb <= T.task_cap;   // (always: tasks <= n / 33 * ... < n / 8)
-                for (uint32_t b = 0; b < nb && run[3] + b < T.task_cap; ++b) T.tasks[run[3] + b] = LongTask{start, b, room ? cj : 0u};
-                run[3] += nb;
-            }
-            run[0] += cj;
-        }
-    }
-    if (r0 + 16 <= rows) {
-        uint4* p = reinterpret_cast<uint4*>(T.off + r0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = make_uint4(offs[4 * q], offs[4 * q + 1], offs[4 * q + 2], offs[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) if (r0 + j < rows) T.off[r0 + j] = offs[j];
-    }
-}
-
-// 3. scatter: a contribution takes the next free position of its destination's segment
-__global__ __launch_bounds__(256) void group_scatter_kernel(const GroupLaunch G) {
-    const int ti = blockIdx.x < G.split_n ? 0 : 1;
-    const TableGroup& T = G.t[ti];
-    const int64_t i = (int64_t)(blockIdx.x - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
-    if (i >= table_n(G, ti)) return;
-    const int32_t d = T.dest[i];
-    const bool ok = d >= 0 && (int64_t)d < T.R;
-    bool single = false;
-    if (ok) {
-        const uint32_t start = T.off[d];
-        single = T.off[d + 1] - start == 1u;
-        // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
-        const uint32_t pos = single ? start : (uint32_t)atomicAdd(T.cnt + d, 1);
-        T.tmpv[pos] = (uint32_t)i;
-        T.keys[pos] = (uint32_t)d;
-    }
-    if (T.flags) T.flags[i] = single ? 1 : 0;
-}
-
-// 4. order: rank of a contribution among the slots of its segment = its place in the stable order.
-// Factored contributions (see emg_backward_args.fac_ws_ent): srcrow[q] = the row of the 4B-row contribution buffer the slot
-// at sorted position q points at, pos_of_slot[slot - 2B] = q for the negatives' slots (where the backward kernel puts
-// their factor), coef[q] = 1 for the subject / object slots.
-__global__ __launch_bounds__(256) void group_order_kernel(const GroupLaunch G) {
-    const int ti = blockIdx.x < G.split_n ? 0 : 1;
-    const TableGroup& T = G.t[ti];
-    const int64_t t = (int64_t)(blockIdx.x - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
-    const int64_t n = table_n(G, ti);
-    if (t < 2) T.counters[GC_LONG_COUNT + t] = 0u;          // window-path task list (apply_rows_kernel) starts empty
-    if (t <= n / kLongSegment) T.arrive[t] = 0;             // per-segment block counters of the long-segment reduction
-    if (t >= (int64_t)T.off[T.R]) return;
-    const uint32_t d = T.keys[t];
-    const uint32_t start = T.off[d], len = T.off[d + 1] - start;
-    const uint32_t mine = T.tmpv[t];
-    uint32_t rank = 0u;
-    for (uint32_t j = 0; j < len; ++j) rank += T.tmpv[start + j] < mine ? 1u : 0u;
-    const uint32_t q = start + rank;
-    T.vals[q] = mine;
-    if ((uint32_t)t == start) T.cnt[d] = 0;                 // the cursor has done its work: the histogram is zero again
-    if (T.fac_codes) {
-        const uint32_t fac_B = (uint32_t)(G.ctl ? G.ctl->B : G.B);
-        if (mine < 2u * fac_B) {
-            T.srcrow[q] = mine;
-            T.coef[q] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
-        } else {
-            const uint32_t i = mine - 2u * fac_B;
-            T.srcrow[q] = (T.fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
-            T.pos_of_slot[i] = q;
-        }
-    }
-}
+__global__ __launch_bounds__(256) void group_hist_kernel(const GroupLaunch G) { group_hist_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void group_scan_kernel(const GroupLaunch G) { group_scan_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void group_scatter_kernel(const GroupLaunch G) { group_scatter_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void group_order_kernel(const GroupLaunch G) { group_order_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) { prepare_ids_body(P, G, blockIdx.x); }
 
 // SORT backend epilogue: flags[original index] = 1 iff its destination occurs exactly once; factored source rows
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
@@ -376,60 +168,6 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
             pos_of_slot[i] = (uint32_t)t;
         }
     }
-}
-
-// corruption codes (Philox / injected) + the destination ids they imply, for every corruption side, ONE launch;
-// with the counting backend also the histogram of both tables
-struct PrepParams {
-    const int32_t* pos; int64_t B; int32_t eta; int32_t n_sides; int32_t sides[4];
-    uint64_t n_choices; const int32_t* entities_list; uint64_t seed; uint64_t counter0;
-    const int32_t* inj_mask; const int32_t* inj_repl;
-    int32_t* codes; int32_t* dest_ent; int32_t* dest_rel;
-    int64_t B_global; int64_t row_offset;  // draw index of (negative je, local row i) = je * B_global + row_offset + i
-    const StepCtl* ctl;                    // graph node: batch = rows [ctl->start, +ctl->B) of `pos`, draws from ctl->draw_counter0
-    int32_t hist;                          // 1: histogram + grouping reset of G's tables
-};
-
-__global__ __launch_bounds__(256) void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t B = P.B;
-    const int32_t* pos = P.pos;
-    uint64_t counter0 = P.counter0, n_choices = P.n_choices;
-    const int32_t* elist = P.entities_list;
-    if (P.ctl) {
-        B = P.ctl->B; pos += 3 * P.ctl->start; counter0 = P.ctl->draw_counter0;
-        if (P.ctl->n_choices > 0) { n_choices = (uint64_t)P.ctl->n_choices; elist = P.ctl->entities_list; }
-    }
-    if (P.hist) { group_reset(G.t[0], j); group_reset(G.t[1], j); }
-    const int64_t per_side = (int64_t)P.eta * B;
-    if (j < B) {
-        const int32_t s = pos[3 * j + 0], p = pos[3 * j + 1], o = pos[3 * j + 2];
-        P.dest_ent[j] = s;
-        P.dest_ent[B + j] = o;
-        P.dest_rel[j] = p;
-        if (P.hist) { hist_add(G.t[0], s); hist_add(G.t[0], o); hist_add(G.t[1], p); }
-    }
-    if (j >= per_side * P.n_sides) return;
-    const int sd = (int)(j / per_side);
-    int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
-    if (!P.ctl && P.B_global != B) {  // this batch is rows [row_offset, row_offset + B) of a larger one: draw what IT would
-        const int64_t je = jj / B;
-        jj = je * P.B_global + P.row_offset + (jj - je * B);
-    }
-    const int side = P.sides[sd];
-    uint32_t keep, idx;
-    if (P.inj_repl) {
-        idx = (uint32_t)P.inj_repl[j];
-        keep = P.inj_mask ? (uint32_t)(P.inj_mask[j] != 0) : 0u;
-    } else {
-        corruption_draw(P.seed, counter0 + (uint64_t)sd, (uint64_t)jj, n_choices, &keep, &idx);
-    }
-    if (side == EMG_SIDE_O) keep = 1u;
-    else if (side == EMG_SIDE_S) keep = 0u;
-    const uint32_t repl = elist ? (uint32_t)elist[idx] : idx;
-    P.codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
-    P.dest_ent[2 * B + j] = (int32_t)(repl & 0x7fffffffu);
-    if (P.hist) hist_add(G.t[0], (int32_t)(repl & 0x7fffffffu));
 }
 
 static void fill_table(TableGroup& T, const GroupWs& w, const int32_t* dest, int64_t n_extra, int per_B, int64_t R,
@@ -480,9 +218,6 @@ static int sort_group(const int32_t* dest, int64_t n, int64_t n_rows, const Grou
     return EMG_OK;
 }
 
-}  // namespace emg
-
-using namespace emg;
 
 extern "C" int64_t emg_apply_workspace_bytes(int64_t n_contrib, int64_t n_rows) {
     if (n_contrib <= 0) return 256;
@@ -519,19 +254,34 @@ extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, vo
 
 // internal form: layout_B > 0 sizes the workspaces' layout for that many positives (a plan's capacity) and ctl, if given,
 // is the device record the kernels read the batch from
-extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
-    EMG_REQUIRE(a, "emg_prepare_batch: null args");
-    EMG_REQUIRE(a->B >= 0 && a->eta >= 1 && a->n_sides >= 1 && a->n_sides <= 4, "emg_prepare_batch: bad sizes");
-    if (a->B == 0) return EMG_OK;
+int launch_riders_alone(const Riders& R, hipStream_t st) {
+    for (int i = 0; i < 2; ++i) {
+        const Rider& r = R.r[i];
+        if (r.kind == RIDE_NONE || r.blocks == 0) continue;
+        const dim3 grid(r.blocks), block(256);
+        if (r.kind == RIDE_IDS) hipLaunchKernelGGL(prepare_ids_kernel, grid, block, 0, st, R.prep, r.G);
+        else if (r.kind == RIDE_SCAN) hipLaunchKernelGGL(group_scan_kernel, grid, block, 0, st, r.G);
+        else if (r.kind == RIDE_SCATTER) hipLaunchKernelGGL(group_scatter_kernel, grid, block, 0, st, r.G);
+        else if (r.kind == RIDE_ORDER) hipLaunchKernelGGL(group_order_kernel, grid, block, 0, st, r.G);
+        EMG_LAUNCH_CHECK();
+    }
+    return EMG_OK;
+}
+
+// validation + layout of emg_prepare_batch without a launch: the four stages of the counting grouping as launchable
+// descriptions (the plan attaches them to the step's big launches as riders)
+int prepare_stages(const emg_prepare_args* a, PrepStages* o) {
+    EMG_REQUIRE(a && o, "emg_prepare_batch: null args");
+    EMG_REQUIRE(a->B > 0 && a->eta >= 1 && a->n_sides >= 1 && a->n_sides <= 4, "emg_prepare_batch: bad sizes");
     EMG_REQUIRE(a->pos && a->codes && a->dest_ent && a->dest_rel && a->ws_ent && a->ws_rel, "emg_prepare_batch: null pointer");
     EMG_REQUIRE(a->inj_repl || a->n_choices > 0, "emg_prepare_batch: n_choices must be positive");
     EMG_REQUIRE(a->n_extra_ent >= 0 && a->n_extra_rel >= 0 && a->n_ent > 0 && a->n_rel > 0, "emg_prepare_batch: bad table sizes");
     EMG_REQUIRE(a->n_ent < ((int64_t)1 << 31) && a->n_rel < ((int64_t)1 << 31), "emg_prepare_batch: too many rows");
-    hipStream_t st = (hipStream_t)stream;
     const StepCtl* ctl = (const StepCtl*)a->ctl;
     EMG_REQUIRE(!ctl || (a->layout_B >= a->B && !a->inj_repl && a->B_global == 0),
                 "emg_prepare_batch: a device-side batch record needs layout_B >= B (its capacity) and excludes injected / sharded draws");
-    PrepParams P{};
+    *o = PrepStages{};
+    PrepParams& P = o->prep;
     P.pos = a->pos; P.B = a->B; P.eta = a->eta; P.n_sides = a->n_sides;
     for (int i = 0; i < a->n_sides; ++i) {
         EMG_REQUIRE(a->sides[i] >= EMG_SIDE_S && a->sides[i] <= EMG_SIDE_SO, "emg_prepare_batch: bad side %d", a->sides[i]);
@@ -548,54 +298,76 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     const int et = a->eta * a->n_sides;
     const int64_t Bl = a->layout_B > 0 ? a->layout_B : a->B;          // the size the workspaces are laid out (and launches sized) for
     const int64_t n_neg = Bl * (int64_t)et;
-    const int64_t n_ce = a->n_extra_ent + (2 + (int64_t)et) * a->B, n_cr = a->n_extra_rel + a->B;
-    const int64_t cap_ce = a->n_extra_ent + (2 + (int64_t)et) * Bl, cap_cr = a->n_extra_rel + Bl;
-    EMG_REQUIRE(!a->factored || (a->n_extra_ent == 0 && cap_ce < ((int64_t)1 << 31)),
+    o->n_ce = a->n_extra_ent + (2 + (int64_t)et) * a->B; o->n_cr = a->n_extra_rel + a->B;
+    o->cap_ce = a->n_extra_ent + (2 + (int64_t)et) * Bl; o->cap_cr = a->n_extra_rel + Bl;
+    EMG_REQUIRE(!a->factored || (a->n_extra_ent == 0 && o->cap_ce < ((int64_t)1 << 31)),
                 "emg_prepare_batch: factored contributions exclude caller-filled extra entity rows");
-    EMG_REQUIRE(cap_ce < ((int64_t)1 << 31), "emg_prepare_batch: too many contributions");
-    GroupWs we, wr;
-    int rc = group_ws_layout(a->ws_ent, a->ws_ent_bytes, cap_ce, a->n_ent, 0, &we);
-    if (rc == EMG_OK) rc = group_ws_layout(a->ws_rel, a->ws_rel_bytes, cap_cr, a->n_rel, 0, &wr);
+    EMG_REQUIRE(o->cap_ce < ((int64_t)1 << 31), "emg_prepare_batch: too many contributions");
+    int rc = group_ws_layout(a->ws_ent, a->ws_ent_bytes, o->cap_ce, a->n_ent, 0, &o->we);
+    if (rc == EMG_OK) rc = group_ws_layout(a->ws_rel, a->ws_rel_bytes, o->cap_cr, a->n_rel, 0, &o->wr);
     if (rc != EMG_OK) return rc;
-    GroupLaunch G{};
+    GroupLaunch& G = o->G;
     G.n_tables = 2; G.B = a->B; G.ctl = ctl;
-    fill_table(G.t[0], we, a->dest_ent, a->n_extra_ent, 2 + et, a->n_ent, a->single_flags, a->factored ? a->codes : nullptr);
-    fill_table(G.t[1], wr, a->dest_rel, a->n_extra_rel, 1, a->n_rel, nullptr, nullptr);
-    const bool both = we.counting && wr.counting;
-    if (both && !a->ws_clean) {
-        rc = clean_ws(we, a->ws_ent, st);
-        if (rc == EMG_OK) rc = clean_ws(wr, a->ws_rel, st);
+    fill_table(G.t[0], o->we, a->dest_ent, a->n_extra_ent, 2 + et, a->n_ent, a->single_flags, a->factored ? a->codes : nullptr);
+    fill_table(G.t[1], o->wr, a->dest_rel, a->n_extra_rel, 1, a->n_rel, nullptr, nullptr);
+    o->both = o->we.counting && o->wr.counting;
+    // the histogram rides in the id kernel unless caller-filled extra rows come first (the ids of those are in memory)
+    o->fused_hist = o->both && a->n_extra_ent == 0 && a->n_extra_rel == 0;
+    P.hist = o->fused_hist ? 1 : 0;
+    int64_t threads = n_neg > Bl ? n_neg : Bl;
+    if (o->fused_hist) { const int64_t sb = o->we.scan_blocks > o->wr.scan_blocks ? o->we.scan_blocks : o->wr.scan_blocks; if (sb > threads) threads = sb; }
+    o->nb_ids = (unsigned)cdiv(threads, 256);
+    if (o->both) {   // launch geometry of scan / scatter / order (as counting_tail)
+        G.split_scan = (unsigned)G.t[0].scan_blocks;
+        o->nb_scan = G.split_scan + (unsigned)G.t[1].scan_blocks;
+        G.split_n = (unsigned)cdiv(o->cap_ce + 1, 256);
+        o->nb_n = G.split_n + (unsigned)cdiv(o->cap_cr + 1, 256);
+    }
+    return EMG_OK;
+}
+
+}  // namespace emg
+
+using namespace emg;
+
+extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
+    EMG_REQUIRE(a, "emg_prepare_batch: null args");
+    EMG_REQUIRE(a->B >= 0, "emg_prepare_batch: bad sizes");
+    if (a->B == 0) return EMG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PrepStages S;
+    int rc = prepare_stages(a, &S);
+    if (rc != EMG_OK) return rc;
+    if (S.both && !a->ws_clean) {
+        rc = clean_ws(S.we, a->ws_ent, st);
+        if (rc == EMG_OK) rc = clean_ws(S.wr, a->ws_rel, st);
         if (rc != EMG_OK) return rc;
     }
-    // the histogram rides in the id kernel unless caller-filled extra rows come first (the ids of those are in memory)
-    const bool fused_hist = both && a->n_extra_ent == 0 && a->n_extra_rel == 0;
-    P.hist = fused_hist ? 1 : 0;
-    int64_t threads = n_neg > Bl ? n_neg : Bl;
-    if (fused_hist) { const int64_t sb = we.scan_blocks > wr.scan_blocks ? we.scan_blocks : wr.scan_blocks; if (sb > threads) threads = sb; }
-    hipLaunchKernelGGL(prepare_ids_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, st, P, G);
+    hipLaunchKernelGGL(prepare_ids_kernel, dim3(S.nb_ids), dim3(256), 0, st, S.prep, S.G);
     EMG_LAUNCH_CHECK();
-    if (both) {
-        if (!fused_hist) {
-            G.split_n = (unsigned)cdiv(cap_ce > we.scan_blocks ? cap_ce : we.scan_blocks, 256);
-            const unsigned nb = G.split_n + (unsigned)cdiv(cap_cr > wr.scan_blocks ? cap_cr : wr.scan_blocks, 256);
-            hipLaunchKernelGGL(group_hist_kernel, dim3(nb), dim3(256), 0, st, G);
+    if (S.both) {
+        if (!S.fused_hist) {
+            GroupLaunch H = S.G;
+            H.split_n = (unsigned)cdiv(S.cap_ce > S.we.scan_blocks ? S.cap_ce : S.we.scan_blocks, 256);
+            const unsigned nb = H.split_n + (unsigned)cdiv(S.cap_cr > S.wr.scan_blocks ? S.cap_cr : S.wr.scan_blocks, 256);
+            hipLaunchKernelGGL(group_hist_kernel, dim3(nb), dim3(256), 0, st, H);
             EMG_LAUNCH_CHECK();
         }
-        return counting_tail(G, cap_ce, cap_cr, st);
+        return counting_tail(S.G, S.cap_ce, S.cap_cr, st);
     }
-    EMG_REQUIRE(!ctl, "emg_prepare_batch: a device-side batch record needs the counting backend for both tables");
+    EMG_REQUIRE(!a->ctl, "emg_prepare_batch: a device-side batch record needs the counting backend for both tables");
     // mixed / sort backends: table by table
     for (int ti = 0; ti < 2; ++ti) {
-        const GroupWs& w = ti ? wr : we;
+        const GroupWs& w = ti ? S.wr : S.we;
         const int32_t* dest = ti ? a->dest_rel : a->dest_ent;
-        const int64_t n = ti ? n_cr : n_ce, R = ti ? a->n_rel : a->n_ent;
+        const int64_t n = ti ? S.n_cr : S.n_ce, R = ti ? a->n_rel : a->n_ent;
         uint8_t* flags = ti ? nullptr : a->single_flags;
         const int32_t* fc = (ti == 0 && a->factored) ? a->codes : nullptr;
         if (!w.counting) { rc = sort_group(dest, n, R, w, flags, st, fc, a->B); if (rc != EMG_OK) return rc; continue; }
         if (!a->ws_clean) { rc = clean_ws(w, ti ? a->ws_rel : a->ws_ent, st); if (rc != EMG_OK) return rc; }
         GroupLaunch G1{};
         G1.n_tables = 1; G1.B = a->B;
-        G1.t[0] = G.t[ti]; G1.t[1] = G.t[ti];
+        G1.t[0] = S.G.t[ti]; G1.t[1] = S.G.t[ti];
         G1.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, 256);
         hipLaunchKernelGGL(group_hist_kernel, dim3(G1.split_n), dim3(256), 0, st, G1);
         EMG_LAUNCH_CHECK();

@@ -19,9 +19,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "emg_group.hpp"
+#include "emg_group_kernels.hpp"
 
 namespace emg {
+
+int train_backward_impl(const emg_backward_args* a, const Riders* riders, void* stream);                                  // emg_score.hip
+int apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const Riders* riders, void* stream);   // emg_apply.hip
 
 enum Stage { ST_PREPARE = 0, ST_FUSED, ST_FORWARD, ST_LOSS, ST_BACKWARD, ST_APPLY_ENT, ST_APPLY_REL, ST_CLIP, ST_COUNT };
 
@@ -76,8 +79,29 @@ struct Timed {  // HIP events around one stage (only the first `timing_max` laun
     }
 };
 
-static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t main) {
+// emg_prepare_batch's arguments for a batch in a slot (ctl: the batch comes from that device record instead of b)
+static void fill_prepare_args(const Plan* P, const SlotState& sl, const emg_plan_batch& b, const StepCtl* ctl, emg_prepare_args& a) {
     const emg_plan_config& c = P->cfg;
+    a = emg_prepare_args{};
+    a.pos = c.X + 3 * b.start; a.B = b.B; a.eta = c.eta; a.n_sides = c.n_sides;
+    for (int i = 0; i < c.n_sides; ++i) a.sides[i] = c.sides[i];
+    a.n_choices = b.n_choices > 0 ? b.n_choices : c.n_ent; a.entities_list = b.entities_list;
+    a.seed = c.seed;
+    a.draw_counter0 = (uint64_t)(((int64_t)(b.epoch - 1) * c.batches_count + (b.batch - 1)) * c.n_sides);
+    a.inj_mask = b.inj_mask; a.inj_repl = b.inj_repl;
+    a.codes = sl.buf.codes; a.dest_ent = sl.buf.dest_ent; a.n_ent = c.n_ent; a.dest_rel = sl.buf.dest_rel; a.n_rel = c.n_rel;
+    a.ws_ent = sl.buf.ws_ent; a.ws_ent_bytes = sl.buf.ws_ent_bytes; a.ws_rel = sl.buf.ws_rel; a.ws_rel_bytes = sl.buf.ws_rel_bytes;
+    a.single_flags = c.inplace ? sl.buf.single : nullptr;
+    a.factored = c.factored;
+    a.ws_clean = 1;            // emg_plan_create zeroed the control regions; every grouping leaves them zero
+    a.layout_B = c.cap_B;      // one workspace layout for every batch size of the run
+    if (ctl) {              // graph capture: rows, size and draw counter come from the device record
+        a.pos = c.X; a.B = c.cap_B; a.ctl = ctl;
+        a.n_choices = c.n_ent; a.entities_list = nullptr; a.inj_mask = a.inj_repl = nullptr;
+    }
+}
+
+static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t main) {
     hipStream_t st = main;
     if (P->n_side > 0) {
         const int si = P->side_rr;
@@ -92,22 +116,7 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
         }
     }
     emg_prepare_args a{};
-    a.pos = c.X + 3 * b.start; a.B = b.B; a.eta = c.eta; a.n_sides = c.n_sides;
-    for (int i = 0; i < c.n_sides; ++i) a.sides[i] = c.sides[i];
-    a.n_choices = b.n_choices > 0 ? b.n_choices : c.n_ent; a.entities_list = b.entities_list;
-    a.seed = c.seed;
-    a.draw_counter0 = (uint64_t)(((int64_t)(b.epoch - 1) * c.batches_count + (b.batch - 1)) * c.n_sides);
-    a.inj_mask = b.inj_mask; a.inj_repl = b.inj_repl;
-    a.codes = sl.buf.codes; a.dest_ent = sl.buf.dest_ent; a.n_ent = c.n_ent; a.dest_rel = sl.buf.dest_rel; a.n_rel = c.n_rel;
-    a.ws_ent = sl.buf.ws_ent; a.ws_ent_bytes = sl.buf.ws_ent_bytes; a.ws_rel = sl.buf.ws_rel; a.ws_rel_bytes = sl.buf.ws_rel_bytes;
-    a.single_flags = c.inplace ? sl.buf.single : nullptr;
-    a.factored = c.factored;
-    a.ws_clean = 1;            // emg_plan_create zeroed the control regions; every grouping leaves them zero
-    a.layout_B = c.cap_B;      // one workspace layout for every batch size of the run
-    if (P->ctl) {              // graph capture: rows, size and draw counter come from the device record
-        a.pos = c.X; a.B = c.cap_B; a.ctl = P->ctl;
-        a.n_choices = c.n_ent; a.entities_list = nullptr; a.inj_mask = a.inj_repl = nullptr;
-    }
+    fill_prepare_args(P, sl, b, P->ctl, a);
     int rc;
     {
         Timed t(P, ST_PREPARE, st);
@@ -120,7 +129,8 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     return EMG_OK;
 }
 
-static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step, const float* hyper6, hipStream_t main) {
+static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step, const float* hyper6, hipStream_t main,
+                   const Riders* ride_a = nullptr, const Riders* ride_b = nullptr) {
     const emg_plan_config& c = P->cfg;
     const int32_t et = c.eta * c.n_sides;
     const int64_t B = b.B, n_ce = (2 + et) * B;
@@ -145,7 +155,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     if (c.fused) {
         ba.fused_loss = c.loss;
         Timed t(P, ST_FUSED, main);
-        rc = emg_train_backward_ex(&ba, main);
+        rc = train_backward_impl(&ba, ride_a, main);
         if (rc != EMG_OK) return rc;
     } else {
         float* sp = c.scores; float* sn = sp + B;
@@ -165,7 +175,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         // rows wider than the register-tiled kernel run as column blocks: TransE-L2's gradient then needs the full norms
         if (c.model == EMG_TRANSE_L2 && c.k_int > 512) { ba.bw_scores_pos = sp; ba.bw_scores_neg = sn; }
         Timed t(P, ST_BACKWARD, main);
-        rc = emg_train_backward_ex(&ba, main);
+        rc = train_backward_impl(&ba, ride_a, main);
         if (rc != EMG_OK) return rc;
     }
     // The two tables' applies are independent: ONE pair of launches over both groupings
@@ -199,7 +209,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     const bool big = n_ce >= c.aux_min_rows;
     if (pair) {   // (any batch size: C1 0.134 -> 0.126 ms/step, C2 0.100 -> 0.089 against two launch pairs in sequence)
         Timed t(P, ST_APPLY_ENT, main);
-        rc = emg_apply_grouped_pair(&ae, &ar, main);
+        rc = apply_pair_impl(&ae, &ar, ride_b, main);
         if (rc != EMG_OK) return rc;
     } else {
         const bool use_aux = P->aux != nullptr && big;
@@ -387,30 +397,61 @@ static int capture_steps(Plan* P, int len, const float* hyper6, hipGraphExec_t* 
     dummy.B = c.cap_B;
     EMG_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
     int rc = EMG_OK;
+    // RIDER form (three slots): no side stream, no event — the preparation of later batches rides at the front of the
+    // step's two launches (emg_group_kernels.hpp): fused(t) carries the id kernel of batch t + 2 and the scatter of batch
+    // t + 1, apply(t) their scan / ordering.  A fork / join per step in a graph costs more than the step's small kernels
+    // (tools/hbm_ceiling: 22 us per step against 10.6 for the same six kernels in a line).
+    static const bool no_riders = getenv("EMG_RIDERS") && atoi(getenv("EMG_RIDERS")) == 0;   // A/B aid: everything in a line
+    const bool ride = c.n_slots >= 3 && !no_riders;
     auto body = [&]() -> int {
-        EMG_HIP(hipEventRecord(P->fork, main));
-        const int ahead = P->n_side;   // batches prepared ahead inside the graph (0: everything on the one stream)
-        int prepared = 0;              // steps [0, prepared) have had their preparation enqueued
-        for (int i = 0; i < len; ++i) {
-            const int want = i + 1 + ahead < len ? i + 1 + ahead : len;
-            for (; prepared < want; ++prepared) {
-                P->ctl = ctl + prepared;
-                int r = prepare(P, P->slots[prepared % c.n_slots], dummy, main);
-                if (r != EMG_OK) return r;
+        const int saved_side = P->n_side;
+        P->n_side = 0;   // (prepare() on the capture's stream)
+        auto stages = [&](int i, PrepStages& S) -> int {
+            emg_prepare_args a;
+            fill_prepare_args(P, P->slots[i % c.n_slots], dummy, ctl + i, a);
+            return prepare_stages(&a, &S);
+        };
+        int r = EMG_OK;
+        if (ride) {
+            P->ctl = ctl;
+            r = prepare(P, P->slots[0], dummy, main);                 // batch 0: all four stages
+            if (r == EMG_OK && len > 1) {                              // batch 1: ids + scan
+                PrepStages S;
+                r = stages(1, S);
+                if (r == EMG_OK) {
+                    Riders R{};
+                    add_rider(R, RIDE_IDS, S.nb_ids, S.G, &S.prep);
+                    add_rider(R, RIDE_SCAN, S.nb_scan, S.G, nullptr);
+                    r = launch_riders_alone(R, main);
+                }
             }
-            SlotState& sl = P->slots[i % c.n_slots];
-            if (P->n_side > 0) EMG_HIP(hipStreamWaitEvent(main, sl.ready, 0));
-            P->ctl = ctl + i;
-            int r = compute(P, sl, dummy, 1, hyper6, main);
-            if (r != EMG_OK) return r;
-            if (P->n_side > 0) { EMG_HIP(hipEventRecord(sl.done, main)); sl.done_in_capture = true; }
         }
-        for (int si = 0; si < P->n_side; ++si)   // every forked stream back into the origin stream
-            if (P->side_joined[si]) {
-                EMG_HIP(hipEventRecord(P->side_join[si], P->side[si]));
-                EMG_HIP(hipStreamWaitEvent(main, P->side_join[si], 0));
+        for (int i = 0; i < len && r == EMG_OK; ++i) {
+            Riders RA{}, RB{};
+            if (ride) {
+                PrepStages S;
+                if (i + 2 < len) {
+                    r = stages(i + 2, S);
+                    if (r != EMG_OK) break;
+                    add_rider(RA, RIDE_IDS, S.nb_ids, S.G, &S.prep);
+                    add_rider(RB, RIDE_SCAN, S.nb_scan, S.G, nullptr);
+                }
+                if (i + 1 < len) {
+                    r = stages(i + 1, S);
+                    if (r != EMG_OK) break;
+                    add_rider(RA, RIDE_SCATTER, S.nb_n, S.G, nullptr);
+                    add_rider(RB, RIDE_ORDER, S.nb_n, S.G, nullptr);
+                }
+            } else {
+                P->ctl = ctl + i;
+                r = prepare(P, P->slots[i % c.n_slots], dummy, main);
+                if (r != EMG_OK) break;
             }
-        return EMG_OK;
+            P->ctl = ctl + i;
+            r = compute(P, P->slots[i % c.n_slots], dummy, 1, hyper6, main, ride ? &RA : nullptr, ride ? &RB : nullptr);
+        }
+        P->n_side = saved_side;
+        return r;
     };
     rc = body();
     P->ctl = nullptr;

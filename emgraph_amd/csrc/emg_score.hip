@@ -19,7 +19,7 @@
 // definition, read by no other group of this batch.  All other rows go to the contribution buffer and
 // are summed in a fixed order by emg_apply_grouped (no float atomics anywhere).
 // HBM-bound by design: algorithmic bytes per group in DESIGN.md §4.
-#include "emg_group.hpp"
+#include "emg_group_kernels.hpp"
 
 namespace emg {
 
@@ -419,8 +419,8 @@ template <int MODEL, int W, int NV, bool FUSED, int IP>
 struct keep_rows {
     static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && IP != 0));
 };
-template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
-__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P0) {
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP, bool RIDE = false>
+__device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
     using R = Row<MODEL, W, NV>;
     GroupParams P = P0;
     if (P0.ctl) {   // a node of a captured step graph: which rows, which step, which learning rates come from the device record
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
         P.opt.lr = P0.ctl->hyper_ent[0]; P.opt.lr_t = P0.ctl->hyper_ent[5];
     }
     const int lg = threadIdx.x % LPG;
-    int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPG;
-    if ((int64_t)blockIdx.x * (kThreads / LPG) >= P.B) return;   // (a launch sized for the plan's capacity: workgroups past the batch)
+    int64_t g = ((int64_t)bx * kThreads + threadIdx.x) / LPG;
+    if ((int64_t)bx * (kThreads / LPG) >= P.B) return;   // (a launch sized for the plan's capacity: workgroups past the batch)
     const bool active = g < P.B;
     if (!active) g = P.B - 1;
     const int64_t B = P.B;
@@ -586,6 +586,19 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
     }
 }
 
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P) {
+    train_backward_body<MODEL, W, NV, LPG, FUSED, IP>(P, blockIdx.x);
+}
+// the same with RIDERS: the first workgroups of the launch do the table-independent preparation of the next batches
+// (emg_plan.hip); instantiated for the fused 16-byte-row forms only (compile time)
+template <int MODEL, int W, int NV, int LPG, int IP>
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
+    unsigned bx;
+    if (run_riders(riders, &bx)) return;
+    train_backward_body<MODEL, W, NV, LPG, true, IP>(P, bx);
+}
+
 // destination ids of the contribution rows of a batch (depends only on the batch ids and codes)
 __global__ void build_dest_kernel(const int32_t* __restrict__ pos, int64_t B, int eta, const int32_t* __restrict__ codes,
                                   int32_t* __restrict__ dest_ent, int32_t* __restrict__ dest_rel) {
@@ -648,15 +661,22 @@ __global__ __launch_bounds__(kThreads) void train_forward_generic_kernel(const G
 enum class Pass { Forward, Backward, Fused };
 
 template <int MODEL, int W, int NV, int LPG>
-static void launch_group(Pass pass, const GroupParams& P, hipStream_t st) {
+static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const Riders& riders) {
     const int groups_per_block = kThreads / LPG;
-    const unsigned grid = (unsigned)cdiv(P.B, groups_per_block);
+    const unsigned grid = (unsigned)cdiv(P.B, groups_per_block) + riders.total;   // (riders.total != 0 only where can_ride())
     if (pass == Pass::Forward)
         hipLaunchKernelGGL((train_forward_kernel<MODEL, W, NV, LPG>), dim3(grid), dim3(kThreads), 0, st, P);
     else {
         const int ip = !P.single_ent ? 0 : (P.opt.opt == EMG_OPT_SGD ? 1 : 2);
         const bool fused = pass == Pass::Fused;
 #define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
+        if constexpr (W == 4) {
+            if (fused && ip != 0 && riders.total) {
+                if (ip == 1) hipLaunchKernelGGL((train_fused_riders_kernel<MODEL, W, NV, LPG, 1>), dim3(grid), dim3(kThreads), 0, st, P, riders);
+                else hipLaunchKernelGGL((train_fused_riders_kernel<MODEL, W, NV, LPG, 2>), dim3(grid), dim3(kThreads), 0, st, P, riders);
+                return;
+            }
+        }
         if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else EMG_BW(true, 2); }
         else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
 #undef EMG_BW
@@ -665,29 +685,31 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st) {
 
 // returns false when no register-tiled variant fits
 template <int MODEL>
-static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st) {
+static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st, const Riders& riders) {
     const int n = P.width > 0 ? P.width : (is_complex<MODEL>::value ? P.khalf : P.k_int);
     if (vec) {
         P.nchunks = n / 4;
         const int c = P.nchunks;
-        if (c <= 16) launch_group<MODEL, 4, 1, 16>(pass, P, st);
-        else if (c <= 32) launch_group<MODEL, 4, 1, 32>(pass, P, st);
-        else if (c <= 64) launch_group<MODEL, 4, 1, 64>(pass, P, st);
-        else if (c <= 128) launch_group<MODEL, 4, 2, 64>(pass, P, st);
+        if (c <= 16) launch_group<MODEL, 4, 1, 16>(pass, P, st, riders);
+        else if (c <= 32) launch_group<MODEL, 4, 1, 32>(pass, P, st, riders);
+        else if (c <= 64) launch_group<MODEL, 4, 1, 64>(pass, P, st, riders);
+        else if (c <= 128) launch_group<MODEL, 4, 2, 64>(pass, P, st, riders);
         else return false;
     } else {
         P.nchunks = n;
         const int c = P.nchunks;
-        if (c <= 64) launch_group<MODEL, 1, 1, 64>(pass, P, st);
-        else if (c <= 128) launch_group<MODEL, 1, 2, 64>(pass, P, st);
-        else if (c <= 256) launch_group<MODEL, 1, 4, 64>(pass, P, st);
-        else if (c <= 512) launch_group<MODEL, 1, 8, 64>(pass, P, st);
+        if (c <= 64) launch_group<MODEL, 1, 1, 64>(pass, P, st, riders);
+        else if (c <= 128) launch_group<MODEL, 1, 2, 64>(pass, P, st, riders);
+        else if (c <= 256) launch_group<MODEL, 1, 4, 64>(pass, P, st, riders);
+        else if (c <= 512) launch_group<MODEL, 1, 8, 64>(pass, P, st, riders);
         else return false;
     }
     return true;
 }
 
-static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) {
+static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st, const Riders* riders_in = nullptr) {
+    static const Riders no_riders{};
+    const Riders* riders_p = riders_in && riders_in->total ? riders_in : nullptr;
     const bool cplx = (model == EMG_COMPLEX || model == EMG_HOLE);
     EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "unknown model id %d", model);
     EMG_REQUIRE(P.k_int > 0 && (!cplx || P.k_int % 2 == 0), "bad k_int %d for model %d", P.k_int, model);
@@ -703,13 +725,22 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) 
         if (P.single_ent)
             vec = vec && (!P.ent_state0 || aligned16(P.ent_state0)) && (!P.ent_state1 || aligned16(P.ent_state1));
     }
+    if (riders_p) {   // only the fused, in-place, 16-byte-row kernels carry riders; everything else: the stages alone, first
+        const bool can_ride = pass == Pass::Fused && vec && P.single_ent && n <= 512;
+        if (!can_ride) {
+            int rc = launch_riders_alone(*riders_p, st);
+            if (rc != EMG_OK) return rc;
+            riders_p = nullptr;
+        }
+    }
+    const Riders& riders = riders_p ? *riders_p : no_riders;
     bool ok = false;
     switch (model) {
-        case EMG_TRANSE_L1: ok = dispatch_model<EMG_TRANSE_L1>(pass, P, vec, st); break;
-        case EMG_TRANSE_L2: ok = dispatch_model<EMG_TRANSE_L2>(pass, P, vec, st); break;
-        case EMG_DISTMULT: ok = dispatch_model<EMG_DISTMULT>(pass, P, vec, st); break;
-        case EMG_COMPLEX: ok = dispatch_model<EMG_COMPLEX>(pass, P, vec, st); break;
-        case EMG_HOLE: ok = dispatch_model<EMG_HOLE>(pass, P, vec, st); break;
+        case EMG_TRANSE_L1: ok = dispatch_model<EMG_TRANSE_L1>(pass, P, vec, st, riders); break;
+        case EMG_TRANSE_L2: ok = dispatch_model<EMG_TRANSE_L2>(pass, P, vec, st, riders); break;
+        case EMG_DISTMULT: ok = dispatch_model<EMG_DISTMULT>(pass, P, vec, st, riders); break;
+        case EMG_COMPLEX: ok = dispatch_model<EMG_COMPLEX>(pass, P, vec, st, riders); break;
+        case EMG_HOLE: ok = dispatch_model<EMG_HOLE>(pass, P, vec, st, riders); break;
     }
     if (!ok && pass == Pass::Backward) {
         // WIDE rows (more than 512 columns per half): given dL/dscore every gradient is separable by column, so the
@@ -727,11 +758,11 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st) 
             if (Q.ent_state1) Q.ent_state1 += c0;
             bool ok2 = false;
             switch (model) {
-                case EMG_TRANSE_L1: ok2 = dispatch_model<EMG_TRANSE_L1>(pass, Q, vec, st); break;
-                case EMG_TRANSE_L2: ok2 = dispatch_model<EMG_TRANSE_L2>(pass, Q, vec, st); break;
-                case EMG_DISTMULT: ok2 = dispatch_model<EMG_DISTMULT>(pass, Q, vec, st); break;
-                case EMG_COMPLEX: ok2 = dispatch_model<EMG_COMPLEX>(pass, Q, vec, st); break;
-                case EMG_HOLE: ok2 = dispatch_model<EMG_HOLE>(pass, Q, vec, st); break;
+                case EMG_TRANSE_L1: ok2 = dispatch_model<EMG_TRANSE_L1>(pass, Q, vec, st, no_riders); break;
+                case EMG_TRANSE_L2: ok2 = dispatch_model<EMG_TRANSE_L2>(pass, Q, vec, st, no_riders); break;
+                case EMG_DISTMULT: ok2 = dispatch_model<EMG_DISTMULT>(pass, Q, vec, st, no_riders); break;
+                case EMG_COMPLEX: ok2 = dispatch_model<EMG_COMPLEX>(pass, Q, vec, st, no_riders); break;
+                case EMG_HOLE: ok2 = dispatch_model<EMG_HOLE>(pass, Q, vec, st, no_riders); break;
             }
             if (!ok2) return fail(EMG_ENOSUP, "train backward: column block of %d does not fit", Q.width);
             EMG_LAUNCH_CHECK();
@@ -799,9 +830,16 @@ extern "C" int emg_build_dest(const int32_t* pos, int64_t B, int32_t eta, const 
     return EMG_OK;
 }
 
-extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
+namespace emg {
+int train_backward_impl(const emg_backward_args* a, const Riders* riders, void* stream);
+}
+extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) { return emg::train_backward_impl(a, nullptr, stream); }
+
+// riders (optional): preparation stages of later batches carried by this launch; a pass that cannot carry them (column
+// blocks of wide rows, B == 0) launches them on their own first
+int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, void* stream) {
     EMG_REQUIRE(a, "emg_train_backward_ex: null args");
-    if (a->B == 0) return EMG_OK;
+    if (a->B == 0) return riders ? launch_riders_alone(*riders, (hipStream_t)stream) : EMG_OK;
     EMG_REQUIRE(a->ent && a->rel && a->pos && a->contrib_ent && a->contrib_rel, "emg_train_backward_ex: null pointer");
     EMG_REQUIRE(a->eta == 0 || a->codes, "emg_train_backward_ex: eta>0 needs codes");
     EMG_REQUIRE(a->ldc >= a->k_int, "emg_train_backward_ex: ldc < k_int");
@@ -851,7 +889,7 @@ extern "C" int emg_train_backward_ex(const emg_backward_args* a, void* stream) {
         EMG_REQUIRE(a->layout_B > 0, "emg_train_backward_ex: a device-side step record needs layout_B (the launch size)");
         P.B = a->layout_B;
     }
-    return run_group_pass(fused ? Pass::Fused : Pass::Backward, a->model, P, (hipStream_t)stream);
+    return run_group_pass(fused ? Pass::Fused : Pass::Backward, a->model, P, (hipStream_t)stream, riders);
 }
 
 extern "C" int emg_train_backward(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel,
