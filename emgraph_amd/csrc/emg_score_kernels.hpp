@@ -1,0 +1,651 @@
+// emg_score_kernels.hpp — device code of the gather + score kernels (see emg_score.hip for the design): shared by
+// emg_score.hip (forward / backward forms, dispatch, C-ABI) and emg_fused_m*.hip (one translation unit per model for the
+// fused in-place forms: they are the largest kernels of the library and compile in parallel that way).
+#pragma once
+#include "emg_group_kernels.hpp"
+
+namespace emg {
+
+template <int MODEL>
+struct is_complex {
+    static constexpr bool value = (MODEL == EMG_COMPLEX || MODEL == EMG_HOLE);
+};
+
+// A model row in registers: real models E floats; complex models [re(E) | im(E)].
+template <int MODEL, int W, int NV>
+struct Row {
+    static constexpr int E = W * NV;
+    static constexpr int N = is_complex<MODEL>::value ? 2 * E : E;
+    float x[N];
+};
+
+template <int MODEL, int W, int NV, int LPG>
+__device__ __forceinline__ void load_row(Row<MODEL, W, NV>& r, const float* __restrict__ base, int lg, int nchunks,
+                                         int khalf) {
+    constexpr int E = W * NV;
+    RowTile<W, NV> t;
+    load_tile<W, NV, LPG>(t, base, lg, nchunks);
+#pragma unroll
+    for (int e = 0; e < E; ++e) r.x[e] = t.x[e];
+    if constexpr (is_complex<MODEL>::value) {
+        load_tile<W, NV, LPG>(t, base + khalf, lg, nchunks);
+#pragma unroll
+        for (int e = 0; e < E; ++e) r.x[E + e] = t.x[e];
+    }
+}
+
+#ifndef EMG_INPLACE_NT
+#define EMG_INPLACE_NT 0
+#endif
+#ifndef EMG_STREAM_STORES
+#define EMG_STREAM_STORES 1
+#endif
+// (rows of the contribution buffers: written here, read once by the apply — streamed past the caches)
+template <int MODEL, int W, int NV, int LPG>
+__device__ __forceinline__ void store_row(const Row<MODEL, W, NV>& r, float* __restrict__ base, int lg, int nchunks,
+                                          int khalf) {
+    constexpr int E = W * NV;
+    constexpr bool STREAM = EMG_STREAM_STORES != 0;
+    RowTile<W, NV> t;
+#pragma unroll
+    for (int e = 0; e < E; ++e) t.x[e] = r.x[e];
+    store_tile<W, NV, LPG, STREAM>(t, base, lg, nchunks);
+    if constexpr (is_complex<MODEL>::value) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) t.x[e] = r.x[E + e];
+        store_tile<W, NV, LPG, STREAM>(t, base + khalf, lg, nchunks);
+    }
+}
+
+// per-lane partial of the k-reduction for roles (a = subject row, p = relation row, b = object row)
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ float partial_score(const Row<MODEL, W, NV>& a, const Row<MODEL, W, NV>& p,
+                                               const Row<MODEL, W, NV>& b) {
+    constexpr int E = W * NV;
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1) {
+            acc += fabsf((a.x[e] + p.x[e]) - b.x[e]);  // TransE.py:210: e_s + e_p - e_o, ord=1
+        } else if constexpr (MODEL == EMG_TRANSE_L2) {
+            const float d = (a.x[e] + p.x[e]) - b.x[e];
+            acc = fmaf(d, d, acc);
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            acc = fmaf(a.x[e] * p.x[e], b.x[e], acc);  // DistMult.py:201
+        } else {
+            const float sr = a.x[e], si = a.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = b.x[e], oi = b.x[E + e];
+            // ComplEx.py:293-297
+            acc += (pr * sr) * orr + (pr * si) * oi + (pi * sr) * oi - (pi * si) * orr;
+        }
+    }
+    return acc;
+}
+
+template <int MODEL>
+__device__ __forceinline__ float finalize_score(float sum, float scale, int flags) {
+    if constexpr (MODEL == EMG_TRANSE_L1) return -sum;
+    if constexpr (MODEL == EMG_TRANSE_L2) return (flags & EMG_SCORE_PARTIAL) ? sum : -sqrtf(sum);
+    if constexpr (MODEL == EMG_HOLE) return (flags & EMG_SCORE_PARTIAL) ? sum : scale * sum;
+    return sum;
+}
+
+// inner coefficient from g = dL/dscore and the k-reduced sum (TransE-L2: nrm = sqrt(sum of squares))
+template <int MODEL>
+__device__ __forceinline__ float inner_coef(float g, float nrm, float scale) {
+    if constexpr (MODEL == EMG_TRANSE_L2) return nrm > 0.f ? g / nrm : 0.f;
+    if constexpr (MODEL == EMG_HOLE) return g * scale;
+    return g;
+}
+
+// ga += dscore/da * gi etc. for roles (a, p, b)
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ void accum_grads(const Row<MODEL, W, NV>& a, const Row<MODEL, W, NV>& p,
+                                            const Row<MODEL, W, NV>& b, float gi, Row<MODEL, W, NV>& ga,
+                                            Row<MODEL, W, NV>& gp, Row<MODEL, W, NV>& gb) {
+    constexpr int E = W * NV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1) {
+            const float t = gi * sgnf((a.x[e] + p.x[e]) - b.x[e]);
+            ga.x[e] -= t; gp.x[e] -= t; gb.x[e] += t;
+        } else if constexpr (MODEL == EMG_TRANSE_L2) {
+            const float t = gi * ((a.x[e] + p.x[e]) - b.x[e]);
+            ga.x[e] -= t; gp.x[e] -= t; gb.x[e] += t;
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            ga.x[e] = fmaf(gi, p.x[e] * b.x[e], ga.x[e]);
+            gp.x[e] = fmaf(gi, a.x[e] * b.x[e], gp.x[e]);
+            gb.x[e] = fmaf(gi, a.x[e] * p.x[e], gb.x[e]);
+        } else {
+            const float sr = a.x[e], si = a.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = b.x[e], oi = b.x[E + e];
+            ga.x[e] = fmaf(gi, pr * orr + pi * oi, ga.x[e]);
+            ga.x[E + e] = fmaf(gi, pr * oi - pi * orr, ga.x[E + e]);
+            gp.x[e] = fmaf(gi, sr * orr + si * oi, gp.x[e]);
+            gp.x[E + e] = fmaf(gi, sr * oi - si * orr, gp.x[E + e]);
+            gb.x[e] = fmaf(gi, pr * sr - pi * si, gb.x[e]);
+            gb.x[E + e] = fmaf(gi, pr * si + pi * sr, gb.x[E + e]);
+        }
+    }
+}
+
+// A value that is identical in all lanes of a group.  When the group IS the wave (LPG == 64) tell the
+// compiler so (readfirstlane -> SGPR): branches on it become scalar branches instead of being if-converted
+// into both-sides-plus-select, which doubles the live registers of the role-dependent code.
+template <int LPG>
+__device__ __forceinline__ int uniform_if_wave(int v) {
+    if constexpr (LPG == 64) return __builtin_amdgcn_readfirstlane(v);
+    return v;
+}
+
+// value held by lane `first + j` of the wave (first = the group's lane 0), j uniform within the group
+template <int LPG>
+__device__ __forceinline__ int group_lane_value(int v, int first, int j) {
+    if constexpr (LPG == 64) return __builtin_amdgcn_readlane(v, j);
+    return __shfl(v, first + j, 64);
+}
+
+struct GroupParams {
+    const float* ent; int64_t n_ent; int64_t ld_ent;
+    const float* rel; int64_t n_rel; int64_t ld_rel;
+    int32_t k_int; int32_t khalf; int32_t nchunks; float scale;
+    int32_t width;                                       // columns (per half for complex models) this launch covers; 0 = all
+    const int32_t* pos; int64_t B; int32_t eta; const int32_t* codes; int32_t flags;
+    float* scores_pos; float* scores_neg;
+    // backward / fused
+    const float* g_pos; const float* g_neg;              // external dL/dscore (fused_loss < 0)
+    const float* bw_scores_pos; const float* bw_scores_neg;  // global final scores (TransE-L2 on a k-slice)
+    int32_t fused_loss; float margin; double* loss_accum;
+    float* contrib_ent; float* contrib_rel; int64_t ldc;
+    const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
+    float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
+    OptParams opt;
+    FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
+    const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
+};
+
+#ifndef EMG_BW_THREADS
+#define EMG_BW_THREADS 256
+#endif
+constexpr int kThreads = EMG_BW_THREADS;
+constexpr int kUnroll = 4;
+
+// ---------------------------------------------------------------------------------------------
+// forward: scores_pos[g], scores_neg[j*B+g]
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, int W, int NV, int LPG>
+__global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupParams P) {
+    using R = Row<MODEL, W, NV>;
+    const int lg = threadIdx.x % LPG;
+    int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPG;
+    const bool active = g < P.B;
+    if (!active) g = P.B - 1;  // keep the whole wave convergent for the shuffles
+
+    const int32_t s = P.pos[3 * g + 0], p = P.pos[3 * g + 1], o = P.pos[3 * g + 2];
+    R rs, rp, ro;
+    load_row<MODEL, W, NV, LPG>(rs, P.ent + (int64_t)s * P.ld_ent, lg, P.nchunks, P.khalf);
+    load_row<MODEL, W, NV, LPG>(rp, P.rel + (int64_t)p * P.ld_rel, lg, P.nchunks, P.khalf);
+    load_row<MODEL, W, NV, LPG>(ro, P.ent + (int64_t)o * P.ld_ent, lg, P.nchunks, P.khalf);
+
+    {
+        const float sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
+        if (active && lg == 0) P.scores_pos[g] = finalize_score<MODEL>(sum, P.scale, P.flags);
+    }
+
+    for (int j0 = 0; j0 < P.eta; j0 += kUnroll) {
+        int32_t code[kUnroll];
+        R re[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int j = min(j0 + u, P.eta - 1);
+            code[u] = uniform_if_wave<LPG>(P.codes[(int64_t)j * P.B + g]);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int32_t repl = code[u] & 0x7fffffff;
+            load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+        }
+        float part[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const bool keep_s = code[u] < 0;  // bit 31
+            if (keep_s) part[u] = partial_score<MODEL, W, NV>(rs, rp, re[u]);
+            else part[u] = partial_score<MODEL, W, NV>(re[u], rp, ro);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const float sum = group_sum<LPG>(part[u]);
+            const int j = j0 + u;
+            if (active && lg == 0 && j < P.eta)
+                P.scores_neg[(int64_t)j * P.B + g] = finalize_score<MODEL>(sum, P.scale, P.flags);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-place optimizer update of one table row from registers (singleton destinations)
+// ---------------------------------------------------------------------------------------------
+//   IP == 1: plain SGD (no state; stays lean)   IP == 2: any optimizer (state RMW; elements are fenced with
+//   sched_barrier so the compiler does not interleave eight sqrt/div expansions and blow up the VGPR budget)
+template <int MODEL, int W, int NV, int LPG, int IP>
+__device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row, const Row<MODEL, W, NV>& cur,
+                                               const Row<MODEL, W, NV>& grad, int lg) {
+    // chunk-wise (one 16-byte chunk live at a time) so the singleton path costs almost no extra VGPRs:
+    // occupancy is what keeps enough row loads in flight for this HBM-bound kernel
+    constexpr int E = W * NV;
+    constexpr int HALVES = is_complex<MODEL>::value ? 2 : 1;
+    float* wrow = P.ent_rw + row * P.ld_ent;
+    float* s0row = (IP == 2 && P.ent_state0) ? P.ent_state0 + row * P.ld_ent : nullptr;
+    float* s1row = (IP == 2 && P.ent_state1) ? P.ent_state1 + row * P.ld_ent : nullptr;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int c = lg + it * LPG;
+            if (c < P.nchunks) {
+                const int off = h * P.khalf + c * W;
+                float wv[W], s0v[W], s1v[W];
+                if constexpr (W == 4) {
+                    if (s0row) { const float4 t = *reinterpret_cast<const float4*>(s0row + off); s0v[0] = t.x; s0v[1] = t.y; s0v[2] = t.z; s0v[3] = t.w; }
+                    if (s1row) { const float4 t = *reinterpret_cast<const float4*>(s1row + off); s1v[0] = t.x; s1v[1] = t.y; s1v[2] = t.z; s1v[3] = t.w; }
+                } else {
+                    if (s0row) s0v[0] = s0row[off];
+                    if (s1row) s1v[0] = s1row[off];
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    wv[w] = cur.x[h * E + it * W + w];
+                    const float g = grad.x[h * E + it * W + w];
+                    if constexpr (IP == 1) {
+                        wv[w] = opt_sgd_elem(P.opt, wv[w], g);
+                    } else {
+                        opt_update_elem(P.opt, wv[w], g, &s0v[w], &s1v[w]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (W == 4) {
+#if EMG_INPLACE_NT
+                    typedef float nt_float4 __attribute__((ext_vector_type(4)));
+                    const nt_float4 nv = {wv[0], wv[1], wv[2], wv[3]};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<nt_float4*>(wrow + off));
+#else
+                    *reinterpret_cast<float4*>(wrow + off) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+#endif
+                    if (s0row) *reinterpret_cast<float4*>(s0row + off) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
+                    if (s1row) *reinterpret_cast<float4*>(s1row + off) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
+                } else {
+                    wrow[off] = wv[0];
+                    if (s0row) s0row[off] = s0v[0];
+                    if (s1row) s1row[off] = s1v[0];
+                }
+            }
+        }
+    }
+    if (P.tag_ent && lg == 0) P.tag_ent[row] = P.step;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward / fused kernel, register-lean form.
+//
+// Every model here is (bi)linear enough that the loop over a positive's negatives needs only
+//   q_o, q_s : the two HOISTED query rows (object side from (s,p), subject side from (p,o)); a negative's
+//              score is <q, e> (TransE: -||q - e||), its gradient row is gi*q (TransE: +-gi*sgn/diff);
+//   A_o, A_s : two ACCUMULATORS  sum_j gi_j * e_j  (TransE: sum_j t_j) over the object- / subject-corrupted
+//              negatives; the gradients of the kept rows s, p, o are linear in them and are formed once,
+//              after the loop, from s, p, o RE-LOADED at that point (L2-hot) instead of kept live.
+// => 4 persistent rows instead of 6 + no per-negative role copies: ~100 VGPRs with FOUR replacement rows in
+// flight per wave (occupancy x loads in flight is what an HBM-bound gather kernel lives on).
+//   FUSED = true : scores, pair-local loss and dL/dscore are computed here (P.fused_loss)
+//   FUSED = false: dL/dscore comes from P.g_pos / P.g_neg
+//   IP    = 0: all rows to the contribution buffer; 1/2: singleton destinations updated in place
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ void make_queries(const Row<MODEL, W, NV>& s, const Row<MODEL, W, NV>& p,
+                                             const Row<MODEL, W, NV>& o, Row<MODEL, W, NV>& qo,
+                                             Row<MODEL, W, NV>& qs) {
+    constexpr int E = W * NV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            qo.x[e] = s.x[e] + p.x[e];  // (s+p) - e
+            qs.x[e] = o.x[e] - p.x[e];  // (e+p) - o = e - (o-p)
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            qo.x[e] = p.x[e] * s.x[e];
+            qs.x[e] = p.x[e] * o.x[e];
+        } else {
+            const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
+            qo.x[e] = pr * sr - pi * si;      qo.x[E + e] = pr * si + pi * sr;    // SURVEY B-2, object side
+            qs.x[e] = pr * orr + pi * oi;     qs.x[E + e] = pr * oi - pi * orr;   // subject side
+        }
+    }
+}
+
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ float neg_partial(const Row<MODEL, W, NV>& q, const Row<MODEL, W, NV>& e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < Row<MODEL, W, NV>::N; ++i) {
+        if constexpr (MODEL == EMG_TRANSE_L1) acc += fabsf(q.x[i] - e.x[i]);
+        else if constexpr (MODEL == EMG_TRANSE_L2) { const float d = q.x[i] - e.x[i]; acc = fmaf(d, d, acc); }
+        else acc = fmaf(q.x[i], e.x[i], acc);
+    }
+    return acc;
+}
+
+// gradient row of the replacement entity + accumulator update.  OBJ: the object was replaced (d = q - e)
+template <int MODEL, int W, int NV, bool OBJ>
+__device__ __forceinline__ void neg_grads(const Row<MODEL, W, NV>& q, const Row<MODEL, W, NV>& e, float gi,
+                                          Row<MODEL, W, NV>& row, Row<MODEL, W, NV>& acc) {
+#pragma unroll
+    for (int i = 0; i < Row<MODEL, W, NV>::N; ++i) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            const float d = OBJ ? q.x[i] - e.x[i] : e.x[i] - q.x[i];
+            const float t = (MODEL == EMG_TRANSE_L1) ? gi * sgnf(d) : gi * d;
+            row.x[i] = OBJ ? t : -t;  // dscore/de = +sgn(d) when e is the object, -sgn(d) when it is the subject
+            acc.x[i] += t;
+        } else {
+            row.x[i] = gi * q.x[i];
+            acc.x[i] = fmaf(gi, e.x[i], acc.x[i]);
+        }
+    }
+}
+
+// gradients of the kept rows from the accumulators (+ the positive's own term, inner coefficient gp_i)
+template <int MODEL, int W, int NV>
+__device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const Row<MODEL, W, NV>& p,
+                                             const Row<MODEL, W, NV>& o, const Row<MODEL, W, NV>& Ao,
+                                             const Row<MODEL, W, NV>& As, float gp_i, Row<MODEL, W, NV>& gs,
+                                             Row<MODEL, W, NV>& gp, Row<MODEL, W, NV>& go) {
+    constexpr int E = W * NV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if constexpr (MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2) {
+            const float d = (s.x[e] + p.x[e]) - o.x[e];
+            const float tp = (MODEL == EMG_TRANSE_L1) ? gp_i * sgnf(d) : gp_i * d;
+            gs.x[e] = -Ao.x[e] - tp;
+            gp.x[e] = -Ao.x[e] - As.x[e] - tp;
+            go.x[e] = As.x[e] + tp;
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            const float bo = fmaf(gp_i, o.x[e], Ao.x[e]);  // effective object row seen by (s,p)
+            const float bs = fmaf(gp_i, s.x[e], As.x[e]);  // effective subject row seen by (p,o)
+            gs.x[e] = p.x[e] * bo;
+            go.x[e] = p.x[e] * bs;
+            gp.x[e] = fmaf(s.x[e], bo, As.x[e] * o.x[e]);
+        } else {
+            const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
+            const float br = fmaf(gp_i, orr, Ao.x[e]), bi = fmaf(gp_i, oi, Ao.x[E + e]);  // b = Ao + gp_i*o
+            const float ar = fmaf(gp_i, sr, As.x[e]), ai = fmaf(gp_i, si, As.x[E + e]);   // a = As + gp_i*s
+            gs.x[e] = pr * br + pi * bi;              gs.x[E + e] = pr * bi - pi * br;     // GA(p, b)
+            go.x[e] = pr * ar - pi * ai;              go.x[E + e] = pr * ai + pi * ar;     // GB(p, a)
+            // GP(s, b) + GP(As, o)
+            gp.x[e] = (sr * br + si * bi) + (As.x[e] * orr + As.x[E + e] * oi);
+            gp.x[E + e] = (sr * bi - si * br) + (As.x[e] * oi - As.x[E + e] * orr);
+        }
+    }
+}
+
+#ifndef EMG_BW_MINWAVES
+#define EMG_BW_MINWAVES 1
+#endif
+// U = replacement rows in flight per wave and trip.  Measured on C3 (MI355X, fused kernel alone): U = 2: 0.302 ms,
+// 4: 0.263, 5: 0.302, 6: 0.314, 8: 0.311, 10: 0.305; a software pipeline (next U rows in flight during the arithmetic
+// of this trip) 0.285 (U = 2) / 0.300 (U = 4: 194 VGPRs, 2 waves/SIMD); workgroups of 64 / 128 / 512 threads 0.288 /
+// 0.239 / 0.274 against 0.223 with 256 on the same box.
+#ifndef EMG_BW_U
+#define EMG_BW_U 4
+#endif
+
+// KEEP: the s, p, o rows stay in registers across the loop over the negatives instead of being re-read at the end
+// (the re-read was 1.10x the algorithmic traffic by PMC: after 20 replacement rows per wave on every CU of the XCD
+// they are no longer in L2).  Only where it is free: instantiations whose occupancy does not drop (checked with
+// -Rpass-analysis=kernel-resource-usage: 16-byte single-chunk rows; complex rows only in the fused in-place form,
+// 140 -> 158 VGPRs at the same 3 waves/SIMD).
+template <int MODEL, int W, int NV, bool FUSED, int IP>
+struct keep_rows {
+    static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && IP != 0));
+};
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
+__device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
+    using R = Row<MODEL, W, NV>;
+    GroupParams P = P0;
+    if (P0.ctl) {   // a node of a captured step graph: which rows, which step, which learning rates come from the device record
+        P.B = P0.ctl->B; P.pos = P0.pos + 3 * P0.ctl->start; P.step = P0.ctl->step;
+        P.opt.lr = P0.ctl->hyper_ent[0]; P.opt.lr_t = P0.ctl->hyper_ent[5];
+    }
+    const int lg = threadIdx.x % LPG;
+    int64_t g = ((int64_t)bx * kThreads + threadIdx.x) / LPG;
+    if ((int64_t)bx * (kThreads / LPG) >= P.B) return;   // (a launch sized for the plan's capacity: workgroups past the batch)
+    const bool active = g < P.B;
+    if (!active) g = P.B - 1;
+    const int64_t B = P.B;
+    constexpr bool kBilinear = !(MODEL == EMG_TRANSE_L1 || MODEL == EMG_TRANSE_L2);   // replacement row's gradient = gi * q
+
+    const int32_t s = P.pos[3 * g + 0], p = P.pos[3 * g + 1], o = P.pos[3 * g + 2];
+    const float* srow = P.ent + (int64_t)s * P.ld_ent;
+    const float* prow = P.rel + (int64_t)p * P.ld_rel;
+    const float* orow = P.ent + (int64_t)o * P.ld_ent;
+    // ALL corruption codes and in-place flags of the group in ONE gather each, issued together with the s, p, o rows
+    // and before anything is stored: lane j holds negative j's code and flag, lanes eta / eta+1 the flags of the
+    // subject / object slot.  Loaded where they are used, each sits behind the previous negative's stores (a byte load
+    // may alias them as far as the compiler knows): a serialised round trip per negative (C3: 0.265 -> 0.251 ms).
+    const bool gathered = P.eta + 2 <= LPG;   // kernel-uniform
+    const int first = (threadIdx.x & 63) / LPG * LPG;
+    int my_code = 0, my_flag = 0, my_pos = 0;   // my_pos: where negative lg's factor goes (its slot's sorted position)
+    if (gathered) {
+        if (lg < P.eta) my_code = P.codes[(int64_t)lg * B + g];
+        if (kBilinear && P.fac.coef && lg < P.eta) my_pos = (int)P.fac.pos_of_slot[(int64_t)lg * B + g];
+        if (IP != 0 && lg < P.eta + 2)
+            my_flag = P.single_ent[lg < P.eta ? 2 * B + (int64_t)lg * B + g : (int64_t)(lg - P.eta) * B + g];
+    }
+    R qo, qs, Ao, As;
+    float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
+    constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
+    R ks, kp, ko;  // live across the loop only when KEEP (dead otherwise: no registers)
+    {
+        R rs, rp, ro;
+        load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
+        load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
+        if constexpr (KEEP) { ks = rs; kp = rp; ko = ro; }
+        if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
+            if (MODEL == EMG_TRANSE_L2 && P.bw_scores_pos) {
+                pos_nrm = -P.bw_scores_pos[g];
+            } else {
+                const float sum = group_sum<LPG>(partial_score<MODEL, W, NV>(rs, rp, ro));
+                pos_score = finalize_score<MODEL>(sum, P.scale, 0);
+                if constexpr (MODEL == EMG_TRANSE_L2) pos_nrm = sqrtf(sum);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < R::N; ++e) Ao.x[e] = As.x[e] = 0.f;
+    PosTerms pos_terms{0.f, 0.f};
+    if constexpr (FUSED) {
+        if (P.scores_pos && active && lg == 0) P.scores_pos[g] = pos_score;
+        pos_terms = local_loss_pos(P.fused_loss, pos_score);
+    } else {
+        gpos = P.g_pos[g];
+    }
+
+    constexpr int U = EMG_BW_U;
+    auto code_of = [&](int j) -> int32_t {
+        return gathered ? group_lane_value<LPG>(my_code, first, j) : uniform_if_wave<LPG>(P.codes[(int64_t)j * B + g]);
+    };
+    auto flag_of = [&](int i, int64_t slot) -> int {   // i: negative index, eta = subject slot, eta + 1 = object slot
+        if constexpr (IP == 0) return 0;
+        return gathered ? group_lane_value<LPG>(my_flag, first, i) : uniform_if_wave<LPG>((int)P.single_ent[slot]);
+    };
+    // the replacement rows of negatives j0 .. j0+U-1
+    auto fetch = [&](int j0, int32_t (&code)[U], R (&re)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) code[u] = code_of(min(j0 + u, P.eta - 1));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t repl = code[u] & 0x7fffffff;
+            load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+        }
+    };
+    for (int j0 = 0; j0 < P.eta; j0 += U) {
+        int32_t code[U];
+        float gj[U];
+        R re[U];
+        fetch(j0, code, re);
+        if constexpr (!FUSED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, P.eta - 1) * B + g];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u;
+            if (j >= P.eta) break;
+            const bool keep_s = code[u] < 0;  // subject kept => the OBJECT was replaced
+            const int32_t repl = code[u] & 0x7fffffff;
+            float nrm = 0.f;
+            if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
+                if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
+                    nrm = -P.bw_scores_neg[(int64_t)j * B + g];
+                } else {
+                    float part;
+                    if (keep_s) part = neg_partial<MODEL, W, NV>(qo, re[u]);
+                    else part = neg_partial<MODEL, W, NV>(qs, re[u]);
+                    const float sum = group_sum<LPG>(part);
+                    if constexpr (MODEL == EMG_TRANSE_L2) nrm = sqrtf(sum);
+                    if constexpr (FUSED) {
+                        const float neg = finalize_score<MODEL>(sum, P.scale, 0);
+                        gj[u] = local_loss_neg(P.fused_loss, pos_score, pos_terms, neg, P.margin, loss_acc, gpos);
+                        if (P.scores_neg && active && lg == 0) P.scores_neg[(int64_t)j * B + g] = neg;
+                    }
+                }
+            }
+            const float gi = inner_coef<MODEL>(gj[u], nrm, P.scale);
+            R row;
+            if (keep_s) neg_grads<MODEL, W, NV, true>(qo, re[u], gi, row, Ao);
+            else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
+            if (active) {
+                const int64_t slot = 2 * B + (int64_t)j * B + g;
+                if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
+                else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
+                    const int at = gathered ? group_lane_value<LPG>(my_pos, first, j) : (int)P.fac.pos_of_slot[(int64_t)j * B + g];
+                    if (lg == 0) P.fac.coef[at] = gi;
+                }
+                else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
+            }
+        }
+    }
+    if (kBilinear && P.fac.coef && active) {   // the two query rows every factored negative of this group points at
+        store_row<MODEL, W, NV, LPG>(qo, P.contrib_ent + (2 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        store_row<MODEL, W, NV, LPG>(qs, P.contrib_ent + (3 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
+    }
+    if (active) {
+        // kept rows: form their gradients from the accumulators
+        R rs, rp, ro, gs, gp, go;
+        if constexpr (KEEP) {
+            rs = ks; rp = kp; ro = ko;
+        } else {  // re-load s, p, o (read a moment ago) instead of holding three more rows per group
+            load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        }
+        finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
+        store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
+        if (IP != 0 && flag_of(P.eta, g)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
+        else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
+        if (IP != 0 && flag_of(P.eta + 1, B + g)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
+        else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+    }
+    if constexpr (FUSED) {
+        // loss: one value per group (lane 0), block-reduced in double, one atomic per block
+        double v = (active && lg == 0) ? (double)loss_acc : 0.0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        __shared__ double part[kThreads / 64];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) t += part[w];
+            if (t != 0.0) atomicAdd(P.loss_accum, t);
+        }
+    }
+}
+
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kernel(const GroupParams P) {
+    train_backward_body<MODEL, W, NV, LPG, FUSED, IP>(P, blockIdx.x);
+}
+// the same with RIDERS: the first workgroups of the launch do the table-independent preparation of the next batches
+// (emg_plan.hip); instantiated for the fused 16-byte-row forms only (compile time)
+template <int MODEL, int W, int NV, int LPG, int IP>
+__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
+    unsigned bx;
+    if (run_riders(riders, &bx)) return;
+    train_backward_body<MODEL, W, NV, LPG, true, IP>(P, bx);
+}
+
+// destination ids of the contribution rows of a batch (depends only on the batch ids and codes)
+static __global__ void build_dest_kernel(const int32_t* __restrict__ pos, int64_t B, int eta, const int32_t* __restrict__ codes,
+                                  int32_t* __restrict__ dest_ent, int32_t* __restrict__ dest_rel) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B) {
+        dest_ent[t] = pos[3 * t + 0];
+        dest_ent[B + t] = pos[3 * t + 2];
+        dest_rel[t] = pos[3 * t + 1];
+    }
+    if (t < (int64_t)eta * B) dest_ent[2 * B + t] = codes[t] & 0x7fffffff;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic forward fallback (any k, any alignment): one wave per group, strided scalar loads
+// ---------------------------------------------------------------------------------------------
+template <int MODEL>
+__device__ __forceinline__ float strided_partial(const float* __restrict__ a, const float* __restrict__ p,
+                                                 const float* __restrict__ b, int khalf, int n, int lane) {
+    float acc = 0.f;
+    for (int c = lane; c < n; c += 64) {
+        if constexpr (MODEL == EMG_TRANSE_L1) {
+            acc += fabsf((a[c] + p[c]) - b[c]);
+        } else if constexpr (MODEL == EMG_TRANSE_L2) {
+            const float d = (a[c] + p[c]) - b[c];
+            acc = fmaf(d, d, acc);
+        } else if constexpr (MODEL == EMG_DISTMULT) {
+            acc = fmaf(a[c] * p[c], b[c], acc);
+        } else {
+            const float sr = a[c], si = a[khalf + c], pr = p[c], pi = p[khalf + c], orr = b[c], oi = b[khalf + c];
+            acc += (pr * sr) * orr + (pr * si) * oi + (pi * sr) * oi - (pi * si) * orr;
+        }
+    }
+    return acc;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kThreads) void train_forward_generic_kernel(const GroupParams P) {
+    const int lane = threadIdx.x & 63;
+    int64_t g = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / 64;
+    const bool active = g < P.B;
+    if (!active) g = P.B - 1;
+    const int n = is_complex<MODEL>::value ? P.khalf : P.k_int;
+    const float* rs = P.ent + (int64_t)P.pos[3 * g + 0] * P.ld_ent;
+    const float* rp = P.rel + (int64_t)P.pos[3 * g + 1] * P.ld_rel;
+    const float* ro = P.ent + (int64_t)P.pos[3 * g + 2] * P.ld_ent;
+    float sum = group_sum<64>(strided_partial<MODEL>(rs, rp, ro, P.khalf, n, lane));
+    if (active && lane == 0) P.scores_pos[g] = finalize_score<MODEL>(sum, P.scale, P.flags);
+    for (int j = 0; j < P.eta; ++j) {
+        const int32_t code = P.codes[(int64_t)j * P.B + g];
+        const float* re = P.ent + (int64_t)(code & 0x7fffffff) * P.ld_ent;
+        const bool keep_s = code < 0;
+        sum = group_sum<64>(strided_partial<MODEL>(keep_s ? rs : re, rp, keep_s ? re : ro, P.khalf, n, lane));
+        if (active && lane == 0) P.scores_neg[(int64_t)j * P.B + g] = finalize_score<MODEL>(sum, P.scale, P.flags);
+    }
+}
+
+
+// the fused in-place forms of one model (emg_fused_m<model>.hip): shape 0..3 = 16 / 32 / 64 lanes per group with one
+// 16-byte chunk per lane, 64 lanes with two; ip 1 = SGD, 2 = any optimizer
+typedef void (*fused_launch_fn)(int shape, int ip, unsigned grid, hipStream_t st, const GroupParams& P, const Riders& riders);
+void launch_fused_m0(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
+void launch_fused_m1(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
+void launch_fused_m2(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
+void launch_fused_m3(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
+void launch_fused_m4(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
+
+}  // namespace emg
