@@ -82,26 +82,25 @@ class NumpyDatasetAdapter(EmgraphBaseDatasetAdaptor):
         return dataset_type in self.dataset.keys()
 
     def get_next_batch(self, batches_count=-1, dataset_type="train", use_filter=False):
-        """:79-131: contiguous slices of ceil(n / batches_count) rows, int32, in file order (no shuffling);
-        batches_count = -1 means one triple per batch.  With use_filter the lists of known objects of (s, p, ?) and
-        known subjects of (?, p, o) follow each batch, shaped [n, 1] as the SQL backend returns them."""
+        """Generator over the batches of one split (the protocol of numpy_adapter.py:79-131): rows in stored order, cut
+        into ``batches_count`` contiguous pieces of ceil(n / batches_count) rows, as int32; ``batches_count = -1`` =
+        one triple per batch.  Each item is a list: [triples] + [edge values of those rows, if the split has any]
+        + [known objects of (s, p, ?), known subjects of (?, p, o)] when ``use_filter`` — the two lists shaped [n, 1], as
+        the reference's SQL backend returns them."""
         if not self.mapped_status[dataset_type]:
             self.map_data()
+        rows = self.dataset[dataset_type]
         n = self.get_size(dataset_type)
-        if batches_count == -1:
-            batch_size, batches_count = 1, n
-        else:
-            batch_size = int(np.ceil(n / batches_count))
-        for i in range(batches_count):
-            out = np.int32(self.dataset[dataset_type][i * batch_size:(i + 1) * batch_size, :])
-            output = [out]
-            if dataset_type in self.focusE_numeric_edge_values:
-                output.append(self.focusE_numeric_edge_values[dataset_type][i * batch_size:(i + 1) * batch_size, :])
+        step, pieces = (1, n) if batches_count == -1 else (int(np.ceil(n / batches_count)), batches_count)
+        weights = self.focusE_numeric_edge_values.get(dataset_type)
+        for lo in range(0, step * pieces, step):
+            triples = np.int32(rows[lo:lo + step, :])
+            item = [triples]
+            if weights is not None:
+                item.append(weights[lo:lo + step, :])
             if use_filter:
-                objs, subs = self.get_participating_entities(out)
-                output.append(objs)
-                output.append(subs)
-            yield output
+                item.extend(self.get_participating_entities(triples))
+            yield item
 
     def get_participating_entities(self, x_triple):
         """what SQLiteAdapter.get_participating_entities (sqlite_adapter.py:449-508) returns for ONE triple:
@@ -115,40 +114,48 @@ class NumpyDatasetAdapter(EmgraphBaseDatasetAdaptor):
         return idx[ptr[0]:ptr[1]].reshape(-1, 1).astype(np.int64), idx[ptr[1]:ptr[2]].reshape(-1, 1).astype(np.int64)
 
     def map_data(self, remap=False):
-        """:133-154."""
+        """Replace the labels of every split that still holds labels (all splits with ``remap``) by ids, creating the
+        mappings from the train split first if there are none (numpy_adapter.py:133-154)."""
         from ..evaluation.protocol import to_idx
-        if len(self.rel_to_idx) == 0 or len(self.ent_to_idx) == 0:
+        if not self.rel_to_idx or not self.ent_to_idx:
             self.generate_mappings()
-        for key in self.dataset.keys():
-            if (not self.mapped_status[key]) or (remap is True):
-                self.dataset[key] = to_idx(self.dataset[key], ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx)
-                self.mapped_status[key] = True
+        pending = [name for name in self.dataset if remap is True or not self.mapped_status[name]]
+        for name in pending:
+            self.dataset[name] = to_idx(self.dataset[name], ent_to_idx=self.ent_to_idx, rel_to_idx=self.rel_to_idx)
+            self.mapped_status[name] = True
+
+    # what a split must look like: (predicate on the candidate, the reference's message for its failure)
+    _SPLIT_CHECKS = (
+        (lambda d: type(d) == np.ndarray, lambda d: "Invalid type for input data. Expected ndarray, got {}".format(type(d))),
+        (lambda d: np.shape(d)[1] == 3,
+         lambda d: "Invalid size for input data. Expected number of column 3, got {}".format(np.shape(d)[1])),
+    )
 
     def _validate_data(self, data):
-        """:156-179."""
-        if type(data) != np.ndarray:
-            raise ValueError("Invalid type for input data. Expected ndarray, got {}".format(type(data)))
-        if (np.shape(data)[1]) != 3:
-            raise ValueError("Invalid size for input data. Expected number of column 3, got {}".format(np.shape(data)[1]))
+        """ValueError with the reference's message (numpy_adapter.py:156-179) unless ``data`` is an ndarray of 3 columns"""
+        for holds, message in self._SPLIT_CHECKS:
+            if not holds(data):
+                raise ValueError(message(data))
 
     def set_data(self, dataset, dataset_type=None, mapped_status=False, focusE_numeric_edge_values=None):
-        """:181-227."""
+        """Store one split (``dataset`` an array, ``dataset_type`` its name) or several (``dataset`` a dict name -> array,
+        edge values then a dict too); ``mapped_status``: the arrays already hold ids.  With mappings present the new
+        splits are mapped at once (numpy_adapter.py:181-227)."""
         if isinstance(dataset, dict):
-            for key in dataset.keys():
-                self._validate_data(dataset[key])
-                self.dataset[key] = dataset[key]
-                self.mapped_status[key] = mapped_status
-                if focusE_numeric_edge_values is not None:
-                    self.focusE_numeric_edge_values[key] = focusE_numeric_edge_values[key]
+            splits = dataset
+            weights = focusE_numeric_edge_values or {}
         elif dataset_type is not None:
-            self._validate_data(dataset)
-            self.dataset[dataset_type] = dataset
-            self.mapped_status[dataset_type] = mapped_status
-            if focusE_numeric_edge_values is not None:
-                self.focusE_numeric_edge_values[dataset_type] = focusE_numeric_edge_values
+            splits = {dataset_type: dataset}
+            weights = {} if focusE_numeric_edge_values is None else {dataset_type: focusE_numeric_edge_values}
         else:
             raise Exception("Incorrect usage. Expected a dictionary or a combination of dataset and it's type.")
-        if not (len(self.rel_to_idx) == 0 or len(self.ent_to_idx) == 0):
+        for name, rows in splits.items():
+            self._validate_data(rows)
+            self.dataset[name] = rows
+            self.mapped_status[name] = mapped_status
+            if focusE_numeric_edge_values is not None:
+                self.focusE_numeric_edge_values[name] = weights[name]
+        if self.rel_to_idx and self.ent_to_idx:
             self.map_data()
 
     def set_filter(self, filter_triples, mapped_status=False):

@@ -184,16 +184,20 @@ def generate_corruptions_for_eval(X, entities_for_corruption, corrupt_side="s,o"
     return obj_block if corrupt_side == "o" else subj_block
 
 
-def check_filter_size(model, corruption_entities):
-    """protocol.py:982-1011."""
-    warn_msg = """You are attempting to use %d distinct entities to generate synthetic negatives in the evaluation
+_POOL_WARNING = """You are attempting to use %d distinct entities to generate synthetic negatives in the evaluation
     protocol. This may be unnecessary and will lead to a 'harder' task. Besides, it will lead to a much slower
     evaluation procedure. We recommended to set the 'corruption_entities' argument to a reasonably sized set
     of entities. The size of corruption_entities depends on your domain-specific task."""
-    size = len(model.ent_to_idx) if corruption_entities is None else len(corruption_entities)
-    if size >= TOO_MANY_ENTITIES_TH:
-        warnings.warn(warn_msg % size)
-        logger.warning(warn_msg, size)
+
+
+def check_filter_size(model, corruption_entities):
+    """Warn when the corruption pool of an evaluation is very large (the reference's message, protocol.py:982-1011):
+    the pool is every entity the model knows unless a subset is given."""
+    pool = model.ent_to_idx if corruption_entities is None else corruption_entities
+    if len(pool) < TOO_MANY_ENTITIES_TH:
+        return
+    warnings.warn(_POOL_WARNING % len(pool))
+    logger.warning(_POOL_WARNING, len(pool))
 
 
 def filter_unseen_entities(X, model, verbose=False):
@@ -212,63 +216,80 @@ def filter_unseen_entities(X, model, verbose=False):
     return X
 
 
+_SIDES = ("s", "o", "s+o", "s,o")
+_STRATEGIES = ("worst", "best", "middle")
+
+
+def _test_adapter(X, model, filter_unseen, verbose):
+    """(adapter holding the mapped 'test' set, whether the caller supplied it).  An array of labels is wrapped in a
+    NumpyDatasetAdapter carrying the model's mappings (protocol.py:879-895); an adapter is used as it is."""
+    from ..datasets import EmgraphBaseDatasetAdaptor, NumpyDatasetAdapter
+    if isinstance(X, EmgraphBaseDatasetAdaptor):
+        return X, True
+    if not isinstance(X, np.ndarray):
+        msg = "X must be either a numpy array or an EmgraphBaseDatasetAdaptor."
+        logger.error(msg)
+        raise ValueError(msg)
+    if filter_unseen:
+        X = filter_unseen_entities(X, model, verbose=verbose)
+    else:
+        logger.warning("If your test set or filter triples contain unseen entities you may get a"
+                       "runtime error. You can filter them by setting filter_unseen=True")
+    adapter = NumpyDatasetAdapter()
+    adapter.use_mappings(model.rel_to_idx, model.ent_to_idx)
+    adapter.set_data(X, "test")
+    return adapter, False
+
+
+def _install_filter(adapter, own_adapter, filter_triples, model, filter_unseen, verbose):
+    """filter_triples: an array of known positives (any test input), or — with a caller-supplied adapter — a bool saying
+    whether the filter already set in that adapter is to be used (protocol.py:897-929)."""
+    if filter_triples is None:
+        return
+    if isinstance(filter_triples, np.ndarray):
+        if filter_unseen:
+            filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
+        adapter.set_filter(filter_triples)
+        model.set_filter_for_eval()
+    elif not own_adapter:
+        raise Exception("Invalid datatype for filter. Expected a numpy array or preset data in the adapter.")
+    elif not isinstance(filter_triples, bool):
+        raise Exception("Expected a boolean type")
+    elif filter_triples:
+        model.set_filter_for_eval()
+
+
 def evaluate_performance(X, model, filter_triples=None, verbose=False, filter_unseen=True, entities_subset=None,
                          corrupt_side="s,o", ranking_strategy="worst", use_default_protocol=False):
-    """protocol.py:726-979.  Ranks of the positives in ``X`` against their corruptions.
+    """Ranks of the positives in ``X`` against their corruptions (the reference's evaluation protocol,
+    protocol.py:726-979; the ranking itself is ``model.get_ranks`` -> emgraph_amd.evaluation.ranking on the GPU).
 
     ``X``: ndarray [n,3] of labels, or an EmgraphBaseDatasetAdaptor holding a mapped 'test' set (then
-    ``filter_triples`` is a bool: True = use the filter already set in the adapter, :923-929).
-    Returns an int ndarray [n] ('s', 'o', 's+o') or [n,2] = [subject_rank, object_rank] ('s,o')."""
-    from ..datasets import EmgraphBaseDatasetAdaptor, NumpyDatasetAdapter
-    dataset_handle = None
-    try:  # the reference's flow, call for call (:868-979); failures clean the adapter up and re-raise (:975-979)
-        if use_default_protocol:
-            logger.warning("DeprecationWarning: use_default_protocol will be removed in future. "
-                           "Please use corrupt_side argument instead.")
-            corrupt_side = "s,o"
-        assert corrupt_side in ["s", "o", "s+o", "s,o"], "Invalid value for corrupt_side."
-        if isinstance(X, np.ndarray):
-            if filter_unseen:
-                X = filter_unseen_entities(X, model, verbose=verbose)
-            else:
-                logger.warning("If your test set or filter triples contain unseen entities you may get a"
-                               "runtime error. You can filter them by setting filter_unseen=True")
-            dataset_handle = NumpyDatasetAdapter()
-            dataset_handle.use_mappings(model.rel_to_idx, model.ent_to_idx)
-            dataset_handle.set_data(X, "test")
-        elif isinstance(X, EmgraphBaseDatasetAdaptor):
-            dataset_handle = X
-        else:
-            msg = "X must be either a numpy array or an EmgraphBaseDatasetAdaptor."
-            logger.error(msg)
-            raise ValueError(msg)
-        if filter_triples is not None:
-            if isinstance(filter_triples, np.ndarray):
-                if filter_unseen:
-                    filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
-                dataset_handle.set_filter(filter_triples)
-                model.set_filter_for_eval()
-            elif isinstance(X, EmgraphBaseDatasetAdaptor):
-                if not isinstance(filter_triples, bool):
-                    raise Exception("Expected a boolean type")
-                if filter_triples is True:
-                    model.set_filter_for_eval()
-            else:
-                raise Exception("Invalid datatype for filter. Expected a numpy array or preset data in the adapter.")
-        eval_dict = {}
+    ``filter_triples`` is a bool: True = use the filter already set in the adapter).
+    Returns an int ndarray [n] ('s', 'o', 's+o') or [n,2] = [subject_rank, object_rank] ('s,o').
+    Whatever fails, the model leaves evaluation mode and an adapter created here is cleaned up before the error
+    propagates (:975-979)."""
+    if use_default_protocol:
+        logger.warning("DeprecationWarning: use_default_protocol will be removed in future. "
+                       "Please use corrupt_side argument instead.")
+        corrupt_side = "s,o"
+    adapter = None
+    try:
+        assert corrupt_side in _SIDES, "Invalid value for corrupt_side."
+        adapter, own_adapter = _test_adapter(X, model, filter_unseen, verbose)
+        _install_filter(adapter, own_adapter, filter_triples, model, filter_unseen, verbose)
         check_filter_size(model, entities_subset)
+        assert ranking_strategy in _STRATEGIES, "Invalid ranking_strategy!"
+        settings = {"corrupt_side": corrupt_side, "ranking_strategy": ranking_strategy}
         if entities_subset is not None:
-            subset = set(entities_subset)
-            eval_dict["corruption_entities"] = np.asarray([idx for uri, idx in model.ent_to_idx.items() if uri in subset])
-        eval_dict["corrupt_side"] = corrupt_side
-        assert ranking_strategy in ["worst", "best", "middle"], "Invalid ranking_strategy!"
-        eval_dict["ranking_strategy"] = ranking_strategy
-        model.configure_evaluation_protocol(eval_dict)
-        ranks = model.get_ranks(dataset_handle)
+            wanted = set(entities_subset)
+            settings["corruption_entities"] = np.asarray([i for label, i in model.ent_to_idx.items() if label in wanted])
+        model.configure_evaluation_protocol(settings)
+        ranks = np.array(model.get_ranks(adapter))
+    except BaseException:
         model.end_evaluation()
-        return np.array(ranks)
-    except BaseException as e:
-        model.end_evaluation()
-        if dataset_handle is not None:
-            dataset_handle.cleanup()
-        raise e
+        if adapter is not None:
+            adapter.cleanup()
+        raise
+    model.end_evaluation()
+    return ranks

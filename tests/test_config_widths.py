@@ -66,13 +66,24 @@ def _hyper(lr, step):
 @pytest.mark.parametrize("kind", ["uniform", "zipf"])
 @pytest.mark.parametrize("cfg", list(CONFIGS))
 def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
+    _check_step_vs_oracle(cfg, kind, 20000 if kind == "uniform" else 2000, 512)
+
+
+# BASELINE.json's configurations at their EXACT shapes (C1 WN11 |E| = 38 600 (literature) / 11 relations,
+# B = ceil(110361 / 64) = 1725; C2 FB15k-237 14 541 / 237, B = ceil(272115 / 100) = 2722; C5 FB15k 14 951 / 1 345,
+# B = ceil(483142 / 100) = 4832), eta and optimizer as configured: the default product step against the oracle
+@pytest.mark.parametrize("cfg,n_ent,B", [("C1", 38600, 1725), ("C2", 14541, 2722), ("C5", 14951, 4832)])
+def test_fused_inplace_step_vs_oracle_at_baseline_shape(cfg, n_ent, B):
+    _check_step_vs_oracle(cfg, "uniform", n_ent, B, expect_singletons=None)
+
+
+def _check_step_vs_oracle(cfg, kind, n_ent, B, expect_singletons="by kind"):
     from emgraph_amd import _lib as L
     from emgraph_amd import device as d
     from emgraph_amd.training import Trainer, alloc_table
     d.require_gpu()
     model, k, eta, loss, opt, n_rel = CONFIGS[cfg]
-    n_ent = 20000 if kind == "uniform" else 2000
-    B, seed = 512, 3
+    seed = 3
     lr = 0.1 if opt == "sgd" else 0.01     # SGD: a large step keeps the table's own fp32 rounding below the 1e-4 bar
     ki = 2 * k if model in ("ComplEx", "HolE") else k
     sc = float(F32(2 / k)) if model == "HolE" else 1.0
@@ -120,10 +131,11 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
                            [t.cpu().numpy().copy() for t in sr if t is not None]))
         np.testing.assert_array_equal(codes.cpu().numpy(), co.corrupt_codes(B, eta, 2, n_ent, seed, step - 1))
     # both data-movement paths are exercised where the test says so
-    if kind == "uniform":
-        assert min(n_single) > 0.3 * n_ce, n_single
-    else:
-        assert max(n_single) < 0.3 * n_ce, n_single
+    if expect_singletons is not None:
+        if kind == "uniform":
+            assert min(n_single) > 0.3 * n_ce, n_single
+        else:
+            assert max(n_single) < 0.3 * n_ce, n_single
 
     # ---------------- oracle ----------------
     E, R = E0.copy(), R0.copy()
@@ -159,8 +171,13 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
             np.testing.assert_allclose(sr_np[0], stR["m"], rtol=1e-4, atol=1e-6 * gR)
             np.testing.assert_allclose(se_np[1], stE["v"], rtol=2e-4, atol=1e-8 * gE * gE)
             np.testing.assert_allclose(sr_np[1], stR["v"], rtol=2e-4, atol=1e-8 * gR * gR)
-            np.testing.assert_allclose(dE_t, E, rtol=0, atol=1e-2 * lr)
-            np.testing.assert_allclose(dR_t, R, rtol=0, atol=1e-2 * lr)
+            # the table itself: Adam's normalised step m / (sqrt(v) + eps) amplifies the last bit of a gradient that is
+            # (nearly) zero by cancellation — there its sign is rounding noise, in the oracle's arithmetic as much as here,
+            # and the step may differ by up to Adam's largest step (~3.2 lr at step 1); everywhere else 1e-2 lr
+            for got_t, want_t, g_t, g_max in ((dE_t, E, dE, gE), (dR_t, R, dR, gR)):
+                solid = np.abs(g_t) > 1e-4 * g_max
+                np.testing.assert_allclose(got_t[solid], want_t[solid], rtol=0, atol=1e-2 * lr)
+                np.testing.assert_allclose(got_t[~solid], want_t[~solid], rtol=0, atol=7.0 * lr)
         elif opt == "momentum":
             np.testing.assert_allclose(se_np[0], stE["m"], rtol=1e-4, atol=1e-5 * gE * lr)
             np.testing.assert_allclose(sr_np[0], stR["m"], rtol=1e-4, atol=1e-5 * gR * lr)
@@ -171,7 +188,7 @@ def test_fused_inplace_step_vs_oracle_at_config_width(cfg, kind):
             np.testing.assert_allclose(dE_t, E, rtol=0, atol=1e-2 * lr)
     # rows no triple of either batch touched: bit-identical (Adam's dense-equivalent decay of an all-zero state
     # subtracts lr_t * 0 / (0 + eps) = 0)
-    assert never_e.any() or kind == "zipf"
+    assert never_e.any() or kind == "zipf" or expect_singletons is None
     np.testing.assert_array_equal(dev_tables[1][0][never_e], E0[never_e])
 
     # ---------------- the product's Trainer (fused + in-place + pipelined plan) == the sequence above, bitwise ----

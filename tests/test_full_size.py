@@ -333,3 +333,60 @@ def test_transe_l2_exact_fast_ranking_full_size_equals_exact(world):
     auto = rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F, precision="auto", stats=st)
     np.testing.assert_array_equal(auto, rank_triples_device(L.TRANSE_L2, ent_t, rel_t, k, 1.0, T, "s,o", "worst", filter_triples=F))
     assert st.get("pairs", 0) > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# the ORACLE at |E| = 1M: the C restatement's canonical chain (oracle/emg_oracle.c: orc_count / orc_filter_count, which
+# restate EmbeddingModel.py:1845-2033) for 16 test triples = 32 query rows against all 1M entities, compared bit for bit
+# with the device path in its exact (precision 0) and exact-fast (precision 2) forms, sides 's+o' and 's,o', filtered
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,k_int", [("ComplEx", K_INT), ("TransE_L1", K), ("TransE_L2", K)])
+def test_ranks_equal_c_oracle_at_one_million_entities(world, model, k_int):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex, build_filter_csr, rank_triples_device, ranks_from_counts
+    from oracle import c_oracle as co
+    ent, rel, _, pos = world
+    mid = {"ComplEx": L.COMPLEX, "TransE_L1": L.TRANSE_L1, "TransE_L2": L.TRANSE_L2}[model]
+    # TransE: the first k columns of the same tables (16-byte aligned rows, stride K_INT)
+    ent_m, rel_m = ent[:, :k_int], rel[:, :k_int]
+    E, R = ent_m.cpu().numpy(), rel_m.cpu().numpy()
+    n_oracle, n_dev = 16, 160              # the device ranks 160 triples (the exact-fast path wants >= 128); the oracle the first 16
+    T = pos[:n_dev].copy()
+    T[1] = T[0]                            # duplicates and a shared (s, p): non-trivial filter lists
+    T[3, :2] = T[2, :2]
+    Fil = np.concatenate([pos[:4096], T])
+    F = FilterIndex(Fil)
+    for side, mode in (("s+o", L.EVAL_SPO), ("s,o", L.EVAL_S_O)):
+        Q, pos_int = co.build_queries(mid, E, R, k_int, 1.0, T[:n_oracle], mode)
+        gt, eq = co.count(mid, Q, pos_int, E, k_int, 1.0)
+        ptr, idx = build_filter_csr(Fil, T[:n_oracle], mode, N_ENT)
+        fgt, feq = co.filter_count(mid, Q, pos_int, E, 0, k_int, 1.0, ptr, idx)
+        for strategy in ("worst", "middle"):
+            want = ranks_from_counts(gt, eq, fgt, feq, n_oracle, side, strategy)
+            for precision in (0, 2):
+                got = rank_triples_device(mid, ent_m, rel_m, k_int, 1.0, T, side, strategy, filter_triples=F, precision=precision)
+                np.testing.assert_array_equal(got[:n_oracle], want, err_msg="%s %s %s precision %d" % (model, side, strategy, precision))
+
+
+def test_scores_relative_error_on_well_conditioned_triples(world):
+    """north_star's bar as worded — fp32 scores within 1e-4 RELATIVE — on the triples where |score| is a meaningful
+    denominator (|score| >= 0.1 * sum |terms|: no catastrophic cancellation); printed for the record.  (The general bar,
+    1e-4 * sum |terms|, is what test_scores_full_size_two_paths_and_f64 and tests/test_hip_kernels.py::score_tol assert.)"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    ent, rel, _, pos = world
+    # planted triples: the object's row pulled towards the query so that the score is large relative to its terms
+    Tt = torch.from_numpy(pos[:4096]).cuda()
+    Q, _ = d.eval_build_queries(L.COMPLEX, ent, rel, K_INT, 1.0, Tt, L.EVAL_O)
+    o = Tt[:, 2].long()
+    ent2 = ent.clone()
+    qh = Q[:, :K_INT] / Q[:, :K_INT].norm(dim=1, keepdim=True)
+    ent2[o, :K_INT] = 0.6 * ent2[o, :K_INT] + 0.8 * ent2[o, :K_INT].norm(dim=1, keepdim=True) * qh
+    got = d.score_triples(L.COMPLEX, ent2, rel, K_INT, 1.0, Tt).double()
+    val, mag = complex_score_f64(ent2, rel, Tt)
+    well = val.abs() >= 0.1 * mag
+    assert int(well.sum()) >= 1000, int(well.sum())
+    rel_err = ((got - val).abs() / val.abs())[well]
+    print("ComplEx k=200, |E|=1M: %d well-conditioned triples, max relative score error %.3g, median %.3g"
+          % (int(well.sum()), float(rel_err.max()), float(rel_err.median())))
+    assert float(rel_err.max()) <= 1e-4
