@@ -475,8 +475,6 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             if have_cands:
                 fcount(torch.from_numpy(ptr).to(ent.device, non_blocking=True),
                        torch.from_numpy(idx).to(ent.device, non_blocking=True))
-        if world > 1:
-            parallel.allreduce_sum_(cnt)
         pending.append((cnt, nq, precision == 1 and strategy != "middle", pre))
     out = []
     for cnt, nq, single, pre in pending:
@@ -486,10 +484,14 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
                 stats["pairs"] = stats.get("pairs", 0) + (0 if over else n_pairs)
                 stats["fallback"] = stats.get("fallback", 0) + int(bool(over))
             if over:   # too many undecided candidates for the pair buffer: this tile again, by the exact kernel
-                if world > 1:
-                    raise RuntimeError("prefilter pair buffer overflow under sharded evaluation: use precision=0")
                 cnt[0:2].zero_()
                 pre[1]()
+        if world > 1:
+            # range-sharded evaluation: the counters of this rank's candidate range are exact now (an overflowing tile has
+            # been redone locally — a rank whose range did not overflow has nothing to redo), so the sum over the ranks is
+            # taken HERE, after the overflow check: every rank issues the same collectives in the same order whatever
+            # its own flags said (a fresh Glorot table leaves every candidate undecided: overflow is a normal state)
+            parallel.allreduce_sum_(cnt)
         c = cnt.cpu().numpy().astype(np.int64)
         if single:
             c[1] = 0  # single-counter mode: c[0] already is what the strategy reads (see `need` above)

@@ -220,3 +220,29 @@ def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt):
     m.fit(X[:803])       # 803 rows / 3 batches = 268 per batch (last one 267): odd splits over two ranks
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
              pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes))
+
+
+def sharded_overflow_worker(rank, world, out_dir):
+    """range-sharded exact-fast ranking whose pair buffer OVERFLOWS on every rank (a tiny-norm table: every candidate's
+    comparison integer is 0, every candidate is undecided): each rank redoes its tile with the exact kernel before the
+    counters are summed, and the ranks equal the single-process exact ranks"""
+    import torch
+
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import rank_triples_device
+    from emgraph_amd.training import alloc_table
+    torch.cuda.set_device(0)
+    rs = np.random.RandomState(2)
+    n_ent, n_rel, k = 40000, 5, 64
+    E = (rs.randn(n_ent, 2 * k) * 1e-4).astype(F32)      # scores ~1e-7: int(score * 1e5) == 0 for every candidate
+    R = (rs.randn(n_rel, 2 * k) * 1e-4).astype(F32)
+    dev0 = torch.device("cuda")
+    ent, rel = alloc_table(n_ent, 2 * k, dev0, init=E), alloc_table(n_rel, 2 * k, dev0, init=R)
+    T = np.stack([rs.randint(0, n_ent, 160), rs.randint(0, n_rel, 160), rs.randint(0, n_ent, 160)], 1).astype(np.int32)
+    st = {}
+    got = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision=2,
+                              shard=(rank, world), stats=st)
+    auto = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision="auto",
+                               shard=(rank, world))
+    want = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision=0)
+    np.savez(os.path.join(out_dir, "res_%d.npz" % rank), got=got, auto=auto, want=want, fallback=st.get("fallback", 0))

@@ -156,6 +156,18 @@ def test_sharded_fit_and_eval_two_ranks_match_single_process(tmp_path, name, los
 
 
 @pytest.mark.gpu
+def test_sharded_exact_fast_ranking_survives_pair_buffer_overflow(tmp_path):
+    """the default evaluation precision under world > 1 (it raised where the single-GPU path falls back, and a rank
+    raising alone left the others in a collective): overflow on every rank -> exact kernel locally -> all-reduce"""
+    _spawn(W.sharded_overflow_worker, 2, tmp_path)
+    res = [np.load(os.path.join(tmp_path, "res_%d.npz" % r)) for r in range(2)]
+    for r in res:
+        assert int(r["fallback"]) >= 1, "the test is meant to overflow the pair buffer"
+        np.testing.assert_array_equal(r["got"], r["want"])
+        np.testing.assert_array_equal(r["auto"], r["want"])
+
+
+@pytest.mark.gpu
 def test_rccl_single_rank_collectives_run(tmp_path):
     """RCCL itself (backend "nccl" on ROCm) on this box: a one-rank process group is all a single GPU allows — two
     ranks cannot share a device under RCCL, which is why the two-rank GPU tests above stage their collectives through
