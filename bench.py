@@ -51,6 +51,14 @@ WORKLOADS = {
                 desc="C3 at B=131072 (SURVEY 8d's second batch size)", resident=8),
     "C3p": dict(model="TransE", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
                 desc="C3': TransE-L1 k=200 eta=20 on the |E|=1M table (north_star's HBM-roofline target kernel)"),
+    "C3m": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="multiclass_nll", optimizer="sgd",
+                desc="C3 with the multiclass-NLL loss (softmax over a positive's negatives: forward | loss | backward kernels)"),
+    "C3s": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="self_adversarial", optimizer="sgd",
+                desc="C3 with the self-adversarial loss (forward | loss | backward kernels)"),
+    "C3r": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
+                reg={"lambda": 1e-5, "p": 2},
+                desc="C3 with the LP regulariser (p = 2) folded into the optimizer step: every gradient row through the apply "
+                     "kernel + one dense pass over the untouched rows"),
     "C2": dict(model="DistMult", k=200, eta=10, n_ent=14541, n_rel=237, B=2722, loss="nll", optimizer="adam",
                desc="DistMult k=200 eta=10 NLL Adam, FB15k-237-shaped, B=2722 (batches_count=100)"),
     "C1": dict(model="TransE", k=100, eta=20, n_ent=38600, n_rel=11, B=1725, loss="pairwise", optimizer="adam",
@@ -163,6 +171,7 @@ class StepRunner:
                           optimizer=w["optimizer"] if not (self.sharding == "batch" and w["optimizer"] == "adam") else "adam_lazy",
                           optimizer_params={"lr": 0.0005}, batches_count=self.nb, seed=0, fused=not args.no_fused,
                           inplace=not args.no_inplace, pipeline=not args.no_pipeline,
+                          regularizer="LP" if w.get("reg") else None, regularizer_params=w.get("reg"),
                           sharded=(self.sharding if self.sharding == "batch" else bool(self.sharding)))
         self.tr.set_training_set(self.X, self.B)
         self.i = 0
@@ -241,6 +250,39 @@ class StepRunner:
         torch.cuda.synchronize()
         del self.tr
         torch.cuda.empty_cache()
+
+
+def hbm_ceilings():
+    """tools/hbm_ceiling (a standalone HIP program, built by __graft_entry__.build()): what this box's HBM delivers for
+    the access mixes of the step — float4 copy, row gather, in-place row read-modify-write, and the fused kernel's own mix
+    (23 random 1600-byte rows read per group, 16 written back in place, 5 streamed out).  Run as a child process BEFORE
+    the timed region; None if the binary is missing."""
+    exe = os.path.join(ROOT, "tools", "hbm_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, timeout=120, check=True).stdout.decode()
+        return json.loads(out)
+    except (subprocess.SubprocessError, ValueError, OSError):
+        return None
+
+
+def profiled_avg_us(kernel_substr, tag_glob="r3_*_kernel_stats.md"):
+    """average duration (us) of a kernel in the newest committed rocprofv3 --kernel-trace --stats table of THIS workload
+    (profiles/): printed next to the live HIP-event figure so that `frac` can be re-derived from profiles/ alone"""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob))):
+        for line in open(fn):
+            if kernel_substr in line and line.startswith("|"):
+                cells = [c.strip() for c in line.strip().strip("|").split("|")]
+                try:
+                    best = {"file": "profiles/" + os.path.basename(fn), "kernel": cells[0], "calls": int(cells[1]), "avg_us": float(cells[3]),
+                            "min_us": float(cells[4])}
+                except (ValueError, IndexError):
+                    pass
+                break
+    return best
 
 
 def copy_rate(torch):
@@ -386,6 +428,12 @@ def run_eval(r, args):
                      "undecided_pairs": stf.get("pairs", 0), "undecided_fraction": round(stf.get("pairs", 0) / (n_ranks * w["n_ent"] / world), 6),
                      "tiles_redone_by_exact_kernel": stf.get("fallback", 0), "kernel_ms": round(stf["count_ms"], 3),
                      "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
+    # what the API call pays when nothing is cached (get_ranks / early stopping pass no tables: the half-precision copy, the
+    # norm bounds and the range are rebuilt inside the call) — the figures above build them once per evaluation run, outside
+    ru, dtu, _ = timed(T, precision=2)
+    assert np.array_equal(ru, ranks)
+    ex["planted_positives"]["uncached_tables"] = {"value": round(n_ranks / dtu, 1), "unit": "ranks/s", "seconds": round(dtu, 4),
+                                                  "note": "same call with ent_f16=None: the derived tables are rebuilt inside the timed region"}
     out["exact_fast"] = ex
     out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
                               "DistMult / ComplEx / HolE at k_int in 33..400 and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 (any k) and TransE-L2 (k + 2 <= 400), "
@@ -474,9 +522,21 @@ def run_eval(r, args):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(r, args):
-    """The oracle's fused C port (OpenMP, all host cores) on a bounded sample of the same workload:
-    forward scoring of B*(1+eta) triples per batch.  A reported baseline, not the target."""
+    """The CPU baseline: oracle/emg_cpu_fast.c — an OPTIMISED C/OpenMP forward pass (hoisted query vectors, SIMD
+    reductions, software prefetch; rebuilt with -march=native on this host) — on all host cores over a bounded sample of
+    the same workload: forward scoring of B*(1+eta) triples per batch.  A reported baseline, not the target.  The
+    order-pinned bit-exactness checker (emg_oracle.c, -O2 -ffp-contract=off) is timed beside it for reference."""
     from oracle import c_oracle as co
     w = r.w
     B, eta, k_int = r.B, r.eta, r.k_full
@@ -485,21 +545,32 @@ def cpu_baseline(r, args):
     nb = max(1, min(args.cpu_batches, len(X) // B))
     co.lib()
     codes = [co.corrupt_codes(B, eta, 2, w["n_ent"], 0, i) for i in range(nb)]
-    co.train_forward(mid, r.ent0, r.rel0, k_int, r.scale, X[:256], eta, codes[0][:256 * eta])  # warm
-    t0 = time.perf_counter()
-    done = 0
-    while True:  # cycle over the sample's batches until ~args.cpu_seconds of CPU work has been timed
-        for i in range(nb):
-            co.train_forward(mid, r.ent0, r.rel0, k_int, r.scale, X[i * B:(i + 1) * B], eta, codes[i])
-        done += nb
-        if time.perf_counter() - t0 >= args.cpu_seconds:
-            break
-    dt = time.perf_counter() - t0
-    out = {"value": round(done * B * (1 + eta) / dt, 1), "unit": "triples scored/s", "cores": co.num_threads(),
-           "kind": "port", "sample": "%d passes over %d batches of B=%d (%d triples scored), fused C/OpenMP "
-           "gather+score (forward only), same tables" % (done // nb, nb, B, done * B * (1 + eta)),
+
+    def timed(fn, seconds):
+        fn(mid, r.ent0, r.rel0, k_int, r.scale, X[:256], eta, codes[0][:256 * eta])  # warm
+        t0 = time.perf_counter()
+        done = 0
+        while True:  # cycle over the sample's batches until ~seconds of CPU work has been timed
+            for i in range(nb):
+                fn(mid, r.ent0, r.rel0, k_int, r.scale, X[i * B:(i + 1) * B], eta, codes[i])
+            done += nb
+            if time.perf_counter() - t0 >= seconds:
+                break
+        return done, time.perf_counter() - t0
+
+    done, dt = timed(co.fast_train_forward, args.cpu_seconds)
+    fast = co.fast_lib()
+    out = {"value": round(done * B * (1 + eta) / dt, 1), "unit": "triples scored/s", "cores": int(fast.cpufast_num_threads()),
+           "kind": "port", "cpu": cpu_model(),
+           "build": os.path.basename(fast._so) + (" (-O3 -march=native, omp simd)" if "native" in fast._so else " (-O3 -march=x86-64-v3, omp simd)"),
+           "sample": "%d passes over %d batches of B=%d (%d triples scored), optimised C/OpenMP gather+score (forward only: "
+           "hoisted query vectors, SIMD reductions, prefetch), same tables" % (done // nb, nb, B, done * B * (1 + eta)),
            "seconds": round(dt, 3)}
-    # second figure: the literal op-by-op numpy restatement (3 materialised gathers + elementwise passes, one
+    done2, dt2 = timed(co.train_forward, min(3.0, args.cpu_seconds))
+    out["bit_exact_checker"] = {"value": round(done2 * B * (1 + eta) / dt2, 1), "unit": "triples scored/s",
+                                "note": "oracle/emg_oracle.c (order-pinned scalar reduction, -O2 -ffp-contract=off): the parity checker, "
+                                        "not a performance baseline", "seconds": round(dt2, 3)}
+    # the literal op-by-op numpy restatement (3 materialised gathers + elementwise passes, one
     # thread) — the closest stand-in for the reference's TF-eager-CPU graph; bounded to ~2e5 triples
     from oracle import emgraph_oracle as orc
     Bs = min(B, 8192)
@@ -546,6 +617,7 @@ def main():
     ap.add_argument("--no-inplace", action="store_true", help="A/B: every gradient row through the contribution buffer")
     ap.add_argument("--no-pipeline", action="store_true", help="A/B: batch preparation on the compute stream")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip tools/hbm_ceiling (the box's measured HBM ceilings)")
     args = ap.parse_args()
     if args.quick:
         args.no_others, args.sustained_seconds = True, 0.0
@@ -567,6 +639,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if os.environ.get("EMG_BENCH_ONE_DEVICE") else "nccl")
 
+    ceilings = hbm_ceilings() if (rank == 0 and not args.no_ceilings) else None   # (a child process; also brings the clocks up)
     r = StepRunner(args.workload, args, rank, world, sharding=args.sharding, batch=args.batch)
     w = r.w
     r.run(args.warmup)
@@ -581,8 +654,10 @@ def main():
         "timed_seconds": head["seconds"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload + ": " + w["desc"],
-                   "step": ("one emg_plan_step call: corrupt+group (2 batches ahead, side streams) | fused score+loss+grad "
-                            "(+in-place singleton SGD) | segmented apply (entities || relations)" if r.tr.plan is not None else
+                   "step": (("graph replay (emg_plan_run): fused score+loss+grad (+in-place singleton update) | descriptor-driven apply of both "
+                             "tables; the next batches' corrupt+group stages ride at the front of the two launches" if getattr(r.tr, "graph", False) else
+                             "one emg_plan_step call: corrupt+group (counting sort, 2 batches ahead, side streams) | fused score+loss+grad "
+                             "(+in-place singleton SGD) | descriptor-driven apply (entities + relations, one launch)") if r.tr.plan is not None else
                             "host-driven: corrupt+group | scores | collective | loss | gradients | apply"),
                    "B_per_gpu": r.B0, "global_batch": r.B, "eta": r.eta, "k_int": r.k_full,
                    "k_int_per_gpu": r.k_local, "n_ent": w["n_ent"], "n_rel": w["n_rel"], "resident_batches": r.nb,
@@ -605,16 +680,28 @@ def main():
         ach = stages[dom]["GBps"]
         traffic, src = pmc_traffic(dom, args.workload, r.B, world, args)
         line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "copy_rate_measured": round(copy_rate(torch), 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": traffic, "traffic_source": src,
-                            "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"]}
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                            "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["ms"],
+                            "avg_launch_ms_source": "HIP events around the launch on its stream, 16 instrumented steps of this run",
+                            "copy_rate_torch": round(copy_rate(torch), 1)}
+        if ceilings:   # this box's measured ceilings for the kernel's access mix (tools/hbm_ceiling.hip)
+            line["roofline"]["ceilings_GBps"] = {k: ceilings[k] for k in ("copy4_wg16384_GBps", "copy4_nt_GBps", "read4_GBps", "write4_GBps",
+                                                                          "gather_rows_u4_GBps", "rmw_rows_u4_GBps", "mix23_GBps", "mix23_nt_GBps") if k in ceilings}
+            if dom == "fused" and "mix23_nt_ms" in ceilings:
+                line["roofline"]["mix_ceiling"] = {"what": "the fused kernel's own access mix as a bare microkernel (23 random 1600-B rows read per "
+                                                   "group, 16 written back in place, 5 streamed out non-temporally), same byte count",
+                                                   "ms": ceilings["mix23_nt_ms"], "frac_of_mix_ceiling": round(ceilings["mix23_nt_ms"] / stages[dom]["ms"], 4)}
+        prof = profiled_avg_us("train_fused_riders_kernel<3, 4, 1, 64, 1>" if dom == "fused" else "apply_segments_kernel")
+        if prof and args.workload == "C3":
+            line["roofline"]["profiled"] = dict(prof, frac=round(stages[dom]["alg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                note="rocprofv3 --kernel-trace --stats of `bench.py --no-others --no-eval` (this workload only), committed")
     if not args.no_eval:
         line["eval"] = run_eval(r, args)                           # every rank takes part (range-sharded candidates)
     cpu = cpu_baseline(r, args) if (rank == 0 and world == 1 and not args.no_cpu) else None
     r.close()
     if not args.no_others and world == 1 and args.workload == "C3":
         others = {}
-        for name in ("C3z", "C3b", "C3p", "C1", "C2", "C5"):
+        for name in ("C3z", "C3b", "C3p", "C3m", "C3s", "C3r", "C1", "C2", "C5"):
             ro = StepRunner(name, args, rank, world)
             ro.run(20)
             n = 300 if name != "C3b" else 60

@@ -48,16 +48,32 @@ def create_mappings_and_index(X):
     return rel_to_idx, ent_to_idx, X_idx
 
 
-_LOOKUP_CACHE = []   # [(mapping, len, sorted keys, their ids, direct table or None)]: the last few dictionaries looked up
+import weakref
+
+# sorted key / id tables of the label dictionaries most recently looked up, keyed by the dictionary's identity.  Held
+# WEAKLY where the dictionary allows it (so a deleted model's 1M-entity tables go with it) and validated by size plus a
+# fingerprint of the first / last items (a dictionary changed in place between two calls is rebuilt, not trusted).
+_LOOKUP_CACHE = []   # [(ref or dict, len, fingerprint, sorted keys, their ids, direct table or None)]
+
+
+def _fingerprint(mapping):
+    it = iter(mapping.items())
+    first = next(it, None)
+    last = next(reversed(mapping.items()), None) if first is not None else None
+    return (first, last)
 
 
 def _lookup_tables(mapping):
     """sorted key / id arrays of a label dictionary (+ a direct label -> id table for dense non-negative integer labels),
     remembered for the dictionaries most recently used: evaluate_performance maps the test set and the (large) filter
     set through the same two dictionaries every call."""
-    for ent in _LOOKUP_CACHE:
-        if ent[0] is mapping and ent[1] == len(mapping):
-            return ent[2], ent[3], ent[4]
+    fp = _fingerprint(mapping)
+    for ent in list(_LOOKUP_CACHE):
+        held = ent[0]() if isinstance(ent[0], weakref.ReferenceType) else ent[0]
+        if held is None:
+            _LOOKUP_CACHE.remove(ent)
+        elif held is mapping and ent[1] == len(mapping) and ent[2] == fp:
+            return ent[3], ent[4], ent[5]
     keys = np.array(list(mapping.keys()))
     vals = np.fromiter(mapping.values(), dtype=np.int64, count=len(mapping))
     order = np.argsort(keys, kind="stable")
@@ -66,7 +82,11 @@ def _lookup_tables(mapping):
     if skeys.dtype.kind in "iu" and len(skeys) and int(skeys[0]) >= 0 and int(skeys[-1]) < 8 * len(skeys) + 1024:
         table = np.full(int(skeys[-1]) + 1, -1, dtype=np.int64)
         table[skeys] = svals
-    _LOOKUP_CACHE.insert(0, (mapping, len(mapping), skeys, svals, table))
+    try:
+        holder = weakref.ref(mapping)
+    except TypeError:       # a plain dict cannot be weakly referenced: keep it (at most 4 entries live here)
+        holder = mapping
+    _LOOKUP_CACHE.insert(0, (holder, len(mapping), fp, skeys, svals, table))
     del _LOOKUP_CACHE[4:]
     return skeys, svals, table
 
@@ -87,6 +107,14 @@ def _lookup(col, mapping):
         ids = table[np.where(inside, col, 0)]
         ok = inside & (ids >= 0)
         return np.where(ok, ids, 0), ok
+    if skeys.dtype.kind in "iu" and col.dtype.kind in "iu" and skeys.dtype != col.dtype:
+        # mixed integer types (int64 labels looked up with uint32 ids, ...): compare as int64, never through float64
+        if (col.dtype.kind == "u" and col.size and int(col.max()) > np.iinfo(np.int64).max) or \
+                (skeys.dtype.kind == "u" and int(skeys[-1]) > np.iinfo(np.int64).max):
+            got = [mapping.get(v) for v in col.tolist()]
+            ok = np.array([g is not None for g in got], dtype=bool)
+            return np.array([g if g is not None else 0 for g in got], dtype=np.int64), ok
+        skeys, col = skeys.astype(np.int64), col.astype(np.int64)
     pos = np.searchsorted(skeys, col)
     pos_c = np.minimum(pos, len(skeys) - 1)
     ok = skeys[pos_c] == col

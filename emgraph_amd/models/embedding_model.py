@@ -540,8 +540,13 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                          alloc_table(rel.shape[0], rel.shape[1], torch.device("cuda"), init=rel))
         return self._dev
 
-    def predict(self, X, from_idx=False, chunk=1 << 22):
-        """Scores of the triples X (EmbeddingModel.py:2101-2186)."""
+    def predict(self, X, from_idx=False, chunk=1 << 22, sharded=False):
+        """Scores of the triples X (EmbeddingModel.py:2101-2186).
+
+        ``sharded=True`` (multi-GPU, one process per GPU): a COLLECTIVE — every rank must call it with the same X; rank r
+        scores the r-th contiguous range of the list and the ranges are summed into place.  The default is rank-local
+        (every rank scores everything it is given), so `if rank == 0: model.predict(...)` and models restored in one
+        process of a distributed job work as on a single GPU."""
         if not self.is_fitted:
             msg = "Model has not been fitted."
             logger.error(msg)
@@ -559,7 +564,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
         out = np.zeros(X.shape[0], dtype=np.float32)
         # multi-GPU (one process per GPU, tables replicated): rank r scores the r-th contiguous range of the triple
         # list and the ranges are summed into place (predict shards trivially, no data-path exchange)
-        rank, world = parallel.rank_world()
+        rank, world = parallel.rank_world() if sharded else (0, 1)
         r0, r1 = parallel.entity_range(X.shape[0], rank, world)
         for c0 in range(r0, r1, chunk):  # SURVEY A-17: chunk instead of one giant gather
             c1 = min(c0 + chunk, r1)

@@ -106,3 +106,41 @@ def filter_count(model, Q, pos_int, ent, ent_offset, k_int, scale, fptr, fidx):
                            C.c_int64(ent.shape[0]), C.c_int64(ent.shape[1]), C.c_int64(ent_offset), C.c_int32(k_int),
                            C.c_float(scale), _f(fptr), _f(fidx), _f(gt), _f(eq))
     return gt, eq
+
+
+# ---- the CPU baseline of bench.py (oracle/emg_cpu_fast.c): optimised, not order-pinned -------------------------------
+_fast = None
+FAST_SO = os.path.join(_HERE, "_build", "libemg_cpufast.so")
+FAST_NATIVE_SO = os.path.join(_HERE, "_build", "libemg_cpufast_native.so")
+
+
+def fast_lib(native=True):
+    """the optimised CPU baseline; ``native``: try to rebuild it with -march=native for THIS host first (a few seconds of
+    gcc), falling back to the portable AVX2 + FMA build"""
+    global _fast
+    if _fast is None:
+        so = FAST_SO
+        if native:
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                so = FAST_NATIVE_SO
+            except (subprocess.CalledProcessError, OSError):
+                pass
+        if so == FAST_SO and not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _fast = C.CDLL(so)
+        _fast.cpufast_num_threads.restype = C.c_int
+        _fast._so = so
+    return _fast
+
+
+def fast_train_forward(model, ent, rel, k_int, scale, pos, eta, codes, native=True):
+    ent, rel, pos = _c(ent, np.float32), _c(rel, np.float32), _c(pos, np.int32)
+    B = pos.shape[0]
+    sp = np.empty(B, np.float32)
+    sn = np.empty(B * eta, np.float32)
+    codes = _c(codes, np.int32) if eta else np.zeros(1, np.int32)
+    fast_lib(native).cpufast_train_forward(C.c_int(model), _f(ent), C.c_int64(ent.shape[1]), _f(rel), C.c_int64(rel.shape[1]),
+                                           C.c_int32(k_int), C.c_float(scale), _f(pos), C.c_int64(B), C.c_int32(eta), _f(codes),
+                                           _f(sp), _f(sn))
+    return sp, sn

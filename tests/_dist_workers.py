@@ -145,7 +145,7 @@ def sharded_fit_worker(rank, world, out_dir, name, loss, opt):
         extra["ranks_bf16_single"] = rank_triples_device(mid, ent, rel, k_int, sc, Xi, "s,o", "worst",
                                                          filter_triples=X.astype(np.int32), precision=1)
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
-             ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:]), **extra)
+             ranks=ranks, ranks_sub=ranks_sub, pred=m.predict(X[800:], sharded=True), pred_local=m.predict(X[800:]), **extra)
 
 
 def batch_exchange_worker(rank, world, out_dir):

@@ -335,3 +335,25 @@ def test_model_selection_call_contract():
     ranks = np.stack([np.arange(25) % 5 + 2, np.arange(25) % 3 + 2], 1)     # what the recorder returned for k = 8
     assert mrr_score(ranks) == pytest.approx(doc["test_evaluation"]["mrr"]) and mr_score(ranks) == doc["test_evaluation"]["mr"]
     assert hits_at_n_score(ranks, n=3) == doc["test_evaluation"]["hits_3"]
+
+
+@pytest.mark.parametrize("model", ["TransE_L1", "TransE_L2", "DistMult", "ComplEx", "HolE"])
+def test_cpu_baseline_agrees_with_the_checker(model):
+    """oracle/emg_cpu_fast.c — the OPTIMISED CPU leg bench.py times as cpu_baseline (SIMD reductions, hoisted query
+    vectors) — computes the same scores as the order-pinned checker (oracle/emg_oracle.c) up to fp32 reassociation, at
+    the benchmark's width (k = 200) and at an odd width"""
+    rs = np.random.RandomState(3)
+    for k in (200, 37):
+        n_ent, n_rel, B, eta = 3000, 7, 257, 5
+        ki = 2 * k if model in ("ComplEx", "HolE") else k
+        mid = orc.MODEL_IDS[model]
+        sc = float(F32(2 / k)) if model == "HolE" else 1.0
+        E = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+        R = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+        X = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+        codes = co.corrupt_codes(B, eta, 2, n_ent, 5, 9)
+        sp, sn = co.train_forward(mid, E, R, ki, sc, X, eta, codes)
+        fp, fn = co.fast_train_forward(mid, E, R, ki, sc, X, eta, codes, native=False)
+        mag = np.abs(E).max() ** 2 * np.abs(R).max() * ki if not model.startswith("TransE") else np.abs(sp).max()
+        np.testing.assert_allclose(fp, sp, rtol=1e-4, atol=1e-5 * mag)
+        np.testing.assert_allclose(fn, sn, rtol=1e-4, atol=1e-5 * mag)

@@ -132,6 +132,8 @@ def test_sharded_fit_and_eval_two_ranks_match_single_process(tmp_path, name, los
     res = [np.load(os.path.join(tmp_path, "res_%d.npz" % r)) for r in range(2)]
     for key in ("E", "R", "ranks", "ranks_sub", "pred"):
         np.testing.assert_array_equal(res[0][key], res[1][key])  # both ranks end with the same full model
+    for r in res:   # predict(sharded=True) (a collective over contiguous ranges) == the rank-local default
+        np.testing.assert_array_equal(r["pred"], r["pred_local"])
     if "ranks_bf16" in res[0]:  # bf16 mode: range-sharded counters == single-rank counters, on both ranks
         for r in res:
             np.testing.assert_array_equal(r["ranks_bf16"], r["ranks_bf16_single"])
