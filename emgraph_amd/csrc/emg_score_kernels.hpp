@@ -484,14 +484,30 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
         }
     };
-    for (int j0 = 0; j0 < P.eta; j0 += U) {
-        int32_t code[U];
-        float gj[U];
-        R re[U];
-        fetch(j0, code, re);
+    // ROLLING window of U replacement rows: as soon as a negative's row has been consumed (score, gradient, in-place
+    // update or contribution), ITS registers take the load of the negative U places later — the wave keeps U rows in flight
+    // through the whole loop instead of U -> 0 -> U per trip, with no register beyond the U rows (at 3 waves per SIMD it is
+    // the bytes in flight per wave that bound this kernel: tools/hbm_ceiling's bare mix runs 8 waves deep)
+#ifndef EMG_BW_ROLL
+#define EMG_BW_ROLL 1
+#endif
+    int32_t code[U];
+    float gj[U];
+    R re[U];
+    if constexpr (EMG_BW_ROLL != 0) {
+        if (P.eta > 0) fetch(0, code, re);
         if constexpr (!FUSED) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, P.eta - 1) * B + g];
+            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(u, max(P.eta - 1, 0)) * B + g];
+        }
+    }
+    for (int j0 = 0; j0 < P.eta; j0 += U) {
+        if constexpr (EMG_BW_ROLL == 0) {
+            fetch(j0, code, re);
+            if constexpr (!FUSED) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, P.eta - 1) * B + g];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -528,6 +544,13 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
                     if (lg == 0) P.fac.coef[at] = gi;
                 }
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
+            }
+            if constexpr (EMG_BW_ROLL != 0) {   // refill this row's registers with the negative U places later
+                if (j + U < P.eta) {
+                    code[u] = code_of(j + U);
+                    load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
+                    if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)(j + U) * B + g];
+                }
             }
         }
     }
