@@ -168,7 +168,7 @@ class StepRunner:
                 k_int = ent_l.shape[1]
         self.k_local = k_int
         self.tr = Trainer(MODEL_IDS[w["model"]], k_int, self.scale, ent_l, rel_l, self.eta, loss=w["loss"],
-                          optimizer=w["optimizer"] if not (self.sharding == "batch" and w["optimizer"] == "adam") else "adam_lazy",
+                          optimizer=w["optimizer"],
                           optimizer_params={"lr": 0.0005}, batches_count=self.nb, seed=0, fused=not args.no_fused,
                           inplace=not args.no_inplace, pipeline=not args.no_pipeline,
                           regularizer="LP" if w.get("reg") else None, regularizer_params=w.get("reg"),

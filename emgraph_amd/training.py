@@ -191,15 +191,12 @@ class Trainer:
         self.pipeline = pipeline
         if self.batch_sharded:
             # a destination's contributions come from several ranks: no rank may update a row in place, and the
-            # step has collectives in the middle (single stream; the exchange is what bounds it, not the enqueue)
+            # step has collectives in the middle (single stream; the exchange is what bounds it, not the enqueue).
+            # Optimizer state is REPLICATED: the owner of a destination only SUMS its rows (in global slot order), the sums
+            # are all-gathered and every replica applies the optimizer to them — touched rows from the sums, all others
+            # through the dense pass — so Keras' dense-equivalent Adam and the folded LP regulariser work as on one GPU.
             self.inplace = self.pipeline = pipeline = False
-            if optimizer == "adam":
-                raise ValueError("batch-sharded training cannot run Keras' dense-equivalent Adam (every row of the table "
-                                 "changes every step, i.e. the whole table would be exchanged): use 'adam_lazy', another "
-                                 "optimizer, or k-sharding")
-            if self.reg is not None and optimizer != "sgd":
-                raise NotImplementedError("LP regulariser with a stateful optimizer under batch sharding")
-            self.xgmi_bytes = 0          # bytes this rank sent + received over the interconnect (gradient rows + updated rows)
+            self.xgmi_bytes = 0          # bytes this rank sent + received over the interconnect (gradient rows + summed rows)
             self._owner_ws = {}
         # high priority: the many small kernels must not queue behind the big ones.  TWO side streams used
         # alternately: a preparation chain is latency-bound (each small launch waits for a CU slot), so two
@@ -383,7 +380,7 @@ class Trainer:
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
         h = (lr, self.momentum, ADAM_BETA1, ADAM_BETA2, KERAS_EPS, lr_t)
-        if table is None or self.reg is None or self.batch_sharded:
+        if table is None or self.reg is None:
             return h
         return h + (self.reg[table], float(self.reg[2]))
 
@@ -566,7 +563,6 @@ class Trainer:
         et, eta, k = self.eta_total, self.eta, self.k_int
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
-        hyper = self._hyper(lr)
         dev = self.device
         n_ce = (2 + et) * Bl
         if Bl > 0:
@@ -601,39 +597,57 @@ class Trainer:
             dest_e = dest_r = z32
             gslot_e = gslot_r = z64
             rows_e = rows_r = torch.zeros((0, k), dtype=torch.float32, device=dev)
-        if self.reg is not None:  # dense LP term + its SGD step: the same full pass on every replica, pre-update tables
-            D.lp_regularizer(self.ent, k, self.reg[0], self.reg[2], lr, self.reg_accum)
-            D.lp_regularizer(self.rel, k, self.reg[1], self.reg[2], lr, self.reg_accum)
-        self._exchange_apply(self.ent, self.n_ent, self.state_ent, self.tag_ent, dest_e, gslot_e, rows_e, hyper, "ent")
-        self._exchange_apply(self.rel, self.n_rel, self.state_rel, self.tag_rel, dest_r, gslot_r, rows_r, hyper, "rel")
+        lp = (self.lp_sum[0:1], self.lp_sum[1:2]) if self.reg is not None else (None, None)
+        self._exchange_apply(self.ent, self.n_ent, self.state_ent, self.tag_ent, dest_e, gslot_e, rows_e, self._hyper(lr, 0), "ent", lp[0])
+        self._exchange_apply(self.rel, self.n_rel, self.state_rel, self.tag_rel, dest_r, gslot_r, rows_r, self._hyper(lr, 1), "rel", lp[1])
         if self.normalize:
             D.clip_rows(self.ent, k, 1.0)
 
-    def _exchange_apply(self, table, n_rows, state, tag, dest, gslot, rows, hyper, which):
+    def _exchange_apply(self, table, n_rows, state, tag, dest, gslot, rows, hyper, which, lp_accum=None):
+        """gradient rows -> owners (all_to_all) -> per destination ONE summed row, added in global slot order (the order a
+        single GPU adds them in) -> all-gather of (destination, summed row) -> every replica applies the optimizer to the
+        same sums with its own (replicated, hence identical) state: tables, state and loss are those of one GPU, bit for
+        bit, for every optimizer — Keras Adam's dense decay and a folded LP regulariser included (they need every row)."""
         k = self.k_int
         dest_o, gslot_o, rows_o, sent = parallel.exchange_rows(dest, gslot, rows, n_rows)
         m = int(dest_o.numel())
         if m:
-            # the order a single GPU sums a destination's rows in: by slot of the (global) batch layout; the stable
-            # grouping by destination below keeps it
+            # the sum order: by slot of the (global) batch layout; the stable grouping by destination below keeps it.
+            # Destinations are renumbered 0..u-1 so that the sums land in a compact [u, k] buffer: "SGD with lr = -1 on a
+            # zero table" is 0 - (-1 * g) = g exactly, i.e. emg_apply_grouped used as a segmented sum
             perm = torch.argsort(gslot_o, stable=True)
-            dest_p = dest_o.index_select(0, perm).contiguous()
+            dest_p = dest_o.index_select(0, perm)
+            upd, compact = torch.unique(dest_p, sorted=True, return_inverse=True)
+            u = int(upd.numel())
             ws = self._owner_ws.get(which)
-            need = D.apply_workspace_bytes(m, n_rows, k)
+            need = D.apply_workspace_bytes(m, u, k)
             if ws is None or ws.numel() < need:
                 ws = self._owner_ws[which] = torch.empty(int(need * 1.5) + 1024, dtype=torch.uint8, device=self.device)
-            D.group_dest(dest_p, m, n_rows, ws)
+            cid = compact.to(torch.int32).contiguous()
+            D.group_dest(cid, m, u, ws)
             keys, vals = D.apply_workspace_views(ws, m)
             vals.copy_(perm.index_select(0, vals.to(torch.int64)).to(torch.int32))   # positions in RECEIVE order
-            D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, rows_o, m, False, hyper, ws)
-            upd = torch.unique_consecutive(keys)
-            upd_rows = table.index_select(0, upd.to(torch.int64))
+            sums = alloc_table(u, k, self.device)        # (zero-filled)
+            D.apply_grouped(L.OPT_SGD, sums, k, None, None, None, 1, rows_o, m, False, (-1.0, 0, 0, 0, 0, 0), ws)
+            upd = upd.to(torch.int32)
         else:
             upd = torch.zeros(0, dtype=torch.int32, device=self.device)
-            upd_rows = torch.zeros((0, k), dtype=torch.float32, device=self.device)
-        oid, orow, recvd = parallel.allgather_rows(upd, upd_rows)
-        if oid.numel():
-            table.index_copy_(0, oid.to(torch.int64), orow)
+            sums = alloc_table(1, k, self.device)[:0]
+        oid, orow, recvd = parallel.allgather_rows(upd, sums)
+        ids = torch.cat([upd, oid]) if oid.numel() else upd
+        g = torch.cat([sums, orow.to(sums.dtype)]) if oid.numel() else sums
+        n = int(ids.numel())
+        # every replica: one optimizer step per touched row from its summed gradient (each destination occurs once: a
+        # segment of one row), the dense pass for the rest where the optimizer / regulariser needs one
+        ws2 = self._owner_ws.get(which + "2")
+        need2 = D.apply_workspace_bytes(max(n, 1), n_rows, k)
+        if ws2 is None or ws2.numel() < need2:
+            ws2 = self._owner_ws[which + "2"] = torch.empty(int(need2 * 1.5) + 1024, dtype=torch.uint8, device=self.device)
+        gg = alloc_table(max(n, 1), k, self.device)
+        if n:
+            gg[:n].copy_(g)
+            D.group_dest(ids.contiguous(), n, n_rows, ws2)
+        D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, gg, n, False, hyper, ws2, lp_accum=lp_accum)
         self.xgmi_bytes += sent + recvd
 
     def read_loss(self, reset=True):
@@ -644,7 +658,7 @@ class Trainer:
         if self.batch_sharded:  # every rank saw its rows of each batch only; the LP term was computed by every replica
             data = parallel.allreduce_sum_(self.loss_accum.clone())
         v = float(data.item()) + float(reg.item())
-        if self.reg is not None and not self.batch_sharded:
+        if self.reg is not None:   # (batch-sharded: every replica folded the regulariser over the full tables itself)
             lp = self.lp_sum if not self.sharded else parallel.allreduce_sum_(self.lp_sum.clone())
             lp = lp.cpu()
             v += self.reg[0] * float(lp[0]) + self.reg[1] * float(lp[1])

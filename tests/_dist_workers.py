@@ -200,7 +200,7 @@ def batch_exchange_worker(rank, world, out_dir):
     np.save(os.path.join(out_dir, "W_%d.npy" % rank), W)
 
 
-def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt):
+def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt, reg=None):
     """the REAL batch-sharded training step (HIP kernels + exchange), two ranks sharing cuda:0 over gloo"""
     import torch
 
@@ -212,6 +212,8 @@ def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt):
     X[:n_ent, 0] = np.arange(n_ent)
     X[:n_rel, 1] = np.arange(n_rel)
     kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    if reg is not None:
+        kw.update(regularizer="LP", regularizer_params=reg)
     emp = {"sharding": "batch"}
     if name == "TransE_L2":
         m = models.TransE(embedding_model_params=dict(emp, norm=2), **kw)
@@ -219,7 +221,7 @@ def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt):
         m = getattr(models, name)(embedding_model_params=emp, **kw)
     m.fit(X[:803])       # 803 rows / 3 batches = 268 per batch (last one 267): odd splits over two ranks
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
-             pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes))
+             pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes), losses=np.array(m.epoch_losses))
 
 
 def sharded_overflow_worker(rank, world, out_dir):

@@ -81,16 +81,20 @@ def test_batch_sharded_exchange_is_rank_count_independent_gloo(tmp_path, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "sgd"), ("TransE_L2", "pairwise", "adagrad"),
-                                           ("HolE", "multiclass_nll", "momentum"), ("DistMult", "nll", "adam_lazy")])
-def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss, opt):
+@pytest.mark.parametrize("name,loss,opt,reg", [("ComplEx", "nll", "sgd", None), ("TransE_L2", "pairwise", "adagrad", None),
+                                               ("HolE", "multiclass_nll", "momentum", None), ("DistMult", "nll", "adam_lazy", None),
+                                               ("ComplEx", "nll", "adam", None),                       # the reference's default optimizer
+                                               ("DistMult", "pairwise", "adagrad", {"lambda": 1e-3, "p": 2}),   # LP + a stateful optimizer
+                                               ("TransE_L2", "nll", "adam", {"lambda": 1e-3, "p": 3})])
+def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss, opt, reg):
     """north_star's training split: batch rows split over the ranks, gradient rows sent to the owner of their
-    destination, owner-side optimizer, updated rows all-gathered.  Negatives are drawn by GLOBAL row index and each
-    destination's rows are summed in global slot order, so two ranks must reproduce the single-process run with the
-    same kernels (contribution path, no in-place singletons) BIT for bit; the default single-process plan (in-place
-    singleton updates) differs from it by fp32 rounding only."""
+    destination, which SUMS them in global slot order; the sums are all-gathered and every replica applies the optimizer
+    (replicated state) — so the reference's default optimizer (Keras Adam: every row decays every step) and the LP
+    regulariser with any optimizer run under this split.  Negatives are drawn by GLOBAL row index, so two ranks must
+    reproduce the single-process run with the same kernels (contribution path, no in-place singletons) BIT for bit; the
+    default single-process plan (in-place singleton updates) differs from it by fp32 rounding only."""
     from emgraph_amd import models
-    _spawn(W.batch_sharded_fit_worker, 2, tmp_path, name, loss, opt)
+    _spawn(W.batch_sharded_fit_worker, 2, tmp_path, name, loss, opt, reg)
     res = [np.load(os.path.join(tmp_path, "res_%d.npz" % r)) for r in range(2)]
     for key in ("E", "R", "pred"):
         np.testing.assert_array_equal(res[0][key], res[1][key])          # replicas stay identical
@@ -101,6 +105,8 @@ def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss,
     X[:n_ent, 0] = np.arange(n_ent)
     X[:n_rel, 1] = np.arange(n_rel)
     kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
+    if reg is not None:
+        kw.update(regularizer="LP", regularizer_params=reg)
     emp = {"norm": 2} if name == "TransE_L2" else {}
     cls = models.TransE if name == "TransE_L2" else getattr(models, name)
     import emgraph_amd.training as T
@@ -116,6 +122,9 @@ def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss,
         T.Trainer.__init__ = plain
     np.testing.assert_array_equal(res[0]["E"], m0.trained_model_params[0])
     np.testing.assert_array_equal(res[0]["R"], m0.trained_model_params[1])
+    np.testing.assert_allclose(res[0]["losses"], m0.epoch_losses, rtol=1e-12)   # (data term: a sum over the ranks' double accumulators)
+    if opt == "adam" or reg is not None:
+        return   # (Keras Adam / LP: the in-place plan is a different update order for near-zero gradients; bitwise check above)
     m1 = cls(embedding_model_params=emp, **kw)
     m1.fit(X[:803])
     np.testing.assert_allclose(res[0]["E"], m1.trained_model_params[0], rtol=1e-4, atol=1e-6)
