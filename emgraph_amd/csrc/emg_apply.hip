@@ -604,19 +604,45 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
 //     EmbeddingModel.py:818-820): an untouched row still has g = lambda * p * |w|^(p-1) * sign(w), and its |w|^p
 //     belongs to the loss.  Touched rows got the same term folded into their update (lp_fold), so the regulariser
 //     costs ONE pass over the rows nothing else visited instead of n_rows extra contribution rows.
-__device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64_t block) {
+__device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64_t block, int64_t n_blocks) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (block * blockDim.x + threadIdx.x) >> 6;
     float lp_acc = 0.f;
     ApplyParams P = P0;
     if (P0.ctl) {   // graph node: step number and learning rates from the device record
         const float* h = P0.which ? P0.ctl->hyper_rel : P0.ctl->hyper_ent;
         P.opt.lr = h[0]; P.opt.lr_t = h[5]; P.step = P0.ctl->step;
     }
-    if (r < P.n_rows && P.tag[r] != P.step) {
+    // a wave per row, grid-stride: the launch is capped (a wave per row of a 1M-row table made 1M atomics on the ONE
+    // double that accumulates sum |w|^p — 9 ms per step of the LP-regularised C3 before; now one atomic per wave of a
+    // few thousand)
+    const int64_t nw = (n_blocks * blockDim.x) >> 6;
+    const bool vec = (P.k_int % 4 == 0) && (P.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(P.table) & 15u) == 0) &&
+                     (!P.state0 || (reinterpret_cast<uintptr_t>(P.state0) & 15u) == 0) &&
+                     (!P.state1 || (reinterpret_cast<uintptr_t>(P.state1) & 15u) == 0);
+    for (int64_t r = (block * blockDim.x + threadIdx.x) >> 6; r < P.n_rows; r += nw) {
+        if (P.tag[r] == P.step) continue;
         float* w = P.table + r * P.ld;
         float* s0 = P.state0 ? P.state0 + r * P.ld : nullptr;
         float* s1 = P.state1 ? P.state1 + r * P.ld : nullptr;
+        if (vec) {   // 16-byte chunks: table row and state rows as float4 (the pass is pure bandwidth)
+            for (int c = lane; 4 * c < P.k_int; c += 64) {
+                float4 wv = *reinterpret_cast<const float4*>(w + 4 * c);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (s0) a = *reinterpret_cast<const float4*>(s0 + 4 * c);
+                if (s1) b = *reinterpret_cast<const float4*>(s1 + 4 * c);
+                float ww[4] = {wv.x, wv.y, wv.z, wv.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float g = 0.f;
+                    lp_fold(P.opt, ww[j], g, lp_acc);
+                    opt_update_elem(P.opt, ww[j], g, &aa[j], &bb[j]);
+                }
+                *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+                if (s0) *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+                if (s1) *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+            }
+            continue;
+        }
         for (int c = lane; c < P.k_int; c += 64) {
             float wv = w[c], g = 0.f;
             lp_fold(P.opt, wv, g, lp_acc);
@@ -627,12 +653,17 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-__global__ __launch_bounds__(256) void untouched_rows_kernel(const ApplyParams P) { untouched_rows_body(P, (int64_t)blockIdx.x); }
+static inline unsigned untouched_blocks(int64_t n_rows) {
+    const int64_t b = cdiv(n_rows * 64, 256);
+    return (unsigned)(b < 4096 ? b : 4096);
+}
+
+__global__ __launch_bounds__(256) void untouched_rows_kernel(const ApplyParams P) { untouched_rows_body(P, (int64_t)blockIdx.x, (int64_t)gridDim.x); }
 
 // both tables' dense passes in one launch (a launch is ~7 us of a 0.1 ms small-batch step)
 __global__ __launch_bounds__(256) void untouched_rows_pair_kernel(const ApplyParams P0, const ApplyParams P1, unsigned blocks0) {
-    if (blockIdx.x < blocks0) untouched_rows_body(P0, (int64_t)blockIdx.x);
-    else untouched_rows_body(P1, (int64_t)(blockIdx.x - blocks0));
+    if (blockIdx.x < blocks0) untouched_rows_body(P0, (int64_t)blockIdx.x, (int64_t)blocks0);
+    else untouched_rows_body(P1, (int64_t)(blockIdx.x - blocks0), (int64_t)(gridDim.x - blocks0));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -928,7 +959,7 @@ static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t 
         }
     }
     if (A.dense) {
-        hipLaunchKernelGGL(untouched_rows_kernel, dim3((unsigned)cdiv(P.n_rows * 64, 256)), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(untouched_rows_kernel, dim3(untouched_blocks(P.n_rows)), dim3(256), 0, st, P);
         EMG_LAUNCH_CHECK();
     }
     return EMG_OK;
@@ -999,7 +1030,7 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         }
     }
     if (A0.dense && A1.dense) {   // the dense passes (Keras Adam, folded LP) of both tables: one launch too
-        const unsigned b0 = (unsigned)cdiv(P0.n_rows * 64, 256), b1 = (unsigned)cdiv(P1.n_rows * 64, 256);
+        const unsigned b0 = untouched_blocks(P0.n_rows), b1 = untouched_blocks(P1.n_rows);
         hipLaunchKernelGGL(untouched_rows_pair_kernel, dim3(b0 + b1), dim3(256), 0, st, P0, P1, b0);
         EMG_LAUNCH_CHECK();
         return EMG_OK;
