@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libe
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
 ABI_VERSION = 3
-TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE = range(5)
+TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE, TRANSE_P = range(6)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
 OPT_SGD, OPT_MOMENTUM, OPT_ADAGRAD, OPT_ADAM, OPT_ADAM_LAZY = range(5)

@@ -56,7 +56,7 @@ __global__ void build_queries_kernel(int model, const float* __restrict__ ent, i
     const float* x = ent + (int64_t)(obj ? s : o) * ld_ent;  // the KEPT entity
     const float* pr = rel + (int64_t)p * ld_rel;
     float* q = Q + r * ldq;
-    if (model == EMG_TRANSE_L1 || model == EMG_TRANSE_L2) {
+    if (model == EMG_TRANSE_L1 || model == EMG_TRANSE_L2 || model == EMG_TRANSE_P) {
         // object side: |(s+p) - e| ; subject side: |(e+p) - o| = |e - (o-p)|
         q[c] = obj ? __fadd_rn(x[c], pr[c]) : __fsub_rn(x[c], pr[c]);
     } else if (model == EMG_DISTMULT) {
@@ -87,6 +87,14 @@ __device__ __forceinline__ float chain_score(int model, const float* __restrict_
             acc = __fmaf_rn(d, d, acc);
         }
         return -sqrtf(acc);
+    }
+    if (model == EMG_TRANSE_P) {   // any positive order (scale = ord): -(sum |d|^ord)^(1/ord); ord = inf: -max |d|
+        if (isinf(scale)) {
+            for (int k = 0; k < k_int; ++k) acc = fmaxf(acc, fabsf(__fsub_rn(q[k], e[k])));
+            return -acc;
+        }
+        for (int k = 0; k < k_int; ++k) acc = __fadd_rn(acc, powf(fabsf(__fsub_rn(q[k], e[k])), scale));
+        return -powf(acc, 1.0f / scale);
     }
     for (int k = 0; k < k_int; ++k) acc = __fmaf_rn(q[k], e[k], acc);
     return model == EMG_HOLE ? __fmul_rn(acc, scale) : acc;
@@ -960,8 +968,43 @@ __global__ __launch_bounds__(256, 2) void count_mfma_pipe_kernel(const CountPara
     }
 }
 
+// Any model through the canonical chain itself: a thread per candidate, query rows one after the other (a wave's
+// comparisons of a row are counted with two ballots).  The path of EMG_TRANSE_P (any order of the norm: powf per
+// coordinate, no tiling to exploit) — correctness first; orders 1 and 2 have the tiled / v_sad / MFMA kernels above.
+template <bool DENSE>
+__global__ __launch_bounds__(256) void count_chain_kernel(const CountParams P) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = c < P.n_cand;
+    const int64_t e = ok ? (P.cand ? (int64_t)P.cand[c] : c) : 0;
+    const float* er = P.ent + e * P.ld_ent;
+    for (int64_t r = 0; r < P.n_rows; ++r) {
+        const float sc = chain_score(P.model, P.Q + r * P.ldq, er, P.k_int, P.scale);
+        if constexpr (DENSE) {
+            if (ok) P.S[r * P.lds + c] = sc;
+        } else {
+            const int ci = cmp_int(sc), p = P.pos_int[r];
+            const unsigned long long gt = __ballot(ok && ci > p), eq = __ballot(ok && ci == p);
+            if (lane == 0) {
+                if (gt) atomicAdd(&P.cnt_gt[r], __popcll(gt));
+                if (eq) atomicAdd(&P.cnt_eq[r], __popcll(eq));
+            }
+        }
+    }
+}
+
 static int launch_count(bool dense, int model, CountParams& P, int precision, hipStream_t st) {
-    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "unknown model id %d", model);
+    EMG_REQUIRE(model >= 0 && model <= EMG_TRANSE_P, "unknown model id %d", model);
+    if (model == EMG_TRANSE_P) {
+        EMG_REQUIRE(P.scale > 0.f, "EMG_TRANSE_P: the order of the norm (passed as `scale`) must be positive");
+        if (precision != 0) return fail(EMG_ENOSUP, "EMG_TRANSE_P is evaluated by the exact kernel only");
+        if (P.n_rows == 0 || P.n_cand == 0) return EMG_OK;
+        const dim3 grid((unsigned)cdiv(P.n_cand, 256)), block(256);
+        if (dense) hipLaunchKernelGGL(count_chain_kernel<true>, grid, block, 0, st, P);
+        else hipLaunchKernelGGL(count_chain_kernel<false>, grid, block, 0, st, P);
+        EMG_LAUNCH_CHECK();
+        return EMG_OK;
+    }
     if (precision != 0) return fail(EMG_ENOSUP, "eval precision mode %d is not built in this version", precision);
     if (P.n_rows == 0 || P.n_cand == 0) return EMG_OK;
     const bool transe = model <= EMG_TRANSE_L2;
@@ -1022,7 +1065,7 @@ extern "C" int emg_eval_build_queries(int model, const float* ent, int64_t n_ent
                                       const int32_t* test_spo, int64_t n_q, int side_mode, float* Q, int64_t ldq,
                                       int32_t* pos_int, void* stream) {
     (void)n_ent; (void)n_rel;
-    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "emg_eval_build_queries: unknown model %d", model);
+    EMG_REQUIRE(model >= 0 && model <= EMG_TRANSE_P, "emg_eval_build_queries: unknown model %d", model);
     EMG_REQUIRE(side_mode >= EMG_EVAL_S && side_mode <= EMG_EVAL_S_O, "emg_eval_build_queries: bad side_mode %d", side_mode);
     EMG_REQUIRE(k_int > 0 && ld_ent >= k_int && ld_rel >= k_int && ldq >= k_int, "emg_eval_build_queries: bad strides");
     const bool cplx = (model == EMG_COMPLEX || model == EMG_HOLE);
@@ -1072,7 +1115,7 @@ extern "C" int emg_eval_filter_count(int model, const float* Q, int64_t ldq, con
                                      const float* ent, int64_t n_local, int64_t ld_ent, int64_t ent_offset,
                                      int32_t k_int, float scale, int precision, const int64_t* filt_ptr,
                                      const int32_t* filt_idx, int32_t* fcnt_gt, int32_t* fcnt_eq, void* stream) {
-    EMG_REQUIRE(model >= 0 && model <= EMG_HOLE, "emg_eval_filter_count: unknown model %d", model);
+    EMG_REQUIRE(model >= 0 && model <= EMG_TRANSE_P, "emg_eval_filter_count: unknown model %d", model);
     if (precision != 0) return fail(EMG_ENOSUP, "eval precision mode %d is not built in this version", precision);
     EMG_REQUIRE(n_rows >= 0 && k_int > 0 && ldq >= k_int && ld_ent >= k_int, "emg_eval_filter_count: bad sizes");
     if (n_rows == 0) return EMG_OK;

@@ -170,12 +170,45 @@ __global__ void finalize_scores_kernel(int model, float scale, float* s, int64_t
 
 using namespace emg;
 
+// TransE with any positive order of the norm (EMG_TRANSE_P, `ord` = INFINITY: the largest |component|): one wave per
+// triple; inference only (TransE.py:208-216 with an `ord` other than 1 / 2)
+__global__ __launch_bounds__(256) void score_transe_p_kernel(const float* __restrict__ ent, int64_t ld_ent, const float* __restrict__ rel,
+                                                             int64_t ld_rel, int k_int, float ord, const int32_t* __restrict__ spo, int64_t n,
+                                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= n) return;
+    const float* s = ent + (int64_t)spo[3 * t] * ld_ent;
+    const float* p = rel + (int64_t)spo[3 * t + 1] * ld_rel;
+    const float* o = ent + (int64_t)spo[3 * t + 2] * ld_ent;
+    const bool mx = isinf(ord);
+    float acc = 0.f;
+    for (int c = lane; c < k_int; c += 64) {
+        const float d = fabsf((s[c] + p[c]) - o[c]);
+        acc = mx ? fmaxf(acc, d) : acc + powf(d, ord);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float other = __shfl_xor(acc, off, 64);
+        acc = mx ? fmaxf(acc, other) : acc + other;
+    }
+    if (lane == 0) out[t] = mx ? -acc : -powf(acc, 1.0f / ord);
+}
+
 extern "C" int emg_train_forward(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel,
                                  int64_t n_rel, int64_t ld_rel, int32_t k_int, float scale, const int32_t* pos,
                                  int64_t B, int32_t eta, const int32_t* codes, int32_t flags, float* scores_pos,
                                  float* scores_neg, void* stream) {
     if (B == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && pos && scores_pos, "emg_train_forward: null pointer");
+    if (model == EMG_TRANSE_P) {
+        EMG_REQUIRE(eta == 0, "EMG_TRANSE_P (TransE with an order of the norm other than 1 / 2) is inference only: emg_score_triples, emg_eval_*");
+        EMG_REQUIRE(scale > 0.f && k_int > 0 && ld_ent >= k_int && ld_rel >= k_int, "EMG_TRANSE_P: the order of the norm (passed as `scale`) must be positive");
+        hipLaunchKernelGGL(score_transe_p_kernel, dim3((unsigned)cdiv(B * 64, 256)), dim3(256), 0, (hipStream_t)stream, ent, ld_ent, rel, ld_rel,
+                           (int)k_int, scale, pos, B, scores_pos);
+        EMG_LAUNCH_CHECK();
+        return EMG_OK;
+    }
     EMG_REQUIRE(eta == 0 || (codes && scores_neg), "emg_train_forward: eta>0 needs codes and scores_neg");
     GroupParams P{};
     P.ent = ent; P.n_ent = n_ent; P.ld_ent = ld_ent; P.rel = rel; P.n_rel = n_rel; P.ld_rel = ld_rel;

@@ -340,6 +340,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
                    or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
         precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
+    if model_id == L.TRANSE_P:
+        precision = 0   # TransE with an order of the norm other than 1 / 2: the exact chain kernel (same ranks, no prefilter form)
     if precision not in (0, 1, 2):
         raise ValueError("precision must be 0 (exact f32), 1 (bf16 MFMA), 2 (exact via half-precision prefilter) or 'auto' (0 or 2)")
     if precision == 2 and entities_subset is not None:

@@ -674,13 +674,32 @@ class TransE(EmbeddingModel):
                          regularizer=regularizer, regularizer_params=regularizer_params, initializer=initializer,
                          initializer_params=initializer_params, verbose=verbose, large_graphs=large_graphs)
 
-    def _model_id(self):
+    def _norm(self):
         norm = self.embedding_model_params.get("norm", DEFAULT_NORM_TRANSE)
-        if norm == 1:
-            return L.TRANSE_L1
-        if norm == 2:
-            return L.TRANSE_L2
-        raise ValueError("TransE norm {} is not supported by the HIP path (1 or 2)".format(norm))
+        if norm == "euclidean":
+            norm = 2
+        try:
+            ok = float(norm) > 0
+        except (TypeError, ValueError):
+            ok = False
+        if not ok:
+            raise ValueError("TransE norm {!r}: expected a positive order of the vector norm (1, 2, ..., np.inf)".format(norm))
+        return norm
+
+    def _model_id(self):
+        """norm 1 / 2: the trained, accelerated models; any other positive order (TransE.py:208-216 passes `norm` to tf.norm as
+        ord): EMG_TRANSE_P — predict / get_ranks / evaluate_performance of a restored or hand-set model; fit() needs 1 or 2"""
+        norm = self._norm()
+        return L.TRANSE_L1 if norm == 1 else (L.TRANSE_L2 if norm == 2 else L.TRANSE_P)
+
+    def _scale(self):
+        return float(self._norm()) if self._model_id() == L.TRANSE_P else 1.0
+
+    def fit(self, X, *args, **kwargs):
+        if self._model_id() == L.TRANSE_P:
+            raise ValueError("TransE norm {} is not supported by the HIP training path (1 or 2); inference "
+                             "(predict / evaluate_performance) takes any positive order".format(self._norm()))
+        return super().fit(X, *args, **kwargs)
 
 
 

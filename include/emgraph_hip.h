@@ -40,6 +40,11 @@ extern "C" {
 #define EMG_DISTMULT 2
 #define EMG_COMPLEX 3
 #define EMG_HOLE 4
+/* TransE with ANY positive order of the norm (TransE.py:208-216 hands `norm` to tf.norm as ord): f = -(sum |e_s + r_p - e_o|^ord)^(1/ord),
+ * ord = +inf: the largest |component|.  INFERENCE ONLY — emg_score_triples and the emg_eval_* / emg_rank_1vsall family at
+ * precision 0; the `scale` argument of those calls carries ord.  (Orders 1 and 2 are EMG_TRANSE_L1 / _L2: trained, MFMA- and
+ * v_sad-accelerated.) */
+#define EMG_TRANSE_P 5
 
 /* corruption side: protocol.py:598-608 ('s,o' is an alias of 's+o' there, :591-593) */
 #define EMG_SIDE_S 0
