@@ -320,13 +320,30 @@ __device__ __forceinline__ void long_task_wave(const ApplyParams& P, const OptPa
     float* s0row = (!PLAIN && P.state0) ? P.state0 + (int64_t)key * P.ld : nullptr;
     float* s1row = (!PLAIN && P.state1) ? P.state1 + (int64_t)key * P.ld : nullptr;
     auto update = [&](int c, float (&g)[W]) {   // optimizer step of columns [W c, W c + W) with summed gradient g
-        float w[W];
+        float w[W], a0[W], a1[W];
+        if constexpr (W == 4) {   // table row and state as 16-byte accesses
+            const float4 wv = *reinterpret_cast<const float4*>(wrow + 4 * c);
+            w[0] = wv.x; w[1] = wv.y; w[2] = wv.z; w[3] = wv.w;
+            if (s0row) { const float4 t4 = *reinterpret_cast<const float4*>(s0row + 4 * c); a0[0] = t4.x; a0[1] = t4.y; a0[2] = t4.z; a0[3] = t4.w; }
+            if (s1row) { const float4 t4 = *reinterpret_cast<const float4*>(s1row + 4 * c); a1[0] = t4.x; a1[1] = t4.y; a1[2] = t4.z; a1[3] = t4.w; }
+        } else {
+            w[0] = wrow[c];
+            if (s0row) a0[0] = s0row[c];
+            if (s1row) a1[0] = s1row[c];
+        }
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-            w[j] = wrow[W * c + j];
             lp_fold(opt, w[j], g[j], lp_acc);
-            opt_update_elem(opt, w[j], g[j], s0row ? s0row + W * c + j : nullptr, s1row ? s1row + W * c + j : nullptr);
-            wrow[W * c + j] = w[j];
+            opt_update_elem(opt, w[j], g[j], &a0[j], &a1[j]);
+        }
+        if constexpr (W == 4) {
+            *reinterpret_cast<float4*>(wrow + 4 * c) = make_float4(w[0], w[1], w[2], w[3]);
+            if (s0row) *reinterpret_cast<float4*>(s0row + 4 * c) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+            if (s1row) *reinterpret_cast<float4*>(s1row + 4 * c) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        } else {
+            wrow[c] = w[0];
+            if (s0row) s0row[c] = a0[0];
+            if (s1row) s1row[c] = a1[0];
         }
     };
     const int64_t nblk = (tk.len + kLongSegment - 1) / kLongSegment;
@@ -693,8 +710,19 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
         const int ca = c0 + lane, cb = c0 + 64 + lane;
         const bool oa = ca < nchunks, ob = cb < nchunks;
         float4 accA = zero, accB = zero, wA = zero, wB = zero;
+        // the table row AND its optimizer state (momentum / Adagrad accumulator / Adam m, v) are fetched with the first
+        // contribution rows, as 16-byte loads: the update after the sum then waits for nothing (the state used to be read
+        // element by element after the sum — a dependent round trip per segment and 4x the load instructions; C1 / C2 / C5
+        // with Adam: DESIGN.md 4.1)
+        float4 m0A = zero, m0B = zero, m1A = zero, m1B = zero;
         if (oa) wA = *reinterpret_cast<const float4*>(wrow + 4 * ca);
         if (ob) wB = *reinterpret_cast<const float4*>(wrow + 4 * cb);
+        if constexpr (!PLAIN) {
+            if (s0row && oa) m0A = *reinterpret_cast<const float4*>(s0row + 4 * ca);
+            if (s0row && ob) m0B = *reinterpret_cast<const float4*>(s0row + 4 * cb);
+            if (s1row && oa) m1A = *reinterpret_cast<const float4*>(s1row + 4 * ca);
+            if (s1row && ob) m1B = *reinterpret_cast<const float4*>(s1row + 4 * cb);
+        }
         for (int u = 0; u < len; u += DEPTH) {
             float4 va[DEPTH], vb[DEPTH];
             float cf[DEPTH];
@@ -717,19 +745,24 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
                 }
             }
         }
-        auto finish = [&](int c, float4 wv, const float4& g) {
+        auto finish = [&](int c, float4 wv, const float4& g, float4 m0, float4 m1) {
             const int64_t off = 4 * (int64_t)c;
             float w[4] = {wv.x, wv.y, wv.z, wv.w};
             float gg[4] = {g.x, g.y, g.z, g.w};
+            float a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 lp_fold(opt, w[j], gg[j], lp_acc);
-                opt_update_elem(opt, w[j], gg[j], s0row ? s0row + off + j : nullptr, s1row ? s1row + off + j : nullptr);
+                opt_update_elem(opt, w[j], gg[j], &a0[j], &a1[j]);
             }
             *reinterpret_cast<float4*>(wrow + off) = make_float4(w[0], w[1], w[2], w[3]);
+            if constexpr (!PLAIN) {
+                if (s0row) *reinterpret_cast<float4*>(s0row + off) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                if (s1row) *reinterpret_cast<float4*>(s1row + off) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            }
         };
-        if (oa) finish(ca, wA, accA);
-        if (ob) finish(cb, wB, accB);
+        if (oa) finish(ca, wA, accA, m0A, m1A);
+        if (ob) finish(cb, wB, accB, m0B, m1B);
     }
     if (P.tag && lane == 0) P.tag[dest] = step;
 }
