@@ -114,10 +114,11 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_f_pmc_traffic.json", "r2_e_pmc_traffic.json", "r2_d_pmc_traffic.json", "r2_pmc_traffic.json", "r1_d_pmc_traffic.json"):
+    for fn in ("r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            k = [v for n, v in d["kernels"].items() if "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
+            k = [v for n, v in d["kernels"].items()
+                 if "train_fused_riders_kernel<3, 4, 1, 64, 1>" in n or "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
             if k:
                 return k[0]["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc pass of this command, not measured in this run)" % fn
         except (OSError, ValueError, KeyError):
@@ -331,7 +332,7 @@ def score_kernel_alone(r, reps=50):
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
     traffic = None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_i_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3_e_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r3_e_pmc_traffic.json")) else "r2_i_pmc_traffic.json")))
         k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
         traffic = k[0]["hbm_bytes_per_launch"] if k else None
     except (OSError, ValueError, KeyError):
@@ -339,7 +340,7 @@ def score_kernel_alone(r, reps=50):
     return {"kernel": "train_forward_kernel (gather + score of %d x %d triples)" % (B, 1 + eta), "bound": "hbm",
             "avg_launch_ms": round(ms, 4), "alg_bytes_per_launch": ab, "achieved": round(ab / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": "static: profiles/r2_i_pmc_traffic.json" if traffic else None,
+            "traffic": traffic, "traffic_source": "static: profiles/r3_e_pmc_traffic.json (or r2_i)" if traffic else None,
             "triples_per_s": round(B * (1 + eta) / (ms * 1e-3), 1)}
 
 
