@@ -213,6 +213,13 @@ int main() {
         printf(" \"mix23_GBps\": %.1f, \"mix23_ms\": %.4f,\n", mixb / ms / 1e6, ms);
         ms = time_ms([&] { hipLaunchKernelGGL(mix23<true>, dim3((unsigned)(groups / 4)), dim3(256), 0, 0, table, ids, groups, chunks, ld, stream); }, 10);
         printf(" \"mix23_nt_GBps\": %.1f, \"mix23_nt_ms\": %.4f,\n", mixb / ms / 1e6, ms);
+        // the same mix at the fused kernel's occupancy: dynamic LDS caps the workgroups per CU (3 x 4 waves = 3 waves per SIMD, 2, 1)
+        for (int per_cu : {3, 2, 1}) {
+            const size_t lds = (size_t)(160 * 1024 / per_cu) - 1024;
+            CK(hipFuncSetAttribute((const void*)mix23<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ms = time_ms([&] { hipLaunchKernelGGL(mix23<true>, dim3((unsigned)(groups / 4)), dim3(256), lds, 0, table, ids, groups, chunks, ld, stream); }, 10);
+            printf(" \"mix23_nt_%dwaves_per_simd_GBps\": %.1f, \"mix23_nt_%dwaves_per_simd_ms\": %.4f,\n", per_cu, mixb / ms / 1e6, per_cu, ms);
+        }
     }
     // launch-side prices
     int* limit;
