@@ -14,6 +14,7 @@
 //
 // The plan owns streams and events only; every buffer is the caller's (emg_plan_config), as everywhere in this ABI.
 // Not covered: the k-sharded multi-GPU step (it needs a collective between forward and loss: host-driven).
+#include <functional>
 #include <vector>
 
 #include <stdlib.h>
@@ -41,6 +42,8 @@ struct Plan {
     hipStream_t side[2] = {nullptr, nullptr};
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t scored = nullptr;     // recorded after a step's scoring launches: look-ahead preparation starts behind it
+    bool wait_scored = false;        // the next prepare() waits for `scored` first
     SlotState slots[4];
     int n_side = 0, side_rr = 0;
     int timing_max = 0;
@@ -111,6 +114,7 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
             if (!P->side_joined[si]) { EMG_HIP(hipStreamWaitEvent(st, P->fork, 0)); P->side_joined[si] = true; }
             if (sl.done_in_capture) EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));
         } else {
+            if (P->wait_scored) EMG_HIP(hipStreamWaitEvent(st, P->scored, 0));      // beside the applies, not beside the scoring kernel
             EMG_HIP(hipStreamWaitEvent(st, sl.done, 0));                           // the compute that last used this slot
             if (sl.has_key && sl.ready_recorded) EMG_HIP(hipStreamWaitEvent(st, sl.ready, 0));  // evicted, never consumed
         }
@@ -129,8 +133,10 @@ static int prepare(Plan* P, SlotState& sl, const emg_plan_batch& b, hipStream_t 
     return EMG_OK;
 }
 
+// after_scoring: called between the scoring launches and the applies (emg_plan_step enqueues the look-ahead preparation there)
 static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step, const float* hyper6, hipStream_t main,
-                   const Riders* ride_a = nullptr, const Riders* ride_b = nullptr) {
+                   const Riders* ride_a = nullptr, const Riders* ride_b = nullptr,
+                   const std::function<int()>* after_scoring = nullptr) {
     const emg_plan_config& c = P->cfg;
     const int32_t et = c.eta * c.n_sides;
     const int64_t B = b.B, n_ce = (2 + et) * B;
@@ -176,6 +182,10 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         if (c.model == EMG_TRANSE_L2 && c.k_int > 512) { ba.bw_scores_pos = sp; ba.bw_scores_neg = sn; }
         Timed t(P, ST_BACKWARD, main);
         rc = train_backward_impl(&ba, ride_a, main);
+        if (rc != EMG_OK) return rc;
+    }
+    if (after_scoring) {
+        rc = (*after_scoring)();
         if (rc != EMG_OK) return rc;
     }
     // The two tables' applies are independent: ONE pair of launches over both groupings
@@ -280,6 +290,7 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
         if (hipEventCreateWithFlags(&P->side_join[i], hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
     if (!P->fork && hipEventCreateWithFlags(&P->fork, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
     if (hipStreamCreateWithFlags(&P->cap, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    if (hipEventCreateWithFlags(&P->scored, hipEventDisableTiming) != hipSuccess) return bail("hipEventCreate");
     for (int i = 0; i < cfg->n_slots; ++i) {
         P->slots[i].buf = cfg->slots[i];
         // the grouping workspaces' control regions start out zero (emg_prepare_args.ws_clean)
@@ -311,6 +322,7 @@ extern "C" int emg_plan_destroy(void* plan) {
     for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
     for (int i = 0; i < 2; ++i)
         if (P->side_join[i]) (void)hipEventDestroy(P->side_join[i]);
+    if (P->scored) (void)hipEventDestroy(P->scored);
     if (P->fork) (void)hipEventDestroy(P->fork);
     if (P->join) (void)hipEventDestroy(P->join);
     for (int i = 0; i < 2; ++i)
@@ -341,22 +353,45 @@ extern "C" int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step
         rc = prepare(P, *sl, *cur, main);
         if (rc != EMG_OK) return rc;
     }
-    // batches ahead (nearest first): each goes to a free slot unless already held
-    for (int j = 0; j < n_next && P->n_side > 0; ++j) {
-        const emg_plan_batch& nb = next[j];
-        if (nb.B <= 0 || nb.B > c.cap_B || nb.start < 0 || nb.start + nb.B > c.n_triples) continue;
-        bool held = false;
-        for (int i = 0; i < c.n_slots; ++i) held = held || same_key(P->slots[i], nb);
-        if (held) continue;
-        SlotState* fr = nullptr;
-        for (int i = 0; i < c.n_slots; ++i)
-            if (&P->slots[i] != sl && !P->slots[i].has_key) { fr = &P->slots[i]; break; }
-        if (!fr) break;
-        rc = prepare(P, *fr, nb, main);
+    // batches ahead (nearest first): each goes to a free slot unless already held.  Their preparation chains are enqueued
+    // BETWEEN this step's scoring kernel and its applies and start behind the scoring kernel: at 3 waves per SIMD (168
+    // VGPRs) that kernel has no room for a co-resident wave, so a preparation wave beside it displaces a scoring wave one
+    // for one, while the apply kernel (5 waves per SIMD of 81 VGPRs) leaves room (EMG_PREP_AT_START=1: the round-2 order)
+    auto look_ahead = [&]() -> int {
+        for (int j = 0; j < n_next && P->n_side > 0; ++j) {
+            const emg_plan_batch& nb = next[j];
+            if (nb.B <= 0 || nb.B > c.cap_B || nb.start < 0 || nb.start + nb.B > c.n_triples) continue;
+            bool held = false;
+            for (int i = 0; i < c.n_slots; ++i) held = held || same_key(P->slots[i], nb);
+            if (held) continue;
+            SlotState* fr = nullptr;
+            for (int i = 0; i < c.n_slots; ++i)
+                if (&P->slots[i] != sl && !P->slots[i].has_key) { fr = &P->slots[i]; break; }
+            if (!fr) break;
+            int r = prepare(P, *fr, nb, main);
+            if (r != EMG_OK) return r;
+        }
+        return EMG_OK;
+    };
+    // Measured (same box, alternating): C3 (360 k contributions per batch) 0.333-0.367 ms/step from the start vs 0.368-0.374
+    // behind the scoring kernel — the apply is as short as the chain (0.08 ms) and slows by what it hides (0.085 -> 0.125) —,
+    // B = 131 072 (2.9 M contributions) 2.84-2.89 vs 2.68-2.80: the scoring kernel runs clean (1.56 -> 1.11-1.17 ms) and the
+    // 1.3 ms apply absorbs the 0.45 ms chain.  So: behind the scoring kernel from a million contributions per batch up.
+    static const int at_env = getenv("EMG_PREP_AT_START") ? atoi(getenv("EMG_PREP_AT_START")) : -1;   // A/B aid
+    const bool at_start = at_env >= 0 ? at_env != 0 : (2 + (int64_t)c.eta * c.n_sides) * cur->B < 1000000;
+    const std::function<int()> between = [&]() -> int {
+        EMG_HIP(hipEventRecord(P->scored, main));
+        P->wait_scored = true;
+        const int r = look_ahead();
+        P->wait_scored = false;
+        return r;
+    };
+    if (at_start || P->n_side == 0) {
+        rc = look_ahead();
         if (rc != EMG_OK) return rc;
     }
     if (P->n_side > 0) EMG_HIP(hipStreamWaitEvent(main, sl->ready, 0));
-    rc = compute(P, *sl, *cur, step, hyper6, main);
+    rc = compute(P, *sl, *cur, step, hyper6, main, nullptr, nullptr, (at_start || P->n_side == 0) ? nullptr : &between);
     if (rc != EMG_OK) return rc;
     if (P->n_side > 0) EMG_HIP(hipEventRecord(sl->done, main));
     // EMG_PLAN_KEEP (timing experiment: what does the preparation chain cost the compute kernels it runs beside?):
