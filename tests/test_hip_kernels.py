@@ -1292,3 +1292,85 @@ def test_device_initialisers_distribution_and_determinism():
     assert abs(g.mean() - 0.5) < 1e-3 and abs(g.std() - 0.1) < 1e-3
     z = (g - 0.5) / 0.1
     assert abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3.0) < 5e-2          # skewness, kurtosis of a normal
+
+
+# ------------------------------------------------------------------------------------------------
+# the counting grouping (histogram -> look-back scan -> scatter -> ordering) and the descriptor-driven apply at the edges
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["one_row", "all_one_destination", "sparse_big_table", "many_tiles_dense", "ids_out_of_range",
+                                  "lengths_around_thresholds", "single_contribution"])
+def test_counting_grouping_edge_shapes(case):
+    """emg_group_dest + emg_apply_grouped through the counting backend, bit for bit against the stable order / the sequential
+    sums: a one-row table, every contribution on one destination (one segment = the whole batch: block tasks), a table of
+    600 k rows hit by 3 000 contributions (147 scan tiles, almost all empty: the look-back runs over several rounds of 64
+    predecessors), a dense batch over 70 tiles, destination ids outside the table (dropped), segment lengths on both
+    sides of the singleton / 32-row / 64-row thresholds, and a single contribution."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(sum(map(ord, case)))
+    k = 72   # 18 chunks of 16 bytes: the descriptor-driven kernel (more than 16 chunks, aligned rows)
+    drop = None
+    if case == "one_row":
+        n_rows, dest = 1, np.zeros(500, np.int32)
+    elif case == "all_one_destination":
+        n_rows, dest = 50, np.full(3000, 17, np.int32)
+    elif case == "sparse_big_table":
+        n_rows = 600_000
+        dest = rs.randint(0, n_rows, 3000).astype(np.int32)
+        dest[:40] = dest[40:80]            # a few pairs
+    elif case == "many_tiles_dense":
+        n_rows = 70 * 4096 + 5
+        dest = rs.randint(0, n_rows, 400_000).astype(np.int32)
+    elif case == "ids_out_of_range":
+        n_rows = 300
+        dest = rs.randint(0, n_rows, 4000).astype(np.int32)
+        drop = rs.choice(4000, 200, replace=False)
+        dest[drop[:100]] = n_rows + rs.randint(0, 50, 100)
+        dest[drop[100:]] = -1 - rs.randint(0, 50, 100)
+    elif case == "lengths_around_thresholds":
+        n_rows = 400
+        lens = [1, 2, 3, 31, 32, 33, 34, 63, 64, 65, 127, 128, 129, 1, 1, 2]
+        dest = np.concatenate([np.full(n, 10 + 3 * i, np.int32) for i, n in enumerate(lens)])
+        rs.shuffle(dest)
+    else:
+        n_rows, dest = 1000, np.array([123], np.int32)
+    n_c = len(dest)
+    # 1. the grouping itself: keys ascending, values = the stable order, singleton flags
+    ws = torch.zeros(d.apply_workspace_bytes(n_c, n_rows, k), dtype=torch.uint8, device="cuda")
+    flags = torch.zeros(n_c, dtype=torch.uint8, device="cuda")
+    d.group_dest(cu(dest), n_c, n_rows, ws, flags)
+    valid = (dest >= 0) & (dest < n_rows)
+    order = np.argsort(np.where(valid, dest, np.iinfo(np.int32).max), kind="stable")[:int(valid.sum())]
+    keys, vals = d.apply_workspace_views(ws, n_c)
+    nv = int(valid.sum())
+    np.testing.assert_array_equal(keys.cpu().numpy()[:nv], dest[order])
+    np.testing.assert_array_equal(vals.cpu().numpy()[:nv], order.astype(np.int32))
+    cnt = np.bincount(dest[valid], minlength=n_rows)
+    np.testing.assert_array_equal(flags.cpu().numpy(), (valid & (cnt[np.where(valid, dest, 0)] == 1)).astype(np.uint8))
+    # 2. the apply from that grouping (twice on the same workspace: the control region must come back clean)
+    W = rs.randn(n_rows, k).astype(F32)
+    contrib = rs.randn(n_c, k).astype(F32)
+    lr = F32(0.05)
+    Wt = cu(W)
+    for rep in range(2):
+        d.apply_rows(L.OPT_SGD, Wt, k, None, None, None, 1 + rep, cu(contrib), cu(dest), n_c, (float(lr), 0, 0, 0, 0, 0), ws)
+    exp = W.copy()
+    bounds = np.flatnonzero(np.diff(dest[order])) + 1
+    for rep in range(2):
+        for seg in (np.split(order, bounds) if nv else []):
+            if len(seg) <= 64:
+                g = np.zeros(k, F32)
+                for i in seg:
+                    g = g + contrib[i]
+            else:   # 64-row blocks left to right, then the block sums left to right (the long-segment tree)
+                parts = []
+                for b0 in range(0, len(seg), 64):
+                    p = np.zeros(k, F32)
+                    for i in seg[b0:b0 + 64]:
+                        p = p + contrib[i]
+                    parts.append(p)
+                g = np.zeros(k, F32)
+                for p in parts:
+                    g = g + p
+            exp[dest[seg[0]]] = exp[dest[seg[0]]] - lr * g
+    np.testing.assert_array_equal(Wt.cpu().numpy(), exp)
