@@ -286,6 +286,26 @@ class SadTables:
         self.k_int = k_int
 
 
+def resolve_auto_precision(model_id, k_int, n_test, n_ent, entities_subset=None):
+    """what precision 'auto' means for a call: the exact-fast mode (2) returns the SAME ranks as precision 0, bit for bit,
+    and pays off once the 1-vs-all product is large enough to amortise the half-precision copy of the table; its kernels
+    cover the common widths"""
+    covered = lambda w: 32 < w <= 400   # noqa: E731  (the prefilter kernel pads a width up to its next instantiation)
+    applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
+               or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
+    return 2 if (applies and entities_subset is None and n_test >= 128 and n_ent >= 32768) else 0
+
+
+def derived_tables(model_id, ent, rel, k_int):
+    """the tables the exact-fast mode derives from the embedding tables (half-precision copy + norm bounds, 16-bit image +
+    range, augmented half rows): valid while the tables do not change — a fitted model keeps them (get_ranks)"""
+    if model_id == L.TRANSE_L1:
+        return SadTables(ent, rel, k_int)
+    if model_id == L.TRANSE_L2:
+        return L2Tables(ent, k_int)
+    return PrefilterTables(ent, k_int)
+
+
 _pair_buffers = {}
 _RESCORE_SPB = int(os.environ.get('EMG_RESCORE_SPB', '8'))   # A/B aid: 4 = segments in index order
 
@@ -333,13 +353,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     ``stats`` (dict, optional): receives ``count_ms`` = device time of the 1-vs-all count kernel launches
     (HIP events on the launch stream) and ``count_launches``."""
     if precision == "auto":
-        # the exact-fast mode returns the SAME ranks as precision 0 (bit for bit) and pays off once the 1-vs-all
-        # product is large enough to amortise the half-precision copy of the table; its kernel covers the common widths
         n_test = int(np.asarray(test_triples).reshape(-1, 3).shape[0])
-        covered = lambda w: 32 < w <= 400   # noqa: E731  (the prefilter kernel pads a width up to its next instantiation)
-        applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
-                   or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
-        precision = 2 if (applies and entities_subset is None and n_test >= 128 and int(ent.shape[0]) >= 32768) else 0
+        precision = resolve_auto_precision(model_id, k_int, n_test, int(ent.shape[0]), entities_subset)
     if model_id == L.TRANSE_P:
         precision = 0   # TransE with an order of the norm other than 1 / 2: the exact chain kernel (same ranks, no prefilter form)
     if precision not in (0, 1, 2):
