@@ -39,14 +39,13 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
         const bool fused = pass == Pass::Fused;
 #define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
         if constexpr (W == 4) {
-            if (fused && ip != 0) {   // the fused in-place forms, with or without riders: one translation unit per model
+            if (fused) {   // the fused forms, with or without riders: one translation unit per model
                 static const fused_launch_fn by_model[5] = {launch_fused_m0, launch_fused_m1, launch_fused_m2, launch_fused_m3, launch_fused_m4};
                 const int shape = NV == 2 ? 3 : (LPG == 16 ? 0 : (LPG == 32 ? 1 : 2));
                 by_model[MODEL](shape, ip, grid, st, P, riders);
                 return;
             }
-            if (fused) EMG_BW(true, 0);
-            else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
+            if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2);
         } else {   // scalar rows (k not a multiple of 4)
             if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else EMG_BW(true, 2); }
             else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
@@ -97,8 +96,8 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st, 
         if (P.single_ent)
             vec = vec && (!P.ent_state0 || aligned16(P.ent_state0)) && (!P.ent_state1 || aligned16(P.ent_state1));
     }
-    if (riders_p) {   // only the fused, in-place, 16-byte-row kernels carry riders; everything else: the stages alone, first
-        const bool can_ride = pass == Pass::Fused && vec && P.single_ent && n <= 512;   // (= the train_fused_riders_kernel forms)
+    if (riders_p) {   // only the fused 16-byte-row kernels carry riders; everything else: the stages alone, first
+        const bool can_ride = pass == Pass::Fused && vec && n <= 512;   // (= the train_fused_riders_kernel forms)
         if (!can_ride) {
             int rc = launch_riders_alone(*riders_p, st);
             if (rc != EMG_OK) return rc;

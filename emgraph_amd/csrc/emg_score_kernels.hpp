@@ -4,6 +4,11 @@
 #pragma once
 #include "emg_group_kernels.hpp"
 
+// Every multiply-add of the score and gradient formulas is written out (fmaf where one rounding is meant): the compiler
+// contracts a*b + c*d either way round, and differently in different instantiations of the same template — the in-place
+// and the contribution-row forms of one step must produce the same bits.
+#pragma clang fp contract(off)
+
 namespace emg {
 
 template <int MODEL>
@@ -75,7 +80,10 @@ __device__ __forceinline__ float partial_score(const Row<MODEL, W, NV>& a, const
         } else {
             const float sr = a.x[e], si = a.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = b.x[e], oi = b.x[E + e];
             // ComplEx.py:293-297
-            acc += (pr * sr) * orr + (pr * si) * oi + (pi * sr) * oi - (pi * si) * orr;
+            acc = fmaf(pr * sr, orr, acc);
+            acc = fmaf(pr * si, oi, acc);
+            acc = fmaf(pi * sr, oi, acc);
+            acc = fmaf(-(pi * si), orr, acc);
         }
     }
     return acc;
@@ -117,12 +125,12 @@ __device__ __forceinline__ void accum_grads(const Row<MODEL, W, NV>& a, const Ro
             gb.x[e] = fmaf(gi, a.x[e] * p.x[e], gb.x[e]);
         } else {
             const float sr = a.x[e], si = a.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = b.x[e], oi = b.x[E + e];
-            ga.x[e] = fmaf(gi, pr * orr + pi * oi, ga.x[e]);
-            ga.x[E + e] = fmaf(gi, pr * oi - pi * orr, ga.x[E + e]);
-            gp.x[e] = fmaf(gi, sr * orr + si * oi, gp.x[e]);
-            gp.x[E + e] = fmaf(gi, sr * oi - si * orr, gp.x[E + e]);
-            gb.x[e] = fmaf(gi, pr * sr - pi * si, gb.x[e]);
-            gb.x[E + e] = fmaf(gi, pr * si + pi * sr, gb.x[E + e]);
+            ga.x[e] = fmaf(gi, fmaf(pr, orr, pi * oi), ga.x[e]);
+            ga.x[E + e] = fmaf(gi, fmaf(pr, oi, -(pi * orr)), ga.x[E + e]);
+            gp.x[e] = fmaf(gi, fmaf(sr, orr, si * oi), gp.x[e]);
+            gp.x[E + e] = fmaf(gi, fmaf(sr, oi, -(si * orr)), gp.x[E + e]);
+            gb.x[e] = fmaf(gi, fmaf(pr, sr, -(pi * si)), gb.x[e]);
+            gb.x[E + e] = fmaf(gi, fmaf(pr, si, pi * sr), gb.x[E + e]);
         }
     }
 }
@@ -312,8 +320,8 @@ __device__ __forceinline__ void make_queries(const Row<MODEL, W, NV>& s, const R
             qs.x[e] = p.x[e] * o.x[e];
         } else {
             const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
-            qo.x[e] = pr * sr - pi * si;      qo.x[E + e] = pr * si + pi * sr;    // SURVEY B-2, object side
-            qs.x[e] = pr * orr + pi * oi;     qs.x[E + e] = pr * oi - pi * orr;   // subject side
+            qo.x[e] = fmaf(pr, sr, -(pi * si));   qo.x[E + e] = fmaf(pr, si, pi * sr);      // SURVEY B-2, object side
+            qs.x[e] = fmaf(pr, orr, pi * oi);     qs.x[E + e] = fmaf(pr, oi, -(pi * orr));  // subject side
         }
     }
 }
@@ -373,11 +381,11 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
             const float sr = s.x[e], si = s.x[E + e], pr = p.x[e], pi = p.x[E + e], orr = o.x[e], oi = o.x[E + e];
             const float br = fmaf(gp_i, orr, Ao.x[e]), bi = fmaf(gp_i, oi, Ao.x[E + e]);  // b = Ao + gp_i*o
             const float ar = fmaf(gp_i, sr, As.x[e]), ai = fmaf(gp_i, si, As.x[E + e]);   // a = As + gp_i*s
-            gs.x[e] = pr * br + pi * bi;              gs.x[E + e] = pr * bi - pi * br;     // GA(p, b)
-            go.x[e] = pr * ar - pi * ai;              go.x[E + e] = pr * ai + pi * ar;     // GB(p, a)
+            gs.x[e] = fmaf(pr, br, pi * bi);          gs.x[E + e] = fmaf(pr, bi, -(pi * br));   // GA(p, b)
+            go.x[e] = fmaf(pr, ar, -(pi * ai));       go.x[E + e] = fmaf(pr, ai, pi * ar);      // GB(p, a)
             // GP(s, b) + GP(As, o)
-            gp.x[e] = (sr * br + si * bi) + (As.x[e] * orr + As.x[E + e] * oi);
-            gp.x[E + e] = (sr * bi - si * br) + (As.x[e] * oi - As.x[E + e] * orr);
+            gp.x[e] = fmaf(sr, br, si * bi) + fmaf(As.x[e], orr, As.x[E + e] * oi);
+            gp.x[E + e] = fmaf(sr, bi, -(si * br)) + fmaf(As.x[e], oi, -(As.x[E + e] * orr));
         }
     }
 }
@@ -634,7 +642,10 @@ __device__ __forceinline__ float strided_partial(const float* __restrict__ a, co
             acc = fmaf(a[c] * p[c], b[c], acc);
         } else {
             const float sr = a[c], si = a[khalf + c], pr = p[c], pi = p[khalf + c], orr = b[c], oi = b[khalf + c];
-            acc += (pr * sr) * orr + (pr * si) * oi + (pi * sr) * oi - (pi * si) * orr;
+            acc = fmaf(pr * sr, orr, acc);
+            acc = fmaf(pr * si, oi, acc);
+            acc = fmaf(pi * sr, oi, acc);
+            acc = fmaf(-(pi * si), orr, acc);
         }
     }
     return acc;
@@ -662,8 +673,8 @@ __global__ __launch_bounds__(kThreads) void train_forward_generic_kernel(const G
 }
 
 
-// the fused in-place forms of one model (emg_fused_m<model>.hip): shape 0..3 = 16 / 32 / 64 lanes per group with one
-// 16-byte chunk per lane, 64 lanes with two; ip 1 = SGD, 2 = any optimizer
+// the fused forms of one model (emg_fused_m<model>.hip): shape 0..3 = 16 / 32 / 64 lanes per group with one
+// 16-byte chunk per lane, 64 lanes with two; ip 0 = no in-place updates, 1 = SGD in place, 2 = any optimizer in place
 typedef void (*fused_launch_fn)(int shape, int ip, unsigned grid, hipStream_t st, const GroupParams& P, const Riders& riders);
 void launch_fused_m0(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);
 void launch_fused_m1(int, int, unsigned, hipStream_t, const GroupParams&, const Riders&);

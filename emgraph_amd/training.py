@@ -183,7 +183,7 @@ class Trainer:
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide
         # (with an LP regulariser every row goes through the apply kernel, which folds its gradient in: the in-place
         # path of the fused kernel stays free of the pow / sign code, which would cost it a wave per SIMD)
-        self.inplace = inplace and self.reg is None
+        self.inplace = self._inplace_wanted = inplace and self.reg is None
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
@@ -219,9 +219,23 @@ class Trainer:
             self._make_plan()            # the plan points at the resident training set
         self._alloc_scratch(int(batch_size))
 
+    def _choose_inplace(self, B):
+        """In-place singleton updates pay where singletons are plentiful.  With plain SGD the in-place form of the fused kernel
+        costs nothing (168 VGPRs, 3 waves per SIMD either way); with a STATEFUL optimizer it carries the optimizer's sqrt /
+        divide code three times over and drops to 2 waves per SIMD (224 VGPRs for complex rows) — worth it only if enough
+        slots take that path.  For uniformly drawn negatives a slot's destination is hit once with probability
+        exp(-slots / entities): C1 0.38 (in place), C2 0.11, C5 0.001 (every row through the apply kernel: C5 0.152 -> 0.138
+        ms/step).  Results are the same bits either way (one optimizer rule, one summation order)."""
+        if not self._inplace_wanted or self.batch_sharded:
+            return False
+        if self.opt_id == L.OPT_SGD or os.environ.get("EMG_INPLACE_ALWAYS"):
+            return True
+        return math.exp(-(2 + self.eta_total) * B / max(self.n_ent, 1)) >= 0.3
+
     def _alloc_scratch(self, B):
         if B <= self._cap:
             return
+        self.inplace = self._choose_inplace(B)
         torch.cuda.synchronize()
         dev, k, et = self.device, self.k_int, self.eta_total
         ldc = _padded_ld(k)

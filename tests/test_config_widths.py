@@ -194,7 +194,7 @@ def _check_step_vs_oracle(cfg, kind, n_ent, B, expect_singletons="by kind"):
     # ---------------- the product's Trainer (fused + in-place + pipelined plan) == the sequence above, bitwise ----
     tr = Trainer(MID[model], ki, sc, E0, R0, eta, loss=loss, optimizer=opt, optimizer_params={"lr": lr}, batches_count=2,
                  seed=seed)
-    assert tr.fused and tr.inplace and tr.pipeline
+    assert tr.fused and tr.pipeline   # (in-place singleton updates: chosen by the expected singleton share, same bits either way)
     tr.set_training_set(X, B)
     tr.step(0, B, epoch=1, batch=1, prefetch=[(B, B, 1, 2)])
     tr.step(B, B, epoch=1, batch=2)
@@ -322,3 +322,49 @@ def test_pair_apply_is_bit_identical(case):
     two, _ = _run_steps(True, 1, *FACTORED_CASES[case], pair=True)
     for a, b in zip(one, two):
         np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# the in-place choice is a speed choice: same bits either way
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt", ["adam", "adagrad", "momentum"])
+@pytest.mark.parametrize("model,k", [("HolE", 200), ("ComplEx", 50), ("ComplEx", 150), ("DistMult", 200), ("TransE", 100)])
+def test_inplace_choice_does_not_change_bits(monkeypatch, model, k, opt):
+    """Trainer._choose_inplace picks, for a stateful optimizer, between updating singleton destinations inside the fused
+    kernel and sending every row through the contribution buffer.  Both forms are different instantiations of the same
+    kernel template: tables, optimizer state and loss must agree bit for bit on a popularity-skewed batch (rows with
+    hundreds of contributions next to singletons)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"HolE": L.HOLE, "ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, eta = 2000, 45, 512, 20
+    ki = 2 * k if model in ("HolE", "ComplEx") else k
+    rs = np.random.RandomState(7)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    w = 1.0 / np.arange(1, n_ent + 1)
+    s, o = (rs.choice(n_ent, 2 * B, p=w / w.sum()) for _ in range(2))
+    X = np.stack([s, rs.randint(0, n_rel, 2 * B), o], 1).astype(np.int32)
+    sc = float(F32(2 / k)) if model == "HolE" else 1.0
+
+    def run(always):
+        if always:
+            monkeypatch.setenv("EMG_INPLACE_ALWAYS", "1")
+        else:
+            monkeypatch.delenv("EMG_INPLACE_ALWAYS", raising=False)
+        tr = Trainer(mid, ki, sc, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.01}, batches_count=2,
+                     seed=3)
+        tr.set_training_set(X, B)
+        tr.step(0, B, epoch=1, batch=1, prefetch=[(B, B, 1, 2)])
+        tr.step(B, B, epoch=1, batch=2)
+        Et, Rt = tr.tables_numpy()
+        states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
+        return tr.inplace, Et, Rt, states, tr.read_loss()
+
+    a, b = run(True), run(False)
+    assert a[0] and not b[0], "this shape is meant to make the Trainer choose contribution rows for a stateful optimizer"
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    for x, y in zip(a[3], b[3]):
+        np.testing.assert_array_equal(x, y)
+    assert a[4] == b[4]
