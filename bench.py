@@ -428,7 +428,7 @@ def run_eval(r, args):
                      "equal_to_exact_f32_ranks": True, "exact_f32_ranks_per_s": round(n_ranks / dt, 1),
                      "undecided_pairs": stf.get("pairs", 0), "undecided_fraction": round(stf.get("pairs", 0) / (n_ranks * w["n_ent"] / world), 6),
                      "tiles_redone_by_exact_kernel": stf.get("fallback", 0), "kernel_ms": round(stf["count_ms"], 3),
-                     "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_pairs_kernel"}
+                     "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_segment_kernel (segments of >= 512 pairs: query rows in LDS) / rescore_pairs_kernel"}
     # what the API call pays when nothing is cached (get_ranks / early stopping pass no tables: the half-precision copy, the
     # norm bounds and the range are rebuilt inside the call) — the figures above build them once per evaluation run, outside
     ru, dtu, _ = timed(T, precision=2)

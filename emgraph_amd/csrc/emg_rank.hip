@@ -13,7 +13,11 @@
 // acc + |q_k - e_k|; L2: fmaf(d,d,acc)).  The MFMA kernel, the positive scorer and the filter
 // scorer all produce exactly that chain, so the test entity and every filter entity compare
 // identically wherever they are scored.
+#include <limits.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 #include "emg_common.hpp"
 
@@ -564,6 +568,7 @@ struct RescoreParams {
     int model; const float* Q; int64_t ldq; const int32_t* pos_int; const float* ent; int64_t ld_ent; int64_t ent_offset;
     int k_int; float scale; const uint64_t* pairs; uint32_t cap; const uint32_t* seg_count; uint32_t n_seg;  // segment s: pairs[s*cap ..+min(count, cap))
     uint32_t groups_per_block;   // 4-segment groups per workgroup of the prefilter that wrote the pairs (see the kernel)
+    uint32_t min_pairs, max_pairs;   // this launch takes the segments with min_pairs <= pairs < max_pairs
     int32_t* cnt_gt; int32_t* cnt_eq;
 };
 
@@ -612,7 +617,8 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
     const uint32_t group = r * (8u * (j / r) + xcd) + (j % r);
     const uint32_t seg = group * 4u + wave;   // one wave per segment (the grid is padded: groups past the end do nothing)
     if (seg < P.n_seg) {
-        const uint32_t n = min(P.seg_count[seg], P.cap);
+        uint32_t n = min(P.seg_count[seg], P.cap);
+        if (n < P.min_pairs || n >= P.max_pairs) n = 0u;   // the other launch's segment
         const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
         for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
             const bool live = c0 + lane < n;
@@ -667,6 +673,153 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
                 }
             }
             if (live) rescore_finish(P, row, acc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Re-scoring of the f16 prefilter's segments, QUERY ROWS IN LDS.  A segment holds the undecided pairs of ONE wave of the
+// prefilter: 32 query rows against the entities of one chunk, ~1000 pairs when the positives rank in the middle of the
+// table.  Re-read per pair, the two rows are 2 x 4 k_int bytes of L2 traffic each time (PMC at C4 size: 2.0 G L2
+// requests of which 44 % missed — the query rows of the ~500 segments in flight on an XCD alone are 26 MB, six times its
+// L2).  Here one WORKGROUP takes one segment: its query rows are read once into LDS (32 x (k_int + 4) floats), the four
+// waves share the segment's pairs 64 at a time, and only entity rows still travel — 16-float slices, coalesced, staged
+// through the wave's own LDS region as in rescore_pairs_kernel, two slices ahead of the chain.  The prefilter walks the
+// tiles of its chunk in a per-block ROTATED order; every workgroup starts at the wrap point of its segment instead, so
+// the workgroups an XCD runs side by side (same chunk, neighbouring query blocks) sweep the chunk's entity rows in the
+// same direction at the same time and meet them in that XCD's L2.  Counters: per-row LDS atomics, one global atomic per
+// row and workgroup.  Segments with few pairs, or whose rows do not fit the LDS image, take the per-pair form.
+// ---------------------------------------------------------------------------------------------
+#ifndef RQ_ABLATE
+#define RQ_ABLATE 0   // timing experiments only (wrong results): 1 no entity loads, 2 no LDS staging / chain
+#endif
+constexpr int RQ_ROWS = 32;        // query rows of a segment (one wave of count_mfma_bf16_v3_kernel)
+constexpr int RQ_MIN_PAIRS = 512;  // shorter segments go to rescore_pairs_kernel: a workgroup's eight waves need a batch of 64 each
+constexpr int RQ_THREADS = 512, RQ_WAVES = RQ_THREADS / 64;
+constexpr int RQ_KC = 32, RQ_LD = RQ_KC + 4;   // 32-float slices: every request a whole 128-byte line (16-float slices: PMC 77 B / request)
+
+static inline size_t rescore_segment_lds(int k_int) { return ((size_t)RQ_ROWS * (k_int + 4) + RQ_WAVES * 64 * RQ_LD) * sizeof(float); }
+
+template <int KIND>
+__global__ __launch_bounds__(RQ_THREADS) void rescore_segment_kernel(const RescoreParams P) {
+    extern __shared__ __attribute__((aligned(16))) float rq_lds[];
+    __shared__ int s_rmin, s_rmax, s_wrap, s_gt[RQ_ROWS], s_eq[RQ_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ldq_s = P.k_int + 4;
+    float* const qrows = rq_lds;
+    float* const mye = rq_lds + RQ_ROWS * ldq_s + wave * (64 * RQ_LD);
+    // XCD b & 7 re-scores the segments of the prefilter workgroups that ran there, in their order (see rescore_pairs_kernel)
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, spb = P.groups_per_block * 4u;
+    const uint32_t seg = (xcd + 8u * (j / spb)) * spb + (j % spb);
+    if (seg >= P.n_seg) return;
+    const uint32_t n = min(P.seg_count[seg], P.cap);
+    if (n < P.min_pairs || n >= P.max_pairs) return;   // (short segments: rescore_pairs_kernel, a wave each)
+    const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
+
+    // ---- one pass over the pairs: the span of query rows, and where the tile order wraps ----------------------
+    if (tid == 0) { s_rmin = INT_MAX; s_rmax = -1; s_wrap = INT_MAX; }
+    if (tid < RQ_ROWS) { s_gt[tid] = 0; s_eq[tid] = 0; }
+    __syncthreads();
+    {
+        int rmin = INT_MAX, rmax = -1, wrap = INT_MAX;
+        for (uint32_t i = tid; i < n; i += RQ_THREADS) {
+            const uint64_t pr = sp[i];
+            const int row = (int)(pr >> 32);
+            rmin = min(rmin, row); rmax = max(rmax, row);
+            if (i > 0 && (((uint32_t)pr - (uint32_t)P.ent_offset) >> 7) < (((uint32_t)sp[i - 1] - (uint32_t)P.ent_offset) >> 7))
+                wrap = min(wrap, (int)i);   // the entity tile went down
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            rmin = min(rmin, __shfl_xor(rmin, off, 64)); rmax = max(rmax, __shfl_xor(rmax, off, 64));
+            wrap = min(wrap, __shfl_xor(wrap, off, 64));
+        }
+        if (lane == 0) { atomicMin(&s_rmin, rmin); atomicMax(&s_rmax, rmax); atomicMin(&s_wrap, wrap); }
+    }
+    __syncthreads();
+    const int rmin = s_rmin, nrows = s_rmax - rmin + 1;
+    const uint32_t start = s_wrap == INT_MAX ? 0u : (uint32_t)s_wrap;
+    const bool staged = nrows <= RQ_ROWS;   // workgroup-uniform
+    if (staged) {
+        const int pieces = P.k_int >> 2;   // 16-byte pieces per row
+        for (int t = tid; t < nrows * pieces; t += RQ_THREADS) {
+            const int r = t / pieces, c = t - r * pieces;
+            *reinterpret_cast<float4*>(qrows + r * ldq_s + 4 * c) = *reinterpret_cast<const float4*>(P.Q + (int64_t)(rmin + r) * P.ldq + 4 * c);
+        }
+    }
+    __syncthreads();
+
+    const int sub = lane >> 3, part = lane & 7;   // loader role: pair (8 it + sub) of the wave's 64, 16-byte piece `part` of a slice
+    constexpr int NPF = 2;                        // entity slices in flight per wave beside the one being multiplied
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n; c0 += RQ_THREADS) {
+        const bool live = c0 + lane < n;
+        int64_t row = rmin, e = 0;
+        if (live) {
+            uint32_t at = start + c0 + lane;
+            if (at >= n) at -= n;
+            const uint64_t pr = sp[at];
+            row = (int64_t)(pr >> 32);
+            e = (int64_t)(uint32_t)pr - P.ent_offset;
+        }
+        const float* ep[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) ep[it] = P.ent + __shfl(e, 8 * it + sub, 64) * P.ld_ent + 4 * part;
+        const float* const ql = qrows + (int)(row - rmin) * ldq_s;   // staged: this pair's query row in the LDS image
+        const float* const qg = P.Q + row * P.ldq;                   // otherwise (rows outside one 32-row span): read in place
+        float4 ev[NPF][8];
+        auto fetch = [&](int k0, float4 (&evs)[8]) {   // k_int % 4 == 0: a 4-float piece is whole or absent
+            const bool pin = k0 + 4 * part < P.k_int;
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                evs[it] = (pin && !(RQ_ABLATE & 1)) ? *reinterpret_cast<const float4*>(ep[it] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        float acc = 0.f;
+        auto slice = [&](int k0, float4 (&evs)[8]) {
+            if (RQ_ABLATE & 2) {
+                acc += evs[0].x + evs[1].y + evs[2].z + evs[3].w + evs[4].x + evs[5].y + evs[6].z + evs[7].w;
+                if (k0 + NPF * RQ_KC < P.k_int) fetch(k0 + NPF * RQ_KC, evs);
+                return;
+            }
+            wave_lds_sync();   // the previous slice has been consumed by every lane
+#pragma unroll
+            for (int it = 0; it < 8; ++it) *reinterpret_cast<float4*>(mye + (8 * it + sub) * RQ_LD + 4 * part) = evs[it];
+            wave_lds_sync();
+            if (k0 + NPF * RQ_KC < P.k_int) fetch(k0 + NPF * RQ_KC, evs);   // NPF slices ahead of the chain
+            const int kn = min(RQ_KC, P.k_int - k0);
+#pragma unroll
+            for (int c = 0; c < RQ_KC / 4; ++c) {
+                if (4 * c < kn) {
+                    const float4 a = staged ? *reinterpret_cast<const float4*>(ql + k0 + 4 * c) : *reinterpret_cast<const float4*>(qg + k0 + 4 * c);
+                    const float4 b2 = *reinterpret_cast<const float4*>(mye + lane * RQ_LD + 4 * c);
+                    acc = chain_step<KIND>(a.x, b2.x, acc); acc = chain_step<KIND>(a.y, b2.y, acc);
+                    acc = chain_step<KIND>(a.z, b2.z, acc); acc = chain_step<KIND>(a.w, b2.w, acc);
+                }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            if (u * RQ_KC < P.k_int) fetch(u * RQ_KC, ev[u]);
+        for (int k0 = 0; k0 < P.k_int; k0 += NPF * RQ_KC) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u)
+                if (k0 + u * RQ_KC < P.k_int) slice(k0 + u * RQ_KC, ev[u]);
+        }
+        if (live) {
+            if (!staged) rescore_finish(P, row, acc);
+            else {
+                const float score = P.model == EMG_HOLE ? __fmul_rn(acc, P.scale)
+                                  : (P.model == EMG_TRANSE_L1 ? -acc : (P.model == EMG_TRANSE_L2 ? -sqrtf(acc) : acc));
+                const int ci = cmp_int(score), p = P.pos_int[row];
+                if (ci > p) atomicAdd(&s_gt[row - rmin], 1);
+                else if (ci == p) atomicAdd(&s_eq[row - rmin], 1);
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        if (tid < nrows) {
+            if (s_gt[tid]) atomicAdd(&P.cnt_gt[rmin + tid], s_gt[tid]);
+            if (s_eq[tid]) atomicAdd(&P.cnt_eq[rmin + tid], s_eq[tid]);
         }
     }
 }
@@ -1151,6 +1304,7 @@ extern "C" int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq,
     P.k_int = k_int; P.scale = scale; P.pairs = pairs; P.cap = (uint32_t)(pairs_capacity / n_segments);
     P.seg_count = pair_count; P.n_seg = (uint32_t)n_segments;
     P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
+    P.min_pairs = 0u; P.max_pairs = 0xffffffffu;
     const bool vec = (k_int % 4 == 0) && (ldq % 4 == 0) && (ld_ent % 4 == 0) && aligned16(Q) && aligned16(ent);
     P.groups_per_block = (uint32_t)(segments_per_block / 4);
     const int64_t per = 8 * (int64_t)P.groups_per_block;                    // one workgroup per 4-segment group, XCD-aligned
@@ -1158,6 +1312,36 @@ extern "C" int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq,
     EMG_REQUIRE(blocks < ((int64_t)1 << 31), "emg_eval_rescore_pairs: too many segments");
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)stream;
+    // the f16 prefilter's segments (8 per workgroup, 32 query rows each): query rows in LDS, one workgroup per segment
+    static const bool seg_off = [] { const char* e = getenv("EMG_RESCORE"); return e && !strcmp(e, "pairs"); }();
+    if (vec && segments_per_block == 8 && !seg_off && rescore_segment_lds(k_int) <= 144 * 1024) {
+        static const uint32_t min_pairs = [] { const char* e = getenv("EMG_RESCORE_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)RQ_MIN_PAIRS; }();
+        P.min_pairs = min_pairs;
+        const int64_t nb = cdiv(n_segments, 8);
+        const int64_t sblocks = cdiv(nb, 8) * 8 * 8;
+        EMG_REQUIRE(sblocks < ((int64_t)1 << 31), "emg_eval_rescore_pairs: too many segments");
+        const size_t lds = rescore_segment_lds(k_int);
+        static std::atomic<uint64_t> done[3];
+        const void* fn = model == EMG_TRANSE_L1 ? (const void*)rescore_segment_kernel<1>
+                       : model == EMG_TRANSE_L2 ? (const void*)rescore_segment_kernel<2> : (const void*)rescore_segment_kernel<0>;
+        const int kind = model == EMG_TRANSE_L1 ? 1 : (model == EMG_TRANSE_L2 ? 2 : 0);
+        if (lds > 48 * 1024) {   // opt in to > 64 KB of dynamic LDS once per device
+            int dev = 0;
+            EMG_HIP(hipGetDevice(&dev));
+            const uint64_t bit = 1ull << (dev & 63);
+            if (!(done[kind].load(std::memory_order_acquire) & bit)) {
+                EMG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+                done[kind].fetch_or(bit, std::memory_order_release);
+            }
+        }
+        const dim3 sgrid((unsigned)sblocks), sblock(RQ_THREADS);
+        if (kind == 1) hipLaunchKernelGGL((rescore_segment_kernel<1>), sgrid, sblock, lds, st, P);
+        else if (kind == 2) hipLaunchKernelGGL((rescore_segment_kernel<2>), sgrid, sblock, lds, st, P);
+        else hipLaunchKernelGGL((rescore_segment_kernel<0>), sgrid, sblock, lds, st, P);
+        EMG_LAUNCH_CHECK();
+        P.max_pairs = P.min_pairs; P.min_pairs = 0u;   // the rest, below: a wave per segment
+        if (P.max_pairs == 0u) return EMG_OK;
+    }
     if (model == EMG_TRANSE_L1) {
         if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 1>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((rescore_pairs_kernel<false, 1>), grid, block, 0, st, P);

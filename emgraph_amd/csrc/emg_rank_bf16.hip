@@ -556,8 +556,8 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     const int64_t cb = xcd + 8 * (slot_id / P.n_qb);
     if (cb >= P.n_cb) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the wave's LDS ring
+    const int l31 = lane & 31, lhi = lane >> 5;                                                      //  base, pair segment and row base too)
     const int64_t n_cand = P.n_cand, ld_ent = P.ld_ent;
     const uint16_t* const ent = P.ent;
 
@@ -702,46 +702,27 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb) X[tb] = Y[tb];
         }
-        // ---- prefilter: (row, entity) pairs of the accumulators inside [lo, hi) of their row, once per tile ------
-        auto emit_tile = [&](bool full) {
-            unsigned long long m = 0ull;   // bit (16 j + 4 tb + i): this lane's value (j, tb, i) is undecided
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r0 = wave * 32 + 8 * j + 4 * lhi;
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
-                const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V3_BM + r0);
-#pragma unroll
-                for (int tb = 0; tb < 4; ++tb) {
-                    const bool cok = full || (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = acc[tb][4 * j + i];
-                        m |= (cok && v >= e4[i] && !(v >= g4[i])) ? (1ull << (16 * j + 4 * tb + i)) : 0ull;
-                    }
-                }
-            }
-            const int n_l = __popcll(m);
-            int incl = n_l;  // inclusive prefix over the wave
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            const int total = __shfl(incl, 63, 64);
-            if (pair_n + (unsigned)total > P.pair_cap) { pair_over = 1u; return; }   // the caller falls back to the exact kernel
-            uint64_t* dst = pair_base + pair_n + (unsigned)(incl - n_l);
-            pair_n += (unsigned)total;
-            const uint64_t row0 = (uint64_t)(qb * V3_BM + wave * 32 + 4 * lhi);
-            const uint64_t col0 = (uint64_t)(P.ent_offset + (tile0 + ctile) * V3_BN + l31);
-            while (m) {   // row = row0 + 8 j + i, entity = col0 + 32 tb
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                *dst++ = ((row0 + (uint64_t)(8 * (bit >> 4) + (bit & 3))) << 32) | (uint32_t)(col0 + 32u * (unsigned)((bit >> 2) & 3));
-            }
+        // ---- prefilter: the (row, entity) pairs of accumulators inside [lo, hi) of their row --------------------
+        // The two compares of a value leave LANE MASKS in scalar registers; `undecided` is one s_andn2 of them and the
+        // (wave-uniform) test for "any in these four registers" a scalar branch: a tile with nothing to emit costs one
+        // compare per value more than the counting epilogue.  A mask that is not empty is emitted on the spot — slot =
+        // pairs so far + v_mbcnt of the mask — so no per-lane bitmap, prefix scan or bit loop is ever built.
+        const uint32_t row_s = (uint32_t)(qb * V3_BM + wave * 32), col_s = (uint32_t)(P.ent_offset + (tile0 + ctile) * V3_BN);   // scalars
+        const unsigned lhi4 = 4u * (unsigned)lhi;
+        auto emit_mask = [&](uint64_t m, int r, int tb) {   // r = 4 j + i: row = row0 + 8 j + i, entity = col0 + 32 tb
+            const unsigned n = (unsigned)__builtin_popcountll(m);
+            if (pair_n + n > P.pair_cap) { pair_over = 1u; return; }   // the caller redoes this query tile with the exact kernel
+            const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            // (the scalar halves are made opaque: otherwise the 16 + 4 lane-dependent sums are hoisted out of the tile loop and
+            // held in — spilled — vector registers for an emission that may never come)
+            unsigned hi_s = row_s + (unsigned)(8 * (r >> 2) + (r & 3)), lo_s = col_s + 32u * (unsigned)tb;
+            asm volatile("" : "+s"(hi_s), "+s"(lo_s));
+            if (__builtin_amdgcn_inverse_ballot_w64(m))   // low word: entity, high word: query row
+                *reinterpret_cast<uint2*>(pair_base + pair_n + before) = make_uint2(lo_s + (unsigned)l31, hi_s + lhi4);
+            pair_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(pair_n + n));
         };
         // ---- tile epilogue: compare-and-count, clear -----------------------------------------------------
         auto epilogue = [&](auto FULL) {
-            bool any_tie = false;   // (wave-uniform) some accumulator of this tile lies inside its row's band
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r0 = wave * 32 + 8 * j + 4 * lhi;  // query rows of accumulator registers 4j..4j+3
@@ -755,6 +736,29 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                         for (int i = 0; i < 4; ++i)
                             cnt[2 * j + (i >> 1)] += (cok && acc[tb][4 * j + i] >= g4[i]) ? (1u << (16 * (i & 1))) : 0u;
                     }
+                } else if constexpr (PRE) {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        const uint64_t cokm = FULL.value ? ~0ull : __builtin_amdgcn_ballot_w64((tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand);
+                        uint64_t mu[4], any = 0ull;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = acc[tb][4 * j + i];
+                            const uint64_t mg = __builtin_amdgcn_ballot_w64(v >= g4[i]) & cokm;
+                            const uint64_t me = __builtin_amdgcn_ballot_w64(v >= e4[i]) & cokm;
+                            cnt[2 * j + (i >> 1)] += __builtin_amdgcn_inverse_ballot_w64(mg) ? (1u << (16 * (i & 1))) : 0u;
+                            mu[i] = me & ~mg;
+                            any |= mu[i];
+                        }
+                        // (count here: left to itself the compiler defers the 64 counter updates of a tile to its end and
+                        // carries their 64 lane masks there — 128 scalar registers it does not have)
+                        asm volatile("" : "+v"(cnt[2 * j]), "+v"(cnt[2 * j + 1]));
+                        if (any) {   // wave-uniform
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (mu[i]) emit_mask(mu[i], 4 * j + i, tb);
+                        }
+                    }
                 } else if constexpr (FULL.value) {
                     unsigned long long tie = 0ull;  // lanes holding a score equal to the positive's (rare)
 #pragma unroll
@@ -766,16 +770,13 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                             tie |= __builtin_amdgcn_fcmpf(v, g4[i], 3) ^ __builtin_amdgcn_fcmpf(v, e4[i], 3);
                         }
                     if (tie) {
-                        if constexpr (PRE) any_tie = true;
-                        else {
 #pragma unroll
-                            for (int tb = 0; tb < 4; ++tb)
+                        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    const float v = acc[tb][4 * j + i];
-                                    cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
-                                }
-                        }
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = acc[tb][4 * j + i];
+                                cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
+                            }
                     }
                 } else {
 #pragma unroll
@@ -786,14 +787,10 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
                             const float v = acc[tb][4 * j + i];
                             const bool gt = v >= g4[i], ge = v >= e4[i];
                             cnt[2 * j + (i >> 1)] += (cok && gt) ? (1u << (16 * (i & 1))) : 0u;
-                            if constexpr (!PRE) cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
+                            cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
                         }
                     }
-                    if constexpr (PRE) any_tie = true;
                 }
-            }
-            if constexpr (PRE) {
-                if (any_tie) emit_tile(FULL.value);
             }
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb)
@@ -922,6 +919,13 @@ __global__ __launch_bounds__(256) void filter_count_bf16_kernel(int model, const
 }
 
 // k-steps of 16 the prefilter kernel is instantiated for, and what they ask of the operand rows
+// Entity tiles per chunk of the PREFILTER: the chunk is what the re-scoring pass sweeps with the query rows of one segment
+// in LDS, and its f32 rows (tiles x 128 x 4 k_int bytes) should sit in one XCD's 4 MB L2 next to the other segments' sweeps.
+static int v3_prefilter_tiles() {
+    static const int t = [] { const char* e = getenv("EMG_PRE_TILES"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 32 ? v : 32; }();
+    return t;
+}
+
 static int v3_prefilter_steps(int k16) {
     static const int have[] = {4, 7, 8, 10, 13, 16, 19, 22, 25};
     for (int nq : have)
@@ -958,7 +962,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         // register-stationary query fragments + deep LDS-DMA ring (see its header); common k only
         P.n_qb = cdiv(P.n_rows, V3_BM);
         P.n_tiles = cdiv(P.n_cand, V3_BN);
-        P.tiles_per_chunk = 32;  // <= 32: the epilogue's packed counters are 8 bits wide
+        P.tiles_per_chunk = P.pairs ? v3_prefilter_tiles() : 32;  // <= 32: the epilogue's packed counters are 8 bits wide
         P.n_cb = cdiv(P.n_tiles, P.tiles_per_chunk);
         const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
         EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
@@ -1041,7 +1045,7 @@ extern "C" int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, c
 
 // grid of the register-stationary kernel for (n_rows, n_cand): the prefilter's pair buffer has one segment per wave
 static int64_t v3_blocks(int64_t n_rows, int64_t n_cand) {
-    const int64_t n_qb = cdiv(n_rows, V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), 32);
+    const int64_t n_qb = cdiv(n_rows, V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), v3_prefilter_tiles());
     return 8 * n_qb * cdiv(n_cb, 8);
 }
 
