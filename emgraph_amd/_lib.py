@@ -125,6 +125,10 @@ SIGNATURES.update({
     "emg_eval_prefilter_band": (_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p, _p]),
     "emg_eval_prefilter_f16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i64, _p]),
     "emg_eval_prefilter_segments": (_i64, [_i64, _i64]),
+    "emg_eval_prefilter_segments_k": (_i64, [_i64, _i64, _i32]),
+    "emg_eval_prefilter_waves": (_i32, [_i32]),
+    "emg_eval_prefilter_max_cols": (_i32, []),
+    "emg_eval_rescore_pairs_rows": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p]),
     "emg_eval_prefilter_ld": (_i64, [_i32]),
     "emg_eval_rescore_pairs": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _p, _p, _p]),
     "emg_eval_rescore_pairs_ex": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _i32, _p, _p, _p]),

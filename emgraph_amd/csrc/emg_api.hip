@@ -97,7 +97,8 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
     size_t band_off = 0, bounds_off = 0, pairs_off = 0, pcount_off = 0, q2_off = 0, thr_off = 0;
     int64_t n_seg = 0, pair_cap = 0;
     if (precision_mode == 2) {
-        n_seg = sad ? emg_eval_sad_segments(n_rows, nc) : emg_eval_prefilter_segments(n_rows, nc);
+        const int32_t pre_cols = (k_int + (l2 ? 2 : 0) + 15) / 16 * 16;   // contraction width of the half-precision prefilter
+        n_seg = sad ? emg_eval_sad_segments(n_rows, nc) : emg_eval_prefilter_segments_k(n_rows, nc, pre_cols);
         int64_t per = ((int64_t)1 << 27) / (n_seg > 0 ? n_seg : 1);   // <= 1 GiB of pairs in total
         per = per < 64 ? 64 : (per > 2048 ? 2048 : per);
         pair_cap = n_seg * per;
@@ -164,8 +165,9 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
             else step(r);
         }
         if (rc == EMG_OK && !exact) {
-            step(emg_eval_rescore_pairs_ex(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg,
-                                           sad ? 4 : 8, cnt, cnt + n_rows, stream));
+            step(emg_eval_rescore_pairs_rows(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg,
+                                             sad ? 4 : emg_eval_prefilter_waves((k_int + (l2 ? 2 : 0) + 15) / 16 * 16), sad ? 0 : 32,
+                                             cnt, cnt + n_rows, stream));
             uint32_t over = 0;   // some wave ran out of pair room: these counters are void, the exact kernel redoes them
             if (rc == EMG_OK && (hipMemcpyAsync(&over, pcount + n_seg, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                                  hipStreamSynchronize(st) != hipSuccess))

@@ -695,13 +695,14 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
 #endif
 constexpr int RQ_ROWS = 32;        // query rows of a segment (one wave of count_mfma_bf16_v3_kernel)
 constexpr int RQ_MIN_PAIRS = 512;  // shorter segments go to rescore_pairs_kernel: a workgroup's eight waves need a batch of 64 each
-constexpr int RQ_THREADS = 512, RQ_WAVES = RQ_THREADS / 64;
 constexpr int RQ_KC = 32, RQ_LD = RQ_KC + 4;   // 32-float slices: every request a whole 128-byte line (16-float slices: PMC 77 B / request)
 
-static inline size_t rescore_segment_lds(int k_int) { return ((size_t)RQ_ROWS * (k_int + 4) + RQ_WAVES * 64 * RQ_LD) * sizeof(float); }
+// RQ_WAVES = 8 up to ~570 columns; 4 where the image of wider rows leaves room for four staging regions only (<= 830)
+static inline size_t rescore_segment_lds(int k_int, int waves) { return ((size_t)RQ_ROWS * (k_int + 4) + (size_t)waves * 64 * RQ_LD) * sizeof(float); }
 
-template <int KIND>
-__global__ __launch_bounds__(RQ_THREADS) void rescore_segment_kernel(const RescoreParams P) {
+template <int KIND, int RQ_WAVES>
+__global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const RescoreParams P) {
+    constexpr int RQ_THREADS = 64 * RQ_WAVES;
     extern __shared__ __attribute__((aligned(16))) float rq_lds[];
     __shared__ int s_rmin, s_rmax, s_wrap, s_gt[RQ_ROWS], s_eq[RQ_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1293,8 +1294,17 @@ extern "C" int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq,
                                          const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
                                          int64_t n_segments, int32_t segments_per_block, int32_t* cnt_gt, int32_t* cnt_eq,
                                          void* stream) {
+    return emg_eval_rescore_pairs_rows(model, Q, ldq, pos_int, ent, ld_ent, ent_offset, k_int, scale, pairs, pairs_capacity, pair_count,
+                                       n_segments, segments_per_block, segments_per_block == 8 ? 32 : 0, cnt_gt, cnt_eq, stream);
+}
+
+extern "C" int emg_eval_rescore_pairs_rows(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                           int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale,
+                                           const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
+                                           int64_t n_segments, int32_t segments_per_block, int32_t rows_per_segment,
+                                           int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
     EMG_REQUIRE(segments_per_block >= 4 && segments_per_block % 4 == 0 && segments_per_block <= 64,
-                "emg_eval_rescore_pairs_ex: segments_per_block must be a multiple of 4 (4 = emg_eval_prefilter_sad, 8 = emg_eval_prefilter_f16)");
+                "emg_eval_rescore_pairs: segments_per_block must be a multiple of 4 (emg_eval_prefilter_waves; 4 = emg_eval_prefilter_sad)");
     EMG_REQUIRE(model >= EMG_TRANSE_L1 && model <= EMG_HOLE, "emg_eval_rescore_pairs: unknown model id %d", model);
     EMG_REQUIRE(Q && pos_int && ent && pairs && pair_count && cnt_gt && cnt_eq, "emg_eval_rescore_pairs: null pointer");
     if (n_segments <= 0) return EMG_OK;
@@ -1314,30 +1324,39 @@ extern "C" int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq,
     hipStream_t st = (hipStream_t)stream;
     // the f16 prefilter's segments (8 per workgroup, 32 query rows each): query rows in LDS, one workgroup per segment
     static const bool seg_off = [] { const char* e = getenv("EMG_RESCORE"); return e && !strcmp(e, "pairs"); }();
-    if (vec && segments_per_block == 8 && !seg_off && rescore_segment_lds(k_int) <= 144 * 1024) {
+    const int seg_waves = rescore_segment_lds(k_int, 8) <= 144 * 1024 ? 8 : (rescore_segment_lds(k_int, 4) <= 144 * 1024 ? 4 : 0);
+    if (vec && rows_per_segment > 0 && rows_per_segment <= RQ_ROWS && !seg_off && seg_waves) {
         static const uint32_t min_pairs = [] { const char* e = getenv("EMG_RESCORE_MIN"); return e ? (uint32_t)atoi(e) : (uint32_t)RQ_MIN_PAIRS; }();
-        P.min_pairs = min_pairs;
-        const int64_t nb = cdiv(n_segments, 8);
-        const int64_t sblocks = cdiv(nb, 8) * 8 * 8;
+        P.min_pairs = seg_waves == 8 ? min_pairs : min_pairs / 2;
+        const int64_t nb = cdiv(n_segments, segments_per_block);
+        const int64_t sblocks = cdiv(nb, 8) * 8 * segments_per_block;
         EMG_REQUIRE(sblocks < ((int64_t)1 << 31), "emg_eval_rescore_pairs: too many segments");
-        const size_t lds = rescore_segment_lds(k_int);
-        static std::atomic<uint64_t> done[3];
-        const void* fn = model == EMG_TRANSE_L1 ? (const void*)rescore_segment_kernel<1>
-                       : model == EMG_TRANSE_L2 ? (const void*)rescore_segment_kernel<2> : (const void*)rescore_segment_kernel<0>;
+        const size_t lds = rescore_segment_lds(k_int, seg_waves);
         const int kind = model == EMG_TRANSE_L1 ? 1 : (model == EMG_TRANSE_L2 ? 2 : 0);
-        if (lds > 48 * 1024) {   // opt in to > 64 KB of dynamic LDS once per device
+        static std::atomic<uint64_t> done[6];
+        const void* fn8[3] = {(const void*)rescore_segment_kernel<0, 8>, (const void*)rescore_segment_kernel<1, 8>, (const void*)rescore_segment_kernel<2, 8>};
+        const void* fn4[3] = {(const void*)rescore_segment_kernel<0, 4>, (const void*)rescore_segment_kernel<1, 4>, (const void*)rescore_segment_kernel<2, 4>};
+        const void* fn = seg_waves == 8 ? fn8[kind] : fn4[kind];
+        if (lds > 48 * 1024) {   // opt in to > 64 KB of dynamic LDS once per device and kernel
             int dev = 0;
             EMG_HIP(hipGetDevice(&dev));
             const uint64_t bit = 1ull << (dev & 63);
-            if (!(done[kind].load(std::memory_order_acquire) & bit)) {
+            std::atomic<uint64_t>& flag = done[kind + (seg_waves == 8 ? 0 : 3)];
+            if (!(flag.load(std::memory_order_acquire) & bit)) {
                 EMG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-                done[kind].fetch_or(bit, std::memory_order_release);
+                flag.fetch_or(bit, std::memory_order_release);
             }
         }
-        const dim3 sgrid((unsigned)sblocks), sblock(RQ_THREADS);
-        if (kind == 1) hipLaunchKernelGGL((rescore_segment_kernel<1>), sgrid, sblock, lds, st, P);
-        else if (kind == 2) hipLaunchKernelGGL((rescore_segment_kernel<2>), sgrid, sblock, lds, st, P);
-        else hipLaunchKernelGGL((rescore_segment_kernel<0>), sgrid, sblock, lds, st, P);
+        const dim3 sgrid((unsigned)sblocks), sblock(64 * seg_waves);
+        if (seg_waves == 8) {
+            if (kind == 1) hipLaunchKernelGGL((rescore_segment_kernel<1, 8>), sgrid, sblock, lds, st, P);
+            else if (kind == 2) hipLaunchKernelGGL((rescore_segment_kernel<2, 8>), sgrid, sblock, lds, st, P);
+            else hipLaunchKernelGGL((rescore_segment_kernel<0, 8>), sgrid, sblock, lds, st, P);
+        } else {
+            if (kind == 1) hipLaunchKernelGGL((rescore_segment_kernel<1, 4>), sgrid, sblock, lds, st, P);
+            else if (kind == 2) hipLaunchKernelGGL((rescore_segment_kernel<2, 4>), sgrid, sblock, lds, st, P);
+            else hipLaunchKernelGGL((rescore_segment_kernel<0, 4>), sgrid, sblock, lds, st, P);
+        }
         EMG_LAUNCH_CHECK();
         P.max_pairs = P.min_pairs; P.min_pairs = 0u;   // the rest, below: a wave per segment
         if (P.max_pairs == 0u) return EMG_OK;

@@ -536,8 +536,12 @@ constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
 // A candidate whose accumulator clears the `>` threshold by more than the band is counted here (cnt_gt); one that
 // misses the `>=` threshold by more than the band is dropped; the few in between are EMITTED as (row, entity) pairs
 // and re-scored exactly by emg_eval_rescore_pairs — so the counters, and the ranks, equal the exact path's bit for bit.
-template <int NQ, int SQ, int MODE>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter
-__global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
+// WAVES = 8: 256 query rows per workgroup, two waves per SIMD (<= 256 registers: NQ <= 25, k_int <= 400).  WAVES = 4 (the
+// prefilter above k_int = 400): 128 query rows, ONE wave per SIMD with the whole 512-register file — NQ up to 50 query
+// fragments (200 registers) beside the accumulators; every streamed entity byte is used by half as many rows.
+template <int NQ, int SQ, int MODE, int WAVES = 8>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter
+__global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
+    constexpr int V3_BM = 32 * WAVES;           // query rows per workgroup
     constexpr bool ONE = MODE == 1;
     constexpr bool PRE = MODE == 2;
     constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
@@ -545,10 +549,10 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     constexpr int RPB = 256 / RB;               // rows per 256-byte LDS bank row
     constexpr int STAGE = V3_BN * RB;           // 8 KB / 16 KB
     constexpr int NS = V3_RING / STAGE;         // 16 / 8 slots
-    constexpr int G = STAGE / 8192;             // LDS-DMA instructions per wave and slice
+    constexpr int G = STAGE / (1024 * WAVES);   // LDS-DMA instructions per wave and slice
     constexpr int D = (NQ + SQ - 1) / SQ;       // slices per tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ring | thresholds
-    float* thr_s = reinterpret_cast<float*>(smem + V3_RING);                // [0,256): gt, [256,512): ge
+    float* thr_s = reinterpret_cast<float*>(smem + V3_RING);                // [0,V3_BM): gt, [V3_BM, 2 V3_BM): ge
 
     const int64_t id = blockIdx.x;
     const int64_t xcd = id & 7, slot_id = id >> 3;
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     int cslot = 0;
     // prefilter: this wave's private segment of the pair buffer
     unsigned pair_n = 0u, pair_over = 0u;
-    uint64_t* const pair_base = PRE ? P.pairs + ((uint64_t)blockIdx.x * 8u + (unsigned)wave) * P.pair_cap : nullptr;
+    uint64_t* const pair_base = PRE ? P.pairs + ((uint64_t)blockIdx.x * (unsigned)WAVES + (unsigned)wave) * P.pair_cap : nullptr;
     auto load_step = [&](bf16x8 (&dst)[4], int slot, int ks) {
         const unsigned char* st = bptr + slot * STAGE + sl[ks];
 #pragma unroll
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void count_mfma_bf16_v3_kernel(const CountB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
     if constexpr (PRE) {
         if (lane == 0) {
-            P.pair_count[blockIdx.x * 8u + (unsigned)wave] = pair_n;
+            P.pair_count[blockIdx.x * (unsigned)WAVES + (unsigned)wave] = pair_n;
             if (pair_over) atomicOr(P.pair_count + P.n_segments, 1u);
         }
     }
@@ -838,13 +842,13 @@ static int allow_full_lds(const void* kernel, std::atomic<uint64_t>& done) {
     return EMG_OK;
 }
 
-template <int NQ, int SQ, int MODE>
+template <int NQ, int SQ, int MODE, int WAVES = 8>
 static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
-    const size_t lds_bytes = (size_t)V3_RING + 2 * V3_BM * sizeof(float);
+    const size_t lds_bytes = (size_t)V3_RING + 2 * (32 * WAVES) * sizeof(float);
     static std::atomic<uint64_t> devices_done{0};  // one flag per template instance and device
-    int rc = allow_full_lds((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, MODE>, devices_done);
+    int rc = allow_full_lds((const void*)count_mfma_bf16_v3_kernel<NQ, SQ, MODE, WAVES>, devices_done);
     if (rc != EMG_OK) return rc;
-    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, MODE>), dim3((unsigned)nblk), dim3(512), lds_bytes, st, P);
+    hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, MODE, WAVES>), dim3((unsigned)nblk), dim3(64 * WAVES), lds_bytes, st, P);
     return EMG_OK;
 }
 
@@ -926,8 +930,9 @@ static int v3_prefilter_tiles() {
     return t;
 }
 
+constexpr int V3_WIDE_FROM = 26;   // k-steps from which the prefilter runs as 4 waves x 128 query rows (query fragments > 100 registers)
 static int v3_prefilter_steps(int k16) {
-    static const int have[] = {4, 7, 8, 10, 13, 16, 19, 22, 25};
+    static const int have[] = {4, 7, 8, 10, 13, 16, 19, 22, 25, 32, 38, 44, 50};
     for (int nq : have)
         if (k16 <= nq) return nq;
     return 0;
@@ -972,7 +977,16 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         // the prefilter (exact-fast mode, what evaluate_performance uses by default) at EVERY width up to 400: the next
         // instantiated step count, the extra k-steps multiply the rows' zero padding (exact zeros: nothing changes)
         const int nq = P.pairs != nullptr ? v3_prefilter_steps(P.k16) : P.k16;
-        if (nq == 25) rc = EMG_V3(25);
+        if (nq >= V3_WIDE_FROM) {   // 400 < k_int <= 800: one wave per SIMD, 128 query rows per workgroup
+            P.n_qb = cdiv(P.n_rows, 128);
+            const int64_t wblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
+            EMG_REQUIRE(wblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
+            if (nq == 32) rc = launch_v3<32, 4, 2, 4>(P, wblk, st);
+            else if (nq == 38) rc = launch_v3<38, 4, 2, 4>(P, wblk, st);
+            else if (nq == 44) rc = launch_v3<44, 4, 2, 4>(P, wblk, st);
+            else rc = launch_v3<50, 4, 2, 4>(P, wblk, st);
+        }
+        else if (nq == 25) rc = EMG_V3(25);
         else if (nq == 13) rc = EMG_V3(13);
         else if (nq == 8) rc = EMG_V3(8);
         else if (nq == 4) rc = launch_v3<4, 4, 2>(P, nblk, st);
@@ -1043,9 +1057,11 @@ extern "C" int emg_eval_count_bf16(int model, const void* q_bf16, int64_t ldq, c
     return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
 }
 
-// grid of the register-stationary kernel for (n_rows, n_cand): the prefilter's pair buffer has one segment per wave
-static int64_t v3_blocks(int64_t n_rows, int64_t n_cand) {
-    const int64_t n_qb = cdiv(n_rows, V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), v3_prefilter_tiles());
+// grid of the register-stationary kernel for (n_rows, n_cand) at `k_cols` contraction columns: the prefilter's pair buffer
+// has one segment per wave (8 waves x 256 query rows per workgroup up to 400 columns, 4 waves x 128 rows above)
+static bool v3_wide(int32_t k_cols) { return v3_prefilter_steps((k_cols + 15) / 16) >= V3_WIDE_FROM; }
+static int64_t v3_blocks(int64_t n_rows, int64_t n_cand, int32_t k_cols) {
+    const int64_t n_qb = cdiv(n_rows, v3_wide(k_cols) ? 128 : V3_BM), n_cb = cdiv(cdiv(n_cand, V3_BN), v3_prefilter_tiles());
     return 8 * n_qb * cdiv(n_cb, 8);
 }
 
@@ -1056,8 +1072,16 @@ extern "C" int64_t emg_eval_prefilter_ld(int32_t k_cols) {
     return need > plain ? need : plain;
 }
 
+extern "C" int32_t emg_eval_prefilter_max_cols(void) { return 800; }
+
+extern "C" int32_t emg_eval_prefilter_waves(int32_t k_cols) { return v3_wide(k_cols) ? 4 : 8; }
+
+extern "C" int64_t emg_eval_prefilter_segments_k(int64_t n_rows, int64_t n_cand, int32_t k_cols) {
+    return (n_rows <= 0 || n_cand <= 0) ? 0 : emg_eval_prefilter_waves(k_cols) * v3_blocks(n_rows, n_cand, k_cols);
+}
+
 extern "C" int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand) {
-    return (n_rows <= 0 || n_cand <= 0) ? 0 : 8 * v3_blocks(n_rows, n_cand);
+    return emg_eval_prefilter_segments_k(n_rows, n_cand, 400);
 }
 
 extern "C" int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
@@ -1067,7 +1091,7 @@ extern "C" int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq,
     EMG_REQUIRE(q_f16 && pos_int && band && ent_f16 && cnt_gt && pairs && pair_count, "emg_eval_prefilter_f16: null pointer");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31) && ent_offset + n_cand < ((int64_t)1 << 31), "emg_eval_prefilter_f16: ids must fit 31 bits");
     if (n_rows == 0 || n_cand == 0) return EMG_OK;
-    const int64_t n_seg = emg_eval_prefilter_segments(n_rows, n_cand);
+    const int64_t n_seg = emg_eval_prefilter_segments_k(n_rows, n_cand, k_pad);
     EMG_REQUIRE(pairs_capacity >= n_seg && pairs_capacity / n_seg < ((int64_t)1 << 31), "emg_eval_prefilter_f16: pair buffer smaller than one entry per wave (%lld)", (long long)n_seg);
     CountBf16Params P{};
     P.Q = (const uint16_t*)q_f16; P.ldq = ldq; P.pos_int = pos_int; P.n_rows = n_rows;
@@ -1085,7 +1109,7 @@ extern "C" int emg_eval_prefilter_f16_thr(const void* q_f16, int64_t ldq, const 
     EMG_REQUIRE(q_f16 && thr && ent_f16 && cnt_gt && pairs && pair_count, "emg_eval_prefilter_f16_thr: null pointer");
     EMG_REQUIRE(n_rows < ((int64_t)1 << 31) && ent_offset + n_cand < ((int64_t)1 << 31), "emg_eval_prefilter_f16_thr: ids must fit 31 bits");
     if (n_rows == 0 || n_cand == 0) return EMG_OK;
-    const int64_t n_seg = emg_eval_prefilter_segments(n_rows, n_cand);
+    const int64_t n_seg = emg_eval_prefilter_segments_k(n_rows, n_cand, k_pad);
     EMG_REQUIRE(pairs_capacity >= n_seg && pairs_capacity / n_seg < ((int64_t)1 << 31), "emg_eval_prefilter_f16_thr: pair buffer smaller than one entry per wave (%lld)", (long long)n_seg);
     CountBf16Params P{};
     P.Q = (const uint16_t*)q_f16; P.ldq = ldq; P.pos_int = nullptr; P.n_rows = n_rows;

@@ -546,9 +546,20 @@ def prefilter_ld(k_cols):
     return int(L.load().emg_eval_prefilter_ld(k_cols))
 
 
-def eval_prefilter_segments(n_rows, n_cand):
-    """number of segments (= waves of the prefilter kernel) the pair buffer is cut into; pair_count has one more entry"""
-    return int(L.load().emg_eval_prefilter_segments(n_rows, n_cand))
+def eval_prefilter_segments(n_rows, n_cand, k_cols=400):
+    """number of segments (= waves of the prefilter kernel) the pair buffer is cut into at a contraction width of k_cols;
+    pair_count has one more entry"""
+    return int(L.load().emg_eval_prefilter_segments_k(n_rows, n_cand, bf16_pad(k_cols)))
+
+
+def prefilter_waves(k_cols):
+    """segments each workgroup of the prefilter writes at this width (8, or 4 above 400 columns): the re-scoring's
+    segments_per_block"""
+    return int(L.load().emg_eval_prefilter_waves(bf16_pad(k_cols)))
+
+
+def prefilter_max_cols():
+    return int(L.load().emg_eval_prefilter_max_cols())
 
 
 def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_int, scale, cnt_gt, pairs, pair_count):
@@ -558,7 +569,7 @@ def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_in
     lib = L.load()
     pq, n_rows, ldq = _chk_f16(q_f16, "q_f16")
     pe, ne, lde = _chk_f16(ent_f16, "ent_f16")
-    n_seg = eval_prefilter_segments(n_rows, ne)
+    n_seg = eval_prefilter_segments(n_rows, ne, k_int)
     L.check(lib.emg_eval_prefilter_f16(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
                                        _chk_vec(band, torch.float32, "band", n_rows), n_rows, pe, ne, lde, ent_offset,
                                        bf16_pad(k_int), scale, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
@@ -568,17 +579,19 @@ def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_in
 
 
 def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pairs, pair_count, n_seg, cnt_gt, cnt_eq,
-                       segments_per_block=4):
-    """exact re-scoring of the prefilter's undecided pairs (counts read on the device); ``segments_per_block``: 8 after the
-    half-precision MFMA prefilter, 4 after the fixed-point one (XCD affinity of the re-scoring, include/emgraph_hip.h)"""
+                       segments_per_block=4, rows_per_segment=0):
+    """exact re-scoring of the prefilter's undecided pairs (counts read on the device); ``segments_per_block``: waves per
+    workgroup of the prefilter that wrote them (prefilter_waves(width); 4 after the fixed-point one) — the XCD affinity of the
+    re-scoring; ``rows_per_segment``: 32 after the half-precision MFMA prefilter (long segments are then re-scored with
+    their query rows in LDS), 0 otherwise (include/emgraph_hip.h)"""
     lib = L.load()
     pq, n_rows, ldq = _chk_table(Q, "Q")
     pe, ne, lde = _chk_table(ent, "ent")
-    L.check(lib.emg_eval_rescore_pairs_ex(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset,
-                                          k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
-                                          _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg, segments_per_block,
-                                          _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
-                                          _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs_ex")
+    L.check(lib.emg_eval_rescore_pairs_rows(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset,
+                                            k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
+                                            _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg, segments_per_block,
+                                            rows_per_segment, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                            _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs_rows")
 
 
 def to_f16_l2(src, k_int, is_query, ld_dst=None):
@@ -613,7 +626,7 @@ def eval_prefilter_f16_thr(q_f16, thr, ent_f16, ent_offset, k_cols, cnt_gt, pair
     lib = L.load()
     pq, n_rows, ldq = _chk_f16(q_f16, "q_f16")
     pe, ne, lde = _chk_f16(ent_f16, "ent_f16")
-    n_seg = eval_prefilter_segments(n_rows, ne)
+    n_seg = eval_prefilter_segments(n_rows, ne, k_cols)
     L.check(lib.emg_eval_prefilter_f16_thr(pq, ldq, _chk_vec(thr, torch.float32, "thr", 2 * n_rows), n_rows, pe, ne, lde, ent_offset,
                                            bf16_pad(k_cols), _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
                                            _chk_vec(pairs, torch.int64, "pairs"),

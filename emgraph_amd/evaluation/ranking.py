@@ -290,7 +290,7 @@ def resolve_auto_precision(model_id, k_int, n_test, n_ent, entities_subset=None)
     """what precision 'auto' means for a call: the exact-fast mode (2) returns the SAME ranks as precision 0, bit for bit,
     and pays off once the 1-vs-all product is large enough to amortise the half-precision copy of the table; its kernels
     cover the common widths"""
-    covered = lambda w: 32 < w <= 400   # noqa: E731  (the prefilter kernel pads a width up to its next instantiation)
+    covered = lambda w: 32 < w <= D.prefilter_max_cols()   # noqa: E731  (the prefilter kernel pads a width up to its next instantiation)
     applies = ((model_id in (L.DISTMULT, L.COMPLEX, L.HOLE) and covered(k_int)) or (model_id == L.TRANSE_L1 and k_int >= 16)
                or (model_id == L.TRANSE_L2 and covered(k_int + 2)))
     return 2 if (applies and entities_subset is None and n_test >= 128 and n_ent >= 32768) else 0
@@ -307,7 +307,6 @@ def derived_tables(model_id, ent, rel, k_int):
 
 
 _pair_buffers = {}
-_RESCORE_SPB = int(os.environ.get('EMG_RESCORE_SPB', '8'))   # A/B aid: 4 = segments in index order
 
 
 def _pair_buffer(device, n_seg):
@@ -453,7 +452,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             Qh, Q2 = D.to_f16_l2(Q, k_int, True)
             band = D.eval_prefilter_band(Q2, Qh, k_int, bounds[:3])
             thr = D.eval_l2_thresholds(Q, pos_int, band, bounds, k_int)
-            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0])
+            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0], k_int + 2)
             pairs, pcount = _pair_buffer(ent.device, n_seg)
             ev = _ev_start(stats)
             try:
@@ -461,7 +460,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], _RESCORE_SPB)
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1],
+                                     D.prefilter_waves(k_int + 2), 32)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         elif precision == 2 and have_cands:
@@ -470,7 +470,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             kp = D.prefilter_ld(k_int)
             Qb = D.to_f16(Q, k_int, ld_dst=kp)
             band = prefilter_band(Q, Qb, k_int, bounds)
-            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0])
+            n_seg = D.eval_prefilter_segments(n_rows, slab.shape[0], k_int)
             pairs, pcount = _pair_buffer(ent.device, n_seg)
             ev = _ev_start(stats)
             try:
@@ -479,7 +479,8 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], _RESCORE_SPB)
+                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1],
+                                     D.prefilter_waves(k_int), 32)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         if have_cands and pre is None:

@@ -25,7 +25,7 @@ from .. import device as D
 from .. import parallel
 from ..datasets import EmgraphBaseDatasetAdaptor
 from ..evaluation.metrics import hits_at_n_score, mrr_score
-from ..evaluation.protocol import create_mappings_and_index, to_idx
+from ..evaluation.protocol import _lookup, create_mappings_and_index, to_idx
 from ..evaluation.ranking import FilterIndex, rank_triples_device
 from ..training import Trainer, alloc_table
 
@@ -252,8 +252,13 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             msg = "Invalid entity type: {}".format(embedding_type)
             logger.error(msg)
             raise ValueError(msg)
-        idxs = np.vectorize(lookup_dict.get)(entities)
-        return emb_list[idxs]
+        # one sorted-key search for the whole array (the reference maps label by label: np.vectorize(dict.get)); a label the
+        # model was not fitted on fails like the reference's None index does
+        labels = np.asarray(entities)
+        idxs, known = _lookup(labels.reshape(-1), lookup_dict)
+        if not known.all():
+            raise IndexError("get_embeddings: label(s) not seen in training: %r" % (labels.reshape(-1)[~known][:5].tolist(),))
+        return emb_list[idxs.reshape(labels.shape)]
 
     def is_fitted_on(self, X):
         """EmbeddingModel.py:2188-2210."""

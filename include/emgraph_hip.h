@@ -406,10 +406,18 @@ int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t ldq, const v
  * path's arithmetic (k-ordered fmaf chain, int32(score*1e5)) and adds them to cnt_gt / cnt_eq, reading the counts
  * on the device (no host round trip between the two calls).  The resulting counters equal
  * emg_eval_count(precision 0) bit for bit. */
-int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand);
+int64_t emg_eval_prefilter_segments(int64_t n_rows, int64_t n_cand);   /* = emg_eval_prefilter_segments_k(.., 400) */
+/* Above 400 contraction columns (ComplEx / HolE k > 200, DistMult k > 400; up to emg_eval_prefilter_max_cols() = 800) the
+ * prefilter runs as 4 waves x 128 query rows per workgroup — one wave per SIMD, whose 512 registers hold up to 50 query
+ * fragments — instead of 8 x 256: the segment count depends on the width, and emg_eval_prefilter_waves(k_cols) (8 or 4)
+ * is the segments_per_block of the re-scoring call. */
+int64_t emg_eval_prefilter_segments_k(int64_t n_rows, int64_t n_cand, int32_t k_cols);
+int32_t emg_eval_prefilter_waves(int32_t k_cols);
+int32_t emg_eval_prefilter_max_cols(void);
 /* row stride (elements, zero padded) the half-precision prefilter wants of BOTH operands for a contraction over k_cols
- * columns: the kernel is instantiated for 4, 7, 8, 10, 13, 16, 19, 22 and 25 k-steps of 16 and fetches entity rows 64
- * columns at a time; a width in between runs the next instantiation over the zero padding (k_cols <= 400) */
+ * columns: the kernel is instantiated for 4, 7, 8, 10, 13, 16, 19, 22, 25 (8 waves) and 32, 38, 44, 50 (4 waves) k-steps
+ * of 16 and fetches entity rows 64 columns at a time; a width in between runs the next instantiation over the zero
+ * padding (k_cols <= 800) */
 int64_t emg_eval_prefilter_ld(int32_t k_cols);
 int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
                            int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset,
@@ -426,6 +434,13 @@ int emg_eval_rescore_pairs_ex(int model, const float* Q, int64_t ldq, const int3
                               int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
                               int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments,
                               int32_t segments_per_block, int32_t* cnt_gt, int32_t* cnt_eq, void* stream);
+/* the same, told how many consecutive query rows a segment covers (32: the waves of emg_eval_prefilter_f16[_thr]; 0: not
+ * known): segments of >= 512 pairs are then re-scored by one workgroup each with the segment's query rows held in LDS */
+int emg_eval_rescore_pairs_rows(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
+                                int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments,
+                                int32_t segments_per_block, int32_t rows_per_segment, int32_t* cnt_gt, int32_t* cnt_eq,
+                                void* stream);
 int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64_t n_rows, const void* ent_bf16,
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);

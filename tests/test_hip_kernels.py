@@ -830,6 +830,7 @@ def test_rank_1vsall_one_call_matches_python_path(model):
 
 
 @pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 30000, 300), ("DistMult", 200, 9000, 200), ("HolE", 100, 5000, 150),
+                                              ("ComplEx", 300, 8000, 200), ("DistMult", 777, 3000, 140),
                                               ("DistMult", 24, 700, 60), ("TransE_L1", 40, 900, 40), ("ComplEx", 200, 4000, 50),
                                               ("TransE_L1", 200, 20000, 300), ("TransE_L1", 37, 3000, 70), ("TransE_L2", 64, 2000, 90),
                                               ("TransE_L2", 200, 20000, 300), ("TransE_L2", 126, 6000, 140)])
@@ -1056,7 +1057,9 @@ def test_apply_rows_long_segments_block_tree(k, opt):
                                                      ("ComplEx", 128, 8000, 150, 0.1), ("DistMult", 350, 5000, 140, 0.1),
                                                      ("DistMult", 130, 6000, 140, 0.1), ("ComplEx", 85, 5000, 150, 0.2),
                                                      ("DistMult", 353, 4000, 130, 0.1), ("HolE", 9, 30000, 140, 0.5),
-                                                     ("DistMult", 401, 3000, 130, 0.1)])
+                                                     ("DistMult", 401, 3000, 130, 0.1), ("ComplEx", 256, 9000, 200, 0.1),
+                                                     ("HolE", 400, 6000, 140, 0.3), ("DistMult", 600, 5000, 150, 0.05),
+                                                     ("ComplEx", 330, 4000, 70, 0.1), ("DistMult", 801, 3000, 130, 0.1)])
 def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
     """precision=2 (bf16 MFMA prefilter with a rigorous per-row error band + exact f32 re-scoring of the undecided
     candidates) == precision=0 (exact f32 MFMA chain) for every side, strategy and filter setting; exact ties are
@@ -1083,7 +1086,8 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
                 fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, stats=st)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
-    kint_ok = ki <= 400      # every width up to 400 runs the prefilter (padded to its next instantiation); 401 takes the exact kernel
+    kint_ok = ki <= 800      # every width up to 800 runs the prefilter (padded to its next instantiation: 8 waves x 256 rows up
+                             # to 400 columns, 4 waves x 128 rows above); 801 takes the exact kernel
     if kint_ok and 2 * nq > 128:
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
 

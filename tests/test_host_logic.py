@@ -35,9 +35,10 @@ def test_prefilter_layout_queries_are_host_arithmetic():
     functions of the sizes, answered without a GPU"""
     from emgraph_amd import _lib as L
     lib = L.load()
-    # half-precision MFMA prefilter: instantiated for 4, 7, 8, 10, 13, 16, 19, 22, 25 k-steps of 16, rows fetched 64 columns at a time
+    # half-precision MFMA prefilter: instantiated for 4, 7, 8, 10, 13, 16, 19, 22, 25 and (4-wave form) 32, 38, 44, 50 k-steps of 16,
+    # rows fetched 64 columns at a time
     for k_cols, ld in ((8, 64), (64, 64), (65, 128), (100, 128), (128, 128), (130, 192), (200, 256), (202, 256), (256, 256),
-                       (257, 320), (300, 320), (353, 448), (400, 448), (401, 448), (800, 832)):
+                       (257, 320), (300, 320), (353, 448), (400, 448), (401, 512), (600, 640), (800, 832), (801, 832)):
         assert lib.emg_eval_prefilter_ld(k_cols) == ld, (k_cols, lib.emg_eval_prefilter_ld(k_cols))
         assert lib.emg_eval_prefilter_ld(k_cols) >= k_cols and lib.emg_eval_prefilter_ld(k_cols) % 64 == 0
     assert lib.emg_eval_prefilter_ld(0) == 0
@@ -47,6 +48,9 @@ def test_prefilter_layout_queries_are_host_arithmetic():
     # one pair-buffer segment per wave of the prefilter grids (8 waves per 256 rows x 4096 entities; 4 waves per 128 x 4096)
     assert lib.emg_eval_prefilter_segments(0, 10) == 0 and lib.emg_eval_sad_segments(5, 0) == 0
     assert lib.emg_eval_prefilter_segments(8192, 1_000_000) == 8 * 8 * 32 * 31
+    assert lib.emg_eval_prefilter_segments_k(8192, 1_000_000, 400) == 8 * 8 * 32 * 31
+    assert lib.emg_eval_prefilter_segments_k(8192, 1_000_000, 800) == 4 * 8 * 64 * 31   # 4 waves x 128 query rows above 400 columns
+    assert lib.emg_eval_prefilter_waves(400) == 8 and lib.emg_eval_prefilter_waves(416) == 4 and lib.emg_eval_prefilter_max_cols() == 800
     assert lib.emg_eval_sad_segments(4096, 1_000_000) == 4 * 8 * 32 * 31
 
 

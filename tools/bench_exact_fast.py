@@ -8,7 +8,8 @@ from emgraph_amd import device as D
 from emgraph_amd.evaluation import FilterIndex, PrefilterTables, rank_triples_device
 from emgraph_amd.training import alloc_table
 
-n_ent, n_rel, k, n_test = 1_000_000, 1000, 200, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+n_ent, n_rel, n_test = 1_000_000, 1000, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 ki = 2 * k
 rs = np.random.RandomState(7)
 E = (rs.randn(n_ent, ki) * 0.1).astype(np.float32)
