@@ -854,6 +854,13 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
 
 struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; };
 
+#ifdef EMG_TRACE   // timing aid (tools/trace_waves.py): wall-clock stamps (10 ns) of every wave of the last launch
+__device__ unsigned long long emg_trace_buf[4 * 65536];
+#define EMG_STAMP(slot) do { if (lane == 0 && gw < 65536) emg_trace_buf[4 * gw + (slot)] = wall_clock64(); } while (0)
+#else
+#define EMG_STAMP(slot) do { } while (0)
+#endif
+
 template <bool PLAIN, bool RIDE>
 __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
     // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
@@ -865,10 +872,24 @@ __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunc
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)bx * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)nbx * blockDim.x) >> 6;
+    EMG_STAMP(0);
     // (a loop with a run-time index, not two inlined copies: one set of live registers.  The second table's few items go
     // to the other end of the grid, where waves have less of the first table's work)
-    for (int ti = 0; ti < K.n_tables; ++ti) apply_segments_table<PLAIN>(K.P[ti], K.partial[ti], K.ldp[ti], ti ? nw - 1 - gw : gw, nw, lane);
+    for (int ti = 0; ti < K.n_tables; ++ti) {
+        apply_segments_table<PLAIN>(K.P[ti], K.partial[ti], K.ldp[ti], ti ? nw - 1 - gw : gw, nw, lane);
+        EMG_STAMP(1 + ti);
+    }
 }
+
+#ifdef EMG_TRACE
+extern "C" int emg_trace_read(unsigned long long* host, int64_t n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(emg_trace_buf), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int emg_trace_clear(void) {
+    static unsigned long long zeros[4 * 65536];
+    return hipMemcpyToSymbol(HIP_SYMBOL(emg_trace_buf), zeros, sizeof(zeros)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace emg
 
