@@ -16,6 +16,8 @@
 #include <string.h>
 #include <cstring>
 
+#include <atomic>
+
 #include "emg_group_kernels.hpp"
 
 namespace emg {
@@ -987,13 +989,40 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     return EMG_OK;
 }
 
+// Workgroups of apply_segments_kernel<PLAIN, RIDE> the device holds at once.  The grid is persistent with STATIC shares: a
+// launch of more waves than are resident runs as a full round followed by a partly empty one (per-wave stamps,
+// tools/trace_waves.py, C3: 5120 of 8192 waves start at 0 and live 38 us, the other 3072 start at 34-41 us: 78 us for
+// 1.6 rounds of work) — so never launch more than fit.
+static unsigned segments_capacity(bool plain, bool ride) {
+    static std::atomic<unsigned> cached[4][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024u;
+    std::atomic<unsigned>& c = cached[(plain ? 2 : 0) + (ride ? 1 : 0)][dev & 63];
+    unsigned v = c.load(std::memory_order_relaxed);
+    if (v) return v;
+    const void* fn = plain ? (ride ? (const void*)apply_segments_kernel<true, true> : (const void*)apply_segments_kernel<true, false>)
+                           : (ride ? (const void*)apply_segments_kernel<false, true> : (const void*)apply_segments_kernel<false, false>);
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    v = (unsigned)per_cu * (unsigned)cus;
+    c.store(v, std::memory_order_relaxed);
+    return v;
+}
+static unsigned segments_grid(unsigned wanted, bool plain, bool ride) {
+    static const bool fixed = getenv("EMG_SEG_BLOCKS") != nullptr;   // A/B aid: the grid as given
+    const unsigned cap = segments_capacity(plain, ride);
+    return fixed || wanted <= cap ? wanted : cap;
+}
+
 static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t st) {
     if (A.any && A.segs) {
         SegmentsLaunch K{};
         K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
         static const Riders none{};
-        if (plain_sgd(P)) hipLaunchKernelGGL((apply_segments_kernel<true, false>), dim3(A.grid), dim3(256), 0, st, K, none);
-        else hipLaunchKernelGGL((apply_segments_kernel<false, false>), dim3(A.grid), dim3(256), 0, st, K, none);
+        const unsigned g1 = segments_grid(A.grid, plain_sgd(P), false);
+        if (plain_sgd(P)) hipLaunchKernelGGL((apply_segments_kernel<true, false>), dim3(g1), dim3(256), 0, st, K, none);
+        else hipLaunchKernelGGL((apply_segments_kernel<false, false>), dim3(g1), dim3(256), 0, st, K, none);
         EMG_LAUNCH_CHECK();
     } else if (A.any) {
         const dim3 grid(A.grid), block(256);
@@ -1064,12 +1093,12 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         K.P[1] = P1; K.partial[1] = A1.partial; K.ldp[1] = A1.ldp; K.n_tables = 2;
         const bool plain = plain_sgd(P0) && plain_sgd(P1);
         if (riders && riders->total) {
-            const dim3 grid((A0.grid > A1.grid ? A0.grid : A1.grid) + riders->total);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true) + riders->total);
             if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, true>), grid, dim3(256), 0, st, K, *riders);
             else hipLaunchKernelGGL((apply_segments_kernel<false, true>), grid, dim3(256), 0, st, K, *riders);
         } else {
             static const Riders none{};
-            const dim3 grid(A0.grid > A1.grid ? A0.grid : A1.grid);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, false));
             if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, false>), grid, dim3(256), 0, st, K, none);
             else hipLaunchKernelGGL((apply_segments_kernel<false, false>), grid, dim3(256), 0, st, K, none);
         }
