@@ -606,11 +606,21 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
 }
 // the same with RIDERS: the first workgroups of the launch do the table-independent preparation of the next batches
 // (emg_plan.hip); instantiated for the fused 16-byte-row forms only (compile time)
+#ifdef EMG_TRACE   // timing aid (tools/trace_waves.py fused): wall-clock stamps (10 ns) of every wave of the last fused launch
+static __device__ unsigned long long emg_trace_fused_buf[4 * 65536];
+#endif
 template <int MODEL, int W, int NV, int LPG, int IP>
 __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
     unsigned bx;
     if (run_riders(riders, &bx)) return;
+#ifdef EMG_TRACE
+    const unsigned tw = (bx * kThreads + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0 && tw < 65536) emg_trace_fused_buf[4 * tw] = wall_clock64();
+#endif
     train_backward_body<MODEL, W, NV, LPG, true, IP>(P, bx);
+#ifdef EMG_TRACE
+    if ((threadIdx.x & 63) == 0 && tw < 65536) emg_trace_fused_buf[4 * tw + 1] = wall_clock64();
+#endif
 }
 
 // destination ids of the contribution rows of a batch (depends only on the batch ids and codes)
