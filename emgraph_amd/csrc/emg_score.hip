@@ -61,8 +61,14 @@ static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st, 
     if (vec) {
         P.nchunks = n / 4;
         const int c = P.nchunks;
-        if (c <= 16) launch_group<MODEL, 4, 1, 16>(pass, P, st, riders);
-        else if (c <= 32) launch_group<MODEL, 4, 1, 32>(pass, P, st, riders);
+        // Narrow rows share a wave (4 / 2 groups of 16 / 32 lanes) — unless the batch is so small that the launch would not
+        // even put two waves on every SIMD: then a wave per group (idle lanes cost nothing when every wave is waiting for
+        // memory; two groups in lock-step execute BOTH sides of every in-place / contribution branch).  Same bits: the
+        // lane reduction's extra levels add zeros.
+        static const int wide_env = getenv("EMG_WIDE_GROUPS") ? atoi(getenv("EMG_WIDE_GROUPS")) : -1;   // A/B aid
+        const bool wide = pass != Pass::Forward && (wide_env >= 0 ? wide_env != 0 : P.B <= 2048);
+        if (c <= 16 && !wide) launch_group<MODEL, 4, 1, 16>(pass, P, st, riders);
+        else if (c <= 32 && !wide) launch_group<MODEL, 4, 1, 32>(pass, P, st, riders);
         else if (c <= 64) launch_group<MODEL, 4, 1, 64>(pass, P, st, riders);
         else if (c <= 128) launch_group<MODEL, 4, 2, 64>(pass, P, st, riders);
         else return false;

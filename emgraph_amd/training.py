@@ -220,17 +220,20 @@ class Trainer:
         self._alloc_scratch(int(batch_size))
 
     def _choose_inplace(self, B):
-        """In-place singleton updates pay where singletons are plentiful.  With plain SGD the in-place form of the fused kernel
-        costs nothing (168 VGPRs, 3 waves per SIMD either way); with a STATEFUL optimizer it carries the optimizer's sqrt /
-        divide code three times over and drops to 2 waves per SIMD (224 VGPRs for complex rows) — worth it only if enough
-        slots take that path.  For uniformly drawn negatives a slot's destination is hit once with probability
-        exp(-slots / entities): C1 0.38 (in place), C2 0.11, C5 0.001 (every row through the apply kernel: C5 0.152 -> 0.138
-        ms/step).  Results are the same bits either way (one optimizer rule, one summation order)."""
+        """In-place singleton updates are the plain-SGD form of the step: the fused kernel reads a singleton's row anyway
+        and writes it back updated (168 VGPRs, 3 waves per SIMD — the same as without), the apply never sees 70 % of C3's
+        slots.  With a STATEFUL optimizer the in-place form also reads and writes the state rows from inside the scoring
+        loop (224 VGPRs for complex rows, 2 waves per SIMD, a dependent round trip per update) while the apply moves the
+        same bytes with everything in flight; measured (MI355X, in place / through the apply, ms per step): C1 Adam
+        0.081 / 0.078, C1 at B = 6900 0.268 / 0.148, at B = 27 600 0.488 / 0.468, C1 Adagrad 0.064 / 0.064, C3 Adagrad
+        0.842 / 0.755, C3 Adam 2.42 / 2.36 (Keras Adam's dense pass dominates), C2 0.062 / 0.058, C5 0.152 / 0.130 — never
+        better, so only SGD takes it.  Results are the same bits either way (one optimizer rule, one summation order:
+        tests/test_config_widths.py::test_inplace_choice_does_not_change_bits)."""
         if not self._inplace_wanted or self.batch_sharded:
             return False
-        if self.opt_id == L.OPT_SGD or os.environ.get("EMG_INPLACE_ALWAYS"):
-            return True
-        return math.exp(-(2 + self.eta_total) * B / max(self.n_ent, 1)) >= 0.3
+        if os.environ.get("EMG_INPLACE") in ("0", "1"):      # A/B aid
+            return os.environ["EMG_INPLACE"] == "1"
+        return self.opt_id == L.OPT_SGD or bool(os.environ.get("EMG_INPLACE_ALWAYS"))
 
     def _alloc_scratch(self, B):
         if B <= self._cap:
