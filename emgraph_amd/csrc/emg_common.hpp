@@ -158,6 +158,16 @@ __device__ __forceinline__ float lp_grad(const OptParams& P, float w) {
     const float a = fabsf(w);
     return P.lp_lambda * (float)P.lp_p * (P.lp_p == 1 ? 1.f : lp_pow(a, P.lp_p - 1)) * sgnf(w);
 }
+// the same for p in {1, 2, 3} only (the fused kernel's in-place form: no powf, whose inlined code costs it a wave per SIMD);
+// same expressions, same bits as lp_fold for these p
+__device__ __forceinline__ void lp_fold_p123(const OptParams& P, float w, float& g, float& lp_acc) {
+#pragma clang fp contract(off)
+    const float a = fabsf(w);
+    const float a2 = a * a;
+    const float pm1 = P.lp_p == 1 ? 1.f : (P.lp_p == 2 ? a : a2);          // |w|^(p-1)
+    g += P.lp_lambda * (float)P.lp_p * pm1 * sgnf(w);
+    lp_acc += P.lp_p == 1 ? a : (P.lp_p == 2 ? a2 : a2 * a);
+}
 // every row's update sees the gradient of the WHOLE loss: data term (summed contributions, 0 for a row no triple of
 // the batch touches) + the regulariser's, both evaluated at the pre-update value (EmbeddingModel.py:786-820)
 __device__ __forceinline__ void lp_fold(const OptParams& P, float w, float& g, float& lp_acc) {

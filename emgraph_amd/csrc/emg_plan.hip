@@ -153,6 +153,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.contrib_ent = c.contrib_ent; ba.contrib_rel = c.contrib_rel; ba.ldc = c.ldc;
     ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
     for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
+    if (c.inplace && c.lp_lambda_ent != 0.f) { ba.hyper[6] = he[6]; ba.hyper[7] = he[7]; ba.lp_accum = c.lp_sum; }   // (plain SGD: checked at creation)
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
     if (c.factored) { ba.fac_ws_ent = sl.buf.ws_ent; ba.fac_ws_ent_bytes = sl.buf.ws_ent_bytes; }
     ba.layout_B = c.cap_B;
@@ -268,8 +269,8 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     EMG_REQUIRE(cfg->ent && cfg->rel && cfg->X && cfg->contrib_ent && cfg->contrib_rel && cfg->loss_accum && cfg->tag_ent && cfg->tag_rel,
                 "emg_plan_create: null buffer");
     EMG_REQUIRE(cfg->fused || (cfg->scores && cfg->g), "emg_plan_create: the unfused step needs the score / gradient buffers");
-    EMG_REQUIRE(!(cfg->inplace && (cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f)),
-                "emg_plan_create: in-place singleton updates and a folded LP regulariser exclude each other");
+    EMG_REQUIRE(!(cfg->inplace && (cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f)) || (cfg->opt == EMG_OPT_SGD && cfg->lp_p <= 3),
+                "emg_plan_create: in-place singleton updates fold an LP regulariser for plain SGD and p <= 3 only");
     EMG_REQUIRE((cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f) || cfg->lp_sum, "emg_plan_create: LP needs lp_sum");
     Plan* P = new Plan();
     P->cfg = *cfg;

@@ -35,7 +35,7 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
     if (pass == Pass::Forward)
         hipLaunchKernelGGL((train_forward_kernel<MODEL, W, NV, LPG>), dim3(grid), dim3(kThreads), 0, st, P);
     else {
-        const int ip = !P.single_ent ? 0 : (P.opt.opt == EMG_OPT_SGD ? 1 : 2);
+        const int ip = !P.single_ent ? 0 : (P.opt.opt == EMG_OPT_SGD ? (P.opt.lp_lambda != 0.f ? 3 : 1) : 2);
         const bool fused = pass == Pass::Fused;
 #define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
         if constexpr (W == 4) {
@@ -45,10 +45,10 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
                 by_model[MODEL](shape, ip, grid, st, P, riders);
                 return;
             }
-            if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2);
+            if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else if (ip == 2) EMG_BW(false, 2); else EMG_BW(false, 3);
         } else {   // scalar rows (k not a multiple of 4)
-            if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else EMG_BW(true, 2); }
-            else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
+            if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else if (ip == 2) EMG_BW(true, 2); else EMG_BW(true, 3); }
+            else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else if (ip == 2) EMG_BW(false, 2); else EMG_BW(false, 3); }
         }
 #undef EMG_BW
     }
@@ -288,10 +288,17 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
         P.ent_rw = const_cast<float*>(a->ent);
         P.ent_state0 = a->ent_state0; P.ent_state1 = a->ent_state1; P.tag_ent = a->tag_ent; P.step = a->step;
         P.opt = make_opt_params(a->opt, a->hyper);
-        // the in-place path stays free of the regulariser's pow / sign code (it costs the fused kernel a wave per SIMD):
-        // with an LP regulariser every gradient row goes through emg_apply_grouped, which folds it in
-        EMG_REQUIRE(a->hyper[6] == 0.f, "emg_train_backward_ex: in-place singleton updates cannot fold an LP regulariser "
-                                        "(pass single_ent = NULL and let emg_apply_grouped apply every row)");
+        // A folded LP regulariser (hyper[6] = lambda, hyper[7] = p): plain SGD has its own in-place form (IP 3: the pow / sign
+        // code stays out of the other forms, where it costs the fused kernel a wave per SIMD); with a stateful optimizer every
+        // gradient row goes through emg_apply_grouped, which folds it in
+        if (a->hyper[6] != 0.f) {
+            EMG_REQUIRE(a->opt == EMG_OPT_SGD, "emg_train_backward_ex: in-place singleton updates fold an LP regulariser for plain SGD "
+                                               "only (pass single_ent = NULL and let emg_apply_grouped apply every row)");
+            EMG_REQUIRE(a->lp_accum && a->hyper[7] >= 1.f && a->hyper[7] <= 3.f && a->tag_ent,
+                        "emg_train_backward_ex: a folded LP regulariser with in-place updates needs lp_accum, p in {1, 2, 3} and the tag array");
+            P.opt.lp_lambda = a->hyper[6]; P.opt.lp_p = (int)a->hyper[7];
+            P.lp_accum = a->lp_accum;
+        }
     }
     EMG_REQUIRE(a->layout_B == 0 || a->layout_B >= a->B, "emg_train_backward_ex: layout_B < B");
     P.ctl = (const StepCtl*)a->ctl;

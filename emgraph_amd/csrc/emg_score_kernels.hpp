@@ -166,6 +166,7 @@ struct GroupParams {
     const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
     float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
     OptParams opt;
+    double* lp_accum;                                    // IP 3: += sum |w_pre|^p over the rows updated in place
     FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
     const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
 };
@@ -235,13 +236,13 @@ __global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupPara
 //   sched_barrier so the compiler does not interleave eight sqrt/div expansions and blow up the VGPR budget)
 template <int MODEL, int W, int NV, int LPG, int IP>
 __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row, const Row<MODEL, W, NV>& cur,
-                                               const Row<MODEL, W, NV>& grad, int lg) {
+                                               const Row<MODEL, W, NV>& grad, int lg, float& lp_acc) {
     // chunk-wise (one 16-byte chunk live at a time) so the singleton path costs almost no extra VGPRs:
     // occupancy is what keeps enough row loads in flight for this HBM-bound kernel
     constexpr int E = W * NV;
     constexpr int HALVES = is_complex<MODEL>::value ? 2 : 1;
     float* wrow = P.ent_rw + row * P.ld_ent;
-    float* s0row = (IP == 2 && P.ent_state0) ? P.ent_state0 + row * P.ld_ent : nullptr;
+    float* s0row = (IP == 2 && P.ent_state0) ? P.ent_state0 + row * P.ld_ent : nullptr;   // (IP 1 / 3: plain SGD, no state)
     float* s1row = (IP == 2 && P.ent_state1) ? P.ent_state1 + row * P.ld_ent : nullptr;
 #pragma unroll
     for (int h = 0; h < HALVES; ++h) {
@@ -264,6 +265,10 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
                     const float g = grad.x[h * E + it * W + w];
                     if constexpr (IP == 1) {
                         wv[w] = opt_sgd_elem(P.opt, wv[w], g);
+                    } else if constexpr (IP == 3) {   // SGD with the LP regulariser folded in: the rule of emg_apply_grouped's finish
+                        float gl = g;
+                        lp_fold_p123(P.opt, wv[w], gl, lp_acc);
+                        wv[w] = opt_sgd_elem(P.opt, wv[w], gl);
                     } else {
                         opt_update_elem(P.opt, wv[w], g, &s0v[w], &s1v[w]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -303,7 +308,8 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
 // flight per wave (occupancy x loads in flight is what an HBM-bound gather kernel lives on).
 //   FUSED = true : scores, pair-local loss and dL/dscore are computed here (P.fused_loss)
 //   FUSED = false: dL/dscore comes from P.g_pos / P.g_neg
-//   IP    = 0: all rows to the contribution buffer; 1/2: singleton destinations updated in place
+//   IP    = 0: all rows to the contribution buffer; 1 (SGD) / 2 (stateful) / 3 (SGD + folded LP regulariser): singleton
+//           destinations updated in place
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, int W, int NV>
 __device__ __forceinline__ void make_queries(const Row<MODEL, W, NV>& s, const Row<MODEL, W, NV>& p,
@@ -408,7 +414,7 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 // 140 -> 158 VGPRs at the same 3 waves/SIMD).
 template <int MODEL, int W, int NV, bool FUSED, int IP>
 struct keep_rows {
-    static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && IP != 0));
+    static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
 };
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
 __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
@@ -444,7 +450,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             my_flag = P.single_ent[lg < P.eta ? 2 * B + (int64_t)lg * B + g : (int64_t)(lg - P.eta) * B + g];
     }
     R qo, qs, Ao, As;
-    float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f;
+    float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f, lp_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
     R ks, kp, ko;  // live across the loop only when KEEP (dead otherwise: no registers)
     {
@@ -546,7 +552,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
-                if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg);
+                if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg, lp_acc);
                 else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
                     const int at = gathered ? group_lane_value<LPG>(my_pos, first, j) : (int)P.fac.pos_of_slot[(int64_t)j * B + g];
                     if (lg == 0) P.fac.coef[at] = gi;
@@ -578,11 +584,12 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_of(P.eta, g)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg);
+        if (IP != 0 && flag_of(P.eta, g)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_of(P.eta + 1, B + g)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg);
+        if (IP != 0 && flag_of(P.eta + 1, B + g)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
+    if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place
     if constexpr (FUSED) {
         // loss: one value per group (lane 0), block-reduced in double, one atomic per block
         double v = (active && lg == 0) ? (double)loss_acc : 0.0;

@@ -183,11 +183,12 @@ def build_dest(pos, eta, codes, dest_ent, dest_rel):
 def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
                       margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
                       scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
-                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None):
+                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None, lp_accum=None):
     """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
     singleton updates (single_ent flags from group_dest).  ``fac_ws_ent`` (bilinear models): FACTORED entity
     contributions — the entity workspace of ``prepare_batch(..., factored=True)`` for this batch; ``contrib_ent`` then
-    holds 4*B rows (see include/emgraph_hip.h) and the entity apply is ``apply_grouped(..., factored=True)``."""
+    holds 4*B rows (see include/emgraph_hip.h) and the entity apply is ``apply_grouped(..., factored=True)``.
+    ``hyper`` of 8 values + ``lp_accum`` (plain SGD only): the LP regulariser folded into the in-place updates."""
     lib = L.load()
     B = pos.shape[0]
     a = L.BackwardArgs()
@@ -221,6 +222,7 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     a.tag_ent = _chk_vec(tag_ent, torch.int32, "tag_ent")
     if fac_ws_ent is not None:
         a.fac_ws_ent, a.fac_ws_ent_bytes = fac_ws_ent.data_ptr(), fac_ws_ent.numel() * fac_ws_ent.element_size()
+    a.lp_accum = _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None
     L.check(lib.emg_train_backward_ex(C.byref(a), _stream()), "emg_train_backward_ex")
 
 

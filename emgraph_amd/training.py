@@ -173,7 +173,7 @@ class Trainer:
         # execution plan
         #  fused   : score -> pair-local loss -> gradient in ONE kernel (pairwise / nll / absolute_margin)
         #  inplace : rows whose destination is hit once in the batch are updated from registers
-        #            (needs the pre-update tables for nothing else: off when a regulariser is set)
+        #            (plain SGD only: _choose_inplace)
         #  pipeline: codes + destination grouping of batches t+1, t+2 run on a side stream while batch t computes
         self.batch_sharded = sharded == "batch"
         self.sharded = bool(sharded) and not self.batch_sharded          # k (column) sharding
@@ -181,9 +181,9 @@ class Trainer:
         # forward / loss / backward path handles them in column blocks (emg_score.hip::run_group_pass)
         self.wide = (self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int) > 512
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide
-        # (with an LP regulariser every row goes through the apply kernel, which folds its gradient in: the in-place
-        # path of the fused kernel stays free of the pow / sign code, which would cost it a wave per SIMD)
-        self.inplace = self._inplace_wanted = inplace and self.reg is None
+        # (an LP regulariser is folded into every update: by the apply kernel, and by the in-place form of plain SGD — its
+        # own instantiation (IP 3), so that the pow / sign code stays out of the forms that have no regulariser)
+        self.inplace = self._inplace_wanted = inplace and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3))
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
@@ -515,9 +515,10 @@ class Trainer:
               else self.lr)
         hyper_e, hyper_r = self._hyper(lr, 0), self._hyper(lr, 1)
         lp_e, lp_r = (self.lp_sum[0:1], self.lp_sum[1:2]) if len(hyper_e) == 8 else (None, None)
-        inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper_e[:6],
+        fold = single is not None and len(hyper_e) == 8     # in-place updates fold the regulariser themselves (plain SGD)
+        inplace_kw = dict(single_ent=single, opt_id=self.opt_id, step=self.step_count, hyper=hyper_e if fold else hyper_e[:6],
                           ent_state0=self.state_ent[0], ent_state1=self.state_ent[1], tag_ent=self.tag_ent,
-                          fac_ws_ent=sl["ws_ent"] if self.factored else None)
+                          fac_ws_ent=sl["ws_ent"] if self.factored else None, lp_accum=lp_e if fold else None)
         if self.fused:
             self._timed("fused", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr,

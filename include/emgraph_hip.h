@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 3
+#define EMG_ABI_VERSION 4
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */
@@ -215,7 +215,12 @@ typedef struct emg_backward_args {
      * product gi * q exactly where the unfactored path adds the stored row). */
     void* fac_ws_ent; int64_t fac_ws_ent_bytes;
     int64_t layout_B; const void* ctl;   /* as in emg_prepare_args: layout of fac_ws_ent; device record, pos = row 0 of the resident set */
-} emg_backward_args;   /* hyper[6] (folded LP, see emg_apply_grouped) must be 0 when single_ent != NULL */
+    double* lp_accum;   /* folded LP with in-place updates (below): += sum |w|^p (pre-update) over the rows updated in place */
+} emg_backward_args;
+/* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
+ * only for opt = EMG_OPT_SGD — a singleton row is then updated in place with g + lambda p |w|^(p-1) sign(w), the rule the
+ * apply uses for every other row, tagged, and its |w|^p added to *lp_accum; with a stateful optimizer and a regulariser
+ * pass single_ent = NULL (every row through emg_apply_grouped). */
 int emg_train_backward_ex(const emg_backward_args* args, void* stream);
 
 /* ---- K8 in two halves (emg_apply_rows = both):

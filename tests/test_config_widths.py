@@ -368,3 +368,40 @@ def test_inplace_choice_does_not_change_bits(monkeypatch, model, k, opt):
     for x, y in zip(a[3], b[3]):
         np.testing.assert_array_equal(x, y)
     assert a[4] == b[4]
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("model,k", [("ComplEx", 100), ("DistMult", 200), ("TransE", 100)])
+def test_inplace_sgd_folds_the_lp_regulariser(monkeypatch, model, k, p):
+    """SGD + LP: singleton destinations are updated inside the fused kernel with the regulariser's gradient folded in (its own
+    instantiation, p <= 3), everything else by the apply kernel and the dense pass — the same tables, bit for bit, as sending
+    every row through the apply; the regulariser's value (per-lane float partial sums, then double atomics, from three kernels instead of two) to 1e-9.
+    p = 4 keeps every row in the apply (the in-place form carries no powf)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, eta = 30000, 45, 512, 10          # most of a batch's slots are singletons
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(11)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 3 * B), rs.randint(0, n_rel, 3 * B), rs.randint(0, n_ent, 3 * B)], 1).astype(np.int32)
+
+    def run(force_off):
+        if force_off:
+            monkeypatch.setenv("EMG_INPLACE", "0")
+        else:
+            monkeypatch.delenv("EMG_INPLACE", raising=False)
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer="sgd", optimizer_params={"lr": 0.05}, batches_count=3,
+                     seed=3, regularizer="LP", regularizer_params={"lambda": 1e-3, "p": p})
+        tr.set_training_set(X, B)
+        for b in range(3):
+            tr.step(b * B, B, epoch=1, batch=b + 1, prefetch=[((b + 1) * B, B, 1, b + 2)] if b < 2 else None)
+        Et, Rt = tr.tables_numpy()
+        return tr.inplace, Et, Rt, tr.read_loss()
+
+    a, b = run(False), run(True)
+    assert a[0] == (p <= 3) and not b[0]
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)     # (per-lane float partial sums group differently in the two forms)

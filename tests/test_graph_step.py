@@ -32,6 +32,7 @@ def _fit(monkeypatch, graph, name, k, X, ent0, rel0, **kw):
     ("ComplEx", 100, "nll", "sgd", {"optimizer_params": {"lr": 0.05, "decay_cycle": 1, "decay_lr_rate": 2, "end_lr": 1e-4}}),
     ("HolE", 40, "absolute_margin", "adagrad", {}),
     ("ComplEx", 36, "nll", "momentum", {"regularizer": "LP", "regularizer_params": {"lambda": 1e-3, "p": 2}}),
+    ("DistMult", 72, "nll", "sgd", {"regularizer": "LP", "regularizer_params": {"lambda": 1e-3, "p": 3}}),   # in-place SGD folding LP
     ("DistMult", 72, "pairwise", "adam", {"embedding_model_params": {"corrupt_sides": ["s", "o"]}}),
     ("TransE", 68, "nll", "adam", {"embedding_model_params": {"negative_corruption_entities": "batch"}}),
 ])
