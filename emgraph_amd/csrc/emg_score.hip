@@ -47,8 +47,9 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
             }
             if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else if (ip == 2) EMG_BW(false, 2); else EMG_BW(false, 3);
         } else {   // scalar rows (k not a multiple of 4)
-            if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else if (ip == 2) EMG_BW(true, 2); else EMG_BW(true, 3); }
-            else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else if (ip == 2) EMG_BW(false, 2); else EMG_BW(false, 3); }
+            // (ip == 3 — in-place SGD folding the LP regulariser — exists for 16-byte rows only: run_group_pass refuses it here)
+            if (fused) { if (ip == 0) EMG_BW(true, 0); else if (ip == 1) EMG_BW(true, 1); else EMG_BW(true, 2); }
+            else { if (ip == 0) EMG_BW(false, 0); else if (ip == 1) EMG_BW(false, 1); else EMG_BW(false, 2); }
         }
 #undef EMG_BW
     }
@@ -102,6 +103,9 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st, 
         if (P.single_ent)
             vec = vec && (!P.ent_state0 || aligned16(P.ent_state0)) && (!P.ent_state1 || aligned16(P.ent_state1));
     }
+    if (pass != Pass::Forward && P.single_ent && P.opt.opt == EMG_OPT_SGD && P.opt.lp_lambda != 0.f && !vec)
+        return fail(EMG_ENOSUP, "train backward: in-place updates fold an LP regulariser for 16-byte aligned rows only (k, or k per "
+                                "half for complex models, a multiple of 4); pass single_ent = NULL");
     if (riders_p) {   // only the fused 16-byte-row kernels carry riders; everything else: the stages alone, first
         const bool can_ride = pass == Pass::Fused && vec && n <= 512;   // (= the train_fused_riders_kernel forms)
         if (!can_ride) {

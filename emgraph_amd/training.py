@@ -183,7 +183,9 @@ class Trainer:
         self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide
         # (an LP regulariser is folded into every update: by the apply kernel, and by the in-place form of plain SGD — its
         # own instantiation (IP 3), so that the pow / sign code stays out of the forms that have no regulariser)
-        self.inplace = self._inplace_wanted = inplace and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3))
+        n_cols = self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int
+        self.inplace = self._inplace_wanted = inplace and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3
+                                                                                and n_cols % 4 == 0))
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
