@@ -802,9 +802,11 @@ __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const 
     if (P.tag && lane == 0) P.tag[key] = step;
 }
 
+// heavy / relief: the last `heavy` waves of the grid take `relief` items fewer each (they carry the other table's long
+// segments, see apply_segments_kernel); the others share what that leaves
 template <bool PLAIN>
 __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
-                                                     int64_t nw, int lane) {
+                                                     int64_t nw, int lane, int64_t heavy = 0, int64_t relief = 0) {
     OptParams opt = P.opt;
     if constexpr (PLAIN) { opt.opt = EMG_OPT_SGD; opt.lp_lambda = 0.f; }   // (known at compile time: the update folds to w - lr g)
     int32_t step = P.step;
@@ -829,8 +831,17 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
         }
     }
     const int64_t total = (int64_t)n_multi + n_single;
-    const int64_t share = (total + nw - 1) / nw;
-    const int64_t i0 = gw * share, i1 = min(total, i0 + share);
+    int64_t share = (total + nw - 1) / nw, i0, i1;
+    if (heavy > 0 && relief > 0) {
+        relief = min(relief, share);
+        share = (total + heavy * relief + nw - 1) / nw;
+        const int64_t light = nw - heavy;
+        if (gw < light) { i0 = gw * share; i1 = i0 + share; }
+        else { i0 = light * share + (gw - light) * (share - relief); i1 = i0 + (share - relief); }
+        i0 = min(i0, total); i1 = min(i1, total);
+    } else {
+        i0 = gw * share; i1 = min(total, i0 + share);
+    }
     for (int64_t base = i0; base < i1; base += 64) {
         const int64_t it = base + lane;
         Seg sg{0u, 0u, 0u};
@@ -854,7 +865,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
-struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; };
+struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; int32_t relief; };
 
 #ifdef EMG_TRACE   // timing aid (tools/trace_waves.py): wall-clock stamps (10 ns) of every wave of the last launch
 __device__ unsigned long long emg_trace_buf[4 * 65536];
@@ -877,9 +888,25 @@ __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunc
     EMG_STAMP(0);
     // (a loop with a run-time index, not two inlined copies: one set of live registers.  The second table's few items go
     // to the other end of the grid, where waves have less of the first table's work)
-    for (int ti = 0; ti < K.n_tables; ++ti) {
-        apply_segments_table<PLAIN>(K.P[ti], K.partial[ti], K.ldp[ti], ti ? nw - 1 - gw : gw, nw, lane);
-        EMG_STAMP(1 + ti);
+    // Two tables: the second one's items (relations: few rows, many contributions each) go one per wave to the far end of
+    // the grid.  A segment costs its dependent trips of EMG_SEG_DEPTH rows, so those waves take that many entity items fewer
+    // (per-wave stamps, C3: 4600 waves ended at 52-57 us, the 540 that also carried a 16-row relation segment at 71).
+    int64_t heavy = 0, relief = 0;
+    if (K.n_tables == 2 && K.relief) {
+        const ApplyParams& R = K.P[1];
+        const int64_t n_multi = R.counters[GC_MULTI], n_single = R.skip_single ? 0 : R.counters[GC_SINGLE];
+        const int64_t rows = (int64_t)R.counters[GC_VALID] - (int64_t)R.counters[GC_SINGLE];
+        const int64_t items = n_multi + n_single;
+        if (items > 0 && items <= nw) {
+            const int64_t trips = n_multi ? (rows / n_multi + EMG_SEG_DEPTH - 1) / EMG_SEG_DEPTH : 1;   // of an average multi-row segment
+            heavy = items; relief = trips;
+        }
+    }
+    apply_segments_table<PLAIN>(K.P[0], K.partial[0], K.ldp[0], gw, nw, lane, heavy, relief);
+    EMG_STAMP(1);
+    if (K.n_tables == 2) {
+        apply_segments_table<PLAIN>(K.P[1], K.partial[1], K.ldp[1], nw - 1 - gw, nw, lane);
+        EMG_STAMP(2);
     }
 }
 
@@ -1091,6 +1118,8 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         SegmentsLaunch K{};
         K.P[0] = P0; K.partial[0] = A0.partial; K.ldp[0] = A0.ldp;
         K.P[1] = P1; K.partial[1] = A1.partial; K.ldp[1] = A1.ldp; K.n_tables = 2;
+        static const bool no_relief = getenv("EMG_APPLY_RELIEF") && atoi(getenv("EMG_APPLY_RELIEF")) == 0;   // A/B aid
+        K.relief = no_relief ? 0 : 1;
         const bool plain = plain_sgd(P0) && plain_sgd(P1);
         if (riders && riders->total) {
             const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true) + riders->total);
