@@ -446,7 +446,7 @@ def run_eval(r, args):
                                                   "note": "same call with ent_f16=None: the derived tables are rebuilt inside the timed region"}
     out["exact_fast"] = ex
     out["product_default"] = ("evaluate_performance / get_ranks pick precision 'auto': the exact_fast path (bit-equal ranks) for "
-                              "DistMult / ComplEx / HolE at k_int in 33..400 and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 (any k) and TransE-L2 (k + 2 <= 400), "
+                              "DistMult / ComplEx / HolE at k_int in 33..800 and (transe_l1.exact_fast, transe_l2.exact_fast) for TransE-L1 (any k) and TransE-L2 (k + 2 <= 800), "
                               ">= 128 test triples, >= 32768 entities, no candidate subset; the exact f32 kernel (`value`) otherwise")
     if not args.quick:
         # query-tile sweep (B_q in {128, 512, 2048} query rows per pass over the table), bf16 mode

@@ -1138,7 +1138,8 @@ def test_sad_prefilter_ranks_equal_exact_ranks_transe_l1(k, n_ent, nq, scale):
 @pytest.mark.parametrize("k,n_ent,nq,scale,huge", [(200, 30000, 300, 0.1, False), (126, 9000, 200, 1.0, False), (398, 6000, 150, 0.05, False),
                                                    (200, 20000, 150, 0.0005, False), (100, 5000, 140, 0.3, False), (200, 5000, 40, 0.1, False),
                                                    (200, 8000, 160, 0.1, True), (150, 7000, 150, 0.1, False), (50, 30000, 200, 0.2, False),
-                                                   (75, 9000, 140, 0.1, False), (351, 3000, 130, 0.1, False), (7, 20000, 150, 0.5, False)])
+                                                   (75, 9000, 140, 0.1, False), (351, 3000, 130, 0.1, False), (7, 20000, 150, 0.5, False),
+                                                   (500, 5000, 150, 0.1, False), (798, 3000, 140, 0.05, False)])   # (4-wave prefilter form)
 def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, huge):
     """TransE-L2, precision=2 (||q-e||^2 as a contraction over k+2 coordinates through the half-precision MFMA prefilter,
     thresholds derived for the squared distance, undecided candidates re-scored with the canonical f32 chain) ==
@@ -1177,7 +1178,7 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
                                            stats=st, ent_f16=tabs if side != "o" else None, query_chunk=200 if side == "s" else 4096)
                 np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
                 used += st.get("pairs", 0) + st.get("fallback", 0)
-    if k + 2 <= 400 and nq > 128:
+    if k + 2 <= 800 and nq > 128:
         assert used > 0        # the prefilter ran
 
 
