@@ -529,6 +529,39 @@ def run_eval(r, args):
                 "roofline": {"bound": "mfma", "achieved": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
                              "unit": "TFLOP/s (kernel_ms includes the re-scoring)",
                              "frac": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}}}
+        # ComplEx k = 400 (k_int = 800): the 4-wave form of the prefilter (128 query rows per workgroup, up to 50 query
+        # fragments in one wave's 512 registers), positives planted near the top as above
+        del ent_t, rel_t
+        kw_ = 800
+        ent_w = alloc_table(w["n_ent"], kw_, dev, init=None)
+        rel_w = alloc_table(w["n_rel"], kw_, dev, init=None)
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        ent_w[:, :kw_] = torch.randn(w["n_ent"], kw_, device=dev, generator=g) * 0.1
+        rel_w[:, :kw_] = torch.randn(w["n_rel"], kw_, device=dev, generator=g) * 0.1
+        Tw = T[:1024]
+        Qw, _ = D.eval_build_queries(3, ent_w, rel_w, kw_, 1.0, torch.from_numpy(Tw).to(dev), 1)
+        ow = torch.from_numpy(Tw[:, 2].astype(np.int64)).to(dev)
+        qh = Qw[:, :kw_] / Qw[:, :kw_].norm(dim=1, keepdim=True)
+        ent_w[ow] = (1 - 0.15 ** 2) ** 0.5 * ent_w[ow] + 0.15 * ent_w[ow].norm(dim=1, keepdim=True) * qh
+        from emgraph_amd.evaluation import PrefilterTables
+        tabs_w = PrefilterTables(ent_w, kw_)
+        res_w = {}
+        for prec, kwargs in ((0, {}), (2, dict(ent_f16=tabs_w))):
+            rank_triples_device(3, ent_w, rel_w, kw_, 1.0, Tw[:192], "s+o", "worst", filter_triples=F, shard=shard, precision=prec, **kwargs)
+            torch.cuda.synchronize()
+            stw = {}
+            t0 = time.perf_counter()
+            rw = rank_triples_device(3, ent_w, rel_w, kw_, 1.0, Tw, "s+o", "worst", filter_triples=F, shard=shard, precision=prec, stats=stw, **kwargs)
+            torch.cuda.synchronize()
+            res_w[prec] = (rw, time.perf_counter() - t0, stw)
+        out["complex_k400"] = {
+            "value": round(2 * len(Tw) / res_w[0][1], 1), "unit": "ranks/s", "test_triples": len(Tw), "k_int": kw_,
+            "kernel": "count_mfma_pipe_kernel (exact f32)", "kernel_ms": round(res_w[0][2]["count_ms"], 3),
+            "exact_fast": {"value": round(2 * len(Tw) / res_w[2][1], 1), "unit": "ranks/s",
+                           "equal_to_exact_f32_ranks": bool(np.array_equal(res_w[0][0], res_w[2][0])),
+                           "undecided_pairs": int(res_w[2][2].get("pairs", 0)), "tiles_redone_by_exact_kernel": int(res_w[2][2].get("fallback", 0)),
+                           "kernel_ms": round(res_w[2][2]["count_ms"], 3), "mean_rank": float(np.mean(res_w[2][0])),
+                           "kernels": "count_mfma_bf16_v3_kernel<50,4,2,4> (4 waves x 128 query rows) + rescore_segment_kernel<0,4> / rescore_pairs_kernel"}}
     return out
 
 
