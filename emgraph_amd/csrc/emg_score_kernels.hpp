@@ -402,7 +402,9 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 // U = replacement rows in flight per wave and trip.  Measured on C3 (MI355X, fused kernel alone): U = 2: 0.302 ms,
 // 4: 0.263, 5: 0.302, 6: 0.314, 8: 0.311, 10: 0.305; a software pipeline (next U rows in flight during the arithmetic
 // of this trip) 0.285 (U = 2) / 0.300 (U = 4: 194 VGPRs, 2 waves/SIMD); workgroups of 64 / 128 / 512 threads 0.288 /
-// 0.239 / 0.274 against 0.223 with 256 on the same box.
+// 0.239 / 0.274 against 0.223 with 256 on the same box.  Four waves per SIMD (round 3, one box, step ms): U = 3 without KEEP
+// forced to 128 VGPRs (44 B scratch) 0.392-0.394, U = 2 without KEEP (123 VGPRs) 0.373, U = 4 without KEEP (150 VGPRs, 3 waves)
+// 0.374 against 0.369-0.370 as built: occupancy beyond 3 waves buys nothing, rows in flight per wave do.
 #ifndef EMG_BW_U
 #define EMG_BW_U 4
 #endif
@@ -414,7 +416,10 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 // 140 -> 158 VGPRs at the same 3 waves/SIMD).
 template <int MODEL, int W, int NV, bool FUSED, int IP>
 struct keep_rows {
-    static constexpr bool value = W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
+#ifndef EMG_BW_KEEP
+#define EMG_BW_KEEP 1   // 0: A/B aid — never keep s, p, o across the loop
+#endif
+    static constexpr bool value = EMG_BW_KEEP != 0 && W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
 };
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
 __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
