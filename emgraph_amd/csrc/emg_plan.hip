@@ -282,7 +282,8 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     for (int i = 0; i < P->n_side; ++i)
         // LOW priority: the preparation runs two batches ahead and has a whole step of slack; at high priority (round 2: "the
         // small kernels of a chain must not queue behind the big ones") its waves displace scoring waves — C3 0.369 vs
-        // 0.363 ms/step in three alternating pairs, B = 131 072 / Zipf / TransE unchanged
+        // 0.363 ms/step in three alternating pairs, B = 131 072 / Zipf / TransE unchanged.  (Streams confined to every 2nd / 4th /
+        // 8th CU with hipExtStreamCreateWithCUMask: 0.43-0.48 ms/step — far worse.)
         if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, side_high ? hi : lo) != hipSuccess) return bail("hipStreamCreateWithPriority");
     if (P->n_side > 0) {
         if (hipStreamCreateWithFlags(&P->aux, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
