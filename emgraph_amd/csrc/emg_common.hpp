@@ -81,21 +81,26 @@ struct RowTile {
     float x[W * NV];
 };
 
-template <int W, int NV, int LPG>
+// ZERO = false: lanes past the row's end keep what they re-read (finite values of the row itself) — for operands whose
+// partner is zero there anyway; the select that zeroes a value needs the value, i.e. it ends the load's flight
+template <int W, int NV, int LPG, bool ZERO = true>
 __device__ __forceinline__ void load_tile(RowTile<W, NV>& t, const float* __restrict__ row, int lg, int nchunks) {
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
+        // NO branch around the load: a lane past the row's end re-reads the last chunk (the same cache line as its
+        // neighbour's) and zeroes the value.  A load under a lane predicate compiles to `s_cbranch_execz` around it, i.e.
+        // a path without the load, and hipcc then waits for every OLDER load with s_waitcnt vmcnt(0) — which also waits for
+        // the loads issued after it: the fused kernel's rolling window of replacement rows degenerated to one row in flight.
         const int c = lg + it * LPG;
-        if (c < nchunks) {
-            if constexpr (W == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(row + 4 * c);
-                t.x[4 * it + 0] = v.x; t.x[4 * it + 1] = v.y; t.x[4 * it + 2] = v.z; t.x[4 * it + 3] = v.w;
-            } else {
-                t.x[it] = row[c];
-            }
+        const bool on = c < nchunks;
+        const int cc = on ? c : nchunks - 1;
+        if constexpr (W == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 4 * cc);
+            t.x[4 * it + 0] = (on || !ZERO) ? v.x : 0.f; t.x[4 * it + 1] = (on || !ZERO) ? v.y : 0.f;
+            t.x[4 * it + 2] = (on || !ZERO) ? v.z : 0.f; t.x[4 * it + 3] = (on || !ZERO) ? v.w : 0.f;
         } else {
-#pragma unroll
-            for (int w = 0; w < W; ++w) t.x[W * it + w] = 0.f;
+            const float v = row[cc];
+            t.x[it] = (on || !ZERO) ? v : 0.f;
         }
     }
 }

@@ -24,16 +24,16 @@ struct Row {
     float x[N];
 };
 
-template <int MODEL, int W, int NV, int LPG>
+template <int MODEL, int W, int NV, int LPG, bool ZERO = true>
 __device__ __forceinline__ void load_row(Row<MODEL, W, NV>& r, const float* __restrict__ base, int lg, int nchunks,
                                          int khalf) {
     constexpr int E = W * NV;
     RowTile<W, NV> t;
-    load_tile<W, NV, LPG>(t, base, lg, nchunks);
+    load_tile<W, NV, LPG, ZERO>(t, base, lg, nchunks);
 #pragma unroll
     for (int e = 0; e < E; ++e) r.x[e] = t.x[e];
     if constexpr (is_complex<MODEL>::value) {
-        load_tile<W, NV, LPG>(t, base + khalf, lg, nchunks);
+        load_tile<W, NV, LPG, ZERO>(t, base + khalf, lg, nchunks);
 #pragma unroll
         for (int e = 0; e < E; ++e) r.x[E + e] = t.x[e];
     }
@@ -409,6 +409,27 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 #define EMG_BW_U 4
 #endif
 
+// ASYNC replacement rows (EMG_BW_ASYNC, bilinear fused forms with 16-byte rows): the row loads of the rolling window are
+// inline assembly, so hipcc neither counts nor waits for them; the wait before a row's first use is written by hand:
+// s_waitcnt vmcnt((U - 1) * pieces) — at most the loads of the U - 1 younger rows may still be in flight (stores issued
+// since then only make the wait a little earlier than necessary; memory operations of a wave complete in order).  With
+// compiler-visible loads every wait in this loop came out as vmcnt(0): the loop has branches whose sides issue different
+// numbers of stores, and the compiler's count of "operations younger than this load" is its minimum over all paths.
+#ifndef EMG_BW_ASYNC
+#define EMG_BW_ASYNC 0
+#endif
+typedef float emg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ emg_f4 vm_load16_async(const float* p) {
+    emg_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a, emg_f4& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a, emg_f4& b, emg_f4& c, emg_f4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
 // KEEP: the s, p, o rows stay in registers across the loop over the negatives instead of being re-read at the end
 // (the re-read was 1.10x the algorithmic traffic by PMC: after 20 replacement rows per wave on every CU of the XCD
 // they are no longer in L2).  Only where it is free: instantiations whose occupancy does not drop (checked with
@@ -441,19 +462,22 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     const float* srow = P.ent + (int64_t)s * P.ld_ent;
     const float* prow = P.rel + (int64_t)p * P.ld_rel;
     const float* orow = P.ent + (int64_t)o * P.ld_ent;
-    // ALL corruption codes and in-place flags of the group in ONE gather each, issued together with the s, p, o rows
-    // and before anything is stored: lane j holds negative j's code and flag, lanes eta / eta+1 the flags of the
-    // subject / object slot.  Loaded where they are used, each sits behind the previous negative's stores (a byte load
-    // may alias them as far as the compiler knows): a serialised round trip per negative (C3: 0.265 -> 0.251 ms).
-    const bool gathered = P.eta + 2 <= LPG;   // kernel-uniform
+    // The corruption codes, in-place flags and factor positions of LPG negatives at a time in ONE gather each (lane j holds
+    // negative c0 + j's), the first chunk issued together with the s, p, o rows and before anything is stored; lanes 0 / 1 of
+    // my_flag_so hold the flags of the subject / object slot.  NOTHING is loaded inside the loop over the negatives except
+    // their rows: a load in a branch there — round 2's fallback for eta + 2 > LPG was one, never taken — makes hipcc close
+    // every join with s_waitcnt vmcnt(0), which also waits for the replacement rows just requested: the rolling window
+    // below then holds ONE row in flight, not U (PMC, C3: 1572 cycles mean read latency, 1.7 MB in flight on the chip).
     const int first = (threadIdx.x & 63) / LPG * LPG;
-    int my_code = 0, my_flag = 0, my_pos = 0;   // my_pos: where negative lg's factor goes (its slot's sorted position)
-    if (gathered) {
-        if (lg < P.eta) my_code = P.codes[(int64_t)lg * B + g];
-        if (kBilinear && P.fac.coef && lg < P.eta) my_pos = (int)P.fac.pos_of_slot[(int64_t)lg * B + g];
-        if (IP != 0 && lg < P.eta + 2)
-            my_flag = P.single_ent[lg < P.eta ? 2 * B + (int64_t)lg * B + g : (int64_t)(lg - P.eta) * B + g];
-    }
+    int my_code = 0, my_flag = 0, my_pos = 0, my_flag_so = 0;   // my_pos: where the negative's factor goes (its slot's sorted position)
+    auto gather = [&](int c0) {
+        const int j = c0 + lg;
+        my_code = j < P.eta ? P.codes[(int64_t)j * B + g] : 0;
+        if (kBilinear && P.fac.coef) my_pos = j < P.eta ? (int)P.fac.pos_of_slot[(int64_t)j * B + g] : 0;
+        if constexpr (IP != 0) my_flag = j < P.eta ? (int)P.single_ent[2 * B + (int64_t)j * B + g] : 0;
+    };
+    gather(0);
+    if constexpr (IP != 0) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
     R qo, qs, Ao, As;
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f, lp_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
@@ -486,21 +510,26 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     }
 
     constexpr int U = EMG_BW_U;
-    auto code_of = [&](int j) -> int32_t {
-        return gathered ? group_lane_value<LPG>(my_code, first, j) : uniform_if_wave<LPG>(P.codes[(int64_t)j * B + g]);
-    };
-    auto flag_of = [&](int i, int64_t slot) -> int {   // i: negative index, eta = subject slot, eta + 1 = object slot
+    int chunk0 = 0, chunk1 = min(P.eta, LPG);   // the negatives [chunk0, chunk1) are the ones my_code / my_flag / my_pos describe
+    auto code_of = [&](int j) -> int32_t { return group_lane_value<LPG>(my_code, first, j - chunk0); };
+    auto flag_of = [&](int j) -> int {   // negative j of the current chunk
         if constexpr (IP == 0) return 0;
-        return gathered ? group_lane_value<LPG>(my_flag, first, i) : uniform_if_wave<LPG>((int)P.single_ent[slot]);
+        return group_lane_value<LPG>(my_flag, first, j - chunk0);
     };
-    // the replacement rows of negatives j0 .. j0+U-1
+    auto flag_so = [&](int which) -> int {   // 0: the subject slot, 1: the object slot
+        if constexpr (IP == 0) return 0;
+        return group_lane_value<LPG>(my_flag_so, first, which);
+    };
+    // the replacement rows of negatives j0 .. j0+U-1.  Bilinear models take them RAW (lanes past the row's end hold a copy of
+    // its last chunk): the query rows are zero there, so products, factored rows and in-place updates (guarded by the chunk
+    // index) never see them — and no select sits between the load and its first use
     auto fetch = [&](int j0, int32_t (&code)[U], R (&re)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) code[u] = code_of(min(j0 + u, P.eta - 1));
+        for (int u = 0; u < U; ++u) code[u] = code_of(min(j0 + u, chunk1 - 1));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int32_t repl = code[u] & 0x7fffffff;
-            load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
         }
     };
     // ROLLING window of U replacement rows: as soon as a negative's row has been consumed (score, gradient, in-place
@@ -513,27 +542,55 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     int32_t code[U];
     float gj[U];
     R re[U];
-    if constexpr (EMG_BW_ROLL != 0) {
-        if (P.eta > 0) fetch(0, code, re);
+    constexpr int PIECES = NV * (is_complex<MODEL>::value ? 2 : 1);   // 16-byte loads per row and lane
+    constexpr bool kAsync = EMG_BW_ASYNC != 0 && EMG_BW_ROLL != 0 && kBilinear && W == 4 && FUSED && (PIECES == 1 || PIECES == 2 || PIECES == 4) &&
+                            (U - 1) * PIECES <= 15;
+    emg_f4 pa[kAsync ? U : 1][kAsync ? PIECES : 1];
+    auto issue_row = [&](emg_f4 (&dst)[kAsync ? PIECES : 1], int32_t repl) {   // all lanes load: past the row's end, its last chunk again
+        const float* base = P.ent + (int64_t)repl * P.ld_ent;
+#pragma unroll
+        for (int h = 0; h < (is_complex<MODEL>::value ? 2 : 1); ++h)
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int c = min(lg + it * LPG, P.nchunks - 1);
+                dst[h * NV + it] = vm_load16_async(base + h * P.khalf + 4 * c);
+            }
+    };
+    auto take_row = [&](emg_f4 (&src)[kAsync ? PIECES : 1], R& r) {   // wait for THIS row (the U - 1 younger ones may fly on)
+        if constexpr (PIECES == 1) vm_wait<(U - 1) * PIECES>(src[0]);
+        else if constexpr (PIECES == 2) vm_wait<(U - 1) * PIECES>(src[0], src[1]);
+        else vm_wait<(U - 1) * PIECES>(src[0], src[1], src[2], src[3]);
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) { r.x[4 * q + 0] = src[q].x; r.x[4 * q + 1] = src[q].y; r.x[4 * q + 2] = src[q].z; r.x[4 * q + 3] = src[q].w; }
+    };
+    for (; chunk0 < P.eta; chunk0 += LPG) {   // (one trip unless eta > LPG)
+    chunk1 = min(P.eta, chunk0 + LPG);
+    if (chunk0 > 0) gather(chunk0);
+    if constexpr (kAsync) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { code[u] = code_of(min(chunk0 + u, chunk1 - 1)); issue_row(pa[u], code[u] & 0x7fffffff); }
+    } else if constexpr (EMG_BW_ROLL != 0) {
+        fetch(chunk0, code, re);
         if constexpr (!FUSED) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(u, max(P.eta - 1, 0)) * B + g];
+            for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(chunk0 + u, chunk1 - 1) * B + g];
         }
     }
-    for (int j0 = 0; j0 < P.eta; j0 += U) {
+    for (int j0 = chunk0; j0 < chunk1; j0 += U) {
         if constexpr (EMG_BW_ROLL == 0) {
             fetch(j0, code, re);
             if constexpr (!FUSED) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, P.eta - 1) * B + g];
+                for (int u = 0; u < U; ++u) gj[u] = P.g_neg[(int64_t)min(j0 + u, chunk1 - 1) * B + g];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = j0 + u;
-            if (j >= P.eta) break;
+            if (j >= chunk1) break;
             const bool keep_s = code[u] < 0;  // subject kept => the OBJECT was replaced
             const int32_t repl = code[u] & 0x7fffffff;
+            if constexpr (kAsync) take_row(pa[u], re[u]);
             float nrm = 0.f;
             if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
                 if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
@@ -557,20 +614,34 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
-                if (IP != 0 && flag_of(j, slot)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg, lp_acc);
+                if (IP != 0 && flag_of(j)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg, lp_acc);
                 else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
-                    const int at = gathered ? group_lane_value<LPG>(my_pos, first, j) : (int)P.fac.pos_of_slot[(int64_t)j * B + g];
+                    const int at = group_lane_value<LPG>(my_pos, first, j - chunk0);
                     if (lg == 0) P.fac.coef[at] = gi;
                 }
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }
             if constexpr (EMG_BW_ROLL != 0) {   // refill this row's registers with the negative U places later
-                if (j + U < P.eta) {
-                    code[u] = code_of(j + U);
-                    load_row<MODEL, W, NV, LPG>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
-                    if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)(j + U) * B + g];
-                }
+                // UNCONDITIONALLY (past the end: the chunk's last row again, a cache hit): a load under a condition leaves a
+                // path without it, and the wait for an older row then has to be vmcnt(0) — with every refill on every path
+                // hipcc counts them (vmcnt(2 (U - 1))) and U rows really are in flight
+                const int jn = min(j + U, chunk1 - 1);
+                code[u] = code_of(jn);
+                if constexpr (kAsync) issue_row(pa[u], code[u] & 0x7fffffff);
+                else load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
+                if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)jn * B + g];
             }
+        }
+    }
+    }
+    if constexpr (kAsync) {
+        // the refills issued past the end are never taken: their registers must stay theirs until the loads have landed
+        // (hipcc does not know they are being written) — one wait for everything, with every row as its operand
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (PIECES == 1) vm_wait<0>(pa[u][0]);
+            else if constexpr (PIECES == 2) vm_wait<0>(pa[u][0], pa[u][1]);
+            else vm_wait<0>(pa[u][0], pa[u][1], pa[u][2], pa[u][3]);
         }
     }
     if (kBilinear && P.fac.coef && active) {   // the two query rows every factored negative of this group points at
@@ -589,9 +660,9 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_of(P.eta, g)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg, lp_acc);
+        if (IP != 0 && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_of(P.eta + 1, B + g)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg, lp_acc);
+        if (IP != 0 && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
     if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place

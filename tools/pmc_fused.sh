@@ -25,7 +25,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "train_backward" in kn or "apply_rows" in kn or "apply_long" in kn:
+        if "train_backward" in kn or "train_fused" in kn or "apply_segments" in kn or "apply_rows" in kn or "apply_long" in kn:
             agg[kn[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
