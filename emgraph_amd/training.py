@@ -223,7 +223,7 @@ class Trainer:
 
     def _choose_inplace(self, B):
         """In-place singleton updates are the plain-SGD form of the step: the fused kernel reads a singleton's row anyway
-        and writes it back updated (168 VGPRs, 3 waves per SIMD — the same as without), the apply never sees 70 % of C3's
+        and writes it back updated (measured equal in speed to the contribution form of the kernel), the apply never sees 70 % of C3's
         slots.  With a STATEFUL optimizer the in-place form also reads and writes the state rows from inside the scoring
         loop (224 VGPRs for complex rows, 2 waves per SIMD, a dependent round trip per update) while the apply moves the
         same bytes with everything in flight; measured (MI355X, in place / through the apply, ms per step): C1 Adam
