@@ -60,9 +60,13 @@ WORKLOADS = {
                 desc="C3 with the LP regulariser (p = 2) folded into the optimizer step: every gradient row through the apply "
                      "kernel + one dense pass over the untouched rows"),
     "C3a": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adam",
-                desc="C3 with the reference's default optimizer (Keras Adam, constants.py:55 / adam.py:31-48): its update is DENSE — "
-                     "every step decays m, v and moves w of all 1M x 400 entries, 9.6 GB read + written — so the step is bound "
-                     "by that pass, not by the triples"),
+                desc="C3 with the reference's default optimizer (Keras Adam, constants.py:55 / adam.py:31-48).  Its update is DENSE — every "
+                     "step decays m, v and moves w of all 1M x 400 entries, 9.6 GB read + written.  Default for tables >= 256 MB: the "
+                     "decay is DEFERRED (emg_adam_catchup: the missed steps of a row are replayed when a batch is about to read it — "
+                     "same bits, no pass over the whole table)"),
+    "C3d": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adam", deferred=False,
+                desc="C3a with the dense pass as Keras runs it (Trainer(deferred_dense=False)): every row of the table read and written "
+                     "every step"),
     "C3g": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adagrad",
                 desc="C3 with Adagrad (row-sparse state: every touched row and its accumulator through the apply kernel)"),
     "C2": dict(model="DistMult", k=200, eta=10, n_ent=14541, n_rel=237, B=2722, loss="nll", optimizer="adam",
@@ -179,6 +183,7 @@ class StepRunner:
                           optimizer_params={"lr": 0.0005}, batches_count=self.nb, seed=0, fused=not args.no_fused,
                           inplace=not args.no_inplace, pipeline=not args.no_pipeline,
                           regularizer="LP" if w.get("reg") else None, regularizer_params=w.get("reg"),
+                          deferred_dense=w.get("deferred"),
                           sharded=(self.sharding if self.sharding == "batch" else bool(self.sharding)))
         self.tr.set_training_set(self.X, self.B)
         self.i = 0
@@ -744,10 +749,10 @@ def main():
     r.close()
     if not args.no_others and world == 1 and args.workload == "C3":
         others = {}
-        for name in ("C3z", "C3b", "C3p", "C3m", "C3s", "C3r", "C3a", "C3g", "C1", "C2", "C5"):
+        for name in ("C3z", "C3b", "C3p", "C3m", "C3s", "C3r", "C3a", "C3d", "C3g", "C1", "C2", "C5"):
             ro = StepRunner(name, args, rank, world)
             ro.run(20)
-            n = 300 if name not in ("C3b", "C3a") else 60
+            n = 300 if name not in ("C3b", "C3a", "C3d") else 60
             d, ti = ro.timed(n)
             o = step_summary(ro, d, ti, n)
             o["workload"] = WORKLOADS[name]["desc"]

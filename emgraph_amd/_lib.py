@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE, TRANSE_P = range(6)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
@@ -178,12 +178,15 @@ class ApplyArgs(C.Structure):
         ("hyper", _f32 * 8), ("lp_accum", _p), ("workspace", _p), ("workspace_bytes", _i64),
         ("factored", _i32), ("table_index", _i32),
         ("layout_n", _i64), ("ctl", _p),
+        ("deferred_dense", _i32), ("reserved1", _i32),
     ]
 
 
 SIGNATURES.update({
     "emg_apply_grouped_ex": (_int, [C.POINTER(ApplyArgs), _p]),
     "emg_apply_grouped_pair": (_int, [C.POINTER(ApplyArgs), C.POINTER(ApplyArgs), _p]),
+    "emg_adam_catchup": (_int, [_p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _i64, _i64, _p]),
+    "emg_adam_materialize": (_int, [_p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p]),
 })
 
 
@@ -211,6 +214,7 @@ class PlanConfig(C.Structure):
         ("n_slots", _i32), ("slots", PlanSlot * 4),
         ("aux_min_rows", _i64),
         ("ctl_buf", _p), ("ctl_bytes", _i64),
+        ("lr_t_hist", _p),
     ]
 
 

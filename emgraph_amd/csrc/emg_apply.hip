@@ -672,6 +672,76 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Deferred dense decay of Keras Adam (include/emgraph_hip.h: emg_adam_catchup / emg_adam_materialize): replay the dense
+// pass's update (g = 0) of the steps a row has missed, with each step's own lr_t
+// ---------------------------------------------------------------------------------------------------------------
+struct ReplayParams {
+    float* table; float* s0; float* s1; int32_t* tag; int64_t n_rows, ld; int32_t k_int; OptParams opt;
+    const float* lr_t; int32_t upto;
+    const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* keys; const uint32_t* counters; uint32_t task_cap;
+};
+
+__device__ __forceinline__ void adam_replay_row(const ReplayParams& P, int64_t r, int lane) {
+    const int32_t from = P.tag[r];
+    if (from >= P.upto) return;
+    if (from == 0) {   // never written: m = v = 0, every missed update is w - lr_t * 0 / (0 + eps) = w
+        if (lane == 0) P.tag[r] = P.upto;
+        return;
+    }
+    float* w = P.table + r * P.ld;
+    float* s0 = P.s0 + r * P.ld;
+    float* s1 = P.s1 + r * P.ld;
+    OptParams opt = P.opt;
+    if ((P.k_int % 4 == 0) && (P.ld % 4 == 0)) {
+        for (int c = lane; 4 * c < P.k_int; c += 64) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * c), a = *reinterpret_cast<const float4*>(s0 + 4 * c),
+                         b = *reinterpret_cast<const float4*>(s1 + 4 * c);
+            float ww[4] = {wv.x, wv.y, wv.z, wv.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+            for (int32_t st = from + 1; st <= P.upto; ++st) {
+                opt.lr_t = P.lr_t[st];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) opt_update_elem(opt, ww[j], 0.f, &aa[j], &bb[j]);
+            }
+            *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+            *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+            *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        }
+    } else {
+        for (int c = lane; c < P.k_int; c += 64) {
+            float wv = w[c], a = s0[c], b = s1[c];
+            for (int32_t st = from + 1; st <= P.upto; ++st) { opt.lr_t = P.lr_t[st]; opt_update_elem(opt, wv, 0.f, &a, &b); }
+            w[c] = wv; s0[c] = a; s1[c] = b;
+        }
+    }
+    if (lane == 0) P.tag[r] = P.upto;
+}
+
+// the rows a prepared batch will read and update = the destinations of its grouping's lists (each exactly once)
+__global__ __launch_bounds__(256) void adam_catchup_kernel(const ReplayParams P) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.counters[GC_SINGLE];
+    const int64_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
+    for (int64_t i = gw; i < n_multi + n_single + n_tasks; i += nw) {
+        int64_t dest;
+        if (i < n_multi) dest = P.multi[i].dest;
+        else if (i < n_multi + n_single) dest = P.keys[P.single[i - n_multi]];
+        else {
+            const LongTask tk = P.tasks[i - n_multi - n_single];
+            if (tk.block != 0u) continue;          // one entry per long segment: its first block's
+            dest = P.keys[tk.head];
+        }
+        if (dest >= 0 && dest < P.n_rows) adam_replay_row(P, dest, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_materialize_kernel(const ReplayParams P) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = gw; r < P.n_rows; r += nw) adam_replay_row(P, r, lane);
+}
+
 static inline unsigned untouched_blocks(int64_t n_rows) {
     const int64_t b = cdiv(n_rows * 64, 256);
     return (unsigned)(b < 4096 ? b : 4096);
@@ -962,7 +1032,8 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = a->lp_accum;
     P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
-    A.dense = opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f;
+    A.dense = (opt == EMG_OPT_ADAM && !a->deferred_dense) || P.opt.lp_lambda != 0.f;
+    EMG_REQUIRE(!(a->deferred_dense && P.opt.lp_lambda != 0.f), "emg_apply_grouped: deferred dense decay and a folded LP regulariser exclude each other");
     if (n_contrib <= 0) return EMG_OK;
     A.any = true;
     A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(a->table) && aligned16(a->contrib) &&
@@ -1192,4 +1263,47 @@ extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld,
     if (rc != EMG_OK) return rc;
     return emg_apply_grouped(opt, table, n_rows, ld, k_int, state0, state1, tag, step, contrib, ldc, n_contrib, 0,
                              hyper, nullptr, workspace, workspace_bytes, stream);
+}
+
+static int replay_params(ReplayParams& P, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                         int32_t* tag, const float* hyper, const float* lr_t_hist, int32_t upto_step) {
+    EMG_REQUIRE(table && state0 && state1 && tag && hyper && lr_t_hist, "emg_adam_catchup / materialize: null pointer");
+    EMG_REQUIRE(n_rows > 0 && ld >= k_int && k_int > 0 && upto_step >= 0, "emg_adam_catchup / materialize: bad arguments");
+    P = ReplayParams{};
+    P.table = table; P.s0 = state0; P.s1 = state1; P.tag = tag; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
+    float h8[8] = {hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], 0.f, 0.f};
+    P.opt = make_opt_params(EMG_OPT_ADAM, h8);
+    P.lr_t = lr_t_hist; P.upto = upto_step;
+    return EMG_OK;
+}
+
+extern "C" int emg_adam_catchup(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
+                                const float* hyper, const float* lr_t_hist, int32_t upto_step, const void* workspace,
+                                int64_t workspace_bytes, int64_t layout_n, void* stream) {
+    ReplayParams P;
+    int rc = replay_params(P, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_t_hist, upto_step);
+    if (rc != EMG_OK) return rc;
+    EMG_REQUIRE(workspace && layout_n > 0, "emg_adam_catchup: needs the grouping workspace of the batch (emg_prepare_batch)");
+    GroupWs w;
+    rc = group_ws_layout(const_cast<void*>(workspace), workspace_bytes, layout_n, n_rows, 0, &w);
+    if (rc != EMG_OK) return rc;
+    EMG_REQUIRE(w.counting, "emg_adam_catchup: needs the counting grouping (segment descriptors)");
+    P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.keys = w.keys; P.counters = w.counters; P.task_cap = w.task_cap;
+    if (upto_step == 0) return EMG_OK;
+    int64_t waves = layout_n / 2;
+    waves = waves < 256 ? 256 : (waves > 16384 ? 16384 : waves);
+    hipLaunchKernelGGL(adam_catchup_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, P);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int emg_adam_materialize(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
+                                    const float* hyper, const float* lr_t_hist, int32_t upto_step, void* stream) {
+    ReplayParams P;
+    int rc = replay_params(P, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_t_hist, upto_step);
+    if (rc != EMG_OK) return rc;
+    if (upto_step == 0) return EMG_OK;
+    hipLaunchKernelGGL(adam_materialize_kernel, dim3(untouched_blocks(n_rows)), dim3(256), 0, (hipStream_t)stream, P);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
 }

@@ -159,6 +159,14 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.layout_B = c.cap_B;
     if (P->ctl) { ba.pos = c.X; ba.B = c.cap_B; ba.ctl = P->ctl; }
     int rc;
+    if (c.lr_t_hist) {   // deferred dense decay (Keras Adam): bring the rows this batch reads and updates up to step - 1
+        rc = emg_adam_catchup(c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, hyper6, c.lr_t_hist, step - 1,
+                              sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, main);
+        if (rc != EMG_OK) return rc;
+        rc = emg_adam_catchup(c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hyper6, c.lr_t_hist, step - 1,
+                              sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, main);
+        if (rc != EMG_OK) return rc;
+    }
     if (c.fused) {
         ba.fused_loss = c.loss;
         Timed t(P, ST_FUSED, main);
@@ -210,6 +218,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             aa.layout_n = c.cap_B; aa.table_index = 1;
         }
         if (P->ctl) { aa.ctl = P->ctl; aa.n_contrib = aa.layout_n; }
+        aa.deferred_dense = c.lr_t_hist ? 1 : 0;
         aa.ldc = c.ldc;
     };
     emg_apply_args ae, ar;
@@ -272,6 +281,9 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     EMG_REQUIRE(!(cfg->inplace && (cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f)) || (cfg->opt == EMG_OPT_SGD && cfg->lp_p <= 3),
                 "emg_plan_create: in-place singleton updates fold an LP regulariser for plain SGD and p <= 3 only");
     EMG_REQUIRE((cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f) || cfg->lp_sum, "emg_plan_create: LP needs lp_sum");
+    EMG_REQUIRE(!cfg->lr_t_hist || (cfg->opt == EMG_OPT_ADAM && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && !cfg->normalize &&
+                                    cfg->ent_state0 && cfg->ent_state1 && cfg->rel_state0 && cfg->rel_state1),
+                "emg_plan_create: deferred dense decay (lr_t_hist) is for EMG_OPT_ADAM without regulariser / row normalisation");
     Plan* P = new Plan();
     P->cfg = *cfg;
     P->n_side = cfg->n_slots - 1 > 2 ? 2 : cfg->n_slots - 1;
@@ -415,7 +427,7 @@ static bool graph_capable(const Plan* P) {
     const bool cplx = c.model == EMG_COMPLEX || c.model == EMG_HOLE;
     const int n = cplx ? c.k_int / 2 : c.k_int;
     const int64_t et = (int64_t)c.eta * c.n_sides;
-    return c.ctl_buf && c.ctl_bytes >= (int64_t)sizeof(CtlBlock) && c.fused && (n % 4 == 0) && c.k_int / 4 > 16 && c.k_int % 4 == 0 &&
+    return c.ctl_buf && c.ctl_bytes >= (int64_t)sizeof(CtlBlock) && !c.lr_t_hist && c.fused && (n % 4 == 0) && c.k_int / 4 > 16 && c.k_int % 4 == 0 &&
            c.ld_ent % 4 == 0 && c.ld_rel % 4 == 0 && c.ldc % 4 == 0 &&
            group_backend_counting((2 + et) * c.cap_B, c.n_ent) && group_backend_counting(c.cap_B, c.n_rel) &&
            !(getenv("EMG_APPLY") && strcmp(getenv("EMG_APPLY"), "window") == 0);

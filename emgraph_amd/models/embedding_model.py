@@ -445,6 +445,7 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
     def _eval_tables(self, tr):
         """full-width device tables of the CURRENT training state (early stopping)"""
         if not getattr(self, "_sharded", False):
+            tr.materialize()   # (deferred dense decay: every row up to date before it is read)
             return tr.ent, tr.rel
         cplx = self.internal_k != self.k
         ent = parallel.unshard_columns(parallel.gather_slabs(tr.ent), self.k, cplx)

@@ -95,11 +95,14 @@ class Trainer:
     def __init__(self, model_id, k_int, scale, ent_init, rel_init, eta, loss="nll", loss_params=None,
                  optimizer="adam", optimizer_params=None, corrupt_sides=("s,o",), batches_count=1, seed=0,
                  regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda", fused=True,
-                 inplace=True, pipeline=True, sharded=False):
+                 inplace=True, pipeline=True, sharded=False, deferred_dense=None):
         """``sharded=True`` / ``"k"``: ent_init / rel_init are this rank's COLUMN slabs (emgraph_amd.parallel.shard_columns)
         and k_int is the local width; every step all-reduces the partial scores.
         ``sharded="batch"``: full tables on every rank; each rank scores its rows of the global batch, gradient rows
-        travel to the owner of their destination, which applies them and all-gathers the updated rows (parallel.py)."""
+        travel to the owner of their destination, which applies them and all-gathers the updated rows (parallel.py).
+        ``deferred_dense`` (Adam on one GPU, no regulariser; default: tables of >= 256 MB, or env EMG_ADAM_DEFERRED=0/1): Keras Adam's dense decay is
+        replayed only for the rows a batch reads and updates (emg_adam_catchup) instead of passing over the whole table every
+        step — same bits; ``materialize()`` brings every row up to date before the tables are read."""
         D.require_gpu()
         self.device = torch.device(device)
         self.model_id, self.k_int, self.scale, self.eta = model_id, int(k_int), float(scale), int(eta)
@@ -186,6 +189,15 @@ class Trainer:
         n_cols = self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int
         self.inplace = self._inplace_wanted = inplace and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3
                                                                                 and n_cols % 4 == 0))
+        # default: on where the dense pass is what a step costs — an entity table of 256 MB or more (C3 with Adam: 2.6 -> 1.65
+        # ms/step); small tables keep the dense pass (6-14 us at C1 / C2 / C5, inside the step graph)
+        env_def = os.environ.get("EMG_ADAM_DEFERRED")
+        want_deferred = deferred_dense if deferred_dense is not None else \
+            (env_def == "1" if env_def in ("0", "1") else self.n_ent * k_int * 4 >= (256 << 20))
+        self.deferred = bool(want_deferred) and self.opt_id == L.OPT_ADAM and self.reg is None and not self.sharded \
+            and not self.batch_sharded and not normalize_ent_emb
+        self._lr_t_hist = None          # device float32 [steps]: lr_t of every optimizer step so far (deferred decay)
+        self._lr_t_filled = 0
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
@@ -280,6 +292,7 @@ class Trainer:
             L.check(L.load().emg_plan_destroy(self.plan), "emg_plan_destroy")
             self.plan = None
         if self.sharded or self.batch_sharded or self.X is None or os.environ.get("EMG_PY_PLAN"):
+            self.deferred = False   # (the deferred dense decay lives in the plan's step)
             return   # multi-GPU steps have a collective in the middle: driven from the host (see step / _compute)
         c = L.PlanConfig()
         c.model, c.k_int, c.scale, c.eta, c.n_sides = self.model_id, self.k_int, self.scale, self.eta, self.n_sides
@@ -311,6 +324,10 @@ class Trainer:
         c.aux_min_rows = AUX_MIN_ROWS
         self._ctl_buf = torch.zeros(4096, dtype=torch.uint8, device=self.device)   # emg_step_ctl records of a graph replay
         c.ctl_buf, c.ctl_bytes = self._ctl_buf.data_ptr(), self._ctl_buf.numel()
+        if self.deferred:
+            if self._lr_t_hist is None:
+                self._lr_t_hist = torch.zeros(1 << 22, dtype=torch.float32, device=self.device)
+            c.lr_t_hist = self._lr_t_hist.data_ptr()
         h = C.c_void_p()
         L.check(L.load().emg_plan_create(C.byref(c), C.byref(h)), "emg_plan_create")
         self.plan = h
@@ -342,6 +359,8 @@ class Trainer:
     def _plan_step(self, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch):
         import ctypes as C
         self.step_count += 1
+        if self.deferred:
+            self._fill_lr_t(self.step_count)
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
         cur = L.PlanBatch()
@@ -688,6 +707,33 @@ class Trainer:
             self.lp_sum.zero_()
         return v
 
+    def _fill_lr_t(self, upto):
+        """lr_t of the steps (filled, upto]: the value _hyper hands the kernels, float32-rounded the same way"""
+        if upto <= self._lr_t_filled:
+            return
+        upto = min(max(upto, self._lr_t_filled + 8192), self._lr_t_hist.numel() - 1)   # ahead in blocks: one upload per 8192 steps
+        if upto >= self._lr_t_hist.numel():
+            raise RuntimeError("deferred dense decay: more than %d optimizer steps" % self._lr_t_hist.numel())
+        lr = self.lr
+        vals = [lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t) for t in range(self._lr_t_filled + 1, upto + 1)]
+        self._lr_t_hist[self._lr_t_filled + 1:upto + 1] = torch.tensor(vals, dtype=torch.float64).to(torch.float32).to(self.device)
+        self._lr_t_filled = upto
+
+    def materialize(self):
+        """deferred dense decay: bring every row of both tables (and its Adam state) up to the current step"""
+        if not self.deferred or self.step_count == 0 or self._lr_t_hist is None:
+            return
+        import ctypes as C
+        h = (C.c_float * 8)(*(self._hyper(self.lr) + (0.0, 0.0)))
+        lib = L.load()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for tab, n, s0, s1, tag in ((self.ent, self.n_ent, self.state_ent[0], self.state_ent[1], self.tag_ent),
+                                    (self.rel, self.n_rel, self.state_rel[0], self.state_rel[1], self.tag_rel)):
+            L.check(lib.emg_adam_materialize(tab.data_ptr(), n, tab.stride(0), self.k_int, s0.data_ptr(), s1.data_ptr(),
+                                             tag.data_ptr(), h, self._lr_t_hist.data_ptr(), self.step_count, st),
+                    "emg_adam_materialize")
+
     def tables_numpy(self):
+        self.materialize()
         # (.cpu() of a device tensor is a fresh host copy already; only padded rows need compacting)
         return np.ascontiguousarray(self.ent.cpu().numpy()), np.ascontiguousarray(self.rel.cpu().numpy())

@@ -405,3 +405,41 @@ def test_inplace_sgd_folds_the_lp_regulariser(monkeypatch, model, k, p):
     np.testing.assert_array_equal(a[1], b[1])
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_allclose(a[3], b[3], rtol=1e-9)     # (per-lane float partial sums group differently in the two forms)
+
+
+@pytest.mark.parametrize("model,k", [("ComplEx", 50), ("DistMult", 64), ("TransE", 100)])
+def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k):
+    """Keras Adam decays m, v and moves w of EVERY row every step.  With deferred_dense a row nothing touches is left alone and
+    the missed steps are replayed — the dense pass's own update with g = 0 and each step's lr_t — when a batch is about to
+    read it (emg_adam_catchup) or when the tables are read (materialize): tables, both state arrays and the loss must equal
+    the dense form bit for bit, on a table of which a batch touches a fifth (rows stay untouched for several steps, some
+    for all of them)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, eta, nb = 40000, 30, 1024, 6, 4
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(5)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+
+    def run(deferred):
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer="adam", optimizer_params={"lr": 0.01}, batches_count=nb,
+                     seed=3, deferred_dense=deferred)
+        tr.set_training_set(X, B)
+        assert tr.deferred == deferred
+        for ep in (1, 2, 3):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1, prefetch=[(((b + 1) % nb) * B, B, ep + (b + 1) // nb, (b + 1) % nb + 1)])
+        Et, Rt = tr.tables_numpy()
+        states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
+        return Et, Rt, states, tr.read_loss()
+
+    a, b = run(True), run(False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    assert a[3] == b[3]
+    assert not np.array_equal(a[0], E0)

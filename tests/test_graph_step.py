@@ -110,3 +110,29 @@ def test_graph_and_single_steps_interleave(monkeypatch):
         np.testing.assert_array_equal(got[0], ref[0])
         np.testing.assert_array_equal(got[1], ref[1])
         assert got[2] == ref[2]
+
+
+@pytest.mark.parametrize("name,k", [("ComplEx", 36), ("TransE", 100)])
+def test_fit_with_deferred_adam_decay_equals_dense_fit(monkeypatch, name, k):
+    """fit() with Keras Adam's dense decay deferred (forced here on a small table; the default from 256 MB) == fit() with the dense
+    pass, bit for bit — parameters, epoch losses, and the ranks an evaluation in between (early stopping reads the live
+    tables: every row is brought up to date first) would see"""
+    n_ent, n_rel, n = 2500, 6, 3000       # (a batch of 600 x 6 slots touches about half of the rows)
+    X = synth_graph(n_ent, n_rel, n, seed=4)
+    rs = np.random.RandomState(2)
+    ki = 2 * k if name == "ComplEx" else k
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    kw = dict(eta=4, epochs=4, batches_count=5, seed=9, loss="nll", optimizer="adam", optimizer_params={"lr": 0.01})
+    es = dict(early_stopping=True, early_stopping_params={"x_valid": X[:64], "criteria": "mrr", "burn_in": 1, "check_interval": 1,
+                                                           "stop_interval": 10, "corrupt_side": "s,o"})
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EMG_ADAM_DEFERRED", mode)
+        monkeypatch.setenv("EMG_GRAPH", "0")
+        m = _models()[name](k=k, initializer="constant", initializer_params={"entity": ent0, "relation": rel0}, **kw)
+        m.fit(X, **es)
+        assert m._trainer.deferred == (mode == "1")
+        out[mode] = (np.array(m.trained_model_params[0]), np.array(m.trained_model_params[1]), list(m.epoch_losses), m.predict(X[:50]))
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
