@@ -443,3 +443,47 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k):
         np.testing.assert_array_equal(x, y)
     assert a[3] == b[3]
     assert not np.array_equal(a[0], E0)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+@pytest.mark.parametrize("model,k,eta", [("DistMult", 32, 20), ("DistMult", 64, 40), ("TransE", 100, 40), ("ComplEx", 32, 70)])
+def test_more_negatives_than_lanes_per_group(monkeypatch, model, k, eta, opt):
+    """The fused kernel gathers the corruption codes / in-place flags / factor positions of LPG negatives at a time (LPG = lanes
+    per group: 16, 32 or 64 by row width).  More negatives than that run as several chunks — here 20 and 40 negatives on
+    16- / 32-lane groups and 70 on 64 lanes — and must give the bits of the one-chunk form (a wave per group, LPG = 64,
+    which EMG_WIDE_GROUPS=1 selects for the narrow rows; the 70-negative case is checked against the unfused kernels)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    if eta > 62 and opt == "adam":
+        pytest.skip("the unfused comparison is a tolerance check: Adam's normalised step amplifies last-bit gradient noise "
+                    "(the chunk logic is the optimizer's business nowhere; the narrow-row cases cover Adam bit for bit)")
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B = 3000, 7, 300
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(k + eta)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 2 * B), rs.randint(0, n_rel, 2 * B), rs.randint(0, n_ent, 2 * B)], 1).astype(np.int32)
+
+    def run(wide, fused=True):
+        monkeypatch.setenv("EMG_WIDE_GROUPS", "1" if wide else "0")
+        monkeypatch.setenv("EMG_GRAPH", "0")
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.02}, batches_count=2, seed=3,
+                     fused=fused)
+        tr.set_training_set(X, B)
+        tr.step(0, B, epoch=1, batch=1, prefetch=[(B, B, 1, 2)])
+        tr.step(B, B, epoch=1, batch=2)
+        Et, Rt = tr.tables_numpy()
+        return Et, Rt, tr.read_loss()
+
+    a = run(False)
+    b = run(True) if eta <= 62 else run(False, fused=False)
+    if eta <= 62:
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+    else:      # (the unfused kernels sum the loss in another order and form dL/dscore in their own kernel)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-6)
+    assert not np.array_equal(a[0], E0)
