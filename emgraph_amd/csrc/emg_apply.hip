@@ -673,54 +673,92 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Deferred dense decay of Keras Adam (include/emgraph_hip.h: emg_adam_catchup / emg_adam_materialize): replay the dense
-// pass's update (g = 0) of the steps a row has missed, with each step's own lr_t
+// Deferred dense pass (include/emgraph_hip.h: emg_deferred_catchup / emg_deferred_materialize): replay the dense pass's
+// update (Keras Adam's decay, the LP regulariser's gradient) of the steps a row has missed, with each step's own learning rate
 // ---------------------------------------------------------------------------------------------------------------
 struct ReplayParams {
     float* table; float* s0; float* s1; int32_t* tag; int64_t n_rows, ld; int32_t k_int; OptParams opt;
-    const float* lr_t; int32_t upto;
+    const float* lr_hist; int32_t upto; double* lp_accum;
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* keys; const uint32_t* counters; uint32_t task_cap;
 };
 
-__device__ __forceinline__ void adam_replay_row(const ReplayParams& P, int64_t r, int lane) {
+// one row, steps tag[r]+1 .. upto: what untouched_rows_body does to it in each of them (g = the regulariser's gradient alone).
+// OPT / LPK (0: no regulariser, 1: p in {1, 2, 3}, 2: any p) are compile-time: the replay is ALU work — as many row-steps as
+// the dense pass visits, only without their memory traffic — and the generic optimizer switch / powf cost it twice the time
+template <int OPT, int LPK>
+__device__ __forceinline__ void replay_row(const ReplayParams& P, int64_t r, int lane, float& lp_acc) {
     const int32_t from = P.tag[r];
     if (from >= P.upto) return;
-    if (from == 0) {   // never written: m = v = 0, every missed update is w - lr_t * 0 / (0 + eps) = w
+    if (from == 0 && LPK == 0) {   // never written, no regulariser: zero gradient on the initial state moves nothing
         if (lane == 0) P.tag[r] = P.upto;
         return;
     }
     float* w = P.table + r * P.ld;
-    float* s0 = P.s0 + r * P.ld;
-    float* s1 = P.s1 + r * P.ld;
+    float* s0 = P.s0 ? P.s0 + r * P.ld : nullptr;
+    float* s1 = P.s1 ? P.s1 + r * P.ld : nullptr;
     OptParams opt = P.opt;
-    if ((P.k_int % 4 == 0) && (P.ld % 4 == 0)) {
-        for (int c = lane; 4 * c < P.k_int; c += 64) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * c), a = *reinterpret_cast<const float4*>(s0 + 4 * c),
-                         b = *reinterpret_cast<const float4*>(s1 + 4 * c);
-            float ww[4] = {wv.x, wv.y, wv.z, wv.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
-            for (int32_t st = from + 1; st <= P.upto; ++st) {
-                opt.lr_t = P.lr_t[st];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) opt_update_elem(opt, ww[j], 0.f, &aa[j], &bb[j]);
-            }
-            *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-            *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
-            *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+    opt.opt = OPT;
+    if (LPK == 0) opt.lp_lambda = 0.f;
+    const bool vec = (P.k_int % 4 == 0) && (P.ld % 4 == 0);
+    for (int c = lane; (vec ? 4 * c : c) < P.k_int; c += 64) {
+        float ww[4] = {0.f, 0.f, 0.f, 0.f}, aa[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+        const int n = vec ? 4 : 1;
+        if (vec) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * c);
+            ww[0] = wv.x; ww[1] = wv.y; ww[2] = wv.z; ww[3] = wv.w;
+            if (s0) { const float4 a = *reinterpret_cast<const float4*>(s0 + 4 * c); aa[0] = a.x; aa[1] = a.y; aa[2] = a.z; aa[3] = a.w; }
+            if (s1) { const float4 b = *reinterpret_cast<const float4*>(s1 + 4 * c); bb[0] = b.x; bb[1] = b.y; bb[2] = b.z; bb[3] = b.w; }
+        } else {
+            ww[0] = w[c];
+            if (s0) aa[0] = s0[c];
+            if (s1) bb[0] = s1[c];
         }
-    } else {
-        for (int c = lane; c < P.k_int; c += 64) {
-            float wv = w[c], a = s0[c], b = s1[c];
-            for (int32_t st = from + 1; st <= P.upto; ++st) { opt.lr_t = P.lr_t[st]; opt_update_elem(opt, wv, 0.f, &a, &b); }
-            w[c] = wv; s0[c] = a; s1[c] = b;
+        for (int32_t st = from + 1; st <= P.upto; ++st) {
+            opt.lr = opt.lr_t = P.lr_hist[st];   // (Adam reads lr_t, the others lr: the table holds what that step's update used)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < n) {
+                    float g = 0.f;
+                    if constexpr (LPK == 1) lp_fold_p123(opt, ww[j], g, lp_acc);
+                    else if constexpr (LPK == 2) lp_fold(opt, ww[j], g, lp_acc);
+                    opt_update_elem(opt, ww[j], g, &aa[j], &bb[j]);
+                }
+            }
+        }
+        if (vec) {
+            *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+            if (s0) *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+            if (s1) *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        } else {
+            w[c] = ww[0];
+            if (s0) s0[c] = aa[0];
+            if (s1) s1[c] = bb[0];
         }
     }
     if (lane == 0) P.tag[r] = P.upto;
 }
 
+// the regulariser's partial sums of a workgroup's waves -> ONE double atomic (a launch of 16 k waves adding to one address one
+// by one took longer than the replay itself)
+__device__ __forceinline__ void block_add_double(double* dst, float partial) {
+    __shared__ double s_part[4];
+    double v = (double)partial;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (dst && t != 0.0) atomicAdd(dst, t);
+    }
+}
+
 // the rows a prepared batch will read and update = the destinations of its grouping's lists (each exactly once).  A wave takes
 // a contiguous stretch of items, 64 at a time: lane k fetches item k's destination and its tag in one go (two dependent
 // loads for 64 rows instead of two per row), then the rows that missed a step are replayed one after the other
-__global__ __launch_bounds__(256) void adam_catchup_kernel(const ReplayParams P) {
+template <int OPT, int LPK>
+__global__ __launch_bounds__(256) void deferred_catchup_kernel(const ReplayParams P) {
+    float lp_acc = 0.f;
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t n_multi = P.counters[GC_MULTI], n_single = P.counters[GC_SINGLE];
@@ -744,15 +782,19 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const ReplayParams P)
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
-            adam_replay_row(P, __shfl(dest, k, 64), lane);
+            replay_row<OPT, LPK>(P, __shfl(dest, k, 64), lane, lp_acc);
         }
     }
+    if (LPK != 0) block_add_double(P.lp_accum, lp_acc);
 }
 
-__global__ __launch_bounds__(256) void adam_materialize_kernel(const ReplayParams P) {
+template <int OPT, int LPK>
+__global__ __launch_bounds__(256) void deferred_materialize_kernel(const ReplayParams P) {
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t r = gw; r < P.n_rows; r += nw) adam_replay_row(P, r, lane);
+    float lp_acc = 0.f;
+    for (int64_t r = gw; r < P.n_rows; r += nw) replay_row<OPT, LPK>(P, r, lane, lp_acc);
+    if (LPK != 0) block_add_double(P.lp_accum, lp_acc);
 }
 
 static inline unsigned untouched_blocks(int64_t n_rows) {
@@ -1045,8 +1087,7 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = a->lp_accum;
     P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
-    A.dense = (opt == EMG_OPT_ADAM && !a->deferred_dense) || P.opt.lp_lambda != 0.f;
-    EMG_REQUIRE(!(a->deferred_dense && P.opt.lp_lambda != 0.f), "emg_apply_grouped: deferred dense decay and a folded LP regulariser exclude each other");
+    A.dense = (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) && !a->deferred_dense;
     if (n_contrib <= 0) return EMG_OK;
     A.any = true;
     A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(a->table) && aligned16(a->contrib) &&
@@ -1278,45 +1319,66 @@ extern "C" int emg_apply_rows(int opt, float* table, int64_t n_rows, int64_t ld,
                              hyper, nullptr, workspace, workspace_bytes, stream);
 }
 
-static int replay_params(ReplayParams& P, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
-                         int32_t* tag, const float* hyper, const float* lr_t_hist, int32_t upto_step) {
-    EMG_REQUIRE(table && state0 && state1 && tag && hyper && lr_t_hist, "emg_adam_catchup / materialize: null pointer");
-    EMG_REQUIRE(n_rows > 0 && ld >= k_int && k_int > 0 && upto_step >= 0, "emg_adam_catchup / materialize: bad arguments");
+template <int OPT>
+static void launch_replay_opt(bool catchup, int lpk, const ReplayParams& P, dim3 grid, hipStream_t st) {
+#define EMG_RP(K_) do { if (catchup) hipLaunchKernelGGL((deferred_catchup_kernel<OPT, K_>), grid, dim3(256), 0, st, P); \
+                        else hipLaunchKernelGGL((deferred_materialize_kernel<OPT, K_>), grid, dim3(256), 0, st, P); } while (0)
+    if (lpk == 0) EMG_RP(0); else if (lpk == 1) EMG_RP(1); else EMG_RP(2);
+#undef EMG_RP
+}
+static void launch_replay(bool catchup, const ReplayParams& P, dim3 grid, hipStream_t st) {
+    const int lpk = P.opt.lp_lambda == 0.f ? 0 : (P.opt.lp_p <= 3 ? 1 : 2);
+    switch (P.opt.opt) {
+        case EMG_OPT_SGD: launch_replay_opt<EMG_OPT_SGD>(catchup, lpk, P, grid, st); break;
+        case EMG_OPT_MOMENTUM: launch_replay_opt<EMG_OPT_MOMENTUM>(catchup, lpk, P, grid, st); break;
+        case EMG_OPT_ADAGRAD: launch_replay_opt<EMG_OPT_ADAGRAD>(catchup, lpk, P, grid, st); break;
+        default: launch_replay_opt<EMG_OPT_ADAM>(catchup, lpk, P, grid, st); break;
+    }
+}
+
+static int replay_params(ReplayParams& P, int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                         int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum) {
+    EMG_REQUIRE(opt >= EMG_OPT_SGD && opt <= EMG_OPT_ADAM, "emg_deferred_catchup / materialize: unknown optimizer %d", opt);
+    EMG_REQUIRE(table && tag && hyper && lr_hist, "emg_deferred_catchup / materialize: null pointer");
+    EMG_REQUIRE(!(opt == EMG_OPT_MOMENTUM || opt == EMG_OPT_ADAGRAD) || state0, "emg_deferred_catchup / materialize: optimizer needs state0");
+    EMG_REQUIRE(opt != EMG_OPT_ADAM || (state0 && state1), "emg_deferred_catchup / materialize: adam needs both state tables");
+    EMG_REQUIRE(n_rows > 0 && ld >= k_int && k_int > 0 && upto_step >= 0, "emg_deferred_catchup / materialize: bad arguments");
+    EMG_REQUIRE(hyper[6] == 0.f || hyper[7] >= 1.f, "emg_deferred_catchup / materialize: LP needs p >= 1");
     P = ReplayParams{};
     P.table = table; P.s0 = state0; P.s1 = state1; P.tag = tag; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
-    float h8[8] = {hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], 0.f, 0.f};
-    P.opt = make_opt_params(EMG_OPT_ADAM, h8);
-    P.lr_t = lr_t_hist; P.upto = upto_step;
+    P.opt = make_opt_params(opt, hyper);
+    P.lr_hist = lr_hist; P.upto = upto_step; P.lp_accum = lp_accum;
     return EMG_OK;
 }
 
-extern "C" int emg_adam_catchup(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
-                                const float* hyper, const float* lr_t_hist, int32_t upto_step, const void* workspace,
-                                int64_t workspace_bytes, int64_t layout_n, void* stream) {
+extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                                    int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
+                                    const void* workspace, int64_t workspace_bytes, int64_t layout_n, void* stream) {
     ReplayParams P;
-    int rc = replay_params(P, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_t_hist, upto_step);
+    int rc = replay_params(P, opt, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_hist, upto_step, lp_accum);
     if (rc != EMG_OK) return rc;
-    EMG_REQUIRE(workspace && layout_n > 0, "emg_adam_catchup: needs the grouping workspace of the batch (emg_prepare_batch)");
+    EMG_REQUIRE(workspace && layout_n > 0, "emg_deferred_catchup: needs the grouping workspace of the batch (emg_prepare_batch)");
     GroupWs w;
     rc = group_ws_layout(const_cast<void*>(workspace), workspace_bytes, layout_n, n_rows, 0, &w);
     if (rc != EMG_OK) return rc;
-    EMG_REQUIRE(w.counting, "emg_adam_catchup: needs the counting grouping (segment descriptors)");
+    EMG_REQUIRE(w.counting, "emg_deferred_catchup: needs the counting grouping (segment descriptors)");
     P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.keys = w.keys; P.counters = w.counters; P.task_cap = w.task_cap;
     if (upto_step == 0) return EMG_OK;
     int64_t waves = layout_n / 2;
     waves = waves < 256 ? 256 : (waves > 16384 ? 16384 : waves);
-    hipLaunchKernelGGL(adam_catchup_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, P);
+    launch_replay(true, P, dim3((unsigned)cdiv(waves, 4)), (hipStream_t)stream);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }
 
-extern "C" int emg_adam_materialize(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
-                                    const float* hyper, const float* lr_t_hist, int32_t upto_step, void* stream) {
+extern "C" int emg_deferred_materialize(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                                        int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
+                                        void* stream) {
     ReplayParams P;
-    int rc = replay_params(P, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_t_hist, upto_step);
+    int rc = replay_params(P, opt, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_hist, upto_step, lp_accum);
     if (rc != EMG_OK) return rc;
     if (upto_step == 0) return EMG_OK;
-    hipLaunchKernelGGL(adam_materialize_kernel, dim3(untouched_blocks(n_rows)), dim3(256), 0, (hipStream_t)stream, P);
+    launch_replay(false, P, dim3(untouched_blocks(n_rows)), (hipStream_t)stream);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }

@@ -159,12 +159,12 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.layout_B = c.cap_B;
     if (P->ctl) { ba.pos = c.X; ba.B = c.cap_B; ba.ctl = P->ctl; }
     int rc;
-    if (c.lr_t_hist) {   // deferred dense decay (Keras Adam): bring the rows this batch reads and updates up to step - 1
-        rc = emg_adam_catchup(c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, hyper6, c.lr_t_hist, step - 1,
-                              sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, main);
+    if (c.lr_t_hist) {   // deferred dense pass (Keras Adam / LP): bring the rows this batch reads and updates up to step - 1
+        rc = emg_deferred_catchup(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, he, c.lr_t_hist, step - 1,
+                                  lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, main);
         if (rc != EMG_OK) return rc;
-        rc = emg_adam_catchup(c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hyper6, c.lr_t_hist, step - 1,
-                              sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, main);
+        rc = emg_deferred_catchup(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hr, c.lr_t_hist, step - 1,
+                                  lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, main);
         if (rc != EMG_OK) return rc;
     }
     if (c.fused) {
@@ -281,9 +281,8 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     EMG_REQUIRE(!(cfg->inplace && (cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f)) || (cfg->opt == EMG_OPT_SGD && cfg->lp_p <= 3),
                 "emg_plan_create: in-place singleton updates fold an LP regulariser for plain SGD and p <= 3 only");
     EMG_REQUIRE((cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f) || cfg->lp_sum, "emg_plan_create: LP needs lp_sum");
-    EMG_REQUIRE(!cfg->lr_t_hist || (cfg->opt == EMG_OPT_ADAM && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && !cfg->normalize &&
-                                    cfg->ent_state0 && cfg->ent_state1 && cfg->rel_state0 && cfg->rel_state1),
-                "emg_plan_create: deferred dense decay (lr_t_hist) is for EMG_OPT_ADAM without regulariser / row normalisation");
+    EMG_REQUIRE(!cfg->lr_t_hist || ((cfg->opt == EMG_OPT_ADAM || cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f) && !cfg->normalize),
+                "emg_plan_create: a deferred dense pass (lr_t_hist) is for EMG_OPT_ADAM and / or an LP regulariser, without row normalisation");
     Plan* P = new Plan();
     P->cfg = *cfg;
     P->n_side = cfg->n_slots - 1 > 2 ? 2 : cfg->n_slots - 1;

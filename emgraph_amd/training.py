@@ -194,10 +194,12 @@ class Trainer:
         env_def = os.environ.get("EMG_ADAM_DEFERRED")
         want_deferred = deferred_dense if deferred_dense is not None else \
             (env_def == "1" if env_def in ("0", "1") else self.n_ent * k_int * 4 >= (256 << 20))
-        self.deferred = bool(want_deferred) and self.opt_id == L.OPT_ADAM and self.reg is None and not self.sharded \
+        # (what has a dense pass at all: Keras Adam's decay, the LP regulariser's gradient)
+        self.deferred = bool(want_deferred) and (self.opt_id == L.OPT_ADAM or self.reg is not None) and not self.sharded \
             and not self.batch_sharded and not normalize_ent_emb
-        self._lr_t_hist = None          # device float32 [steps]: lr_t of every optimizer step so far (deferred decay)
+        self._lr_t_hist = None          # device float32 [steps]: learning rate (Adam: lr_t) of every optimizer step (deferred pass)
         self._lr_t_filled = 0
+        self._lr_host = [0.0]           # host copy (index = step)
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
@@ -359,10 +361,10 @@ class Trainer:
     def _plan_step(self, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch):
         import ctypes as C
         self.step_count += 1
-        if self.deferred:
-            self._fill_lr_t(self.step_count)
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
+        if self.deferred:
+            self._fill_lr_t(self.step_count, lr)
         cur = L.PlanBatch()
         keep = [self._plan_batch(cur, (start, B, epoch, batch, n_choices, entities_list)), inj_mask, inj_repl]
         if inj_repl is not None:
@@ -691,6 +693,8 @@ class Trainer:
 
     def read_loss(self, reset=True):
         """data loss (identical on every rank) + LP term (summed over the column slabs when sharded)"""
+        if self.deferred and self.reg is not None:
+            self.materialize()   # the regulariser's value over the rows whose dense updates are still pending
         reg, data = self.reg_accum, self.loss_accum
         if self.sharded:  # sum a COPY over the ranks: the accumulator itself stays rank-local (reset=False calls)
             reg = parallel.allreduce_sum_(self.reg_accum.clone())
@@ -707,31 +711,48 @@ class Trainer:
             self.lp_sum.zero_()
         return v
 
-    def _fill_lr_t(self, upto):
-        """lr_t of the steps (filled, upto]: the value _hyper hands the kernels, float32-rounded the same way"""
-        if upto <= self._lr_t_filled:
-            return
-        upto = min(max(upto, self._lr_t_filled + 8192), self._lr_t_hist.numel() - 1)   # ahead in blocks: one upload per 8192 steps
+    def _step_lr(self, t):
+        """the learning rate optimizer step t uses (Adam: lr_t), assuming fit()'s order of batches (step t = batch (t - 1) mod
+        batches_count of epoch (t - 1) // batches_count); a step issued out of that order corrects its own entry"""
+        if self.opt_id == L.OPT_ADAM:
+            return self.lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t)
+        if self.sgd_params is not None:
+            return sgd_learning_rate(self.sgd_params, self.batches_count, (t - 1) // self.batches_count + 1, (t - 1) % self.batches_count + 1)
+        return self.lr
+
+    def _fill_lr_t(self, upto, lr_now=None):
+        """learning rates of the steps (filled, upto] into the device table the replay reads: the values _hyper hands the
+        kernels, float32-rounded the same way; ``lr_now``: what step ``upto`` really uses"""
         if upto >= self._lr_t_hist.numel():
-            raise RuntimeError("deferred dense decay: more than %d optimizer steps" % self._lr_t_hist.numel())
-        lr = self.lr
-        vals = [lr * math.sqrt(1.0 - ADAM_BETA2 ** t) / (1.0 - ADAM_BETA1 ** t) for t in range(self._lr_t_filled + 1, upto + 1)]
-        self._lr_t_hist[self._lr_t_filled + 1:upto + 1] = torch.tensor(vals, dtype=torch.float64).to(torch.float32).to(self.device)
-        self._lr_t_filled = upto
+            raise RuntimeError("deferred dense pass: more than %d optimizer steps" % self._lr_t_hist.numel())
+        if upto > self._lr_t_filled:
+            hi = min(max(upto, self._lr_t_filled + 8192), self._lr_t_hist.numel() - 1)   # ahead in blocks: one upload per 8192 steps
+            vals = [self._step_lr(t) for t in range(self._lr_t_filled + 1, hi + 1)]
+            self._lr_host.extend(np.asarray(vals, dtype=np.float64).astype(np.float32).tolist())
+            self._lr_t_hist[self._lr_t_filled + 1:hi + 1] = torch.tensor(vals, dtype=torch.float64).to(torch.float32).to(self.device)
+            self._lr_t_filled = hi
+        if lr_now is not None and self.opt_id != L.OPT_ADAM:
+            v = float(np.float32(lr_now))
+            if self._lr_host[upto] != v:      # a step outside fit()'s order (tests drive epochs / batches freely)
+                self._lr_host[upto] = v
+                self._lr_t_hist[upto:upto + 1] = torch.tensor([lr_now], dtype=torch.float64).to(torch.float32).to(self.device)
 
     def materialize(self):
-        """deferred dense decay: bring every row of both tables (and its Adam state) up to the current step"""
+        """deferred dense pass: bring every row of both tables (and its optimizer state) up to the current step"""
         if not self.deferred or self.step_count == 0 or self._lr_t_hist is None:
             return
         import ctypes as C
-        h = (C.c_float * 8)(*(self._hyper(self.lr) + (0.0, 0.0)))
         lib = L.load()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for tab, n, s0, s1, tag in ((self.ent, self.n_ent, self.state_ent[0], self.state_ent[1], self.tag_ent),
-                                    (self.rel, self.n_rel, self.state_rel[0], self.state_rel[1], self.tag_rel)):
-            L.check(lib.emg_adam_materialize(tab.data_ptr(), n, tab.stride(0), self.k_int, s0.data_ptr(), s1.data_ptr(),
-                                             tag.data_ptr(), h, self._lr_t_hist.data_ptr(), self.step_count, st),
-                    "emg_adam_materialize")
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        for i, (tab, n, state, tag) in enumerate(((self.ent, self.n_ent, self.state_ent, self.tag_ent),
+                                                  (self.rel, self.n_rel, self.state_rel, self.tag_rel))):
+            hy = self._hyper(self.lr, i)
+            h = (C.c_float * 8)(*(hy if len(hy) == 8 else hy + (0.0, 0.0)))
+            lp = self.lp_sum[i:i + 1].data_ptr() if self.reg is not None else None
+            L.check(lib.emg_deferred_materialize(self.opt_id, tab.data_ptr(), n, tab.stride(0), self.k_int, ptr(state[0]), ptr(state[1]),
+                                                 tag.data_ptr(), h, self._lr_t_hist.data_ptr(), self.step_count, lp, st),
+                    "emg_deferred_materialize")
 
     def tables_numpy(self):
         self.materialize()

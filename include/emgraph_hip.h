@@ -254,23 +254,26 @@ typedef struct emg_apply_args {
     int32_t factored;
     int32_t table_index;                 /* 0 entity / 1 relation table: which hyper-parameters of `ctl` apply */
     int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
-    int32_t deferred_dense; int32_t reserved1;   /* 1: EMG_OPT_ADAM without its dense pass (the caller runs emg_adam_catchup, below) */
+    int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below */
 } emg_apply_args;
 int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
 int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);
-/* DEFERRED dense decay for Keras Adam on a large table (training/adam.py:31-48: every step decays m, v and moves w of
- * EVERY row — 9.6 GB read + written per step for 1M x 400).  A row nothing touches keeps (w, m, v) as of tag[row], the
- * last step it was written at; before a batch is scored, emg_adam_catchup replays the missed steps tag[row]+1 .. upto
- * — the dense pass's own update with g = 0 and that step's lr_t = lr_t_hist[step], the same float operations in the
- * same order, so the same bits — for exactly the rows the batch will read and update: the destinations of the grouping in
- * `workspace` (emg_prepare_batch's, counting backend).  The apply then runs with deferred_dense = 1 (no dense pass).
- * emg_adam_materialize does the same for every row (before the tables are read: prediction, evaluation, checkpoints).
- * hyper: as in emg_apply_grouped (beta1, beta2, eps are read); lr_t_hist[s] for every step s <= upto. */
-int emg_adam_catchup(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
-                     const float* hyper, const float* lr_t_hist, int32_t upto_step, const void* workspace,
-                     int64_t workspace_bytes, int64_t layout_n, void* stream);
-int emg_adam_materialize(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1, int32_t* tag,
-                         const float* hyper, const float* lr_t_hist, int32_t upto_step, void* stream);
+/* DEFERRED dense pass.  Keras Adam (training/adam.py:31-48) decays m, v and moves w of EVERY row every step; a folded LP
+ * regulariser (regularizers/lp.py:107-113) gives every row a gradient every step: on a 1M x 400 table that is 3.2 - 9.6 GB
+ * read + written per step.  Deferred: a row nothing touches keeps (w, state) as of tag[row], the last step it was written
+ * at; before a batch is scored, emg_deferred_catchup replays the missed steps tag[row]+1 .. upto — the dense pass's own
+ * update (g = the regulariser's gradient alone) with THAT step's learning rate lr_hist[step] (lr_t for Adam, lr otherwise),
+ * the same float operations in the same order, so the same bits — for exactly the rows the batch will read and update: the
+ * destinations of the grouping in `workspace` (emg_prepare_batch's, counting backend).  The apply then runs with
+ * deferred_dense = 1 (no dense pass).  emg_deferred_materialize does the same for every row (before the tables are read,
+ * and — with a regulariser — before a loss is reported: *lp_accum += sum |w|^p of every replayed step).  hyper: the 8 values
+ * of emg_apply_grouped (hyper[0] / hyper[5] are replaced per step by lr_hist). */
+int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                         int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
+                         const void* workspace, int64_t workspace_bytes, int64_t layout_n, void* stream);
+int emg_deferred_materialize(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
+                             int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
+                             void* stream);
 /* LP regulariser folded into the optimizer step (hyper[6] = lambda != 0, hyper[7] = p): the penalty covers the FULL
  * table (regularizers/lp.py:107-113, EmbeddingModel.py:818-820), so its gradient lambda*p*|w|^(p-1)*sign(w) reaches
  * every row.  Rows with contributions (and rows the backward kernel updates in place) add it to their summed
@@ -593,8 +596,9 @@ typedef struct emg_plan_config {
     int32_t n_slots; emg_plan_slot slots[4];
     int64_t aux_min_rows;                            /* entity contribution rows above which apply_rel gets its stream */
     void* ctl_buf; int64_t ctl_bytes;                /* optional device scratch (>= 32 * sizeof(emg_step_ctl)) for emg_plan_run */
-    const float* lr_t_hist;                          /* != NULL with opt = EMG_OPT_ADAM: deferred dense decay (emg_adam_catchup before every
-                                                        scoring kernel, no dense pass); lr_t_hist[s] filled for every step the plan is given */
+    const float* lr_t_hist;                          /* != NULL (EMG_OPT_ADAM and / or LP): deferred dense pass (emg_deferred_catchup before every
+                                                        scoring kernel, none afterwards); [s] = learning rate of step s (Adam: lr_t), filled
+                                                        for every step the plan is given */
 } emg_plan_config;
 typedef struct emg_plan_batch {
     int64_t start; int64_t B; int32_t epoch; int32_t batch;   /* rows [start, start + B) of X; 1-based epoch / batch */

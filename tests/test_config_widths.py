@@ -407,9 +407,11 @@ def test_inplace_sgd_folds_the_lp_regulariser(monkeypatch, model, k, p):
     np.testing.assert_allclose(a[3], b[3], rtol=1e-9)     # (per-lane float partial sums group differently in the two forms)
 
 
+@pytest.mark.parametrize("opt,reg", [("adam", None), ("sgd", 2), ("adagrad", 3), ("adam", 1), ("momentum", 2)])
 @pytest.mark.parametrize("model,k", [("ComplEx", 50), ("DistMult", 64), ("TransE", 100)])
-def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k):
-    """Keras Adam decays m, v and moves w of EVERY row every step.  With deferred_dense a row nothing touches is left alone and
+def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k, opt, reg):
+    """Keras Adam decays m, v and moves w of EVERY row every step, an LP regulariser gives every row a gradient every step.  With
+    deferred_dense a row nothing touches is left alone and
     the missed steps are replayed — the dense pass's own update with g = 0 and each step's lr_t — when a batch is about to
     read it (emg_adam_catchup) or when the tables are read (materialize): tables, both state arrays and the loss must equal
     the dense form bit for bit, on a table of which a batch touches a fifth (rows stay untouched for several steps, some
@@ -425,8 +427,12 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k):
     X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
 
     def run(deferred):
-        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer="adam", optimizer_params={"lr": 0.01}, batches_count=nb,
-                     seed=3, deferred_dense=deferred)
+        kw = dict(regularizer="LP", regularizer_params={"lambda": 1e-3, "p": reg}) if reg else {}
+        op = {"lr": 0.01}
+        if opt == "sgd":      # (a learning rate that changes per step: the replay takes each step's own from the device table)
+            op = {"lr": 0.05, "decay_cycle": 1, "decay_lr_rate": 2, "end_lr": 1e-4}
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params=op, batches_count=nb,
+                     seed=3, deferred_dense=deferred, **kw)
         tr.set_training_set(X, B)
         assert tr.deferred == deferred
         for ep in (1, 2, 3):
@@ -441,7 +447,10 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k):
     np.testing.assert_array_equal(a[1], b[1])
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
-    assert a[3] == b[3]
+    if reg:   # (the regulariser's value is summed by other kernels in another order: double atomics over float partial sums)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    else:
+        assert a[3] == b[3]
     assert not np.array_equal(a[0], E0)
 
 
