@@ -57,12 +57,12 @@ WORKLOADS = {
                 desc="C3 with the self-adversarial loss (forward | loss | backward kernels)"),
     "C3r": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="sgd",
                 reg={"lambda": 1e-5, "p": 2},
-                desc="C3 with the LP regulariser (p = 2) folded into the optimizer step: every gradient row through the apply "
-                     "kernel + one dense pass over the untouched rows"),
+                desc="C3 with the LP regulariser (p = 2) folded into the optimizer step (singletons in place in the scoring kernel); the "
+                     "dense pass over untouched rows is DEFERRED for tables >= 256 MB (emg_deferred_catchup, same bits)"),
     "C3a": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adam",
                 desc="C3 with the reference's default optimizer (Keras Adam, constants.py:55 / adam.py:31-48).  Its update is DENSE — every "
                      "step decays m, v and moves w of all 1M x 400 entries, 9.6 GB read + written.  Default for tables >= 256 MB: the "
-                     "decay is DEFERRED (emg_adam_catchup: the missed steps of a row are replayed when a batch is about to read it — "
+                     "decay is DEFERRED (emg_deferred_catchup: the missed steps of a row are replayed when a batch is about to read it — "
                      "same bits, no pass over the whole table)"),
     "C3d": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adam", deferred=False,
                 desc="C3a with the dense pass as Keras runs it (Trainer(deferred_dense=False)): every row of the table read and written "

@@ -100,9 +100,10 @@ class Trainer:
         and k_int is the local width; every step all-reduces the partial scores.
         ``sharded="batch"``: full tables on every rank; each rank scores its rows of the global batch, gradient rows
         travel to the owner of their destination, which applies them and all-gathers the updated rows (parallel.py).
-        ``deferred_dense`` (Adam on one GPU, no regulariser; default: tables of >= 256 MB, or env EMG_ADAM_DEFERRED=0/1): Keras Adam's dense decay is
-        replayed only for the rows a batch reads and updates (emg_adam_catchup) instead of passing over the whole table every
-        step — same bits; ``materialize()`` brings every row up to date before the tables are read."""
+        ``deferred_dense`` (one GPU, Adam and / or an LP regulariser; default: tables of >= 256 MB, or env EMG_ADAM_DEFERRED=0/1):
+        the dense pass (Keras Adam's decay, the regulariser's gradient) is replayed only for the rows a batch reads and
+        updates (emg_deferred_catchup) instead of passing over the whole table every step — same bits; ``materialize()``
+        brings every row up to date before the tables are read."""
         D.require_gpu()
         self.device = torch.device(device)
         self.model_id, self.k_int, self.scale, self.eta = model_id, int(k_int), float(scale), int(eta)

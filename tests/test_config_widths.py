@@ -413,7 +413,7 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k, opt, reg):
     """Keras Adam decays m, v and moves w of EVERY row every step, an LP regulariser gives every row a gradient every step.  With
     deferred_dense a row nothing touches is left alone and
     the missed steps are replayed — the dense pass's own update with g = 0 and each step's lr_t — when a batch is about to
-    read it (emg_adam_catchup) or when the tables are read (materialize): tables, both state arrays and the loss must equal
+    read it (emg_deferred_catchup) or when the tables are read (materialize): tables, both state arrays and the loss must equal
     the dense form bit for bit, on a table of which a batch touches a fifth (rows stay untouched for several steps, some
     for all of them)."""
     from emgraph_amd import _lib as L
