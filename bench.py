@@ -124,7 +124,7 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
+    for fn in ("r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items()
@@ -279,7 +279,7 @@ def hbm_ceilings():
         return None
 
 
-def profiled_avg_us(kernel_substr, tag_glob="r3_*_kernel_stats.md"):
+def profiled_avg_us(kernel_substr, tag_glob="r3_*_c3_kernel_stats.md"):
     """average duration (us) of a kernel in the newest committed rocprofv3 --kernel-trace --stats table of THIS workload
     (profiles/): printed next to the live HIP-event figure so that `frac` can be re-derived from profiles/ alone"""
     import glob
@@ -343,7 +343,7 @@ def score_kernel_alone(r, reps=50):
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
     traffic = None
     try:
-        fn = next(f for f in ("r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        fn = next(f for f in ("r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
         d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
         traffic = k[0]["hbm_bytes_per_launch"] if k else None
