@@ -788,6 +788,134 @@ __global__ __launch_bounds__(256) void deferred_catchup_kernel(const ReplayParam
     if (LPK != 0) block_add_double(P.lp_accum, lp_acc);
 }
 
+// ---- the same, rows pipelined (16-byte rows of at most 64 T chunks).  The one-row-at-a-time form above is a chain of dependent
+// latencies per row (tag -> row loads -> per-step learning-rate loads -> stores, then the next chunk trip): 317 us for C3's
+// entity table with SGD + LP where the bytes take 140.  Here a row's loads (all trips, all state rows, its 64 next learning
+// rates: lane l holds step from+1+l) are issued while the row before it is replayed; nothing in the loop is conditional —
+// lanes past the row's end clamp to its last chunk and redo that chunk's work, storing the same bytes — so the compiler's
+// s_waitcnt leaves the next row's loads in flight.  Rows that missed more than 64 steps take the generic path afterwards.
+template <int OPT, int T>
+struct ReplayRegs {
+    float4 w[T], a[T], b[T];
+    float lr;
+};
+template <int OPT, int T>
+__device__ __forceinline__ void replay_issue(const ReplayParams& P, ReplayRegs<OPT, T>& R, int32_t row, int32_t from, int lane, int nchunks) {
+    const int64_t base = (int64_t)row * P.ld;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int c = min(lane + 64 * t, nchunks - 1);
+        R.w[t] = *reinterpret_cast<const float4*>(P.table + base + 4 * c);
+        if constexpr (OPT != EMG_OPT_SGD) R.a[t] = *reinterpret_cast<const float4*>(P.s0 + base + 4 * c);
+        if constexpr (OPT == EMG_OPT_ADAM) R.b[t] = *reinterpret_cast<const float4*>(P.s1 + base + 4 * c);
+    }
+    R.lr = P.lr_hist[min(from + 1 + lane, P.upto)];
+}
+template <int OPT, int LPK, int T>
+__device__ __forceinline__ void replay_finish(const ReplayParams& P, ReplayRegs<OPT, T>& R, int32_t row, int32_t from, int lane, int nchunks,
+                                              float& lp_acc) {
+    OptParams opt = P.opt;
+    opt.opt = OPT;
+    if (LPK == 0) opt.lp_lambda = 0.f;
+    const int n = P.upto - from;   // 1..64, the same for the whole wave
+    float ww[T][4], aa[T][4], bb[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        ww[t][0] = R.w[t].x; ww[t][1] = R.w[t].y; ww[t][2] = R.w[t].z; ww[t][3] = R.w[t].w;
+        if constexpr (OPT != EMG_OPT_SGD) { aa[t][0] = R.a[t].x; aa[t][1] = R.a[t].y; aa[t][2] = R.a[t].z; aa[t][3] = R.a[t].w; }
+        else { aa[t][0] = aa[t][1] = aa[t][2] = aa[t][3] = 0.f; }
+        if constexpr (OPT == EMG_OPT_ADAM) { bb[t][0] = R.b[t].x; bb[t][1] = R.b[t].y; bb[t][2] = R.b[t].z; bb[t][3] = R.b[t].w; }
+        else { bb[t][0] = bb[t][1] = bb[t][2] = bb[t][3] = 0.f; }
+    }
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    for (int i = 0; i < n; ++i) {
+        opt.lr = opt.lr_t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R.lr), i));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g = 0.f;
+                if constexpr (LPK == 1) lp_fold_p123(opt, ww[t][j], g, acc[t]);
+                opt_update_elem(opt, ww[t][j], g, &aa[t][j], &bb[t][j]);
+            }
+        }
+    }
+    const int64_t base = (int64_t)row * P.ld;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const bool on = lane + 64 * t < nchunks;
+        const int c = min(lane + 64 * t, nchunks - 1);
+        *reinterpret_cast<float4*>(P.table + base + 4 * c) = make_float4(ww[t][0], ww[t][1], ww[t][2], ww[t][3]);
+        if constexpr (OPT != EMG_OPT_SGD) *reinterpret_cast<float4*>(P.s0 + base + 4 * c) = make_float4(aa[t][0], aa[t][1], aa[t][2], aa[t][3]);
+        if constexpr (OPT == EMG_OPT_ADAM) *reinterpret_cast<float4*>(P.s1 + base + 4 * c) = make_float4(bb[t][0], bb[t][1], bb[t][2], bb[t][3]);
+        if (LPK != 0) lp_acc += on ? acc[t] : 0.f;
+    }
+}
+
+template <int OPT, int LPK, int T>
+__global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const ReplayParams P) {
+    float lp_acc = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int nchunks = P.k_int / 4;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.counters[GC_SINGLE];
+    const int64_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
+    const int64_t total = n_multi + n_single + n_tasks;
+    const int64_t share = (total + nw - 1) / nw;
+    const int64_t i0 = gw * share, i1 = min(total, i0 + share);
+    for (int64_t base = i0; base < i1; base += 64) {
+        const int64_t i = base + lane;
+        int32_t dest = -1;
+        if (i < i1) {
+            if (i < n_multi) dest = (int32_t)P.multi[i].dest;
+            else if (i < n_multi + n_single) dest = (int32_t)P.keys[P.single[i - n_multi]];
+            else {
+                const LongTask tk = P.tasks[i - n_multi - n_single];
+                if (tk.block == 0u) dest = (int32_t)P.keys[tk.head];
+            }
+        }
+        const bool valid = dest >= 0 && dest < P.n_rows;
+        const int32_t from = valid ? P.tag[dest] : P.upto;
+        const bool due = from < P.upto;
+        const bool moves = due && !(from == 0 && LPK == 0);   // (never written, no regulariser: zero gradient on the initial state moves nothing)
+        const bool fast = moves && P.upto - from <= 64;
+        if (due && (fast || !moves)) P.tag[dest] = P.upto;    // (each destination is in the lists once: nobody else looks at this tag here)
+        unsigned long long todo = __ballot(fast);
+        if (todo) {
+            ReplayRegs<OPT, T> ra, rb;   // two rows' registers, taken in turns (no copies: a copy would wait for the loads it hides)
+            int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            int32_t row = __builtin_amdgcn_readlane(dest, k), fr = __builtin_amdgcn_readlane(from, k);
+            replay_issue<OPT, T>(P, ra, row, fr, lane, nchunks);
+            for (;;) {
+                bool more = todo != 0ull;
+                k = more ? __ffsll((long long)todo) - 1 : k;   // (no row left: the same row once more, unused — the loop stays branch-free)
+                todo &= todo - 1ull;
+                const int32_t rown = __builtin_amdgcn_readlane(dest, k), frn = __builtin_amdgcn_readlane(from, k);
+                replay_issue<OPT, T>(P, rb, rown, frn, lane, nchunks);
+                replay_finish<OPT, LPK, T>(P, ra, row, fr, lane, nchunks, lp_acc);
+                if (!more) break;
+                more = todo != 0ull;
+                k = more ? __ffsll((long long)todo) - 1 : k;
+                todo &= todo - 1ull;
+                row = __builtin_amdgcn_readlane(dest, k); fr = __builtin_amdgcn_readlane(from, k);
+                replay_issue<OPT, T>(P, ra, row, fr, lane, nchunks);
+                replay_finish<OPT, LPK, T>(P, rb, rown, frn, lane, nchunks, lp_acc);
+                if (!more) break;
+            }
+        }
+        unsigned long long slow = __ballot(moves && !fast);
+        while (slow) {
+            const int k = __ffsll((long long)slow) - 1;
+            slow &= slow - 1ull;
+            replay_row<OPT, LPK>(P, (int64_t)__builtin_amdgcn_readlane(dest, k), lane, lp_acc);
+        }
+    }
+    if (LPK != 0) block_add_double(P.lp_accum, lp_acc);
+}
+
 template <int OPT, int LPK>
 __global__ __launch_bounds__(256) void deferred_materialize_kernel(const ReplayParams P) {
     const int lane = threadIdx.x & 63;
@@ -1326,8 +1454,31 @@ static void launch_replay_opt(bool catchup, int lpk, const ReplayParams& P, dim3
     if (lpk == 0) EMG_RP(0); else if (lpk == 1) EMG_RP(1); else EMG_RP(2);
 #undef EMG_RP
 }
+template <int OPT, int LPK>
+static void launch_catchup_rows(int trips, const ReplayParams& P, dim3 grid, hipStream_t st) {
+    if (trips == 1) hipLaunchKernelGGL((deferred_catchup_rows_kernel<OPT, LPK, 1>), grid, dim3(256), 0, st, P);
+    else if (trips == 2) hipLaunchKernelGGL((deferred_catchup_rows_kernel<OPT, LPK, 2>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((deferred_catchup_rows_kernel<OPT, LPK, 4>), grid, dim3(256), 0, st, P);
+}
+static bool env_replay_rows() {
+    static const bool on = [] { const char* e = getenv("EMG_REPLAY_ROWS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static void launch_replay(bool catchup, const ReplayParams& P, dim3 grid, hipStream_t st) {
     const int lpk = P.opt.lp_lambda == 0.f ? 0 : (P.opt.lp_p <= 3 ? 1 : 2);
+    const bool aligned = aligned16(P.table) && (!P.s0 || aligned16(P.s0)) && (!P.s1 || aligned16(P.s1));
+    if (catchup && lpk != 2 && P.k_int % 4 == 0 && P.ld % 4 == 0 && P.k_int <= 1024 && aligned && env_replay_rows()) {
+        const int trips = (int)cdiv((int64_t)P.k_int / 4, 64);
+#define EMG_RR(O_) do { if (lpk == 0) launch_catchup_rows<O_, 0>(trips, P, grid, st); else launch_catchup_rows<O_, 1>(trips, P, grid, st); } while (0)
+        switch (P.opt.opt) {
+            case EMG_OPT_SGD: EMG_RR(EMG_OPT_SGD); break;
+            case EMG_OPT_MOMENTUM: EMG_RR(EMG_OPT_MOMENTUM); break;
+            case EMG_OPT_ADAGRAD: EMG_RR(EMG_OPT_ADAGRAD); break;
+            default: EMG_RR(EMG_OPT_ADAM); break;
+        }
+#undef EMG_RR
+        return;
+    }
     switch (P.opt.opt) {
         case EMG_OPT_SGD: launch_replay_opt<EMG_OPT_SGD>(catchup, lpk, P, grid, st); break;
         case EMG_OPT_MOMENTUM: launch_replay_opt<EMG_OPT_MOMENTUM>(catchup, lpk, P, grid, st); break;

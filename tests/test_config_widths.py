@@ -454,6 +454,47 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k, opt, reg):
     assert not np.array_equal(a[0], E0)
 
 
+@pytest.mark.parametrize("model,k,opt,reg", [("ComplEx", 200, "adam", None), ("DistMult", 600, "sgd", 2), ("DistMult", 101, "adagrad", 3),
+                                               ("TransE", 256, "momentum", 4), ("ComplEx", 100, "adam", 2)])
+def test_deferred_pass_row_widths_and_long_gaps(model, k, opt, reg):
+    """The catch-up's pipelined form holds a row in 1, 2 or 4 sixteen-byte chunks per lane (k_int <= 256 / 512 / 1024) and the
+    next 64 learning rates in one register; rows that missed more than 64 steps, rows whose width is no multiple of 4 and
+    regularisers with p > 3 take the generic replay.  72 steps of small batches (2.5 % of the rows touched per step: a
+    fifth of the gaps is longer than 64 steps) over these widths == the dense pass, bit for bit."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, eta, nb = 20000, 12, 128, 2, 24
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(11)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+
+    def run(deferred):
+        kw = dict(regularizer="LP", regularizer_params={"lambda": 1e-3, "p": reg}) if reg else {}
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.01}, batches_count=nb,
+                     seed=3, deferred_dense=deferred, **kw)
+        tr.set_training_set(X, B)
+        assert tr.deferred == deferred
+        for ep in (1, 2, 3):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1, prefetch=[(((b + 1) % nb) * B, B, ep + (b + 1) // nb, (b + 1) % nb + 1)])
+        Et, Rt = tr.tables_numpy()
+        states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
+        return Et, Rt, states, tr.read_loss()
+
+    a, b = run(True), run(False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    if reg:   # (per-lane float partial sums of the penalty, grouped by row here and by step there; the reference's loss is f32)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-7)
+    else:
+        assert a[3] == b[3]
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 @pytest.mark.parametrize("model,k,eta", [("DistMult", 32, 20), ("DistMult", 64, 40), ("TransE", 100, 40), ("ComplEx", 32, 70)])
 def test_more_negatives_than_lanes_per_group(monkeypatch, model, k, eta, opt):
