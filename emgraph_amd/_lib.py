@@ -185,7 +185,7 @@ class ApplyArgs(C.Structure):
 SIGNATURES.update({
     "emg_apply_grouped_ex": (_int, [C.POINTER(ApplyArgs), _p]),
     "emg_apply_grouped_pair": (_int, [C.POINTER(ApplyArgs), C.POINTER(ApplyArgs), _p]),
-    "emg_deferred_catchup": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p, _i64, _i64, _p]),
+    "emg_deferred_catchup": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p, _i64, _i64, _i32, _p]),
     "emg_deferred_materialize": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p]),
 })
 

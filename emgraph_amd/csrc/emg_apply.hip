@@ -25,6 +25,7 @@ namespace emg {
 struct ApplyParams {
     float* table; int64_t n_rows; int64_t ld; int32_t k_int;
     float* state0; float* state1; int32_t* tag; int32_t step;
+    int32_t state_lag;   // 1 (Adam, deferred dense pass): m, v of a multi / single destination are as of tag[row], w is current (below)
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
     int32_t skip_single;
@@ -679,6 +680,7 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
 struct ReplayParams {
     float* table; float* s0; float* s1; int32_t* tag; int64_t n_rows, ld; int32_t k_int; OptParams opt;
     const float* lr_hist; int32_t upto; double* lp_accum;
+    int32_t lag;   // 1 (Adam, no regulariser): multi / single destinations get w only; the apply redoes the decay of m, v (ApplyParams.state_lag)
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* keys; const uint32_t* counters; uint32_t task_cap;
 };
 
@@ -811,7 +813,7 @@ __device__ __forceinline__ void replay_issue(const ReplayParams& P, ReplayRegs<O
     }
     R.lr = P.lr_hist[min(from + 1 + lane, P.upto)];
 }
-template <int OPT, int LPK, int T>
+template <int OPT, int LPK, int T, bool LAG>
 __device__ __forceinline__ void replay_finish(const ReplayParams& P, ReplayRegs<OPT, T>& R, int32_t row, int32_t from, int lane, int nchunks,
                                               float& lp_acc) {
     OptParams opt = P.opt;
@@ -848,13 +850,13 @@ __device__ __forceinline__ void replay_finish(const ReplayParams& P, ReplayRegs<
         const bool on = lane + 64 * t < nchunks;
         const int c = min(lane + 64 * t, nchunks - 1);
         *reinterpret_cast<float4*>(P.table + base + 4 * c) = make_float4(ww[t][0], ww[t][1], ww[t][2], ww[t][3]);
-        if constexpr (OPT != EMG_OPT_SGD) *reinterpret_cast<float4*>(P.s0 + base + 4 * c) = make_float4(aa[t][0], aa[t][1], aa[t][2], aa[t][3]);
-        if constexpr (OPT == EMG_OPT_ADAM) *reinterpret_cast<float4*>(P.s1 + base + 4 * c) = make_float4(bb[t][0], bb[t][1], bb[t][2], bb[t][3]);
+        if constexpr (OPT != EMG_OPT_SGD && !LAG) *reinterpret_cast<float4*>(P.s0 + base + 4 * c) = make_float4(aa[t][0], aa[t][1], aa[t][2], aa[t][3]);
+        if constexpr (OPT == EMG_OPT_ADAM && !LAG) *reinterpret_cast<float4*>(P.s1 + base + 4 * c) = make_float4(bb[t][0], bb[t][1], bb[t][2], bb[t][3]);
         if (LPK != 0) lp_acc += on ? acc[t] : 0.f;
     }
 }
 
-template <int OPT, int LPK, int T>
+template <int OPT, int LPK, int T, bool LAG = false>
 __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const ReplayParams P) {
     float lp_acc = 0.f;
     const int lane = threadIdx.x & 63;
@@ -880,8 +882,10 @@ __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const Replay
         const int32_t from = valid ? P.tag[dest] : P.upto;
         const bool due = from < P.upto;
         const bool moves = due && !(from == 0 && LPK == 0);   // (never written, no regulariser: zero gradient on the initial state moves nothing)
-        const bool fast = moves && P.upto - from <= 64;
-        if (due && (fast || !moves)) P.tag[dest] = P.upto;    // (each destination is in the lists once: nobody else looks at this tag here)
+        // LAG: only w of a multi / single destination is written — m, v and the tag stay as of `from`, segment_update redoes
+        // their decay; the heads of block tasks (several waves finish those rows) take the generic replay, complete
+        const bool fast = moves && P.upto - from <= 64 && (!LAG || i < n_multi + n_single);
+        if (due && ((fast && !LAG) || !moves)) P.tag[dest] = P.upto;    // (each destination is in the lists once: nobody else looks at this tag here)
         unsigned long long todo = __ballot(fast);
         if (todo) {
             ReplayRegs<OPT, T> ra, rb;   // two rows' registers, taken in turns (no copies: a copy would wait for the loads it hides)
@@ -895,14 +899,14 @@ __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const Replay
                 todo &= todo - 1ull;
                 const int32_t rown = __builtin_amdgcn_readlane(dest, k), frn = __builtin_amdgcn_readlane(from, k);
                 replay_issue<OPT, T>(P, rb, rown, frn, lane, nchunks);
-                replay_finish<OPT, LPK, T>(P, ra, row, fr, lane, nchunks, lp_acc);
+                replay_finish<OPT, LPK, T, LAG>(P, ra, row, fr, lane, nchunks, lp_acc);
                 if (!more) break;
                 more = todo != 0ull;
                 k = more ? __ffsll((long long)todo) - 1 : k;
                 todo &= todo - 1ull;
                 row = __builtin_amdgcn_readlane(dest, k); fr = __builtin_amdgcn_readlane(from, k);
                 replay_issue<OPT, T>(P, ra, row, fr, lane, nchunks);
-                replay_finish<OPT, LPK, T>(P, rb, rown, frn, lane, nchunks, lp_acc);
+                replay_finish<OPT, LPK, T, LAG>(P, rb, rown, frn, lane, nchunks, lp_acc);
                 if (!more) break;
             }
         }
@@ -961,6 +965,16 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
     float* s0row = (!PLAIN && P.state0) ? P.state0 + (int64_t)dest * P.ld : nullptr;
     float* s1row = (!PLAIN && P.state1) ? P.state1 + (int64_t)dest * P.ld : nullptr;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // state_lag: the catch-up brought w of this row to step - 1 and left m, v (and the tag) where the row was last written —
+    // their decay over the missed steps is two multiplications per element and step, redone here instead of a write + read
+    // of both state rows (emg_deferred_catchup)
+    int lagn = 0;
+    if constexpr (!PLAIN) {
+        if (P.state_lag) {
+            const int32_t from = P.tag[dest];
+            lagn = from > 0 && from < step - 1 ? step - 1 - from : 0;
+        }
+    }
     for (int c0 = 0; c0 < nchunks; c0 += 128) {
         const int ca = c0 + lane, cb = c0 + 64 + lane;
         const bool oa = ca < nchunks, ob = cb < nchunks;
@@ -1005,6 +1019,12 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
             float w[4] = {wv.x, wv.y, wv.z, wv.w};
             float gg[4] = {g.x, g.y, g.z, g.w};
             float a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
+            if constexpr (!PLAIN) {
+                for (int i = 0; i < lagn; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) adam_decay_elem(opt, a0[j], a1[j]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 lp_fold(opt, w[j], gg[j], lp_acc);
@@ -1216,6 +1236,10 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     P.lp_accum = a->lp_accum;
     P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
     A.dense = (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) && !a->deferred_dense;
+    EMG_REQUIRE(a->deferred_dense != 2 || (opt == EMG_OPT_ADAM && P.opt.lp_lambda == 0.f && a->tag && !a->skip_single),
+                "emg_apply_grouped: deferred_dense = 2 (m, v lag behind w) is Adam's, without a regulariser or in-place singletons");
+    EMG_REQUIRE(a->deferred_dense != 2 || segments_path_enabled(), "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply");
+    P.state_lag = a->deferred_dense == 2 ? 1 : 0;
     if (n_contrib <= 0) return EMG_OK;
     A.any = true;
     A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(a->table) && aligned16(a->contrib) &&
@@ -1233,6 +1257,8 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     const int nch = A.vec ? k_int / 4 : k_int;
     A.skinny = nch <= 16;
     A.segs = w.counting && A.vec && !A.skinny && segments_path_enabled();
+    EMG_REQUIRE(!P.state_lag || A.segs, "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply (counting grouping, "
+                                        "16-byte aligned rows of more than 16 chunks)");
     EMG_REQUIRE(!P.ctl || A.segs, "emg_apply_grouped: a device-side step record needs the descriptor-driven apply (counting "
                                   "grouping, 16-byte aligned rows of more than 16 chunks)");
     if (A.segs) {
@@ -1454,6 +1480,11 @@ static void launch_replay_opt(bool catchup, int lpk, const ReplayParams& P, dim3
     if (lpk == 0) EMG_RP(0); else if (lpk == 1) EMG_RP(1); else EMG_RP(2);
 #undef EMG_RP
 }
+static void launch_catchup_rows_lag(int trips, const ReplayParams& P, dim3 grid, hipStream_t st) {
+    if (trips == 1) hipLaunchKernelGGL((deferred_catchup_rows_kernel<EMG_OPT_ADAM, 0, 1, true>), grid, dim3(256), 0, st, P);
+    else if (trips == 2) hipLaunchKernelGGL((deferred_catchup_rows_kernel<EMG_OPT_ADAM, 0, 2, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((deferred_catchup_rows_kernel<EMG_OPT_ADAM, 0, 4, true>), grid, dim3(256), 0, st, P);
+}
 template <int OPT, int LPK>
 static void launch_catchup_rows(int trips, const ReplayParams& P, dim3 grid, hipStream_t st) {
     if (trips == 1) hipLaunchKernelGGL((deferred_catchup_rows_kernel<OPT, LPK, 1>), grid, dim3(256), 0, st, P);
@@ -1469,6 +1500,7 @@ static void launch_replay(bool catchup, const ReplayParams& P, dim3 grid, hipStr
     const bool aligned = aligned16(P.table) && (!P.s0 || aligned16(P.s0)) && (!P.s1 || aligned16(P.s1));
     if (catchup && lpk != 2 && P.k_int % 4 == 0 && P.ld % 4 == 0 && P.k_int <= 1024 && aligned && env_replay_rows()) {
         const int trips = (int)cdiv((int64_t)P.k_int / 4, 64);
+        if (P.lag) { launch_catchup_rows_lag(trips, P, grid, st); return; }
 #define EMG_RR(O_) do { if (lpk == 0) launch_catchup_rows<O_, 0>(trips, P, grid, st); else launch_catchup_rows<O_, 1>(trips, P, grid, st); } while (0)
         switch (P.opt.opt) {
             case EMG_OPT_SGD: EMG_RR(EMG_OPT_SGD); break;
@@ -1504,10 +1536,12 @@ static int replay_params(ReplayParams& P, int opt, float* table, int64_t n_rows,
 
 extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                                     int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
-                                    const void* workspace, int64_t workspace_bytes, int64_t layout_n, void* stream) {
+                                    const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, void* stream) {
     ReplayParams P;
     int rc = replay_params(P, opt, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_hist, upto_step, lp_accum);
     if (rc != EMG_OK) return rc;
+    EMG_REQUIRE(!w_only || (opt == EMG_OPT_ADAM && hyper[6] == 0.f), "emg_deferred_catchup: w_only is Adam's, without a regulariser");
+    P.lag = w_only ? 1 : 0;
     EMG_REQUIRE(workspace && layout_n > 0, "emg_deferred_catchup: needs the grouping workspace of the batch (emg_prepare_batch)");
     GroupWs w;
     rc = group_ws_layout(const_cast<void*>(workspace), workspace_bytes, layout_n, n_rows, 0, &w);

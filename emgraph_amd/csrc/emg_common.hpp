@@ -208,6 +208,16 @@ __device__ __forceinline__ void opt_update_elem(const OptParams& P, float& w, fl
     }
 }
 
+// Adam's m, v after a step whose gradient is zero: opt_update_elem's own expressions with g = 0 (opaque to the compiler: the
+// same instructions, the same roundings — b1 m + (1 - b1) 0 is not b1 m when b1 m is -0)
+__device__ __forceinline__ void adam_decay_elem(const OptParams& P, float& m, float& v) {
+#pragma clang fp contract(off)
+    float g = 0.f;
+    asm volatile("" : "+v"(g));
+    m = P.beta1 * m + (1.f - P.beta1) * g;
+    v = P.beta2 * v + (1.f - P.beta2) * g * g;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Loss pieces shared by loss_kernel (emg_train.hip) and the fused train kernel (emg_score.hip).
 // ---------------------------------------------------------------------------------------------

@@ -159,12 +159,20 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.layout_B = c.cap_B;
     if (P->ctl) { ba.pos = c.X; ba.B = c.cap_B; ba.ctl = P->ctl; }
     int rc;
+    // Adam without regulariser / in-place singletons: the catch-up writes w alone, the apply redoes the decay of m, v (emgraph_hip.h)
+    static const bool lag_env = [] { const char* e = getenv("EMG_DEFERRED_W_ONLY"); return !(e && e[0] == '0'); }();
+    // (only where the descriptor-driven apply runs — 16-byte rows of more than 16 chunks —: it is the one that redoes the decay)
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool seg_rows = c.k_int % 4 == 0 && c.k_int > 64 && c.ld_ent % 4 == 0 && c.ld_rel % 4 == 0 && c.ldc % 4 == 0 && al16(c.ent) &&
+                          al16(c.rel) && al16(c.contrib_ent) && al16(c.contrib_rel) && al16(c.ent_state0) && al16(c.ent_state1) &&
+                          al16(c.rel_state0) && al16(c.rel_state1);
+    const int32_t w_only = (c.lr_t_hist && c.opt == EMG_OPT_ADAM && !lp && !c.inplace && seg_rows && lag_env) ? 1 : 0;
     if (c.lr_t_hist) {   // deferred dense pass (Keras Adam / LP): bring the rows this batch reads and updates up to step - 1
         rc = emg_deferred_catchup(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, he, c.lr_t_hist, step - 1,
-                                  lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, main);
+                                  lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, w_only, main);
         if (rc != EMG_OK) return rc;
         rc = emg_deferred_catchup(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hr, c.lr_t_hist, step - 1,
-                                  lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, main);
+                                  lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, w_only, main);
         if (rc != EMG_OK) return rc;
     }
     if (c.fused) {
@@ -218,7 +226,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             aa.layout_n = c.cap_B; aa.table_index = 1;
         }
         if (P->ctl) { aa.ctl = P->ctl; aa.n_contrib = aa.layout_n; }
-        aa.deferred_dense = c.lr_t_hist ? 1 : 0;
+        aa.deferred_dense = c.lr_t_hist ? (w_only ? 2 : 1) : 0;
         aa.ldc = c.ldc;
     };
     emg_apply_args ae, ar;

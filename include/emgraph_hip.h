@@ -254,7 +254,8 @@ typedef struct emg_apply_args {
     int32_t factored;
     int32_t table_index;                 /* 0 entity / 1 relation table: which hyper-parameters of `ctl` apply */
     int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
-    int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below */
+    int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below;
+                                                  * 2: the same, and the catch-up ran with w_only (m, v of the destinations lag behind w) */
 } emg_apply_args;
 int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
 int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);
@@ -267,10 +268,15 @@ int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, voi
  * destinations of the grouping in `workspace` (emg_prepare_batch's, counting backend).  The apply then runs with
  * deferred_dense = 1 (no dense pass).  emg_deferred_materialize does the same for every row (before the tables are read,
  * and — with a regulariser — before a loss is reported: *lp_accum += sum |w|^p of every replayed step).  hyper: the 8 values
- * of emg_apply_grouped (hyper[0] / hyper[5] are replaced per step by lr_hist). */
+ * of emg_apply_grouped (hyper[0] / hyper[5] are replaced per step by lr_hist).
+ * w_only = 1 (EMG_OPT_ADAM, no regulariser; the apply must then run with deferred_dense = 2): for the destinations the apply
+ * finishes with one wave each (the grouping's multi / single lists, gaps of at most 64 steps) only w is written back — m, v
+ * and tag[row] stay as of the row's last write, and the apply redoes their decay over the missed steps in registers
+ * (two multiplications per element and step) instead of this call writing and the apply re-reading both state rows.
+ * Same bits. */
 int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                          int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
-                         const void* workspace, int64_t workspace_bytes, int64_t layout_n, void* stream);
+                         const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, void* stream);
 int emg_deferred_materialize(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                              int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
                              void* stream);

@@ -455,11 +455,13 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k, opt, reg):
 
 
 @pytest.mark.parametrize("model,k,opt,reg", [("ComplEx", 200, "adam", None), ("DistMult", 600, "sgd", 2), ("DistMult", 101, "adagrad", 3),
-                                               ("TransE", 256, "momentum", 4), ("ComplEx", 100, "adam", 2)])
+                                               ("TransE", 256, "momentum", 4), ("ComplEx", 100, "adam", 2),
+                                               ("ComplEx", 64, "adam", "hubs"), ("DistMult", 300, "adam", "hubs")])
 def test_deferred_pass_row_widths_and_long_gaps(model, k, opt, reg):
     """The catch-up's pipelined form holds a row in 1, 2 or 4 sixteen-byte chunks per lane (k_int <= 256 / 512 / 1024) and the
     next 64 learning rates in one register; rows that missed more than 64 steps, rows whose width is no multiple of 4 and
-    regularisers with p > 3 take the generic replay.  72 steps of small batches (2.5 % of the rows touched per step: a
+    regularisers with p > 3 take the generic replay; Adam without a regulariser writes back w alone and lets the apply redo
+    the decay of m, v (the "hubs" cases add rows the apply finishes with several waves).  72 steps of small batches (2.5 % of the rows touched per step: a
     fifth of the gaps is longer than 64 steps) over these widths == the dense pass, bit for bit."""
     from emgraph_amd import _lib as L
     from emgraph_amd.training import Trainer
@@ -470,6 +472,11 @@ def test_deferred_pass_row_widths_and_long_gaps(model, k, opt, reg):
     E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
     R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
     X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+    if reg == "hubs":   # two rows with ~80 and ~50 contributions per batch (block tasks: several waves finish such a row, and with
+        reg = None      # Adam's w-only catch-up they must find m, v complete), in every second batch only (gaps in between)
+        hub = (np.arange(nb * B) // B) % 2 == 0
+        X[hub & (rs.rand(nb * B) < 0.6), 0] = 7
+        X[hub & (rs.rand(nb * B) < 0.4), 2] = 11
 
     def run(deferred):
         kw = dict(regularizer="LP", regularizer_params={"lambda": 1e-3, "p": reg}) if reg else {}
