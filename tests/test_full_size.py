@@ -179,6 +179,49 @@ def test_factored_contributions_full_size_equal_full_rows(world, kind, monkeypat
     assert not torch.equal(outs[0][0], ent[:, :K_INT])
 
 
+@pytest.mark.parametrize("opt,reg,kind", [("adam", None, "uniform"), ("adam", None, "zipf"), ("sgd", 2, "uniform"), ("adagrad", 3, "zipf")])
+def test_deferred_dense_pass_full_size_equals_dense_pass(world, opt, reg, kind):
+    """C3 size: Keras Adam's decay / the LP regulariser's gradient reach all 1M x 400 values every step.  The default for a table of
+    this size leaves a row alone until a batch is about to read it and replays its missed steps then (emg_deferred_catchup;
+    Adam: w alone, the apply redoes m, v) — five steps of it and of the literal dense pass must leave the same tables, the same
+    optimizer state and the same loss, bit for bit, on a uniform batch and on a Zipf(1.0) batch (hub rows: block tasks)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    ent, rel, _, _ = world
+    rs = np.random.RandomState(17)
+    n = 5 * B
+    if kind == "zipf":
+        w = 1.0 / np.arange(1, N_ENT + 1)
+        perm = rs.permutation(N_ENT)
+        s, o = perm[rs.choice(N_ENT, n, p=w / w.sum())], perm[rs.choice(N_ENT, n, p=w / w.sum())]
+    else:
+        s, o = rs.randint(0, N_ENT, n), rs.randint(0, N_ENT, n)
+    X = np.stack([s, rs.randint(0, N_REL, n), o], 1).astype(np.int32)
+    E, R = ent[:, :K_INT].cpu().numpy(), rel[:, :K_INT].cpu().numpy()
+    kw = dict(regularizer="LP", regularizer_params={"lambda": 1e-5, "p": reg}) if reg else {}
+    outs = []
+    for deferred in (None, False):   # (None: the default, which must be the deferred form at this size)
+        tr = Trainer(L.COMPLEX, K_INT, 1.0, E, R, ETA, loss="nll", optimizer=opt, optimizer_params={"lr": 0.01}, batches_count=5,
+                     seed=0, deferred_dense=deferred, **kw)
+        assert tr.deferred == (deferred is None)
+        tr.set_training_set(X, B)
+        for b in range(5):
+            tr.step(b * B, B, epoch=1, batch=b + 1, prefetch=[((b + 1) * B, B, 1, b + 2)] if b < 4 else None)
+        tr.materialize()
+        torch.cuda.synchronize()
+        state = [t[:, :K_INT].clone() for t in tr.state_ent + tr.state_rel if t is not None]
+        outs.append((tr.ent[:, :K_INT].clone(), tr.rel[:, :K_INT].clone(), state, tr.read_loss()))
+        del tr
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert len(a[2]) == len(b[2]) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    if reg:   # (the penalty's value: double atomics over float partial sums, grouped by row here and by step there)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-7)
+    else:
+        assert a[3] == b[3]
+    assert not torch.equal(a[0], ent[:, :K_INT])
+
+
 def test_zero_learning_rate_step_is_idempotent(world):
     from emgraph_amd import _lib as L
     from emgraph_amd.training import Trainer
