@@ -25,6 +25,7 @@ namespace emg {
 struct ApplyParams {
     float* table; int64_t n_rows; int64_t ld; int32_t k_int;
     float* state0; float* state1; int32_t* tag; int32_t step;
+    int32_t half_rows;   // 1: rows of at most 32 chunks two at a time, one per half-wave (segment_update_half; 0: EMG_APPLY_HALF=0)
     int32_t state_lag;   // 1 (Adam, deferred dense pass): m, v of a multi / single destination are as of tag[row], w is current (below)
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
@@ -1042,6 +1043,76 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
     if (P.tag && lane == 0) P.tag[dest] = step;
 }
 
+// Rows of 17..32 sixteen-byte chunks — k = 100 of the real-valued models, the reference's default width — would run
+// segment_update with 25 of the wave's 64 lanes and one segment's chain of dependent trips per wave.  Here each HALF of the
+// wave takes its own item (a segment has at most kDeferSegment = 32 contributions: its sources fit the half's lanes, and
+// travel inside the half by ds_bpermute instead of v_readlane): two chains per wave, 50 of 64 lanes at k = 100.  The same
+// additions in the same order — the same bits.  dest / len / on are per lane (the same within a half).
+template <int DEPTH, bool PLAIN>
+__device__ __forceinline__ void segment_update_half(const ApplyParams& P, const OptParams& opt, int32_t step, uint32_t dest, int len, bool on,
+                                                    const Src mine, int lane, int nchunks, float& lp_acc) {
+    const int l = lane & 31, hb = lane & 32;
+    const bool oc = on && l < nchunks;
+    const int64_t base = on ? (int64_t)dest * P.ld : 0;
+    float* wrow = P.table + base;
+    float* s0row = (!PLAIN && P.state0) ? P.state0 + base : nullptr;
+    float* s1row = (!PLAIN && P.state1) ? P.state1 + base : nullptr;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lagn = 0;   // (state_lag: see segment_update)
+    if constexpr (!PLAIN) {
+        if (P.state_lag && on) {
+            const int32_t from = P.tag[dest];
+            lagn = from > 0 && from < step - 1 ? step - 1 - from : 0;
+        }
+    }
+    float4 acc = zero, wv = zero, m0 = zero, m1 = zero;
+    if (oc) wv = *reinterpret_cast<const float4*>(wrow + 4 * l);
+    if constexpr (!PLAIN) {
+        if (s0row && oc) m0 = *reinterpret_cast<const float4*>(s0row + 4 * l);
+        if (s1row && oc) m1 = *reinterpret_cast<const float4*>(s1row + 4 * l);
+    }
+    const int lenm = on ? len : 0;
+    const int maxlen = max(__builtin_amdgcn_readlane(lenm, 0), __builtin_amdgcn_readlane(lenm, 32));
+    for (int u = 0; u < maxlen; u += DEPTH) {
+        float4 v[DEPTH];
+        float cf[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            v[j] = zero;
+            const int from_lane = hb + min(u + j, 31);
+            const uint32_t row = (uint32_t)__shfl((int)mine.row, from_lane, 64);
+            cf[j] = __shfl(mine.coef, from_lane, 64);
+            if (oc && u + j < len) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * l);
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {   // added in contribution order
+            if (oc && u + j < len) add_scaled(acc, v[j], cf[j]);
+        }
+    }
+    if (oc) {
+        float w[4] = {wv.x, wv.y, wv.z, wv.w};
+        float gg[4] = {acc.x, acc.y, acc.z, acc.w};
+        float a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
+        if constexpr (!PLAIN) {
+            for (int i = 0; i < lagn; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) adam_decay_elem(opt, a0[j], a1[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lp_fold(opt, w[j], gg[j], lp_acc);
+            opt_update_elem(opt, w[j], gg[j], &a0[j], &a1[j]);
+        }
+        *reinterpret_cast<float4*>(wrow + 4 * l) = make_float4(w[0], w[1], w[2], w[3]);
+        if constexpr (!PLAIN) {
+            if (s0row) *reinterpret_cast<float4*>(s0row + 4 * l) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+            if (s1row) *reinterpret_cast<float4*>(s1row + 4 * l) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        }
+    }
+    if (P.tag && on && l == 0) P.tag[dest] = step;
+}
+
 // a segment of more than kDeferSegment rows in a workspace WITHOUT partial rows (sized by emg_apply_workspace_bytes):
 // one wave sums all of it left to right (slow for hub rows; the documented small-workspace behaviour)
 __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const OptParams& opt, int32_t step, const LongTask tk,
@@ -1077,7 +1148,7 @@ __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const 
 
 // heavy / relief: the last `heavy` waves of the grid take `relief` items fewer each (they carry the other table's long
 // segments, see apply_segments_kernel); the others share what that leaves
-template <bool PLAIN>
+template <bool PLAIN, bool HALF>
 __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
                                                      int64_t nw, int lane, int64_t heavy = 0, int64_t relief = 0) {
     OptParams opt = P.opt;
@@ -1115,6 +1186,8 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     } else {
         i0 = gw * share; i1 = min(total, i0 + share);
     }
+    static_assert(kDeferSegment <= 32, "segment_update_half keeps a segment's sources in 32 lanes");
+    constexpr bool halves = HALF;   // (its own instantiation: both forms in one kernel cost the wide rows a wave per SIMD)
     for (int64_t base = i0; base < i1; base += 64) {
         const int64_t it = base + lane;
         Seg sg{0u, 0u, 0u};
@@ -1123,6 +1196,28 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             else { const uint32_t at = P.single[it - n_multi]; sg = Seg{at, 1u, P.keys[at]}; }
         }
         const int cnt = (int)min((int64_t)64, i1 - base);
+        if constexpr (halves) {   // two items at a time, one per half of the wave (segment_update_half)
+            const int l = lane & 31, hi = lane >> 5;
+            auto item = [&](int k, uint32_t& len, uint32_t& dest, bool& on) -> Src {
+                const int kk = k + hi;
+                const int from_lane = min(kk, 63);
+                len = (uint32_t)__shfl((int)sg.len, from_lane, 64);
+                dest = (uint32_t)__shfl((int)sg.dest, from_lane, 64);
+                const uint32_t start = (uint32_t)__shfl((int)sg.start, from_lane, 64);
+                on = kk < cnt && (int64_t)dest < P.n_rows;   // (defensive: never write outside the table)
+                return (on && (uint32_t)l < len) ? contrib_src(P, (int64_t)start + l) : Src{0u, 0.f};
+            };
+            uint32_t len_n, dest_n;
+            bool on_n;
+            Src nxt = item(0, len_n, dest_n, on_n);
+            for (int k = 0; k < cnt; k += 2) {
+                const uint32_t len = len_n, dest = dest_n;
+                const bool on = on_n;
+                const Src mine = nxt;
+                if (k + 2 < cnt) nxt = item(k + 2, len_n, dest_n, on_n);
+                segment_update_half<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, on, mine, lane, nchunks, lp_acc);
+            }
+        } else {
         Src nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, 0), (uint32_t)__builtin_amdgcn_readlane((int)sg.len, 0), lane);
         for (int k = 0; k < cnt; ++k) {
             const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k);
@@ -1133,6 +1228,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                                       (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
             if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
             segment_update<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
+        }
         }
     }
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
@@ -1147,7 +1243,7 @@ __device__ unsigned long long emg_trace_buf[4 * 65536];
 #define EMG_STAMP(slot) do { } while (0)
 #endif
 
-template <bool PLAIN, bool RIDE>
+template <bool PLAIN, bool RIDE, bool HALF = false>   // HALF: rows of 17..32 chunks, two items per wave (segment_update_half)
 __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
     // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
     unsigned bx = blockIdx.x, nbx = gridDim.x;
@@ -1175,10 +1271,10 @@ __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunc
             heavy = items; relief = trips;
         }
     }
-    apply_segments_table<PLAIN>(K.P[0], K.partial[0], K.ldp[0], gw, nw, lane, heavy, relief);
+    apply_segments_table<PLAIN, HALF>(K.P[0], K.partial[0], K.ldp[0], gw, nw, lane, heavy, relief);
     EMG_STAMP(1);
     if (K.n_tables == 2) {
-        apply_segments_table<PLAIN>(K.P[1], K.partial[1], K.ldp[1], nw - 1 - gw, nw, lane);
+        apply_segments_table<PLAIN, HALF>(K.P[1], K.partial[1], K.ldp[1], nw - 1 - gw, nw, lane);
         EMG_STAMP(2);
     }
 }
@@ -1240,6 +1336,7 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
                 "emg_apply_grouped: deferred_dense = 2 (m, v lag behind w) is Adam's, without a regulariser or in-place singletons");
     EMG_REQUIRE(a->deferred_dense != 2 || segments_path_enabled(), "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply");
     P.state_lag = a->deferred_dense == 2 ? 1 : 0;
+    { const char* e = getenv("EMG_APPLY_HALF"); P.half_rows = (e && e[0] == '0') ? 0 : 1; }   // A/B aid (read per call: tests flip it)
     if (n_contrib <= 0) return EMG_OK;
     A.any = true;
     A.vec = (k_int % 4 == 0) && (ld % 4 == 0) && (ldc % 4 == 0) && aligned16(a->table) && aligned16(a->contrib) &&
@@ -1299,15 +1396,24 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
 // launch of more waves than are resident runs as a full round followed by a partly empty one (per-wave stamps,
 // tools/trace_waves.py, C3: 5120 of 8192 waves start at 0 and live 38 us, the other 3072 start at 34-41 us: 78 us for
 // 1.6 rounds of work) — so never launch more than fit.
-static unsigned segments_capacity(bool plain, bool ride) {
-    static std::atomic<unsigned> cached[4][64];
+typedef void (*SegmentsKernel)(const SegmentsLaunch, const Riders);
+static SegmentsKernel segments_kernel(bool plain, bool ride, bool half) {
+    static const SegmentsKernel fns[8] = {
+        apply_segments_kernel<false, false, false>, apply_segments_kernel<false, false, true>,
+        apply_segments_kernel<false, true, false>,  apply_segments_kernel<false, true, true>,
+        apply_segments_kernel<true, false, false>,  apply_segments_kernel<true, false, true>,
+        apply_segments_kernel<true, true, false>,   apply_segments_kernel<true, true, true>};
+    return fns[(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)];
+}
+static bool segments_half(const ApplyParams& P) { return P.half_rows && P.k_int / 4 <= 32; }
+static unsigned segments_capacity(bool plain, bool ride, bool half) {
+    static std::atomic<unsigned> cached[8][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024u;
-    std::atomic<unsigned>& c = cached[(plain ? 2 : 0) + (ride ? 1 : 0)][dev & 63];
+    std::atomic<unsigned>& c = cached[(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)][dev & 63];
     unsigned v = c.load(std::memory_order_relaxed);
     if (v) return v;
-    const void* fn = plain ? (ride ? (const void*)apply_segments_kernel<true, true> : (const void*)apply_segments_kernel<true, false>)
-                           : (ride ? (const void*)apply_segments_kernel<false, true> : (const void*)apply_segments_kernel<false, false>);
+    const void* fn = (const void*)segments_kernel(plain, ride, half);
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -1315,9 +1421,9 @@ static unsigned segments_capacity(bool plain, bool ride) {
     c.store(v, std::memory_order_relaxed);
     return v;
 }
-static unsigned segments_grid(unsigned wanted, bool plain, bool ride) {
+static unsigned segments_grid(unsigned wanted, bool plain, bool ride, bool half) {
     static const bool fixed = getenv("EMG_SEG_BLOCKS") != nullptr;   // A/B aid: the grid as given
-    const unsigned cap = segments_capacity(plain, ride);
+    const unsigned cap = segments_capacity(plain, ride, half);
     return fixed || wanted <= cap ? wanted : cap;
 }
 
@@ -1326,9 +1432,9 @@ static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t 
         SegmentsLaunch K{};
         K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
         static const Riders none{};
-        const unsigned g1 = segments_grid(A.grid, plain_sgd(P), false);
-        if (plain_sgd(P)) hipLaunchKernelGGL((apply_segments_kernel<true, false>), dim3(g1), dim3(256), 0, st, K, none);
-        else hipLaunchKernelGGL((apply_segments_kernel<false, false>), dim3(g1), dim3(256), 0, st, K, none);
+        const bool half = segments_half(P);
+        const unsigned g1 = segments_grid(A.grid, plain_sgd(P), false, half);
+        hipLaunchKernelGGL(segments_kernel(plain_sgd(P), false, half), dim3(g1), dim3(256), 0, st, K, none);
         EMG_LAUNCH_CHECK();
     } else if (A.any) {
         const dim3 grid(A.grid), block(256);
@@ -1400,15 +1506,14 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         static const bool no_relief = getenv("EMG_APPLY_RELIEF") && atoi(getenv("EMG_APPLY_RELIEF")) == 0;   // A/B aid
         K.relief = no_relief ? 0 : 1;
         const bool plain = plain_sgd(P0) && plain_sgd(P1);
+        const bool half = segments_half(P0) && segments_half(P1);   // (one width for both tables)
         if (riders && riders->total) {
-            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true) + riders->total);
-            if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, true>), grid, dim3(256), 0, st, K, *riders);
-            else hipLaunchKernelGGL((apply_segments_kernel<false, true>), grid, dim3(256), 0, st, K, *riders);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true, half) + riders->total);
+            hipLaunchKernelGGL(segments_kernel(plain, true, half), grid, dim3(256), 0, st, K, *riders);
         } else {
             static const Riders none{};
-            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, false));
-            if (plain) hipLaunchKernelGGL((apply_segments_kernel<true, false>), grid, dim3(256), 0, st, K, none);
-            else hipLaunchKernelGGL((apply_segments_kernel<false, false>), grid, dim3(256), 0, st, K, none);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, false, half));
+            hipLaunchKernelGGL(segments_kernel(plain, false, half), grid, dim3(256), 0, st, K, none);
         }
         EMG_LAUNCH_CHECK();
     } else {

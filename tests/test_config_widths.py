@@ -502,6 +502,45 @@ def test_deferred_pass_row_widths_and_long_gaps(model, k, opt, reg):
         assert a[3] == b[3]
 
 
+@pytest.mark.parametrize("opt,reg", [("sgd", None), ("adam", None), ("adagrad", 2), ("momentum", None)])
+@pytest.mark.parametrize("model,k", [("TransE", 100), ("DistMult", 100), ("DistMult", 128), ("ComplEx", 36), ("TransE", 68)])
+def test_two_segments_per_wave_give_the_one_segment_bits(monkeypatch, model, k, opt, reg):
+    """Rows of 17..32 sixteen-byte chunks (k = 100 of the real-valued models, the reference's default width): the apply kernel
+    gives each half of a wave its own destination row (segment_update_half) instead of one row to 25 of the wave's 64 lanes.
+    Same additions in the same order: tables, optimizer state and loss equal the one-segment form (EMG_APPLY_HALF=0) bit for
+    bit — hub rows (block tasks) and an odd number of items per wave included."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, eta, nb = 5000, 9, 1111, 5, 3
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(23)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+    X[rs.rand(nb * B) < 0.1, 0] = 3     # a hub row: more than 32 contributions per batch
+    kw = dict(regularizer="LP", regularizer_params={"lambda": 1e-3, "p": reg}) if reg else {}
+
+    def run(half):
+        monkeypatch.setenv("EMG_APPLY_HALF", half)
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.02}, batches_count=nb, seed=3, **kw)
+        tr.set_training_set(X, B)
+        for ep in (1, 2):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1, prefetch=[(((b + 1) % nb) * B, B, ep + (b + 1) // nb, (b + 1) % nb + 1)])
+        Et, Rt = tr.tables_numpy()
+        states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
+        return Et, Rt, states, tr.read_loss()
+
+    a, b = run("1"), run("0")
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    assert a[3] == b[3] if not reg else abs(a[3] - b[3]) <= 1e-9 * abs(b[3])
+    assert not np.array_equal(a[0], E0)
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 @pytest.mark.parametrize("model,k,eta", [("DistMult", 32, 20), ("DistMult", 64, 40), ("TransE", 100, 40), ("ComplEx", 32, 70)])
 def test_more_negatives_than_lanes_per_group(monkeypatch, model, k, eta, opt):
