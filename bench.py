@@ -124,7 +124,7 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
+    for fn in ("r3_q_pmc_traffic.json", "r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items()
@@ -343,7 +343,7 @@ def score_kernel_alone(r, reps=50):
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
     traffic = None
     try:
-        fn = next(f for f in ("r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        fn = next(f for f in ("r3_q_pmc_traffic.json", "r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
         d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
         traffic = k[0]["hbm_bytes_per_launch"] if k else None
