@@ -1654,8 +1654,10 @@ extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64
     EMG_REQUIRE(w.counting, "emg_deferred_catchup: needs the counting grouping (segment descriptors)");
     P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.keys = w.keys; P.counters = w.counters; P.task_cap = w.task_cap;
     if (upto_step == 0) return EMG_OK;
+    static const int64_t cap_env = getenv("EMG_CATCHUP_WAVES") ? atoll(getenv("EMG_CATCHUP_WAVES")) : 0;   // A/B aid
+    const int64_t cap = cap_env >= 256 ? cap_env : 16384;
     int64_t waves = layout_n / 2;
-    waves = waves < 256 ? 256 : (waves > 16384 ? 16384 : waves);
+    waves = waves < 256 ? 256 : (waves > cap ? cap : waves);
     launch_replay(true, P, dim3((unsigned)cdiv(waves, 4)), (hipStream_t)stream);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
