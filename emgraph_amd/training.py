@@ -244,7 +244,9 @@ class Trainer:
         same bytes with everything in flight; measured (MI355X, in place / through the apply, ms per step): C1 Adam
         0.081 / 0.078, C1 at B = 6900 0.268 / 0.148, at B = 27 600 0.488 / 0.468, C1 Adagrad 0.064 / 0.064, C3 Adagrad
         0.842 / 0.755, C3 Adam 2.42 / 2.36 (Keras Adam's dense pass dominates), C2 0.062 / 0.058, C5 0.152 / 0.130 — never
-        better, so only SGD takes it.  Results are the same bits either way (one optimizer rule, one summation order:
+        better, so only SGD takes it (round 3, late: with the state row fetched alongside its table row in the rolling window
+        the stateful instantiation needs 283 registers for complex rows — one wave per SIMD — and C3 Adagrad took 1.00 against
+        0.74 through the apply: dropped).  Results are the same bits either way (one optimizer rule, one summation order:
         tests/test_config_widths.py::test_inplace_choice_does_not_change_bits)."""
         if not self._inplace_wanted or self.batch_sharded:
             return False
