@@ -69,6 +69,9 @@ WORKLOADS = {
                      "every step"),
     "C3g": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="adagrad",
                 desc="C3 with Adagrad (row-sparse state: every touched row and its accumulator through the apply kernel)"),
+    "C3mo": dict(model="ComplEx", k=200, eta=20, n_ent=1_000_000, n_rel=1000, B=16384, loss="nll", optimizer="momentum",
+                 desc="C3 with Keras SGD(momentum): Adagrad's bytes (one state row per touched row) without its sqrt / division — an A/B aid, "
+                      "not in `others`"),
     "C2": dict(model="DistMult", k=200, eta=10, n_ent=14541, n_rel=237, B=2722, loss="nll", optimizer="adam",
                desc="DistMult k=200 eta=10 NLL Adam, FB15k-237-shaped, B=2722 (batches_count=100)"),
     "C1": dict(model="TransE", k=100, eta=20, n_ent=38600, n_rel=11, B=1725, loss="pairwise", optimizer="adam",
