@@ -228,6 +228,7 @@ SIGNATURES.update({
     "emg_plan_create": (_int, [C.POINTER(PlanConfig), C.POINTER(_p)]),
     "emg_plan_step": (_int, [_p, C.POINTER(PlanBatch), _i32, C.POINTER(_f32), C.POINTER(PlanBatch), _i32, _p]),
     "emg_plan_graph_ok": (_int, [_p]),
+    "emg_plan_deferred_ok": (_int, [_i64, _i32, _i64, _i64]),
     "emg_plan_run": (_int, [_p, C.POINTER(PlanBatch), _i32, _i32, C.POINTER(_f32), _p]),
     "emg_plan_timing": (_int, [_p, _i32]),
     "emg_plan_stage_ms": (_int, [_p, C.POINTER(_f32), C.POINTER(_i32)]),

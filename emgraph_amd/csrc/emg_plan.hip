@@ -291,6 +291,10 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     EMG_REQUIRE((cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f) || cfg->lp_sum, "emg_plan_create: LP needs lp_sum");
     EMG_REQUIRE(!cfg->lr_t_hist || ((cfg->opt == EMG_OPT_ADAM || cfg->lp_lambda_ent != 0.f || cfg->lp_lambda_rel != 0.f) && !cfg->normalize),
                 "emg_plan_create: a deferred dense pass (lr_t_hist) is for EMG_OPT_ADAM and / or an LP regulariser, without row normalisation");
+    EMG_REQUIRE(!cfg->lr_t_hist || emg_plan_deferred_ok(cfg->cap_B, cfg->eta * cfg->n_sides, cfg->n_ent, cfg->n_rel),
+                "emg_plan_create: a deferred dense pass needs the counting grouping for both tables (emg_plan_deferred_ok): "
+                "n_ent = %lld, n_rel = %lld against %lld gradient rows per batch", (long long)cfg->n_ent, (long long)cfg->n_rel,
+                (long long)((2 + (int64_t)cfg->eta * cfg->n_sides) * cfg->cap_B));
     Plan* P = new Plan();
     P->cfg = *cfg;
     P->n_side = cfg->n_slots - 1 > 2 ? 2 : cfg->n_slots - 1;
@@ -438,6 +442,10 @@ static bool graph_capable(const Plan* P) {
            c.ld_ent % 4 == 0 && c.ld_rel % 4 == 0 && c.ldc % 4 == 0 &&
            group_backend_counting((2 + et) * c.cap_B, c.n_ent) && group_backend_counting(c.cap_B, c.n_rel) &&
            !(getenv("EMG_APPLY") && strcmp(getenv("EMG_APPLY"), "window") == 0);
+}
+
+extern "C" int emg_plan_deferred_ok(int64_t cap_B, int32_t eta_total, int64_t n_ent, int64_t n_rel) {
+    return cap_B > 0 && group_backend_counting((2 + (int64_t)eta_total) * cap_B, n_ent) && group_backend_counting(cap_B, n_rel) ? 1 : 0;
 }
 
 extern "C" int emg_plan_graph_ok(void* plan) { return plan && graph_capable((const Plan*)plan) ? 1 : 0; }

@@ -179,29 +179,131 @@ __global__ void finalize_scores_kernel(int model, float scale, float* s, int64_t
 
 using namespace emg;
 
-// TransE with any positive order of the norm (EMG_TRANSE_P, `ord` = INFINITY: the largest |component|): one wave per
-// triple; inference only (TransE.py:208-216 with an `ord` other than 1 / 2)
+// TransE with any positive order of the norm (EMG_TRANSE_P, `ord` = INFINITY: the largest |component|; TransE.py:208-216
+// hands `norm` to tf.norm as ord).  Generic kernels, a wave per triple (inference) or per positive group (training): any
+// width, rows read through the caches — orders 1 and 2 are the tuned models, this is the reference's remaining freedom.
+//   score      f = -(sum_c |d_c|^ord)^(1/ord),  d = (e_s + e_p) - e_o;  ord = inf: f = -max_c |d_c|
+//   gradient   df/dd_c = -sgn(d_c) |d_c|^(ord-1) / ||d||^(ord-1);  ord = inf: -sgn(d_c) [|d_c| = max] / #maxima (tf.reduce_max's
+//              gradient is shared by tied maxima); a zero vector has gradient zero
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// ||(a + p) - b||_ord of one triple (all 64 lanes; the same value in every lane); *ties: number of components equal to the maximum
+__device__ __forceinline__ float transe_p_norm(const float* a, const float* p, const float* b, int k_int, float ord, int lane, float* ties) {
+    const bool mx = isinf(ord);
+    float acc = 0.f;
+    for (int c = lane; c < k_int; c += 64) {
+        const float d = fabsf((a[c] + p[c]) - b[c]);
+        acc = mx ? fmaxf(acc, d) : acc + powf(d, ord);
+    }
+    if (!mx) return powf(wave_sum_f(acc), 1.0f / ord);
+    acc = wave_max_f(acc);
+    if (ties) {
+        float cnt = 0.f;
+        for (int c = lane; c < k_int; c += 64) cnt += fabsf((a[c] + p[c]) - b[c]) == acc ? 1.f : 0.f;
+        *ties = wave_sum_f(cnt);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void score_transe_p_kernel(const float* __restrict__ ent, int64_t ld_ent, const float* __restrict__ rel,
                                                              int64_t ld_rel, int k_int, float ord, const int32_t* __restrict__ spo, int64_t n,
                                                              float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= n) return;
-    const float* s = ent + (int64_t)spo[3 * t] * ld_ent;
-    const float* p = rel + (int64_t)spo[3 * t + 1] * ld_rel;
-    const float* o = ent + (int64_t)spo[3 * t + 2] * ld_ent;
-    const bool mx = isinf(ord);
-    float acc = 0.f;
-    for (int c = lane; c < k_int; c += 64) {
-        const float d = fabsf((s[c] + p[c]) - o[c]);
-        acc = mx ? fmaxf(acc, d) : acc + powf(d, ord);
+    const float nrm = transe_p_norm(ent + (int64_t)spo[3 * t] * ld_ent, rel + (int64_t)spo[3 * t + 1] * ld_rel,
+                                    ent + (int64_t)spo[3 * t + 2] * ld_ent, k_int, ord, lane, nullptr);
+    if (lane == 0) out[t] = -nrm;
+}
+
+struct TransePTrain {
+    const float* ent; int64_t ld_ent; const float* rel; int64_t ld_rel; int32_t k_int; float ord;
+    const int32_t* pos; int64_t B; int32_t eta; const int32_t* codes;
+    float* scores_pos; float* scores_neg;               // forward
+    const float* g_pos; const float* g_neg;             // backward: dL/dscore
+    float* contrib_ent; float* contrib_rel; int64_t ldc;
+};
+
+// scores of a positive and its eta negatives (eta-major codes: replacement | keep_subject << 31)
+__global__ __launch_bounds__(256) void transe_p_forward_kernel(const TransePTrain P) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= P.B) return;
+    const float* es = P.ent + (int64_t)P.pos[3 * g] * P.ld_ent;
+    const float* ep = P.rel + (int64_t)P.pos[3 * g + 1] * P.ld_rel;
+    const float* eo = P.ent + (int64_t)P.pos[3 * g + 2] * P.ld_ent;
+    const float f = -transe_p_norm(es, ep, eo, P.k_int, P.ord, lane, nullptr);
+    if (lane == 0) P.scores_pos[g] = f;
+    for (int j = 0; j < P.eta; ++j) {
+        const int32_t code = P.codes[(int64_t)j * P.B + g];
+        const float* er = P.ent + (int64_t)(code & 0x7fffffff) * P.ld_ent;
+        const float fn = code < 0 ? -transe_p_norm(es, ep, er, P.k_int, P.ord, lane, nullptr) : -transe_p_norm(er, ep, eo, P.k_int, P.ord, lane, nullptr);
+        if (lane == 0) P.scores_neg[(int64_t)j * P.B + g] = fn;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float other = __shfl_xor(acc, off, 64);
-        acc = mx ? fmaxf(acc, other) : acc + other;
+}
+
+// gradient rows of a positive group, in the contribution layout of every model: slot g = dE[s], B + g = dE[o], 2B + jB + g = the
+// replacement of negative j, relation slot g = dR[p].  The shared rows accumulate in their slots (the lane that owns a column
+// adds to it, positive first, negatives in ascending j: a fixed order).
+__global__ __launch_bounds__(256) void transe_p_backward_kernel(const TransePTrain P) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= P.B) return;
+    const float* es = P.ent + (int64_t)P.pos[3 * g] * P.ld_ent;
+    const float* ep = P.rel + (int64_t)P.pos[3 * g + 1] * P.ld_rel;
+    const float* eo = P.ent + (int64_t)P.pos[3 * g + 2] * P.ld_ent;
+    float* cs = P.contrib_ent + g * P.ldc;
+    float* co = P.contrib_ent + (P.B + g) * P.ldc;
+    float* cp = P.contrib_rel + g * P.ldc;
+    const bool mx = isinf(P.ord);
+    // u_c = -df/dd_c * (-1) ... the triple (a, p, b) with upstream gradient gs gets  da = dp = -gs u,  db = +gs u
+    auto unit = [&](float d, float nrm, float ties) -> float {
+        const float ad = fabsf(d);
+        if (nrm == 0.f || ad == 0.f) return 0.f;
+        const float sg = d > 0.f ? 1.f : -1.f;
+        if (mx) return ad == nrm ? sg / ties : 0.f;
+        return sg * powf(ad, P.ord - 1.f) / powf(nrm, P.ord - 1.f);
+    };
+    {
+        float ties = 1.f;
+        const float nrm = transe_p_norm(es, ep, eo, P.k_int, P.ord, lane, &ties);
+        const float gs = P.g_pos[g];
+        for (int c = lane; c < P.k_int; c += 64) {
+            const float v = gs * unit((es[c] + ep[c]) - eo[c], nrm, ties);
+            cs[c] = -v; cp[c] = -v; co[c] = v;
+        }
     }
-    if (lane == 0) out[t] = mx ? -acc : -powf(acc, 1.0f / ord);
+    for (int j = 0; j < P.eta; ++j) {
+        const int32_t code = P.codes[(int64_t)j * P.B + g];
+        const bool keep_s = code < 0;   // subject kept: the OBJECT was replaced
+        const float* er = P.ent + (int64_t)(code & 0x7fffffff) * P.ld_ent;
+        const float* a = keep_s ? es : er;
+        const float* b = keep_s ? er : eo;
+        float* cr = P.contrib_ent + (2 * P.B + (int64_t)j * P.B + g) * P.ldc;
+        float ties = 1.f;
+        const float nrm = transe_p_norm(a, ep, b, P.k_int, P.ord, lane, &ties);
+        const float gs = P.g_neg[(int64_t)j * P.B + g];
+        for (int c = lane; c < P.k_int; c += 64) {
+            const float v = gs * unit((a[c] + ep[c]) - b[c], nrm, ties);
+            cp[c] = cp[c] - v;
+            if (keep_s) { cs[c] = cs[c] - v; cr[c] = v; }
+            else { co[c] = co[c] + v; cr[c] = -v; }
+        }
+    }
+}
+
+static int transe_p_check(int32_t k_int, float ord, int64_t ld_ent, int64_t ld_rel) {
+    EMG_REQUIRE(ord > 0.f && k_int > 0 && ld_ent >= k_int && ld_rel >= k_int, "EMG_TRANSE_P: the order of the norm (passed as `scale`) must be positive");
+    return EMG_OK;
 }
 
 extern "C" int emg_train_forward(int model, const float* ent, int64_t n_ent, int64_t ld_ent, const float* rel,
@@ -211,10 +313,19 @@ extern "C" int emg_train_forward(int model, const float* ent, int64_t n_ent, int
     if (B == 0) return EMG_OK;
     EMG_REQUIRE(ent && rel && pos && scores_pos, "emg_train_forward: null pointer");
     if (model == EMG_TRANSE_P) {
-        EMG_REQUIRE(eta == 0, "EMG_TRANSE_P (TransE with an order of the norm other than 1 / 2) is inference only: emg_score_triples, emg_eval_*");
-        EMG_REQUIRE(scale > 0.f && k_int > 0 && ld_ent >= k_int && ld_rel >= k_int, "EMG_TRANSE_P: the order of the norm (passed as `scale`) must be positive");
-        hipLaunchKernelGGL(score_transe_p_kernel, dim3((unsigned)cdiv(B * 64, 256)), dim3(256), 0, (hipStream_t)stream, ent, ld_ent, rel, ld_rel,
-                           (int)k_int, scale, pos, B, scores_pos);
+        int rc = transe_p_check(k_int, scale, ld_ent, ld_rel);
+        if (rc != EMG_OK) return rc;
+        EMG_REQUIRE(flags == EMG_SCORE_FINAL, "EMG_TRANSE_P: no partial (column-slab) scores");
+        if (eta == 0) {
+            hipLaunchKernelGGL(score_transe_p_kernel, dim3((unsigned)cdiv(B * 64, 256)), dim3(256), 0, (hipStream_t)stream, ent, ld_ent, rel, ld_rel,
+                               (int)k_int, scale, pos, B, scores_pos);
+        } else {
+            EMG_REQUIRE(codes && scores_neg, "emg_train_forward: eta>0 needs codes and scores_neg");
+            TransePTrain T{};
+            T.ent = ent; T.ld_ent = ld_ent; T.rel = rel; T.ld_rel = ld_rel; T.k_int = k_int; T.ord = scale; T.pos = pos; T.B = B; T.eta = eta;
+            T.codes = codes; T.scores_pos = scores_pos; T.scores_neg = scores_neg;
+            hipLaunchKernelGGL(transe_p_forward_kernel, dim3((unsigned)cdiv(B * 64, 256)), dim3(256), 0, (hipStream_t)stream, T);
+        }
         EMG_LAUNCH_CHECK();
         return EMG_OK;
     }
@@ -266,6 +377,21 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
         EMG_REQUIRE(!a->bw_scores_pos && !a->bw_scores_neg, "emg_train_backward_ex: fused loss cannot take bw_scores");
     } else {
         EMG_REQUIRE(a->g_pos && (a->eta == 0 || a->g_neg), "emg_train_backward_ex: external dL/dscore missing");
+    }
+    if (a->model == EMG_TRANSE_P) {   // any order of the norm: generic kernels, external dL/dscore, every row through the apply
+        EMG_REQUIRE(!fused && !a->single_ent && !a->fac_ws_ent && !a->ctl,
+                    "emg_train_backward_ex: EMG_TRANSE_P trains through emg_train_forward + emg_loss + this call with fused_loss = -1, "
+                    "without in-place updates, factored contributions or device-side step records");
+        int rc = transe_p_check(a->k_int, a->scale, a->ld_ent, a->ld_rel);
+        if (rc == EMG_OK && riders && riders->total) rc = launch_riders_alone(*riders, (hipStream_t)stream);
+        if (rc != EMG_OK) return rc;
+        TransePTrain T{};
+        T.ent = a->ent; T.ld_ent = a->ld_ent; T.rel = a->rel; T.ld_rel = a->ld_rel; T.k_int = a->k_int; T.ord = a->scale; T.pos = a->pos;
+        T.B = a->B; T.eta = a->eta; T.codes = a->codes; T.g_pos = a->g_pos; T.g_neg = a->g_neg;
+        T.contrib_ent = a->contrib_ent; T.contrib_rel = a->contrib_rel; T.ldc = a->ldc;
+        hipLaunchKernelGGL(transe_p_backward_kernel, dim3((unsigned)cdiv(a->B * 64, 256)), dim3(256), 0, (hipStream_t)stream, T);
+        EMG_LAUNCH_CHECK();
+        return EMG_OK;
     }
     GroupParams P{};
     P.ent = a->ent; P.n_ent = a->n_ent; P.ld_ent = a->ld_ent; P.rel = a->rel; P.n_rel = a->n_rel; P.ld_rel = a->ld_rel;

@@ -707,19 +707,13 @@ class TransE(EmbeddingModel):
         return norm
 
     def _model_id(self):
-        """norm 1 / 2: the trained, accelerated models; any other positive order (TransE.py:208-216 passes `norm` to tf.norm as
-        ord): EMG_TRANSE_P — predict / get_ranks / evaluate_performance of a restored or hand-set model; fit() needs 1 or 2"""
+        """norm 1 / 2: the tuned models; any other positive order (TransE.py:208-216 passes `norm` to tf.norm as ord): EMG_TRANSE_P —
+        generic kernels for fit (unfused forward / loss / backward), predict, get_ranks and evaluate_performance (exact path)"""
         norm = self._norm()
         return L.TRANSE_L1 if norm == 1 else (L.TRANSE_L2 if norm == 2 else L.TRANSE_P)
 
     def _scale(self):
         return float(self._norm()) if self._model_id() == L.TRANSE_P else 1.0
-
-    def fit(self, X, *args, **kwargs):
-        if self._model_id() == L.TRANSE_P:
-            raise ValueError("TransE norm {} is not supported by the HIP training path (1 or 2); inference "
-                             "(predict / evaluate_performance) takes any positive order".format(self._norm()))
-        return super().fit(X, *args, **kwargs)
 
 
 

@@ -184,11 +184,16 @@ class Trainer:
         # rows wider than 512 columns (per half for ComplEx / HolE) do not fit the register-tiled kernels: the separate
         # forward / loss / backward path handles them in column blocks (emg_score.hip::run_group_pass)
         self.wide = (self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int) > 512
-        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide
+        # TransE with an order of the norm other than 1 / 2 (EMG_TRANSE_P; `scale` carries the order): generic kernels — the separate
+        # forward / loss / backward step, every gradient row through the apply
+        self.generic = model_id == L.TRANSE_P
+        if self.generic and self.sharded:
+            raise ValueError("TransE with a norm other than 1 / 2 does not train on column slabs (sharding 'k'): use sharding 'batch'")
+        self.fused = fused and loss in ("pairwise", "nll", "absolute_margin") and not self.sharded and not self.wide and not self.generic
         # (an LP regulariser is folded into every update: by the apply kernel, and by the in-place form of plain SGD — its
         # own instantiation (IP 3), so that the pow / sign code stays out of the forms that have no regulariser)
         n_cols = self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int
-        self.inplace = self._inplace_wanted = inplace and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3
+        self.inplace = self._inplace_wanted = inplace and not self.generic and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3
                                                                                 and n_cols % 4 == 0))
         # default: on where the dense pass is what a step costs — an entity table of 256 MB or more (C3 with Adam: 2.6 -> 1.65
         # ms/step); small tables keep the dense pass (6-14 us at C1 / C2 / C5, inside the step graph)
@@ -203,7 +208,7 @@ class Trainer:
         self._lr_host = [0.0]           # host copy (index = step)
         #  factored: bilinear models write a negative's gradient row as (one float) x (one of the group's two query
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
-        self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2) and not self.batch_sharded
+        self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2, L.TRANSE_P) and not self.batch_sharded
                          and os.environ.get("EMG_FACTORED", "1") != "0")
         self.pipeline = pipeline
         if self.batch_sharded:
@@ -329,9 +334,13 @@ class Trainer:
         c.aux_min_rows = AUX_MIN_ROWS
         self._ctl_buf = torch.zeros(4096, dtype=torch.uint8, device=self.device)   # emg_step_ctl records of a graph replay
         c.ctl_buf, c.ctl_bytes = self._ctl_buf.data_ptr(), self._ctl_buf.numel()
+        if self.deferred and not L.load().emg_plan_deferred_ok(self._cap, self.eta_total, self.n_ent, self.n_rel):
+            # the catch-up walks the counting grouping's segment descriptors; a table far longer than a batch has gradient
+            # rows (or EMG_GROUPING=sort) is grouped by the radix-sort backend: keep the dense pass there
+            self.deferred = False
         if self.deferred:
             if self._lr_t_hist is None:
-                self._lr_t_hist = torch.zeros(1 << 22, dtype=torch.float32, device=self.device)
+                self._lr_t_hist = torch.zeros(self.LR_TABLE_STEPS, dtype=torch.float32, device=self.device)
             c.lr_t_hist = self._lr_t_hist.data_ptr()
         h = C.c_void_p()
         L.check(L.load().emg_plan_create(C.byref(c), C.byref(h)), "emg_plan_create")
@@ -363,6 +372,7 @@ class Trainer:
 
     def _plan_step(self, start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch):
         import ctypes as C
+        self._deferred_table_check(1)
         self.step_count += 1
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
@@ -722,6 +732,16 @@ class Trainer:
         if self.sgd_params is not None:
             return sgd_learning_rate(self.sgd_params, self.batches_count, (t - 1) // self.batches_count + 1, (t - 1) % self.batches_count + 1)
         return self.lr
+
+    LR_TABLE_STEPS = 1 << 22    # entries of the deferred pass's learning-rate table (16 MB)
+
+    def _deferred_table_check(self, n_more):
+        """the deferred pass reads each replayed step's learning rate from a table of LR_TABLE_STEPS entries the plan points at; a
+        fit that long (e.g. batches_count = 1000 for 4200 epochs) brings every row up to date once and goes on with the dense pass"""
+        if self.deferred and self._lr_t_hist is not None and self.step_count + n_more >= self._lr_t_hist.numel():
+            self.materialize()
+            self.deferred = False
+            self._make_plan()
 
     def _fill_lr_t(self, upto, lr_now=None):
         """learning rates of the steps (filled, upto] into the device table the replay reads: the values _hyper hands the

@@ -41,9 +41,11 @@ extern "C" {
 #define EMG_COMPLEX 3
 #define EMG_HOLE 4
 /* TransE with ANY positive order of the norm (TransE.py:208-216 hands `norm` to tf.norm as ord): f = -(sum |e_s + r_p - e_o|^ord)^(1/ord),
- * ord = +inf: the largest |component|.  INFERENCE ONLY — emg_score_triples and the emg_eval_* / emg_rank_1vsall family at
- * precision 0; the `scale` argument of those calls carries ord.  (Orders 1 and 2 are EMG_TRANSE_L1 / _L2: trained, MFMA- and
- * v_sad-accelerated.) */
+ * ord = +inf: the largest |component|; the `scale` argument of every call carries ord.  Inference: emg_score_triples and the
+ * emg_eval_* / emg_rank_1vsall family at precision 0.  Training (round 4): the unfused step — emg_train_forward (eta > 0), emg_loss,
+ * emg_train_backward_ex(fused_loss = -1: gradient -g sgn(d)|d|^(ord-1) / ||d||^(ord-1); ord = inf: shared by the tied maxima) — with
+ * every gradient row through emg_apply_grouped (no in-place updates, no fused loss, no column slabs).  Generic kernels: orders 1
+ * and 2 are EMG_TRANSE_L1 / _L2, the tuned (fused, MFMA- and v_sad-accelerated) models. */
 #define EMG_TRANSE_P 5
 
 /* corruption side: protocol.py:598-608 ('s,o' is an alias of 's+o' there, :591-593) */
@@ -623,6 +625,11 @@ int emg_plan_step(void* plan, const emg_plan_batch* cur, int32_t step, const flo
  * emg_plan_graph_ok: 1 if the plan can (fused pair-local loss, 16-byte rows of more than 16 chunks, counting grouping,
  * ctl_buf given); injected draws need emg_plan_step. */
 int emg_plan_graph_ok(void* plan);
+/* 1 if a plan of this shape can DEFER its dense pass (emg_plan_config.lr_t_hist): emg_deferred_catchup walks the segment
+ * descriptors of the counting grouping, which is chosen only while a table is not much longer than its batch has gradient
+ * rows (n_rows <= 16 n + 2^20; EMG_GROUPING=sort forces the radix-sort backend).  emg_plan_create refuses lr_t_hist otherwise:
+ * the caller keeps the dense pass (emgraph_amd/training.py::Trainer._make_plan). */
+int emg_plan_deferred_ok(int64_t cap_B, int32_t eta_total, int64_t n_ent, int64_t n_rel);
 int emg_plan_run(void* plan, const emg_plan_batch* batches, int32_t n, int32_t first_step, const float* hyper6s,
                  void* stream);
 /* HIP-event timing of the next max_samples launches of every stage (0 = off); avg_ms / counts: 9 entries =

@@ -93,9 +93,11 @@ def fn_hole(e_s, e_p, e_o, k):
 
 
 def score_fn(model, e_s, e_p, e_o, k=None):
-    """Dispatch by model name ('TransE' uses norm 1; 'TransE_L2' norm 2)."""
+    """Dispatch by model name ('TransE' uses norm 1; 'TransE_L2' norm 2; 'TransE_P:<ord>' any order tf.norm takes)."""
     if model in ("TransE", "TransE_L1"):
         return fn_transe(e_s, e_p, e_o, 1)
+    if model.startswith("TransE_P:"):
+        return fn_transe(e_s, e_p, e_o, float(model.split(":")[1]))
     if model == "TransE_L2":
         return fn_transe(e_s, e_p, e_o, 2)
     if model == "DistMult":
@@ -428,9 +430,9 @@ def model_loss(model, ent_emb, rel_emb, x_pos, eta, loss="nll", loss_params=None
     return total, scores_pos, per_side_neg
 
 
-def score_grads(model, ent_emb, rel_emb, x, g, k=None):
-    """Adjoint of lookup+_fn: given g = dL/dscore [n] return dense (dE, dR) float64 accumulations
-    (what TF autodiff + IndexedSlices densification would give).  Analytic per model."""
+def score_grad_rows(model, ent_emb, rel_emb, x, g, k=None):
+    """Adjoint of _fn per triple: given g = dL/dscore [n] return the float64 gradient rows (d/de_s, d/de_p, d/de_o), each
+    [n, k_int] — the IndexedSlices TF autodiff hands the optimizer, before densification.  Analytic per model."""
     x = np.asarray(x)
     e_s, e_p, e_o = [a.astype(np.float64) for a in lookup_embeddings(ent_emb, rel_emb, x)]
     g = np.asarray(g, dtype=np.float64)[:, None]
@@ -441,6 +443,21 @@ def score_grads(model, ent_emb, rel_emb, x, g, k=None):
         d = (e_s + e_p) - e_o
         nrm = np.sqrt((d * d).sum(1, keepdims=True))
         u = np.divide(d, nrm, out=np.zeros_like(d), where=nrm > 0)
+        gs, gp, go = -g * u, -g * u, g * u
+    elif model.startswith("TransE_P:"):
+        # tf.norm(ord) = reduce_sum(|d|^ord)^(1/ord) (ord = inf: reduce_max |d|, whose gradient tied maxima share): autodiff gives
+        # d||d||/dd = sgn(d) |d|^(ord-1) / ||d||^(ord-1); a zero vector gets gradient zero here
+        order = float(model.split(":")[1])
+        d = (e_s + e_p) - e_o
+        ad = np.abs(d)
+        if np.isinf(order):
+            top = ad.max(1, keepdims=True)
+            hit = (ad == top) & (top > 0)
+            u = np.sign(d) * hit / np.maximum(hit.sum(1, keepdims=True), 1)
+        else:
+            nrm = (ad ** order).sum(1, keepdims=True) ** (1.0 / order)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = np.where((nrm > 0) & (ad > 0), np.sign(d) * ad ** (order - 1) / nrm ** (order - 1), 0.0)
         gs, gp, go = -g * u, -g * u, g * u
     elif model == "DistMult":
         gs, gp, go = g * e_p * e_o, g * e_s * e_o, g * e_s * e_p
@@ -456,6 +473,14 @@ def score_grads(model, ent_emb, rel_emb, x, g, k=None):
         go = g * np.concatenate([pr * sr - pi * si, pr * si + pi * sr], 1)
     else:
         raise ValueError(model)
+    return gs, gp, go
+
+
+def score_grads(model, ent_emb, rel_emb, x, g, k=None):
+    """Adjoint of lookup+_fn: given g = dL/dscore [n] return dense (dE, dR) float64 accumulations
+    (what TF autodiff + IndexedSlices densification would give)."""
+    x = np.asarray(x)
+    gs, gp, go = score_grad_rows(model, ent_emb, rel_emb, x, g, k=k)
     dE = np.zeros(ent_emb.shape, dtype=np.float64)
     dR = np.zeros(rel_emb.shape, dtype=np.float64)
     np.add.at(dE, x[:, 0], gs)
@@ -477,6 +502,34 @@ def train_grads(model, ent_emb, rel_emb, x_pos, eta, loss, loss_params, x_negs, 
             dE += a
             dR += b
     return dE, dR
+
+
+def train_grads_sparse(model, ent_emb, rel_emb, x_pos, eta, loss, loss_params, x_negs, k=None, chunk=65536):
+    """train_grads for tables too large to densify a float64 gradient for: returns (entity ids, their summed float64 gradient
+    rows, relation ids, their rows, data loss) over the rows the batch touches — the same per-triple rows, grouped by destination
+    (triples taken ``chunk`` at a time: float64 rows of 344 k triples x 400 columns are 1 GB apiece)."""
+    x_pos = np.asarray(x_pos)
+    x_negs = [np.asarray(x) for x in x_negs]
+    scores_pos = score_triples(model, ent_emb, rel_emb, x_pos, k=k)
+    ue = np.unique(np.concatenate([x_pos[:, 0], x_pos[:, 2]] + [x[:, 0] for x in x_negs] + [x[:, 2] for x in x_negs]))
+    ur = np.unique(x_pos[:, 1])
+    ge = np.zeros((len(ue), ent_emb.shape[1]), dtype=np.float64)
+    gr = np.zeros((len(ur), rel_emb.shape[1]), dtype=np.float64)
+    total = F32(0.0)
+    for x_neg in x_negs:
+        scores_neg = np.concatenate([score_triples(model, ent_emb, rel_emb, x_neg[c0:c0 + chunk], k=k)
+                                     for c0 in range(0, len(x_neg), chunk)])
+        pos_in = np.tile(scores_pos, eta) if REQUIRE_SAME_SIZE[loss] else scores_pos
+        total = F32(total + loss_apply(loss, pos_in, scores_neg, eta, loss_params))
+        gp, gn = loss_grads(loss, scores_pos, scores_neg, eta, loss_params)
+        for xx, gg in ((x_pos, gp), (x_neg, gn)):
+            for c0 in range(0, len(xx), chunk):
+                xc = xx[c0:c0 + chunk]
+                gs, gpp, go = score_grad_rows(model, ent_emb, rel_emb, xc, gg[c0:c0 + chunk], k=k)
+                np.add.at(ge, np.searchsorted(ue, xc[:, 0]), gs)
+                np.add.at(ge, np.searchsorted(ue, xc[:, 2]), go)
+                np.add.at(gr, np.searchsorted(ur, xc[:, 1]), gpp)
+    return ue, ge, ur, gr, float(total)
 
 
 # --------------------------------------------------------------------------

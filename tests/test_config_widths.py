@@ -454,6 +454,49 @@ def test_deferred_adam_decay_gives_the_dense_pass_bits(model, k, opt, reg):
     assert not np.array_equal(a[0], E0)
 
 
+def test_deferred_pass_falls_back_to_the_dense_pass_where_it_cannot_run():
+    """(advisor, round 3) emg_deferred_catchup walks the counting grouping's segment descriptors.  A table far longer than a batch
+    has gradient rows is grouped by the radix-sort backend (n_rows > 16 n + 2^20): a Trainer asked to defer there must keep the
+    dense pass instead of failing in its first step — and a fit longer than the learning-rate table the replay reads must bring
+    every row up to date once and go on with the dense pass.  Both equal the dense form bit for bit."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    lib = L.load()
+    assert lib.emg_plan_deferred_ok(16384, 20, 1000000, 1000) == 1          # C3
+    assert lib.emg_plan_deferred_ok(16, 1, 1200000, 5) == 0                  # 48 gradient rows per batch against 1.2 M entities
+    rs = np.random.RandomState(2)
+
+    def run(n_ent, B, eta, nb, ki, deferred, table_steps=None, epochs=2):
+        E0 = (rs.__class__(7).randn(n_ent, ki) * 0.3).astype(F32)
+        R0 = (rs.__class__(8).randn(5, ki) * 0.3).astype(F32)
+        r = rs.__class__(9)
+        X = np.stack([r.randint(0, n_ent, nb * B), r.randint(0, 5, nb * B), r.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+        tr = Trainer(L.DISTMULT, ki, 1.0, E0, R0, eta, loss="nll", optimizer="adam", optimizer_params={"lr": 0.01}, batches_count=nb,
+                     seed=3, deferred_dense=deferred)
+        if table_steps:
+            tr.LR_TABLE_STEPS = table_steps
+        tr.set_training_set(X, B)
+        was = tr.deferred
+        for ep in range(1, epochs + 1):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1)
+        Et, Rt = tr.tables_numpy()
+        return was, tr.deferred, Et, Rt, [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel], tr.read_loss()
+
+    # the sort backend's shape: asked to defer, runs dense
+    a, b = run(1200000, 16, 1, 3, 8, True), run(1200000, 16, 1, 3, 8, False)
+    assert a[0] is False and a[1] is False
+    # a learning-rate table of 6 steps under a fit of 12
+    c, d = run(5000, 64, 2, 4, 72, True, table_steps=6, epochs=3), run(5000, 64, 2, 4, 72, False, epochs=3)
+    assert c[0] is True and c[1] is False
+    for x, y in ((a, b), (c, d)):
+        np.testing.assert_array_equal(x[2], y[2])
+        np.testing.assert_array_equal(x[3], y[3])
+        for u, v in zip(x[4], y[4]):
+            np.testing.assert_array_equal(u, v)
+        assert x[5] == y[5]
+
+
 @pytest.mark.parametrize("model,k,opt,reg", [("ComplEx", 200, "adam", None), ("DistMult", 600, "sgd", 2), ("DistMult", 101, "adagrad", 3),
                                                ("TransE", 256, "momentum", 4), ("ComplEx", 100, "adam", 2),
                                                ("ComplEx", 64, "adam", "hubs"), ("DistMult", 300, "adam", "hubs")])

@@ -433,3 +433,148 @@ def test_scores_relative_error_on_well_conditioned_triples(world):
     print("ComplEx k=200, |E|=1M: %d well-conditioned triples, max relative score error %.3g, median %.3g"
           % (int(well.sum()), float(rel_err.max()), float(rel_err.median())))
     assert float(rel_err.max()) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# the ORACLE at C3's EXACT training shape (|E| = 1M, |R| = 1k, k = 200, eta = 20, B = 16384, NLL): two consecutive steps of the
+# step fit() runs — plain SGD: fused kernel, in-place singletons, factored contributions; Adam (the reference's default,
+# constants.py:55): deferred dense pass + the stateful apply — against orc.train_grads_sparse (the per-triple gradient rows of
+# EmbeddingModel.py:614-822's loss, float64, grouped by destination) and orc.opt_apply (training/sgd.py, adam.py) on the rows
+# the two batches touch; every other row must keep its bits.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_training_steps_vs_oracle_at_c3_exact_shape(world, opt):
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import ADAM_BETA1, ADAM_BETA2, Trainer
+    from oracle import emgraph_oracle as orc
+    ent, rel, _, pos = world
+    E0, R0 = ent[:, :K_INT].cpu().numpy(), rel[:, :K_INT].cpu().numpy()
+    rs = np.random.RandomState(21)
+    second = np.stack([rs.randint(0, N_ENT, B), rs.randint(0, N_REL, B), rs.randint(0, N_ENT, B)], 1).astype(np.int32)
+    X = np.concatenate([pos, second])
+    lr = 0.05 if opt == "sgd" else 0.001
+    tr = Trainer(L.COMPLEX, K_INT, 1.0, E0, R0, ETA, loss="nll", optimizer=opt, optimizer_params={"lr": lr}, batches_count=2, seed=0)
+    tr.set_training_set(X, B)
+    assert tr.fused and tr.factored and tr.inplace == (opt == "sgd") and tr.deferred == (opt == "adam")
+    xnegs = [orc.generate_corruptions_for_fit_philox(X[b * B:(b + 1) * B], eta=ETA, corrupt_side="s,o", entities_size=N_ENT, seed=0, counter=b)
+             for b in (0, 1)]
+    rows_all = np.unique(np.concatenate([X[:, 0], X[:, 2]] + [x[:, 0] for x in xnegs] + [x[:, 2] for x in xnegs]))   # every row either batch touches
+    rels_all = np.unique(X[:, 1])
+    Ep, Rp = E0, R0
+    st = {"E": orc.opt_init(opt, (len(rows_all), K_INT)), "R": orc.opt_init(opt, (len(rels_all), K_INT))}
+    for b in (0, 1):
+        tr.step(b * B, B, epoch=1, batch=b + 1, prefetch=[(B, B, 1, 2)] if b == 0 else None)
+        loss = tr.read_loss()
+        E1, R1 = tr.tables_numpy()                      # (Adam: materialize() brings every row up to this step)
+        xb = X[b * B:(b + 1) * B]
+        ue, ge, ur, gr, oloss = orc.train_grads_sparse("ComplEx", Ep, Rp, xb, ETA, "nll", None, [xnegs[b]])
+        assert loss == pytest.approx(oloss, rel=2e-5), (b, loss, oloss)
+        ulp = 2.0 ** -23
+        for tab, (ids_all, ids, g, W0, W1, key) in (("ent", (rows_all, ue, ge, Ep, E1, "E")), ("rel", (rels_all, ur, gr, Rp, R1, "R"))):
+            at = np.searchsorted(ids_all, ids)
+            gmax = np.abs(g).max()
+            if opt == "sgd":
+                # w1 = w0 - lr g: the gradient within rtol 1e-4 (+ 1e-5 of the largest) through an update stored in float32
+                want = W0[ids].astype(np.float64) - lr * g
+                tol = lr * (1e-4 * np.abs(g) + 1e-5 * gmax) + ulp * np.abs(W0[ids])
+                assert np.all(np.abs(W1[ids] - want) <= tol), (tab, b, float(np.max(np.abs(W1[ids] - want) / tol)))
+                untouched = np.ones(W0.shape[0], bool)
+                untouched[ids] = False
+                np.testing.assert_array_equal(W1[untouched], W0[untouched])
+            else:
+                # the oracle's dense-equivalent Adam on the rows either batch touches (all other rows: m = v = 0, they cannot move)
+                g_all = np.zeros((len(ids_all), K_INT), dtype=np.float32)
+                g_all[at] = g
+                m0, v0 = st[key]["m"].copy(), st[key]["v"].copy()
+                want = orc.opt_apply("adam", W0[ids_all], g_all, st[key], lr=lr)
+                got_m, got_v = [t.cpu().numpy()[ids_all][:, :K_INT] for t in (tr.state_ent if tab == "ent" else tr.state_rel)]
+                # gradients read back through the state: m = b1 m0 + (1 - b1) g, v = b2 v0 + (1 - b2) g^2
+                g_from_m = (got_m.astype(np.float64) - ADAM_BETA1 * m0) / (1 - ADAM_BETA1)
+                assert np.all(np.abs(g_from_m - g_all) <= 1e-4 * np.abs(g_all) + 1e-5 * gmax + 8 * ulp * np.abs(m0) / (1 - ADAM_BETA1)), (tab, b)
+                np.testing.assert_allclose(got_v, st[key]["v"], rtol=3e-4, atol=1e-5 * (1 - ADAM_BETA2) * gmax * gmax)
+                # the step lr_t m / (sqrt(v) + eps) is bounded by ~3.2 lr whatever g; where |g| is far above eps it is a smooth function
+                # of g: agree within 1e-3 of the step there, and never differ by more than a step
+                err = np.abs(W1[ids_all] - want)
+                step = np.abs(want.astype(np.float64) - W0[ids_all])
+                smooth = np.abs(g_all) > 1e-3 * gmax
+                assert np.all(err[smooth] <= 2e-3 * step[smooth] + 2 * ulp * np.abs(want[smooth])), (tab, b, float(err[smooth].max()))
+                assert err.max() <= 4 * lr
+                st[key]["m"], st[key]["v"] = got_m.copy(), got_v.copy()     # step 2 starts from the device's state (no error build-up)
+                never = np.ones(W0.shape[0], bool)
+                never[ids_all] = False
+                np.testing.assert_array_equal(W1[never], E0[never] if tab == "ent" else R0[never])
+        Ep, Rp = E1, R1
+
+
+def test_ranks_assembled_by_the_literal_oracle_at_one_million_entities(world):
+    """the rank ASSEMBLY of the reference (EmbeddingModel.py:1894-1986: filter lookups, perform_comparision, rank = cmp(all) + 1 -
+    cmp(filter)) done by oracle.emgraph_oracle.rank_triple — its own participating_entities and comparison — over the canonical
+    scores of the C oracle, for 4 test triples against all 1M entities: equal to the device ranks (exact and exact-fast paths) for
+    every side and strategy.  ('s+o' = rank_o + rank_s - 1: cmp over both blocks is the sum of the two blocks' counts.)"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.evaluation import FilterIndex, rank_triples_device
+    from oracle import c_oracle as co
+    from oracle import emgraph_oracle as orc
+    ent, rel, _, pos = world
+    E, R = ent[:, :K_INT].cpu().numpy(), rel[:, :K_INT].cpu().numpy()
+    n_dev, n_or = 160, 4
+    T = pos[:n_dev].copy()
+    T[1] = T[0]
+    T[3, :2] = T[2, :2]
+    Fil = np.concatenate([pos[:4096], T])
+    F = FilterIndex(Fil)
+    want = {}
+    for i in range(n_or):
+        Q, _ = co.build_queries(L.COMPLEX, E, R, K_INT, 1.0, T[i:i + 1], L.EVAL_S_O)      # row 0: object side, row 1: subject side
+        dense = co.scores_dense(L.COMPLEX, Q, E, K_INT, 1.0)
+        for side, row, col in (("o", 0, 2), ("s", 1, 0)):
+            scorer = lambda rows, row=row, col=col: dense[row][np.asarray(rows)[:, col]]   # noqa: E731  (canonical score of each corruption)
+            for strategy in ("worst", "middle", "best"):
+                want[(i, side, strategy)] = orc.rank_triple("ComplEx", E, R, T[i], corrupt_side=side, strategy=strategy,
+                                                            filter_triples=Fil, score_override=scorer)
+    for strategy in ("worst", "middle", "best"):
+        for precision in (0, 2):
+            for side in ("s,o", "s+o", "s", "o"):
+                got = rank_triples_device(L.COMPLEX, ent[:, :K_INT], rel[:, :K_INT], K_INT, 1.0, T, side, strategy, filter_triples=F, precision=precision)
+                for i in range(n_or):
+                    ws, wo = want[(i, "s", strategy)], want[(i, "o", strategy)]
+                    exp = {"s,o": [ws, wo], "s+o": ws + wo - 1, "s": ws, "o": wo}[side]
+                    np.testing.assert_array_equal(got[i], exp, err_msg="%s %s precision %d triple %d" % (side, strategy, precision, i))
+
+
+@pytest.mark.parametrize("model", ["TransE_L1", "TransE_L2", "DistMult", "HolE"])
+def test_scores_relative_error_every_model(world, model):
+    """north_star's bar as worded — fp32 scores within 1e-4 relative to |score| — for the other four score functions on the 1M-entity
+    table (ComplEx: test_scores_relative_error_on_well_conditioned_triples): against a float64 restatement of TransE.py:208-216,
+    DistMult.py:201, HolE.py:189, on the triples whose |score| is at least a tenth of the sum of |terms| (all of them for TransE —
+    a norm has no cancellation —, planted objects for the bilinear models)."""
+    from emgraph_amd import _lib as L
+    d = dev()
+    ent, rel, _, pos = world
+    mid = getattr(L, model.upper())
+    k_int = K_INT if model == "HolE" else K
+    scale = float(np.float32(2 / K)) if model == "HolE" else 1.0
+    Tt = torch.from_numpy(pos[:4096]).cuda()
+    ent2 = ent.clone()
+    if not model.startswith("TransE"):
+        Q, _ = d.eval_build_queries(mid, ent, rel, k_int, scale, Tt, L.EVAL_O)
+        o = Tt[:, 2].long()
+        qh = Q[:, :k_int] / Q[:, :k_int].norm(dim=1, keepdim=True)
+        ent2[o, :k_int] = 0.6 * ent2[o, :k_int] + 0.8 * ent2[o, :k_int].norm(dim=1, keepdim=True) * qh
+    e2, r2 = ent2[:, :k_int], rel[:, :k_int]
+    got = d.score_triples(mid, e2, r2, k_int, scale, Tt).double()
+    s, p, o = e2[Tt[:, 0].long()].double(), r2[Tt[:, 1].long()].double(), e2[Tt[:, 2].long()].double()
+    if model == "TransE_L1":
+        val = -((s + p) - o).abs().sum(1); mag = val.abs()
+    elif model == "TransE_L2":
+        val = -(((s + p) - o) ** 2).sum(1).sqrt(); mag = val.abs()
+    elif model == "DistMult":
+        val = (s * p * o).sum(1); mag = (s * p * o).abs().sum(1)
+    else:
+        val, mag = complex_score_f64(ent2, rel, Tt)
+        val, mag = val * scale, mag * scale
+    well = val.abs() >= 0.1 * mag
+    assert int(well.sum()) >= 1000, int(well.sum())
+    rel_err = ((got - val).abs() / val.abs())[well]
+    print("%s k=200, |E|=1M: %d well-conditioned triples, max relative score error %.3g" % (model, int(well.sum()), float(rel_err.max())))
+    assert float(rel_err.max()) <= 1e-4

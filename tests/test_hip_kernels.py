@@ -264,6 +264,62 @@ def test_train_backward_vs_oracle(model, k, eta):
     np.testing.assert_allclose(dR, eR, rtol=1e-4, atol=1e-5 * max(np.abs(eR).max(), 1e-6))
 
 
+@pytest.mark.parametrize("order", [3.0, 1.5, float("inf")])
+@pytest.mark.parametrize("k,eta", [(8, 3), (100, 5), (130, 2)])
+def test_transe_any_norm_forward_backward_vs_oracle(order, k, eta):
+    """TransE.py:208-216 hands `norm` to tf.norm as ord: orders other than 1 / 2 train through the generic kernels (EMG_TRANSE_P,
+    `scale` = the order).  Scores of a positive group within 1e-4 relative, gradient rows (-g sgn(d)|d|^(ord-1) / ||d||^(ord-1);
+    ord = inf: the maximum's gradient, shared by tied maxima) rtol 1e-4 against the oracle's float64 autodiff formula.  The first
+    triple is dyadic with TWO tied maxima, the second is a zero vector (gradient zero)."""
+    from emgraph_amd import _lib as L
+    d = dev()
+    model = "TransE_P:%r" % order
+    n_ent, n_rel, B = 97, 5, 70
+    E, R, ki = make_tables("TransE_L1", k, n_ent, n_rel, seed=k)
+    rs = np.random.RandomState(4)
+    X = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    X[0], X[1] = (90, 4, 91), (92, 4, 92)          # rows nobody else uses (negatives may still draw them: they read, never write)
+    X[2:, 0] %= 90; X[2:, 2] %= 90; X[2:, 1] %= 4
+    R[4] = 0.0
+    E[90] = 0.0; E[91] = 0.0; E[90, 0] = 0.5; E[91, 1] = 0.5; E[90, 2] = 0.25      # d = (0.5, -0.5, 0.25, 0, ...): two tied maxima
+    E[92] = 0.125                                                                      # d = 0
+    codes = co.corrupt_codes(B, eta, 2, n_ent, 5, 6)
+    xneg = orc.generate_corruptions_for_fit_philox(X, eta=eta, corrupt_side="s+o", entities_size=n_ent, seed=5, counter=6)
+    sp, sn = d.train_forward(L.TRANSE_P, cu(E), cu(R), ki, order, cu(X), eta, cu(codes))
+    np.testing.assert_allclose(sp.cpu().numpy(), orc.score_triples(model, E, R, X), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), orc.score_triples(model, E, R, xneg), rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(d.score_triples(L.TRANSE_P, cu(E), cu(R), ki, order, cu(X)).cpu().numpy(), sp.cpu().numpy())
+    gpos = rs.randn(B).astype(F32)
+    gneg = rs.randn(B * eta).astype(F32)
+    ldc = ((ki + 3) // 4) * 4
+    ce = torch.full(((2 + eta) * B, ldc), 7.0, dtype=torch.float32, device="cuda")    # (every slot is written, not accumulated into)
+    cr = torch.full((B, ldc), 7.0, dtype=torch.float32, device="cuda")
+    de = torch.empty((2 + eta) * B, dtype=torch.int32, device="cuda")
+    dr = torch.empty(B, dtype=torch.int32, device="cuda")
+    d.train_backward(L.TRANSE_P, cu(E), cu(R), ki, order, cu(X), eta, cu(codes), cu(gpos), cu(gneg), ce, cr, de, dr)
+    dE = np.zeros((n_ent, ki)); dR = np.zeros((n_rel, ki))
+    np.add.at(dE, de.cpu().numpy(), ce.cpu().numpy()[:, :ki].astype(np.float64))
+    np.add.at(dR, dr.cpu().numpy(), cr.cpu().numpy()[:, :ki].astype(np.float64))
+    eE, eR = orc.score_grads(model, E, R, X, gpos)
+    a, b = orc.score_grads(model, E, R, xneg, gneg)
+    eE += a; eR += b
+    if np.isinf(order):   # a last-bit difference of two near-equal |d| moves the maximum: compare where float32 and float64 agree on it
+        es, ep, eo = orc.lookup_embeddings(E, R, np.concatenate([X, xneg]))
+        ad = np.abs((es + ep) - eo).astype(np.float64)
+        top2 = np.sort(ad, 1)[:, -2:]
+        assert np.all((top2[:, 1] - top2[:, 0] > 1e-6) | (top2[:, 1] == top2[:, 0]))
+    np.testing.assert_allclose(dE, eE, rtol=1e-4, atol=1e-5 * max(np.abs(eE).max(), 1e-6))
+    np.testing.assert_allclose(dR, eR, rtol=1e-4, atol=1e-5 * max(np.abs(eR).max(), 1e-6))
+    assert np.all(np.isfinite(ce.cpu().numpy()[:, :ki]))     # (the zero vector included: gradient zero, not 0 / 0)
+    if np.isinf(order):   # tied maxima share the gradient: relation slot 0 holds -g / 2, +g / 2 of the positive (+ its negatives' terms)
+        own = np.zeros(ki); own[0], own[1] = -gpos[0] / 2, gpos[0] / 2
+        rest = cr.cpu().numpy()[0, :ki] - own
+        exp_rest, _ = np.zeros(ki), None
+        xn0 = xneg[0::B][:eta]
+        _, r0 = orc.score_grads(model, E, R, xn0, gneg[0::B][:eta])
+        np.testing.assert_allclose(rest, r0[4], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("model,k", [("TransE_L1", 700), ("TransE_L2", 1030), ("DistMult", 601), ("ComplEx", 520),
                                      ("HolE", 1100)])
 def test_wide_rows_train_in_column_blocks(model, k):

@@ -5,7 +5,7 @@ for spec in "$@"; do
   label="${spec%%:*}"; envs="${spec#*:}"
   for wl in ${AB_WORKLOADS:-C3 C3b C2}; do
     steps=300; [[ $wl == C3b ]] && steps=60
-    out=$(env $envs python3 bench.py --workload $wl --no-cpu --no-eval --no-others --sustained-seconds 0 --steps $steps --warmup 20 2>/dev/null | tail -1)
+    out=$(env $envs python3 bench.py --workload $wl --no-cpu --no-eval --no-others --sustained-seconds 0 --no-ceilings --steps $steps --warmup 20 2>/dev/null | tail -1)
     python3 - "$label" "$wl" "$out" <<'PY'
 import json, sys
 label, wl, out = sys.argv[1:4]

@@ -3,7 +3,7 @@
 # (separate PMC passes, counters + kernel-trace only).  usage on the GPU box: bash tools/pmc_fused.sh [bench args]
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_fused; rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --quick --steps 6 --warmup 2 --no-cpu --no-eval --no-pipeline $*"
+CMD="python3 bench.py --quick --steps 6 --warmup 2 --no-cpu --no-eval --no-pipeline --no-ceilings $*"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM" \
            "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA" \

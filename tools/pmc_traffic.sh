@@ -3,7 +3,7 @@
 # usage (on the GPU box): bash tools/pmc_traffic.sh <out.json>
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_traffic; mkdir -p $OUT
-CMD="python3 bench.py --quick --steps 6 --warmup 2 --no-cpu --no-eval --no-pipeline"
+CMD="python3 bench.py --quick --steps 6 --warmup 2 --no-cpu --no-eval --no-pipeline --no-ceilings"
 CMD2="python3 tools/bench_score.py"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- $CMD > $OUT/$c.log 2>&1

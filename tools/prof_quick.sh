@@ -3,7 +3,7 @@
 TAG="$1"; shift
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out; rm -rf gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o p -- python3 bench.py --no-cpu --no-eval --no-others --sustained-seconds 0 "$@" > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o p -- python3 bench.py --no-cpu --no-eval --no-others --sustained-seconds 0 --no-ceilings "$@" > gpurun_out/prof_$TAG.log 2>&1
 db=$(ls gpurun_out/prof_$TAG/*/*results.db gpurun_out/prof_$TAG/*results.db 2>/dev/null | head -1)
 python3 profiles/summarize_rocpd.py "$db" gpurun_out/${TAG}_kernel_stats.md > /dev/null
 tail -1 gpurun_out/prof_$TAG.log > gpurun_out/${TAG}_profiled_bench.json
