@@ -88,21 +88,28 @@ def glorot(rs, rows, cols):
     return rs.uniform(-lim, lim, size=(rows, cols)).astype(np.float32)
 
 
-def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None, n_single=0):
-    """ALGORITHMIC HBM bytes of one launch (DESIGN.md 'bytes per unit'); int32 ids, fp32 rows."""
+N_STATE = {"sgd": 0, "momentum": 1, "adagrad": 1, "adam": 2, "adam_lazy": 2}   # optimizer state rows per table row
+
+
+def algorithmic_bytes(stage, B, eta, k_int, n_unique_ent=None, n_unique_rel=None, n_single=0, ns=0, n_caught_up=0):
+    """ALGORITHMIC HBM bytes of one launch (DESIGN.md 'bytes per unit'); int32 ids, fp32 rows.
+    n_single: entity slots whose destination is updated IN PLACE by the scoring kernel; ns: optimizer state rows per table row
+    (SGD 0, momentum / Adagrad 1, Adam 2) — a row's update reads and writes them with the row."""
     row = 4 * k_int
     if stage == "forward":   # spo + codes + (3+eta) rows + (1+eta) scores
         return B * (12 + 4 * eta + (3 + eta) * row + 4 * (1 + eta))
     if stage == "backward":  # spo + codes + g + (3+eta) rows read + (3+eta) rows written
         return B * (12 + 4 * eta + 4 * (1 + eta) + (3 + eta) * row + (3 + eta) * row)
     if stage == "fused":     # spo + codes + singleton flags + (3+eta) rows read + (3+eta) rows written
-        # (a singleton row is written in place, any other row to the contribution buffer: one row each)
-        return B * (12 + 4 * eta + (2 + eta) + (3 + eta) * row + (3 + eta) * row)
-    if stage == "apply_ent":  # non-singleton contribution rows read once + RMW of each such destination
+        # (a singleton row is written in place — with its ns state rows read and written —, any other row to the contribution buffer)
+        return B * (12 + 4 * eta + (2 + eta) + (3 + eta) * row + (3 + eta) * row) + n_single * 2 * ns * row
+    if stage == "apply_ent":  # non-singleton contribution rows read once + read-modify-write of each such destination and its state rows
         n_ns = (2 + eta) * B - n_single
-        return n_ns * row + 2 * (n_unique_ent - n_single) * row + (2 + eta) * B * 8
+        return n_ns * row + 2 * (1 + ns) * (n_unique_ent - n_single) * row + (2 + eta) * B * 8
     if stage == "apply_rel":
-        return B * row + 2 * n_unique_rel * row + B * 8
+        return B * row + 2 * (1 + ns) * n_unique_rel * row + B * 8
+    if stage == "catchup":   # deferred dense pass: (w, state) of every destination the apply will finish read, w written back
+        return n_caught_up * ((1 + ns) + 1) * row
     return 0
 
 
@@ -127,7 +134,8 @@ def pmc_traffic(stage, name, B, world, args):
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    for fn in ("r3_q_pmc_traffic.json", "r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json", "r2_h_pmc_traffic.json", "r2_d_pmc_traffic.json"):
+    import glob
+    for fn in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))), reverse=True):   # newest round first
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items()
@@ -243,14 +251,22 @@ class StepRunner:
             cnt = torch.bincount(sl["dest_ent"][:n_ce].long())
             out["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur,
                              "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
+            ns = N_STATE[self.w["optimizer"]]
+            lag_ip = bool(tr.inplace and tr.deferred and self.w["optimizer"] == "adam")   # (s / o slots go through the apply in this form)
+            if lag_ip:
+                n_single = int(sl["single"][2 * B:n_ce].sum().item())
+                out["_batch"]["singleton_slots_in_place"] = n_single
             for name, v in ms.items():
-                ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single)
+                ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns, n_caught_up=(n_ue - n_single) + n_ur)
                 if name == "apply_ent" and "apply_rel" not in ms:   # pair apply: both tables in the same launches
-                    ab += algorithmic_bytes("apply_rel", B, eta, self.k_local, n_ue, n_ur, n_single)
+                    ab += algorithmic_bytes("apply_rel", B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns)
                 out[name] = {"ms": round(v, 4), "alg_bytes": ab, "GBps": round(ab / (v * 1e-3) / 1e9, 1) if ab else None}
                 if name == "apply_ent" and "apply_rel" not in ms:
                     out[name]["note"] = "entity + relation table through shared launches (emg_apply_grouped_pair)"
-                if getattr(tr, "factored", False) and tr.inplace and name in ("fused", "apply_ent"):
+                if name == "catchup":
+                    out[name]["note"] = ("emg_deferred_catchup of both tables; bytes = an upper bound (every destination the apply finishes; rows "
+                                         "already at the current step are skipped)")
+                if getattr(tr, "factored", False) and tr.inplace and ns == 0 and name in ("fused", "apply_ent"):
                     flags = sl["single"][:n_ce]
                     n_s_so, n_s_neg = int(flags[:2 * B].sum().item()), int(flags[2 * B:].sum().item())
                     mb = moved_bytes_model(name, B, eta, self.k_local, n_s_neg, n_s_so, n_ce - n_single, n_ue - n_single)
@@ -282,7 +298,7 @@ def hbm_ceilings():
         return None
 
 
-def profiled_avg_us(kernel_substr, tag_glob="r3_*_c3_kernel_stats.md"):
+def profiled_avg_us(kernel_substr, tag_glob="r*_c3_kernel_stats.md"):
     """average duration (us) of a kernel in the newest committed rocprofv3 --kernel-trace --stats table of THIS workload
     (profiles/): printed next to the live HIP-event figure so that `frac` can be re-derived from profiles/ alone"""
     import glob
@@ -346,10 +362,13 @@ def score_kernel_alone(r, reps=50):
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
     traffic = None
     try:
-        fn = next(f for f in ("r3_q_pmc_traffic.json", "r3_p_pmc_traffic.json", "r3_o_pmc_traffic.json", "r3_k_pmc_traffic.json", "r3_e_pmc_traffic.json", "r2_i_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
-        d = json.load(open(os.path.join(ROOT, "profiles", fn)))
-        k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
-        traffic = k[0]["hbm_bytes_per_launch"] if k else None
+        import glob
+        for fn in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))), reverse=True):
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
+            if k:
+                traffic = k[0]["hbm_bytes_per_launch"]
+                break
     except (OSError, ValueError, KeyError):
         pass
     return {"kernel": "train_forward_kernel (gather + score of %d x %d triples)" % (B, 1 + eta), "bound": "hbm",
@@ -750,21 +769,45 @@ def main():
         line["eval"] = run_eval(r, args)                           # every rank takes part (range-sharded candidates)
     cpu = cpu_baseline(r, args) if (rank == 0 and world == 1 and not args.no_cpu) else None
     r.close()
+    def run_other(name):
+        ro = StepRunner(name, args, rank, world)
+        ro.run(20)
+        n = 300 if name not in ("C3b", "C3a", "C3d") else 100
+        d, ti = ro.timed(n)
+        o = step_summary(ro, d, ti, n)
+        o["workload"] = WORKLOADS[name]["desc"]
+        o["stages"] = ro.stages()
+        if name == "C3p":
+            o["score_kernel_alone"] = score_kernel_alone(ro)
+        ro.close()
+        return o
+
+    def default_optimizer_block(o):
+        """C3 with the reference's DEFAULT optimizer (Keras Adam, constants.py:55) as a headline block of its own: value, step time and
+        the roofline of its longest byte-moving stage (bytes incl. the optimizer state rows)"""
+        st = o["stages"]
+        bs = [k for k in st if isinstance(st[k], dict) and st[k].get("alg_bytes")]
+        dom = max(bs, key=lambda k: st[k]["ms"])
+        tot = sum(st[k]["alg_bytes"] for k in bs)
+        return {"workload": "C3a: " + WORKLOADS["C3a"]["desc"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                "steps": o["steps"], "host_issue_ms_per_step": o["host_issue_ms_per_step"],
+                "stages_ms": {k: st[k]["ms"] for k in st if isinstance(st[k], dict) and "ms" in st[k]},
+                "roofline": {"kernel": dom, "bound": "hbm", "achieved": st[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(st[dom]["GBps"] / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": st[dom]["alg_bytes"],
+                             "avg_launch_ms": st[dom]["ms"]},
+                "step_alg_bytes": tot, "step_GBps": round(tot / (o["ms_per_step"] * 1e-3) / 1e9, 1),
+                "note": "the headline `value` above is C3 as the REFERENCE can run it: above 5e5 entities EmbeddingModel.py:1266-1274 refuses "
+                        "every optimizer but SGD.  This block is the same workload with the reference's default optimizer (Adam), which this "
+                        "framework does run at that size: singleton negatives replayed + updated inside the scoring kernel, deferred dense pass"}
+
+    if world == 1 and args.workload == "C3" and args.no_others and not args.quick:
+        line["default_optimizer"] = default_optimizer_block(run_other("C3a"))
     if not args.no_others and world == 1 and args.workload == "C3":
         others = {}
         for name in ("C3z", "C3b", "C3p", "C3m", "C3s", "C3r", "C3a", "C3d", "C3g", "C1", "C2", "C5"):
-            ro = StepRunner(name, args, rank, world)
-            ro.run(20)
-            n = 300 if name not in ("C3b", "C3a", "C3d") else 60
-            d, ti = ro.timed(n)
-            o = step_summary(ro, d, ti, n)
-            o["workload"] = WORKLOADS[name]["desc"]
-            o["stages"] = ro.stages()
-            if name == "C3p":
-                o["score_kernel_alone"] = score_kernel_alone(ro)
-            ro.close()
-            others[name] = o
+            others[name] = run_other(name)
         line["others"] = others
+        line["default_optimizer"] = default_optimizer_block(others["C3a"])
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu

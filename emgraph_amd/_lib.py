@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE, TRANSE_P = range(6)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
@@ -84,6 +84,7 @@ class BackwardArgs(C.Structure):
         ("fac_ws_ent", _p), ("fac_ws_ent_bytes", _i64),
         ("layout_B", _i64), ("ctl", _p),
         ("lp_accum", _p),
+        ("lr_hist", _p),
     ]
 
 
@@ -179,13 +180,14 @@ class ApplyArgs(C.Structure):
         ("factored", _i32), ("table_index", _i32),
         ("layout_n", _i64), ("ctl", _p),
         ("deferred_dense", _i32), ("reserved1", _i32),
+        ("single_from_slot", _i64),
     ]
 
 
 SIGNATURES.update({
     "emg_apply_grouped_ex": (_int, [C.POINTER(ApplyArgs), _p]),
     "emg_apply_grouped_pair": (_int, [C.POINTER(ApplyArgs), C.POINTER(ApplyArgs), _p]),
-    "emg_deferred_catchup": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p, _i64, _i64, _i32, _p]),
+    "emg_deferred_catchup": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p, _i64, _i64, _i32, _i64, _p]),
     "emg_deferred_materialize": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, C.POINTER(_f32), _p, _i32, _p, _p]),
 })
 

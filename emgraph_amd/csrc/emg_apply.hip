@@ -29,7 +29,8 @@ struct ApplyParams {
     int32_t state_lag;   // 1 (Adam, deferred dense pass): m, v of a multi / single destination are as of tag[row], w is current (below)
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
-    int32_t skip_single;
+    int32_t skip_single;   // 1: singletons were updated in place; 2: those whose contribution slot is >= single_from were
+    int64_t single_from;
     int32_t win;  // sorted positions per wave
     OptParams opt;
     // segments longer than `defer` rows leave the window kernel as BLOCK TASKS (apply_long_kernel): 64-row blocks of
@@ -191,7 +192,7 @@ __device__ __forceinline__ void apply_rows_body(const ApplyParams& P, int64_t bl
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
-    unsigned long long todo = __ballot(head && !(P.skip_single && last));
+    unsigned long long todo = __ballot(head && !(P.skip_single == 1 && last));
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
-    const unsigned long long todo = __ballot(head && !(P.skip_single && last));
+    const unsigned long long todo = __ballot(head && !(P.skip_single == 1 && last));
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     const int ntodo = __popcll(todo);
@@ -683,6 +684,7 @@ struct ReplayParams {
     const float* lr_hist; int32_t upto; double* lp_accum;
     int32_t lag;   // 1 (Adam, no regulariser): multi / single destinations get w only; the apply redoes the decay of m, v (ApplyParams.state_lag)
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* keys; const uint32_t* counters; uint32_t task_cap;
+    const uint32_t* vals; int64_t single_from;   // single_from > 0: singletons whose contribution slot is >= it are not this pass's (the scoring kernel replays them)
 };
 
 // one row, steps tag[r]+1 .. upto: what untouched_rows_body does to it in each of them (g = the regulariser's gradient alone).
@@ -774,8 +776,10 @@ __global__ __launch_bounds__(256) void deferred_catchup_kernel(const ReplayParam
         int64_t dest = -1;
         if (i < i1) {
             if (i < n_multi) dest = P.multi[i].dest;
-            else if (i < n_multi + n_single) dest = P.keys[P.single[i - n_multi]];
-            else {
+            else if (i < n_multi + n_single) {
+                const uint32_t at = P.single[i - n_multi];
+                if (!(P.single_from > 0 && (int64_t)P.vals[at] >= P.single_from)) dest = P.keys[at];
+            } else {
                 const LongTask tk = P.tasks[i - n_multi - n_single];
                 if (tk.block == 0u) dest = P.keys[tk.head];   // one entry per long segment: its first block's
             }
@@ -873,8 +877,10 @@ __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const Replay
         int32_t dest = -1;
         if (i < i1) {
             if (i < n_multi) dest = (int32_t)P.multi[i].dest;
-            else if (i < n_multi + n_single) dest = (int32_t)P.keys[P.single[i - n_multi]];
-            else {
+            else if (i < n_multi + n_single) {
+                const uint32_t at = P.single[i - n_multi];
+                if (!(P.single_from > 0 && (int64_t)P.vals[at] >= P.single_from)) dest = (int32_t)P.keys[at];
+            } else {
                 const LongTask tk = P.tasks[i - n_multi - n_single];
                 if (tk.block == 0u) dest = (int32_t)P.keys[tk.head];
             }
@@ -1161,7 +1167,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     }
     const int nchunks = P.k_int / 4;
     const uint32_t n_multi = P.counters[GC_MULTI];
-    const uint32_t n_single = P.skip_single ? 0u : P.counters[GC_SINGLE];
+    const uint32_t n_single = P.skip_single == 1 ? 0u : P.counters[GC_SINGLE];
     const uint32_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
     float lp_acc = 0.f;
     if (n_tasks && partial) {
@@ -1186,14 +1192,29 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     } else {
         i0 = gw * share; i1 = min(total, i0 + share);
     }
+    // skip_single = 2: most singletons are no items (the scoring kernel updated them) — one contiguous share of [multi | single]
+    // would give the waves at the front every multi-row segment and the others next to nothing (C3 + Adam: 0.44 ms, all of it
+    // the first sixth of the grid).  Every wave takes its share of EACH list: two stretches.
+    int64_t j0 = 0, j1 = 0;
+    if (P.skip_single == 2) {
+        const int64_t sm = ((int64_t)n_multi + nw - 1) / nw, ss = ((int64_t)n_single + nw - 1) / nw;
+        i0 = min(gw * sm, (int64_t)n_multi); i1 = min(i0 + sm, (int64_t)n_multi);
+        j0 = (int64_t)n_multi + min(gw * ss, (int64_t)n_single); j1 = min(j0 + ss, total);
+    }
     static_assert(kDeferSegment <= 32, "segment_update_half keeps a segment's sources in 32 lanes");
     constexpr bool halves = HALF;   // (its own instantiation: both forms in one kernel cost the wide rows a wave per SIMD)
+    for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) { i0 = j0; i1 = j1; }
     for (int64_t base = i0; base < i1; base += 64) {
         const int64_t it = base + lane;
         Seg sg{0u, 0u, 0u};
         if (it < i1) {
             if (it < (int64_t)n_multi) sg = P.multi[it];
-            else { const uint32_t at = P.single[it - n_multi]; sg = Seg{at, 1u, P.keys[at]}; }
+            else {
+                const uint32_t at = P.single[it - n_multi];
+                sg = Seg{at, 1u, P.keys[at]};
+                if (P.skip_single == 2 && (int64_t)P.vals[at] >= P.single_from) sg.len = 0u;   // updated in place by the scoring kernel: no item
+            }
         }
         const int cnt = (int)min((int64_t)64, i1 - base);
         if constexpr (halves) {   // two items at a time, one per half of the wave (segment_update_half)
@@ -1204,7 +1225,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                 len = (uint32_t)__shfl((int)sg.len, from_lane, 64);
                 dest = (uint32_t)__shfl((int)sg.dest, from_lane, 64);
                 const uint32_t start = (uint32_t)__shfl((int)sg.start, from_lane, 64);
-                on = kk < cnt && (int64_t)dest < P.n_rows;   // (defensive: never write outside the table)
+                on = kk < cnt && (int64_t)dest < P.n_rows && len != 0u;   // (defensive: never write outside the table; len 0: no item)
                 return (on && (uint32_t)l < len) ? contrib_src(P, (int64_t)start + l) : Src{0u, 0.f};
             };
             uint32_t len_n, dest_n;
@@ -1226,10 +1247,11 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             if (k + 1 < cnt)
                 nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, k + 1),
                                       (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
-            if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
+            if ((int64_t)dest >= P.n_rows || len == 0u) continue;   // defensive: never write outside the table; len 0: no item
             segment_update<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
         }
         }
+    }
     }
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
@@ -1263,7 +1285,7 @@ __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunc
     int64_t heavy = 0, relief = 0;
     if (K.n_tables == 2 && K.relief) {
         const ApplyParams& R = K.P[1];
-        const int64_t n_multi = R.counters[GC_MULTI], n_single = R.skip_single ? 0 : R.counters[GC_SINGLE];
+        const int64_t n_multi = R.counters[GC_MULTI], n_single = R.skip_single == 1 ? 0 : R.counters[GC_SINGLE];
         const int64_t rows = (int64_t)R.counters[GC_VALID] - (int64_t)R.counters[GC_SINGLE];
         const int64_t items = n_multi + n_single;
         if (items > 0 && items <= nw) {
@@ -1327,12 +1349,14 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     A = ApplyLaunch{};
     P.table = a->table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
     P.state0 = a->state0; P.state1 = a->state1; P.tag = a->tag; P.step = a->step;
-    P.contrib = a->contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = a->skip_single;
+    P.contrib = a->contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = a->skip_single; P.single_from = a->single_from_slot;
+    EMG_REQUIRE(a->skip_single >= 0 && a->skip_single <= 2 && (a->skip_single != 2 || a->single_from_slot > 0),
+                "emg_apply_grouped: skip_single is 0, 1 or 2 (2: with single_from_slot > 0)");
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = a->lp_accum;
     P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
     A.dense = (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) && !a->deferred_dense;
-    EMG_REQUIRE(a->deferred_dense != 2 || (opt == EMG_OPT_ADAM && P.opt.lp_lambda == 0.f && a->tag && !a->skip_single),
+    EMG_REQUIRE(a->deferred_dense != 2 || (opt == EMG_OPT_ADAM && P.opt.lp_lambda == 0.f && a->tag && a->skip_single != 1),
                 "emg_apply_grouped: deferred_dense = 2 (m, v lag behind w) is Adam's, without a regulariser or in-place singletons");
     EMG_REQUIRE(a->deferred_dense != 2 || segments_path_enabled(), "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply");
     P.state_lag = a->deferred_dense == 2 ? 1 : 0;
@@ -1356,6 +1380,8 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     A.segs = w.counting && A.vec && !A.skinny && segments_path_enabled();
     EMG_REQUIRE(!P.state_lag || A.segs, "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply (counting grouping, "
                                         "16-byte aligned rows of more than 16 chunks)");
+    EMG_REQUIRE(P.skip_single != 2 || A.segs, "emg_apply_grouped: skip_single = 2 needs the descriptor-driven apply (counting grouping, "
+                                              "16-byte aligned rows of more than 16 chunks)");
     EMG_REQUIRE(!P.ctl || A.segs, "emg_apply_grouped: a device-side step record needs the descriptor-driven apply (counting "
                                   "grouping, 16-byte aligned rows of more than 16 chunks)");
     if (A.segs) {
@@ -1641,7 +1667,8 @@ static int replay_params(ReplayParams& P, int opt, float* table, int64_t n_rows,
 
 extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                                     int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
-                                    const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, void* stream) {
+                                    const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, int64_t skip_single_from,
+                                    void* stream) {
     ReplayParams P;
     int rc = replay_params(P, opt, table, n_rows, ld, k_int, state0, state1, tag, hyper, lr_hist, upto_step, lp_accum);
     if (rc != EMG_OK) return rc;
@@ -1653,6 +1680,7 @@ extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64
     if (rc != EMG_OK) return rc;
     EMG_REQUIRE(w.counting, "emg_deferred_catchup: needs the counting grouping (segment descriptors)");
     P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.keys = w.keys; P.counters = w.counters; P.task_cap = w.task_cap;
+    P.vals = w.vals; P.single_from = skip_single_from > 0 ? skip_single_from : 0;
     if (upto_step == 0) return EMG_OK;
     static const int64_t cap_env = getenv("EMG_CATCHUP_WAVES") ? atoll(getenv("EMG_CATCHUP_WAVES")) : 0;   // A/B aid
     const int64_t cap = cap_env >= 256 ? cap_env : 16384;

@@ -187,6 +187,24 @@ __device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float
     return w - P.lr * g;
 }
 
+// num / (sqrt(root) + eps) of Adagrad's and Adam's update.  EMG_OPT_FAST_RECIP (default, round 4): the hardware's v_sqrt_f32 and
+// v_rcp_f32 (1 ulp each) and one multiplication — the step is within 3 ulp of the correctly rounded form (sqrtf and an IEEE
+// division: ~25 instructions of range fix-ups each, the bulk of the arithmetic of a replayed Adam step, which is what bounds the
+// deferred pass's catch-up and the scoring kernel's in-register replay).  eps >= 1e-7 keeps the reciprocal's argument in the normal
+// range.  ONE function for every path (dense pass, catch-up, apply, in-place forms): their results stay bit-identical to each
+// other; against Keras' CPU arithmetic (parity unpinned) the difference is the one TF's own GPU kernels have.
+#ifndef EMG_OPT_FAST_RECIP
+#define EMG_OPT_FAST_RECIP 0
+#endif
+__device__ __forceinline__ float opt_ratio(float num, float root, float eps) {
+#pragma clang fp contract(off)
+#if EMG_OPT_FAST_RECIP
+    return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(root) + eps);
+#else
+    return num / (sqrtf(root) + eps);
+#endif
+}
+
 __device__ __forceinline__ void opt_update_elem(const OptParams& P, float& w, float g, float* s0, float* s1) {
 #pragma clang fp contract(off)  // every op rounded separately: identical bits wherever this is inlined
     if (P.opt == EMG_OPT_SGD) {
@@ -198,13 +216,13 @@ __device__ __forceinline__ void opt_update_elem(const OptParams& P, float& w, fl
     } else if (P.opt == EMG_OPT_ADAGRAD) {  // acc += g^2 ; w -= lr*g/(sqrt(acc)+eps)
         const float a = *s0 + g * g;
         *s0 = a;
-        w = w - P.lr * g / (sqrtf(a) + P.eps);
+        w = w - opt_ratio(P.lr * g, a, P.eps);
     } else {  // Adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t m/(sqrt(v)+eps)
         const float m = P.beta1 * (*s0) + (1.f - P.beta1) * g;
         const float v = P.beta2 * (*s1) + (1.f - P.beta2) * g * g;
         *s0 = m;
         *s1 = v;
-        w = w - P.lr_t * m / (sqrtf(v) + P.eps);
+        w = w - opt_ratio(P.lr_t * m, v, P.eps);
     }
 }
 

@@ -27,7 +27,7 @@ namespace emg {
 int train_backward_impl(const emg_backward_args* a, const Riders* riders, void* stream);                                  // emg_score.hip
 int apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const Riders* riders, void* stream);   // emg_apply.hip
 
-enum Stage { ST_PREPARE = 0, ST_FUSED, ST_FORWARD, ST_LOSS, ST_BACKWARD, ST_APPLY_ENT, ST_APPLY_REL, ST_CLIP, ST_COUNT };
+enum Stage { ST_PREPARE = 0, ST_FUSED, ST_FORWARD, ST_LOSS, ST_BACKWARD, ST_APPLY_ENT, ST_APPLY_REL, ST_CLIP, ST_CATCHUP, ST_COUNT };
 
 struct SlotState {
     emg_plan_slot buf;
@@ -166,13 +166,20 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     const bool seg_rows = c.k_int % 4 == 0 && c.k_int > 64 && c.ld_ent % 4 == 0 && c.ld_rel % 4 == 0 && c.ldc % 4 == 0 && al16(c.ent) &&
                           al16(c.rel) && al16(c.contrib_ent) && al16(c.contrib_rel) && al16(c.ent_state0) && al16(c.ent_state1) &&
                           al16(c.rel_state0) && al16(c.rel_state1);
-    const int32_t w_only = (c.lr_t_hist && c.opt == EMG_OPT_ADAM && !lp && !c.inplace && seg_rows && lag_env) ? 1 : 0;
+    // Adam in place under the deferred pass (round 4): the singletons among the NEGATIVES lag — the scoring kernel fetches (w, m, v)
+    // of such a row together, replays its missed steps in registers and updates it (emg_backward_args.lr_hist); the catch-up and
+    // the apply handle every other destination of the batch (s / o slots, rows hit more than once)
+    const bool lag_ip = c.lr_t_hist && c.inplace && c.opt == EMG_OPT_ADAM;
+    const int32_t w_only = (c.lr_t_hist && c.opt == EMG_OPT_ADAM && !lp && (!c.inplace || lag_ip) && seg_rows && lag_env) ? 1 : 0;
+    if (lag_ip) ba.lr_hist = c.lr_t_hist;
     if (c.lr_t_hist) {   // deferred dense pass (Keras Adam / LP): bring the rows this batch reads and updates up to step - 1
+        Timed t(P, ST_CATCHUP, main);
         rc = emg_deferred_catchup(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, he, c.lr_t_hist, step - 1,
-                                  lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, w_only, main);
+                                  lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, w_only,
+                                  lag_ip ? 2 * B : 0, main);
         if (rc != EMG_OK) return rc;
         rc = emg_deferred_catchup(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hr, c.lr_t_hist, step - 1,
-                                  lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, w_only, main);
+                                  lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, w_only, 0, main);
         if (rc != EMG_OK) return rc;
     }
     if (c.fused) {
@@ -216,7 +223,8 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         for (int i = 0; i < 8; ++i) aa.hyper[i] = h[i];
         if (ent_table) {
             aa.table = c.ent; aa.n_rows = c.n_ent; aa.ld = c.ld_ent; aa.state0 = c.ent_state0; aa.state1 = c.ent_state1;
-            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? 1 : 0; aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
+            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? (lag_ip ? 2 : 1) : 0; aa.single_from_slot = lag_ip ? 2 * B : 0;
+            aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
             aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
             aa.factored = c.factored; aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
         } else {
@@ -295,6 +303,13 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
                 "emg_plan_create: a deferred dense pass needs the counting grouping for both tables (emg_plan_deferred_ok): "
                 "n_ent = %lld, n_rel = %lld against %lld gradient rows per batch", (long long)cfg->n_ent, (long long)cfg->n_rel,
                 (long long)((2 + (int64_t)cfg->eta * cfg->n_sides) * cfg->cap_B));
+    if (cfg->lr_t_hist && cfg->inplace && cfg->opt == EMG_OPT_ADAM) {   // (what the in-kernel replay and the apply's skip_single = 2 need)
+        const bool cplx = cfg->model == EMG_COMPLEX || cfg->model == EMG_HOLE;
+        const int n = cplx ? cfg->k_int / 2 : cfg->k_int;
+        EMG_REQUIRE(cfg->fused && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && n % 4 == 0 && n / 4 <= 64 && cfg->k_int > 64,
+                    "emg_plan_create: in-place Adam under the deferred dense pass needs the fused step, no regulariser and 16-byte rows of 17 "
+                    "... 64 chunks (per half for complex models)");
+    }
     Plan* P = new Plan();
     P->cfg = *cfg;
     P->n_side = cfg->n_slots - 1 > 2 ? 2 : cfg->n_slots - 1;

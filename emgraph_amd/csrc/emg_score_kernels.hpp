@@ -169,6 +169,25 @@ struct GroupParams {
     double* lp_accum;                                    // IP 3: += sum |w_pre|^p over the rows updated in place
     FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
     const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
+    const float* lr_hist; int32_t upto;                  // IP 6 (Adam, deferred dense pass): learning rate of every step; rows are replayed to step `upto`
+};
+
+// In-place forms (template parameter IP of the backward / fused kernels):
+//   0  none: every gradient row goes to the contribution buffer
+//   1  plain SGD                       3  plain SGD folding an LP regulariser (p <= 3)
+//   2  stateful optimizer, state rows read chunk by chunk at the update (a dependent round trip per row: the fallback shape)
+//   4  one state row (momentum / Adagrad)   }  round 4: the state rows of a singleton's replacement entity TRAVEL WITH ITS TABLE ROW
+//   5  two state rows (Adam, dense pass)    }  in the rolling window (a slot that is no singleton re-reads the table row instead:
+//   6  two state rows, LAGGING (Adam with   }  cache hits, and no load sits under a condition) — the update waits for nothing.
+//      the deferred dense pass): (w, m, v) of a singleton are as of tag[row]; the missed steps tag+1 .. upto are replayed in
+//      registers BEFORE the row is scored (the dense pass's own update with g = 0 and each step's lr_t) — what
+//      emg_deferred_catchup does for the other rows with a pass of its own.  s / o slots are not updated in place in this form.
+template <int IP>
+struct ip_traits {
+    static constexpr int n_state = IP == 4 ? 1 : ((IP == 5 || IP == 6) ? 2 : 0);
+    static constexpr bool window_state = n_state != 0;
+    static constexpr bool replay = IP == 6;
+    static constexpr int chunkwise = (IP == 4 || IP == 5) ? 2 : IP;   // the form inplace_update runs for the s / o slots
 };
 
 #ifndef EMG_BW_THREADS
@@ -293,6 +312,70 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
         }
     }
     if (P.tag_ent && lg == 0) P.tag_ent[row] = P.step;
+}
+
+// The same update with the state rows ALREADY IN REGISTERS (IP 4 / 5 / 6: they arrived with the table row): nothing is waited for.
+template <int MODEL, int W, int NV, int LPG, int NS>
+__device__ __forceinline__ void inplace_update_regs(const GroupParams& P, const OptParams& opt, int64_t row, const Row<MODEL, W, NV>& cur,
+                                                    const Row<MODEL, W, NV>& grad, Row<MODEL, W, NV>& s0, Row<MODEL, W, NV>& s1, int lg) {
+    static_assert(W == 4, "16-byte rows");
+    constexpr int E = W * NV;
+    constexpr int HALVES = is_complex<MODEL>::value ? 2 : 1;
+    float* wrow = P.ent_rw + row * P.ld_ent;
+    float* s0row = P.ent_state0 + row * P.ld_ent;
+    float* s1row = NS == 2 ? P.ent_state1 + row * P.ld_ent : nullptr;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int c = lg + it * LPG;
+            float wv[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const int e = h * E + it * W + w;
+                wv[w] = cur.x[e];
+                opt_update_elem(opt, wv[w], grad.x[e], &s0.x[e], NS == 2 ? &s1.x[e] : nullptr);
+                __builtin_amdgcn_sched_barrier(0);   // (one sqrt / divide expansion at a time: see inplace_update)
+            }
+            if (c < P.nchunks) {
+                const int off = h * P.khalf + c * W;
+                *reinterpret_cast<float4*>(wrow + off) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                *reinterpret_cast<float4*>(s0row + off) = make_float4(s0.x[h * E + it * W], s0.x[h * E + it * W + 1], s0.x[h * E + it * W + 2], s0.x[h * E + it * W + 3]);
+                if constexpr (NS == 2)
+                    *reinterpret_cast<float4*>(s1row + off) = make_float4(s1.x[h * E + it * W], s1.x[h * E + it * W + 1], s1.x[h * E + it * W + 2], s1.x[h * E + it * W + 3]);
+            }
+        }
+    }
+    if (P.tag_ent && lg == 0) P.tag_ent[row] = P.step;
+}
+
+// IP 6: (w, m, v) of a row last written at step `from`, brought to step P.upto in registers: the dense pass's update of each
+// missed step (g = 0, that step's lr_t) — emg_apply.hip::replay_finish's arithmetic, so the same bits.  lrv: lane l holds the
+// learning rate of step from + 1 + l (fetched with the row); steps beyond 64 read the table.  Lanes past the row's end keep w.
+template <int MODEL, int W, int NV, int LPG>
+__device__ __forceinline__ void replay_in_window(const GroupParams& P, const OptParams& opt0, int32_t from, float lrv, Row<MODEL, W, NV>& w,
+                                                 Row<MODEL, W, NV>& m, Row<MODEL, W, NV>& v, int lg) {
+    static_assert(LPG == 64, "the replay's step count is per wave");
+    constexpr int E = W * NV;
+    OptParams opt = opt0;
+    const int n = P.upto - from;
+    auto one_step = [&](float lr) {
+        opt.lr = opt.lr_t = lr;
+#pragma unroll
+        for (int e = 0; e < Row<MODEL, W, NV>::N; ++e) {
+            const bool on = lg + ((e % E) / W) * LPG < P.nchunks;
+            float g = 0.f, wv = w.x[e];
+            asm volatile("" : "+v"(g));   // (opaque zero: opt_update_elem's own instructions and roundings, as the dense pass executes them)
+            opt_update_elem(opt, wv, g, &m.x[e], &v.x[e]);
+            w.x[e] = on ? wv : w.x[e];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // the first 64 steps: learning rates from the lane register — NO memory operation in this loop (a load here, even one never
+    // executed, would make every wait of the rolling window a vmcnt(0))
+    const int n1 = n < 64 ? n : 64;
+    for (int i = 0; i < n1; ++i) one_step(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(lrv), i)));
+    for (int i = 64; i < n; ++i) one_step(P.lr_hist[from + 1 + i]);   // (a row untouched for more than 64 steps)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,6 +507,15 @@ __device__ __forceinline__ emg_f4 vm_load16_async(const float* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+__device__ __forceinline__ float vm_load4_async(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// registers written by an asynchronous load issued before a hand-written wait: no use of them may move above it
+__device__ __forceinline__ void vm_landed(emg_f4& a) { asm volatile("" : "+v"(a) : : "memory"); }
+__device__ __forceinline__ void vm_landed(float& a) { asm volatile("" : "+v"(a) : : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_only() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a, emg_f4& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void vm_wait(emg_f4& a, emg_f4& b, emg_f4& c, emg_f4& d) {
@@ -469,15 +561,22 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     // every join with s_waitcnt vmcnt(0), which also waits for the replacement rows just requested: the rolling window
     // below then holds ONE row in flight, not U (PMC, C3: 1572 cycles mean read latency, 1.7 MB in flight on the chip).
     const int first = (threadIdx.x & 63) / LPG * LPG;
+    using IT = ip_traits<IP>;
+    constexpr int NS = IT::n_state;
+    static_assert(!IT::window_state || (W == 4 && LPG == 64 && FUSED), "IP 4 / 5 / 6: fused kernels of 16-byte rows, a wave per group");
     int my_code = 0, my_flag = 0, my_pos = 0, my_flag_so = 0;   // my_pos: where the negative's factor goes (its slot's sorted position)
+    int my_tag = 0;                                              // IP 6: the step the singleton's row was last written at
     auto gather = [&](int c0) {
         const int j = c0 + lg;
         my_code = j < P.eta ? P.codes[(int64_t)j * B + g] : 0;
         if (kBilinear && P.fac.coef) my_pos = j < P.eta ? (int)P.fac.pos_of_slot[(int64_t)j * B + g] : 0;
         if constexpr (IP != 0) my_flag = j < P.eta ? (int)P.single_ent[2 * B + (int64_t)j * B + g] : 0;
+        if constexpr (IT::replay) my_tag = (j < P.eta && my_flag) ? P.tag_ent[my_code & 0x7fffffff] : P.upto;
     };
     gather(0);
-    if constexpr (IP != 0) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
+    if constexpr (IP != 0 && !IT::replay) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
+    OptParams wopt = P.opt;   // (the window forms know their optimizer family: the update's switch folds away)
+    if constexpr (NS == 2) wopt.opt = EMG_OPT_ADAM;
     R qo, qs, Ao, As;
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f, lp_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
@@ -509,7 +608,8 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         gpos = P.g_pos[g];
     }
 
-    constexpr int U = EMG_BW_U;
+    // rows in flight per wave: U table rows — with their state rows (IP 4 / 5 / 6) U * (1 + NS) rows, held to ~48 registers
+    constexpr int U = !IT::window_state ? EMG_BW_U : (R::N * (1 + NS) * 4 <= 48 ? 4 : (R::N * (1 + NS) * 3 <= 48 ? 3 : 2));
     int chunk0 = 0, chunk1 = min(P.eta, LPG);   // the negatives [chunk0, chunk1) are the ones my_code / my_flag / my_pos describe
     auto code_of = [&](int j) -> int32_t { return group_lane_value<LPG>(my_code, first, j - chunk0); };
     auto flag_of = [&](int j) -> int {   // negative j of the current chunk
@@ -523,13 +623,68 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     // the replacement rows of negatives j0 .. j0+U-1.  Bilinear models take them RAW (lanes past the row's end hold a copy of
     // its last chunk): the query rows are zero there, so products, factored rows and in-place updates (guarded by the chunk
     // index) never see them — and no select sits between the load and its first use
+    // IP 4 / 5 / 6: a slot of the window = the replacement row AND the optimizer state rows of a singleton (any other slot re-reads
+    // its table row: the same lines, just requested — the loads are unconditional, only their address is selected) AND, for the
+    // lagging form, the learning rates of the steps the row missed.  All of them asynchronous loads (inline assembly) with a
+    // hand-written wait: between a slot's loads and its use lie the other slots' consumption — the replay LOOP, the in-place /
+    // contribution branch — and hipcc's wait for compiler-visible loads across that control flow is vmcnt(0), which also waits
+    // for the refill just issued (ISA of the first version: no load in flight while a slot is worked on).
+    constexpr int PIECES_S = NV * (is_complex<MODEL>::value ? 2 : 1);              // 16-byte loads per row and lane
+    constexpr int LPS = PIECES_S * (1 + NS) + (IT::replay ? 1 : 0);                 // vector-memory loads per slot
+    static_assert(!IT::window_state || (U - 1) * LPS <= 63, "vmcnt is a 6-bit counter");
+    R st0[IT::window_state ? U : 1], st1[NS == 2 ? U : 1];
+    int32_t tg[IT::replay ? U : 1];
+    float lrv[IT::replay ? U : 1];
+    emg_f4 aw[IT::window_state ? U : 1][IT::window_state ? PIECES_S : 1], a0[IT::window_state ? U : 1][IT::window_state ? PIECES_S : 1],
+           a1[NS == 2 ? U : 1][NS == 2 ? PIECES_S : 1];
+    auto issue_slot = [&](int u, int jn, int32_t repl) {
+        if constexpr (IT::window_state) {
+            const bool f = flag_of(jn) != 0;
+            const float* wb = P.ent + (int64_t)repl * P.ld_ent;
+            const float* b0 = f ? P.ent_state0 + (int64_t)repl * P.ld_ent : wb;
+            const float* b1 = (NS == 2 && f) ? P.ent_state1 + (int64_t)repl * P.ld_ent : wb;
+#pragma unroll
+            for (int h = 0; h < (is_complex<MODEL>::value ? 2 : 1); ++h)
+#pragma unroll
+                for (int it = 0; it < NV; ++it) {
+                    const int off = h * P.khalf + 4 * min(lg + it * LPG, P.nchunks - 1);   // (past the row's end: its last chunk again)
+                    aw[u][h * NV + it] = vm_load16_async(wb + off);
+                    a0[u][h * NV + it] = vm_load16_async(b0 + off);
+                    if constexpr (NS == 2) a1[u][h * NV + it] = vm_load16_async(b1 + off);
+                }
+            if constexpr (IT::replay) {
+                tg[u] = group_lane_value<LPG>(my_tag, first, jn - chunk0);
+                lrv[u] = vm_load4_async(P.lr_hist + min(tg[u] + 1 + lg, P.upto));
+            }
+        }
+    };
+    auto unpack = [&](const emg_f4 (&src)[IT::window_state ? PIECES_S : 1], R& r, bool zero_tail) {
+#pragma unroll
+        for (int q = 0; q < PIECES_S; ++q) {
+            const bool on = !zero_tail || lg + (q % NV) * LPG < P.nchunks;
+            r.x[4 * q + 0] = on ? src[q].x : 0.f; r.x[4 * q + 1] = on ? src[q].y : 0.f;
+            r.x[4 * q + 2] = on ? src[q].z : 0.f; r.x[4 * q + 3] = on ? src[q].w : 0.f;
+        }
+    };
+    auto take_slot = [&](int u, R& w_row) {   // wait for THIS slot's loads: at most the (U - 1) younger slots' may still be in flight
+        if constexpr (IT::window_state) {
+            vm_wait_only<(U - 1) * LPS>();
+#pragma unroll
+            for (int q = 0; q < PIECES_S; ++q) { vm_landed(aw[u][q]); vm_landed(a0[u][q]); if constexpr (NS == 2) vm_landed(a1[u][q]); }
+            if constexpr (IT::replay) vm_landed(lrv[u]);
+            unpack(aw[u], w_row, !kBilinear);   // (TransE: lanes past the row's end must hold zeros; bilinear models meet zero query rows there)
+            unpack(a0[u], st0[u], false);
+            if constexpr (NS == 2) unpack(a1[u], st1[u], false);
+        }
+    };
     auto fetch = [&](int j0, int32_t (&code)[U], R (&re)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) code[u] = code_of(min(j0 + u, chunk1 - 1));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int32_t repl = code[u] & 0x7fffffff;
-            load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+            if constexpr (IT::window_state) issue_slot(u, min(j0 + u, chunk1 - 1), repl);
+            else load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
         }
     };
     // ROLLING window of U replacement rows: as soon as a negative's row has been consumed (score, gradient, in-place
@@ -544,7 +699,8 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     R re[U];
     constexpr int PIECES = NV * (is_complex<MODEL>::value ? 2 : 1);   // 16-byte loads per row and lane
     constexpr bool kAsync = EMG_BW_ASYNC != 0 && EMG_BW_ROLL != 0 && kBilinear && W == 4 && FUSED && (PIECES == 1 || PIECES == 2 || PIECES == 4) &&
-                            (U - 1) * PIECES <= 15;
+                            (U - 1) * PIECES <= 15 && !IT::window_state;
+    static_assert(!IT::window_state || EMG_BW_ROLL != 0, "IP 4 / 5 / 6 use the rolling window");
     emg_f4 pa[kAsync ? U : 1][kAsync ? PIECES : 1];
     auto issue_row = [&](emg_f4 (&dst)[kAsync ? PIECES : 1], int32_t repl) {   // all lanes load: past the row's end, its last chunk again
         const float* base = P.ent + (int64_t)repl * P.ld_ent;
@@ -591,6 +747,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             const bool keep_s = code[u] < 0;  // subject kept => the OBJECT was replaced
             const int32_t repl = code[u] & 0x7fffffff;
             if constexpr (kAsync) take_row(pa[u], re[u]);
+            if constexpr (IT::window_state) take_slot(u, re[u]);
+            if constexpr (IT::replay) {   // a singleton behind the table's step: replay the steps it missed, THEN score it
+                if (flag_of(j) && tg[u] > 0 && tg[u] < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, tg[u], lrv[u], re[u], st0[u], st1[u], lg);
+            }
             float nrm = 0.f;
             if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
                 if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
@@ -614,7 +774,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             else neg_grads<MODEL, W, NV, false>(qs, re[u], gi, row, As);
             if (active) {
                 const int64_t slot = 2 * B + (int64_t)j * B + g;
-                if (IP != 0 && flag_of(j)) inplace_update<MODEL, W, NV, LPG, IP>(P, repl, re[u], row, lg, lp_acc);
+                if (IP != 0 && flag_of(j)) {
+                    if constexpr (IT::window_state) inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, repl, re[u], row, st0[u], st1[NS == 2 ? u : 0], lg);
+                    else inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, repl, re[u], row, lg, lp_acc);
+                }
                 else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
                     const int at = group_lane_value<LPG>(my_pos, first, j - chunk0);
                     if (lg == 0) P.fac.coef[at] = gi;
@@ -628,6 +791,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
                 const int jn = min(j + U, chunk1 - 1);
                 code[u] = code_of(jn);
                 if constexpr (kAsync) issue_row(pa[u], code[u] & 0x7fffffff);
+                else if constexpr (IT::window_state) issue_slot(u, jn, code[u] & 0x7fffffff);
                 else load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
                 if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)jn * B + g];
             }
@@ -642,6 +806,15 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             if constexpr (PIECES == 1) vm_wait<0>(pa[u][0]);
             else if constexpr (PIECES == 2) vm_wait<0>(pa[u][0], pa[u][1]);
             else vm_wait<0>(pa[u][0], pa[u][1], pa[u][2], pa[u][3]);
+        }
+    }
+    if constexpr (IT::window_state) {   // (the refills issued past the end are never taken: their registers stay theirs until the loads have landed)
+        vm_wait_only<0>();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int q = 0; q < PIECES_S; ++q) { vm_landed(aw[u][q]); vm_landed(a0[u][q]); if constexpr (NS == 2) vm_landed(a1[u][q]); }
+            if constexpr (IT::replay) vm_landed(lrv[u]);
         }
     }
     if (kBilinear && P.fac.coef && active) {   // the two query rows every factored negative of this group points at
@@ -660,9 +833,11 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IP>(P, s, rs, gs, lg, lp_acc);
+        // (IP 6: the s / o rows' state lags too and their rows were scored at the start — they go through the apply)
+        constexpr int IPC = IT::chunkwise;
+        if (IP != 0 && !IT::replay && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IPC>(P, s, rs, gs, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IP>(P, o, ro, go, lg, lp_acc);
+        if (IP != 0 && !IT::replay && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IPC>(P, o, ro, go, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
     if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place

@@ -242,22 +242,31 @@ class Trainer:
         self._alloc_scratch(int(batch_size))
 
     def _choose_inplace(self, B):
-        """In-place singleton updates are the plain-SGD form of the step: the fused kernel reads a singleton's row anyway
-        and writes it back updated (measured equal in speed to the contribution form of the kernel), the apply never sees 70 % of C3's
-        slots.  With a STATEFUL optimizer the in-place form also reads and writes the state rows from inside the scoring
-        loop (224 VGPRs for complex rows, 2 waves per SIMD, a dependent round trip per update) while the apply moves the
-        same bytes with everything in flight; measured (MI355X, in place / through the apply, ms per step): C1 Adam
-        0.081 / 0.078, C1 at B = 6900 0.268 / 0.148, at B = 27 600 0.488 / 0.468, C1 Adagrad 0.064 / 0.064, C3 Adagrad
-        0.842 / 0.755, C3 Adam 2.42 / 2.36 (Keras Adam's dense pass dominates), C2 0.062 / 0.058, C5 0.152 / 0.130 — never
-        better, so only SGD takes it (round 3, late: with the state row fetched alongside its table row in the rolling window
-        the stateful instantiation needs 283 registers for complex rows — one wave per SIMD — and C3 Adagrad took 1.00 against
-        0.74 through the apply: dropped).  Results are the same bits either way (one optimizer rule, one summation order:
+        """In-place singleton updates: the fused kernel reads a singleton's row anyway and writes it back updated — no contribution
+        row, and the apply never sees 70 % of C3's slots.  Plain SGD always takes it.  A STATEFUL optimizer takes it where the
+        kernel can fetch the optimizer state rows together with the table row (round 4: fused kernels, 16-byte rows of at most 64
+        chunks — emg_score_kernels.hpp::ip_traits 4 / 5 / 6): round 3's form read the state at the update, a dependent round trip
+        per row at one wave per SIMD, and lost to the apply everywhere (C1 Adam 0.081 / 0.078 ms per step in place / through the
+        apply, C3 Adagrad 0.842 / 0.755).  Under the deferred dense pass (Adam on a large table) the singletons among the negatives
+        are replayed inside the kernel as they are gathered: (w, m, v) read once and written once where catch-up + scoring + apply
+        moved the row twelve times.  Results are the same bits either way (one optimizer rule, one summation order:
         tests/test_config_widths.py::test_inplace_choice_does_not_change_bits)."""
         if not self._inplace_wanted or self.batch_sharded:
             return False
+        stateful = self.opt_id != L.OPT_SGD
+        n_cols = self.k_int // 2 if self.model_id in (L.COMPLEX, L.HOLE) else self.k_int
+        window = self.fused and n_cols % 4 == 0 and n_cols // 4 <= 64 and os.environ.get("EMG_INPLACE_STATE", "1") != "0"
+        # what CAN run in place: SGD anything; a stateful optimizer anything (window form or chunk-wise) unless its dense pass is
+        # deferred — then only Adam through the window form's replay, finished by the descriptor-driven apply (rows of > 16 chunks)
+        can = not (stateful and self.deferred) or (window and self.opt_id == L.OPT_ADAM and self.reg is None and self.k_int > 64)
         if os.environ.get("EMG_INPLACE") in ("0", "1"):      # A/B aid
-            return os.environ["EMG_INPLACE"] == "1"
-        return self.opt_id == L.OPT_SGD or bool(os.environ.get("EMG_INPLACE_ALWAYS"))
+            return os.environ["EMG_INPLACE"] == "1" and can
+        if not stateful or os.environ.get("EMG_INPLACE_ALWAYS"):
+            return can
+        # small batches (the graph-replay range) stay with the apply: its launch is latency-bound there and does not shrink with its
+        # item count, so the in-place work only lengthens the scoring kernel (measured: C1 0.0778 / 0.0747, C2 0.0637 / 0.0585, C5
+        # 0.1527 / 0.1319 ms per step in place / through the apply; C3 Adagrad 0.612 / 0.695, C3 Adam 0.90 / 1.15)
+        return can and window and (2 + self.eta_total) * B > GRAPH_MAX_ROWS
 
     def _alloc_scratch(self, B):
         if B <= self._cap:
@@ -422,7 +431,7 @@ class Trainer:
             import ctypes as C
             ms, cnt = (C.c_float * 9)(), (C.c_int32 * 9)()
             L.check(L.load().emg_plan_stage_ms(self.plan, ms, cnt), "emg_plan_stage_ms")
-            names = ("prepare", "fused", "forward", "loss", "backward", "apply_ent", "apply_rel", "clip")
+            names = ("prepare", "fused", "forward", "loss", "backward", "apply_ent", "apply_rel", "clip", "catchup")
             return {n: [float(ms[i])] for i, n in enumerate(names) if cnt[i] > 0}
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.stage_events or {}).items()}
 

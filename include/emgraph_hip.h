@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 5
+#define EMG_ABI_VERSION 6
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */
@@ -218,6 +218,13 @@ typedef struct emg_backward_args {
     void* fac_ws_ent; int64_t fac_ws_ent_bytes;
     int64_t layout_B; const void* ctl;   /* as in emg_prepare_args: layout of fac_ws_ent; device record, pos = row 0 of the resident set */
     double* lp_accum;   /* folded LP with in-place updates (below): += sum |w|^p (pre-update) over the rows updated in place */
+    /* lr_hist != NULL (EMG_OPT_ADAM in place, fused loss, deferred dense pass — see emg_deferred_catchup): the rows of SINGLETON
+     * NEGATIVES are as of tag_ent[row]; the kernel fetches (w, m, v) of such a row together, replays the steps tag + 1 .. step - 1 in
+     * registers (the dense pass's update with g = 0 and lr_hist[s]), scores the row, applies this step's update and writes
+     * (w, m, v, tag = step): one read and one write of the three rows where catch-up + scoring + apply moved twelve.  The subject /
+     * object slots are NOT updated in place in this form: finish with emg_apply_grouped_ex(skip_single = 2, single_from_slot =
+     * 2 * B) after emg_deferred_catchup(..., skip_single_from = 2 * B) brought every other row of the batch up to date. */
+    const float* lr_hist;
 } emg_backward_args;
 /* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
  * only for opt = EMG_OPT_SGD — a singleton row is then updated in place with g + lambda p |w|^(p-1) sign(w), the rule the
@@ -258,6 +265,8 @@ typedef struct emg_apply_args {
     int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
     int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below;
                                                   * 2: the same, and the catch-up ran with w_only (m, v of the destinations lag behind w) */
+    int64_t single_from_slot;            /* skip_single = 2: only the singletons whose contribution slot is >= this were updated in place (the
+                                          * negatives' slots start at 2 * B: emg_backward_args.lr_hist); the others are applied here */
 } emg_apply_args;
 int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
 int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);
@@ -275,10 +284,13 @@ int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, voi
  * finishes with one wave each (the grouping's multi / single lists, gaps of at most 64 steps) only w is written back — m, v
  * and tag[row] stay as of the row's last write, and the apply redoes their decay over the missed steps in registers
  * (two multiplications per element and step) instead of this call writing and the apply re-reading both state rows.
- * Same bits. */
+ * Same bits.
+ * skip_single_from > 0: singleton destinations whose contribution slot is >= it are left alone — the scoring kernel replays them
+ * itself as it gathers them (emg_backward_args.lr_hist). */
 int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                          int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
-                         const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, void* stream);
+                         const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, int64_t skip_single_from,
+                         void* stream);
 int emg_deferred_materialize(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                              int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
                              void* stream);
@@ -633,7 +645,7 @@ int emg_plan_deferred_ok(int64_t cap_B, int32_t eta_total, int64_t n_ent, int64_
 int emg_plan_run(void* plan, const emg_plan_batch* batches, int32_t n, int32_t first_step, const float* hyper6s,
                  void* stream);
 /* HIP-event timing of the next max_samples launches of every stage (0 = off); avg_ms / counts: 9 entries =
- * prepare, fused, forward, loss, backward, apply_ent, apply_rel, clip, (unused) */
+ * prepare, fused, forward, loss, backward, apply_ent, apply_rel, clip, catchup (the deferred pass's emg_deferred_catchup calls) */
 int emg_plan_timing(void* plan, int32_t max_samples);
 int emg_plan_stage_ms(void* plan, float* avg_ms, int32_t* counts);
 int emg_plan_destroy(void* plan);

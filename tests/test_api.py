@@ -353,8 +353,9 @@ def test_constructor_errors_match_reference():
                dict(loss="bce")):
         with pytest.raises(ValueError):
             TransE(**kw)
-    with pytest.raises(ValueError):
-        TransE(k=4, epochs=1, embedding_model_params={"norm": 3}).fit(TOY)
+    with pytest.raises(ValueError):      # (any POSITIVE order trains — TransE.py:208-216 — but not this)
+        TransE(k=4, epochs=1, embedding_model_params={"norm": -1}).fit(TOY)
+    TransE(k=4, epochs=1, batches_count=1, embedding_model_params={"norm": 3}).fit(TOY)
     assert ComplEx(k=6).internal_k == 12
     m = TransE(k=3, eta=5)
     assert m.get_hyperparameter_dict()["eta"] == 5 and m.get_hyperparameter_dict()["optimizer"] == "adam"

@@ -347,11 +347,9 @@ def test_inplace_choice_does_not_change_bits(monkeypatch, model, k, opt):
     X = np.stack([s, rs.randint(0, n_rel, 2 * B), o], 1).astype(np.int32)
     sc = float(F32(2 / k)) if model == "HolE" else 1.0
 
-    def run(always):
-        if always:
-            monkeypatch.setenv("EMG_INPLACE_ALWAYS", "1")
-        else:
-            monkeypatch.delenv("EMG_INPLACE_ALWAYS", raising=False)
+    def run(inplace, window=True):
+        monkeypatch.setenv("EMG_INPLACE", "1" if inplace else "0")
+        monkeypatch.setenv("EMG_INPLACE_STATE", "1" if window else "0")
         tr = Trainer(mid, ki, sc, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.01}, batches_count=2,
                      seed=3)
         tr.set_training_set(X, B)
@@ -361,13 +359,66 @@ def test_inplace_choice_does_not_change_bits(monkeypatch, model, k, opt):
         states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
         return tr.inplace, Et, Rt, states, tr.read_loss()
 
-    a, b = run(True), run(False)
-    assert a[0] and not b[0], "this shape is meant to make the Trainer choose contribution rows for a stateful optimizer"
+    # in place with the state rows travelling in the rolling window (round 4: ip 4 / 5) | through the contribution buffer | in place
+    # with the state read chunk by chunk at the update (round 3: ip 2)
+    a, b, c = run(True), run(False), run(True, window=False)
+    assert a[0] and not b[0] and c[0]
+    for other in (b, c):
+        np.testing.assert_array_equal(a[1], other[1])
+        np.testing.assert_array_equal(a[2], other[2])
+        for x, y in zip(a[3], other[3]):
+            np.testing.assert_array_equal(x, y)
+        assert a[4] == other[4]
+
+
+@pytest.mark.parametrize("model,k,case", [("ComplEx", 52, "fifth"), ("DistMult", 68, "fifth"), ("TransE", 100, "fifth"), ("HolE", 128, "fifth"),
+                                          ("ComplEx", 100, "long_gaps"), ("DistMult", 200, "long_gaps"), ("TransE", 256, "hubs")])
+def test_adam_replayed_in_the_scoring_kernel_gives_the_dense_pass_bits(monkeypatch, model, k, case):
+    """Keras Adam under the deferred dense pass with in-place singletons (ip 6, round 4): the scoring kernel fetches (w, m, v) of a
+    singleton negative's row together, replays the steps the row missed (the dense pass's own update, g = 0, each step's lr_t) in
+    registers, scores it, updates it and writes the three rows once; emg_deferred_catchup and the apply (skip_single = 2) handle
+    the subject / object slots and the rows hit more than once.  Tables, both state arrays and the loss must equal the DENSE form
+    with every gradient row through the apply, bit for bit: on a table of which a batch touches a fifth, on one where a fifth of
+    the gaps is longer than the 64 learning rates a lane register holds (the replay then reads the table), and with hub rows
+    (block tasks finished by several waves)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "HolE": L.HOLE, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    if case == "fifth":
+        n_ent, n_rel, B, eta, nb, epochs = 40000, 30, 1024, 6, 4, 3
+    else:
+        n_ent, n_rel, B, eta, nb, epochs = 20000, 12, 128, 2, 24, 3
+    ki = 2 * k if model in ("ComplEx", "HolE") else k
+    sc = float(F32(2 / k)) if model == "HolE" else 1.0
+    rs = np.random.RandomState(5)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+    if case == "hubs":
+        hub = (np.arange(nb * B) // B) % 2 == 0
+        X[hub & (rs.rand(nb * B) < 0.6), 0] = 7
+        X[hub & (rs.rand(nb * B) < 0.4), 2] = 11
+
+    def run(deferred, inplace):
+        monkeypatch.setenv("EMG_INPLACE", "1" if inplace else "0")
+        # (TransE at k = 256: |score| > 75, where the NLL's clip has no gradient — the pairwise loss has)
+        tr = Trainer(mid, ki, sc, E0, R0, eta, loss="pairwise" if model == "TransE" else "nll", optimizer="adam", optimizer_params={"lr": 0.01},
+                     batches_count=nb, seed=3, deferred_dense=deferred)
+        tr.set_training_set(X, B)
+        assert tr.deferred == deferred and tr.inplace == inplace
+        for ep in range(1, epochs + 1):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1, prefetch=[(((b + 1) % nb) * B, B, ep + (b + 1) // nb, (b + 1) % nb + 1)])
+        Et, Rt = tr.tables_numpy()
+        return Et, Rt, [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel], tr.read_loss()
+
+    a, b = run(True, True), run(False, False)
+    np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
-    np.testing.assert_array_equal(a[2], b[2])
-    for x, y in zip(a[3], b[3]):
+    for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
-    assert a[4] == b[4]
+    assert a[3] == b[3]
+    assert not np.array_equal(a[0], E0)
 
 
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
