@@ -252,8 +252,7 @@ class StepRunner:
             out["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur,
                              "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
             ns = N_STATE[self.w["optimizer"]]
-            lag_ip = bool(tr.inplace and tr.deferred and self.w["optimizer"] == "adam")   # (s / o slots go through the apply in this form)
-            if lag_ip:
+            if getattr(tr, "inplace_mode", 0) == 2 and tr.deferred:   # Adam's lagging form: the s / o slots go through the apply
                 n_single = int(sl["single"][2 * B:n_ce].sum().item())
                 out["_batch"]["singleton_slots_in_place"] = n_single
             for name, v in ms.items():
@@ -738,6 +737,18 @@ def main():
     }
     if world > 1 and r.sharding == "batch":
         line["xgmi_bytes_per_step_per_rank"] = int(r.tr.xgmi_bytes / max(1, r.tr.step_count))
+        # what the two forms of the gradient exchange put on the links per step and rank (uniform destinations; the sums' all-gather
+        # is the same for both): FULL ROWS (implemented: every gradient row travels to the owner of its destination) against the
+        # FACTORED form of the bilinear models (not implemented: a negative's row is g * q, so a group would send its subject /
+        # object / relation rows to their owners, its two query rows to every owner that holds one of its negatives — all of
+        # them at eta = 20 — and 12 bytes per negative)
+        row, W_, Bl_, eta_ = 4 * r.k_full, world, r.B0, r.eta
+        away = (W_ - 1) / W_
+        owners_hit = W_ * (1 - (1 - 1 / W_) ** eta_)          # owners that hold at least one of a group's negatives
+        line["exchange_bytes_model_per_step_per_rank"] = {
+            "full_rows_out": int(Bl_ * ((2 + eta_) * away * (row + 8) + away * (row + 8))),
+            "factored_out": int(Bl_ * (3 * away * (row + 8) + 2 * max(0.0, owners_hit - 1) * row + eta_ * away * 12)),
+            "note": "measured: xgmi_bytes_per_step_per_rank (full rows out + the padded all-gather of the summed rows in)"}
     if args.sustained_seconds > 0:
         n = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
         dts, tis = r.timed(n)

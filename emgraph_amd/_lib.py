@@ -85,6 +85,7 @@ class BackwardArgs(C.Structure):
         ("layout_B", _i64), ("ctl", _p),
         ("lp_accum", _p),
         ("lr_hist", _p),
+        ("inplace_window", _i32), ("reserved2", _i32),
     ]
 
 
@@ -92,6 +93,7 @@ SIGNATURES.update({
     "emg_build_dest": (_int, [_p, _i64, _i32, _p, _p, _p, _p]),
     "emg_train_backward_ex": (_int, [C.POINTER(BackwardArgs), _p]),
     "emg_group_dest": (_int, [_p, _i64, _i64, _p, _i64, _p, _p]),
+    "emg_group_dest_keyed": (_int, [_p, _p, _i64, _i64, _p, _i64, _p]),
     "emg_apply_grouped": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,
                                  C.POINTER(_f32), _p, _p, _i64, _p]),
     "emg_apply_grouped_factored": (_int, [_int, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _i64, _i32,

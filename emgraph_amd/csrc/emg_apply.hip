@@ -1169,6 +1169,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     const uint32_t n_multi = P.counters[GC_MULTI];
     const uint32_t n_single = P.skip_single == 1 ? 0u : P.counters[GC_SINGLE];
     const uint32_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
+    const int64_t single_from = (P.ctl && P.skip_single == 2) ? 2 * (int64_t)P.ctl->B : P.single_from;   // (graph node: the batch size is the record's)
     float lp_acc = 0.f;
     if (n_tasks && partial) {
         const unsigned per = waves_per_task(P, nchunks);
@@ -1213,7 +1214,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             else {
                 const uint32_t at = P.single[it - n_multi];
                 sg = Seg{at, 1u, P.keys[at]};
-                if (P.skip_single == 2 && (int64_t)P.vals[at] >= P.single_from) sg.len = 0u;   // updated in place by the scoring kernel: no item
+                if (P.skip_single == 2 && (int64_t)P.vals[at] >= single_from) sg.len = 0u;   // updated in place by the scoring kernel: no item
             }
         }
         const int cnt = (int)min((int64_t)64, i1 - base);

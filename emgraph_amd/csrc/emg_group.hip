@@ -252,6 +252,34 @@ extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, vo
     return counting_tail(G, n, 0, st);
 }
 
+// emg_group_dest with an explicit ORDER KEY: the contributions of a destination are ordered by ascending order_key[i] (distinct
+// within a destination) instead of by input index — the owner of a table range in the batch-sharded step receives gradient rows
+// from every rank and must add them in the order of their slots in the GLOBAL batch (what one GPU does).  The apply then finds
+// row i of the receive buffer through the factored arrays (srcrow = i, coef = 1): emg_apply_grouped_factored.
+extern "C" int emg_group_dest_keyed(const int32_t* dest, const uint32_t* order_key, int64_t n, int64_t n_rows, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    EMG_REQUIRE(n >= 0 && n_rows > 0 && n_rows < ((int64_t)1 << 31), "emg_group_dest_keyed: bad sizes");
+    if (n == 0) return EMG_OK;
+    EMG_REQUIRE(dest && order_key && workspace, "emg_group_dest_keyed: null pointer");
+    EMG_REQUIRE(n < ((int64_t)1 << 31), "emg_group_dest_keyed: too many contributions");
+    hipStream_t st = (hipStream_t)stream;
+    GroupWs w;
+    int rc = group_ws_layout(workspace, workspace_bytes, n, n_rows, 0, &w);
+    if (rc != EMG_OK) return rc;
+    if (!w.counting) return fail(EMG_ENOSUP, "emg_group_dest_keyed: needs the counting grouping (n_rows <= 16 n + 2^20)");
+    rc = clean_ws(w, workspace, st);
+    if (rc != EMG_OK) return rc;
+    GroupLaunch G{};
+    G.n_tables = 1; G.B = 0;
+    fill_table(G.t[0], w, dest, n, 0, n_rows, nullptr, nullptr);
+    G.t[0].order_key = order_key;
+    G.t[1] = G.t[0];
+    G.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, 256);
+    hipLaunchKernelGGL(group_hist_kernel, dim3(G.split_n), dim3(256), 0, st, G);
+    EMG_LAUNCH_CHECK();
+    return counting_tail(G, n, 0, st);
+}
+
 // internal form: layout_B > 0 sizes the workspaces' layout for that many positives (a plan's capacity) and ctl, if given,
 // is the device record the kernels read the batch from
 int launch_riders_alone(const Riders& R, hipStream_t st) {

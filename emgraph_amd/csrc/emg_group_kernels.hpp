@@ -19,6 +19,9 @@ struct TableGroup {
     Seg* multi; uint32_t* single; LongTask* tasks; uint32_t task_cap; int32_t scan_blocks;
     int32_t* arrive; uint32_t* counters; unsigned long long* status;
     uint8_t* flags; const int32_t* fac_codes;   // optional: per-slot singleton flags; factored contributions (codes of the batch)
+    // optional (emg_group_dest_keyed): the order of a destination's contributions is ascending order_key[i] instead of ascending
+    // input index i; vals[q] then holds the key and srcrow[q] the input index (coef[q] = 1): the apply reads rows through srcrow
+    const uint32_t* order_key;
 };
 struct GroupLaunch {
     TableGroup t[2]; int32_t n_tables; int32_t pad0;
@@ -183,7 +186,8 @@ __device__ __forceinline__ void group_scatter_body(const GroupLaunch& G, unsigne
         single = T.off[d + 1] - start == 1u;
         // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
         const uint32_t pos = single ? start : (uint32_t)atomicAdd(T.cnt + d, 1);
-        T.tmpv[pos] = (uint32_t)i;
+        T.tmpv[pos] = T.order_key ? T.order_key[i] : (uint32_t)i;
+        if (T.order_key) T.pos_of_slot[pos] = (uint32_t)i;
         T.keys[pos] = (uint32_t)d;
     }
     if (T.flags) T.flags[i] = single ? 1 : 0;
@@ -227,6 +231,7 @@ __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned 
     }
     const uint32_t q = start + rank;
     T.vals[q] = mine;
+    if (T.order_key) { T.srcrow[q] = T.pos_of_slot[t]; T.coef[q] = 1.f; }   // (pos_of_slot: the scatter's second payload here)
     if ((uint32_t)t == start) T.cnt[d] = 0;                 // the cursor has done its work: the histogram is zero again
     if (T.fac_codes) {
         const uint32_t fac_B = (uint32_t)(G.ctl ? G.ctl->B : G.B);

@@ -152,6 +152,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     ba.pos = pos; ba.B = B; ba.codes = sl.buf.codes; ba.margin = c.margin; ba.loss_accum = c.loss_accum;
     ba.contrib_ent = c.contrib_ent; ba.contrib_rel = c.contrib_rel; ba.ldc = c.ldc;
     ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
+    ba.inplace_window = c.inplace == 2 ? 1 : 0;   // (a stateful optimizer's window form)
     for (int i = 0; i < 6; ++i) ba.hyper[i] = hyper6[i];
     if (c.inplace && c.lp_lambda_ent != 0.f) { ba.hyper[6] = he[6]; ba.hyper[7] = he[7]; ba.lp_accum = c.lp_sum; }   // (plain SGD: checked at creation)
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
@@ -169,7 +170,8 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     // Adam in place under the deferred pass (round 4): the singletons among the NEGATIVES lag — the scoring kernel fetches (w, m, v)
     // of such a row together, replays its missed steps in registers and updates it (emg_backward_args.lr_hist); the catch-up and
     // the apply handle every other destination of the batch (s / o slots, rows hit more than once)
-    const bool lag_ip = c.lr_t_hist && c.inplace && c.opt == EMG_OPT_ADAM;
+    const bool lag_ip = c.lr_t_hist && c.inplace == 2 && c.opt == EMG_OPT_ADAM;
+    const bool neg_only = lag_ip;   // (the lagging form leaves the s / o slots to the apply)
     const int32_t w_only = (c.lr_t_hist && c.opt == EMG_OPT_ADAM && !lp && (!c.inplace || lag_ip) && seg_rows && lag_env) ? 1 : 0;
     if (lag_ip) ba.lr_hist = c.lr_t_hist;
     if (c.lr_t_hist) {   // deferred dense pass (Keras Adam / LP): bring the rows this batch reads and updates up to step - 1
@@ -223,7 +225,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         for (int i = 0; i < 8; ++i) aa.hyper[i] = h[i];
         if (ent_table) {
             aa.table = c.ent; aa.n_rows = c.n_ent; aa.ld = c.ld_ent; aa.state0 = c.ent_state0; aa.state1 = c.ent_state1;
-            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? (lag_ip ? 2 : 1) : 0; aa.single_from_slot = lag_ip ? 2 * B : 0;
+            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? (neg_only ? 2 : 1) : 0; aa.single_from_slot = neg_only ? 2 * B : 0;
             aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
             aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
             aa.factored = c.factored; aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
@@ -303,10 +305,15 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
                 "emg_plan_create: a deferred dense pass needs the counting grouping for both tables (emg_plan_deferred_ok): "
                 "n_ent = %lld, n_rel = %lld against %lld gradient rows per batch", (long long)cfg->n_ent, (long long)cfg->n_rel,
                 (long long)((2 + (int64_t)cfg->eta * cfg->n_sides) * cfg->cap_B));
-    if (cfg->lr_t_hist && cfg->inplace && cfg->opt == EMG_OPT_ADAM) {   // (what the in-kernel replay and the apply's skip_single = 2 need)
+    EMG_REQUIRE(cfg->inplace >= 0 && cfg->inplace <= 2, "emg_plan_create: inplace is 0 (off), 1 (singletons in place) or 2 (a stateful optimizer's "
+                                                        "window form)");
+    EMG_REQUIRE(cfg->inplace != 2 || (cfg->opt != EMG_OPT_SGD && cfg->fused), "emg_plan_create: inplace = 2 is for stateful optimizers in the fused step");
+    EMG_REQUIRE(!(cfg->lr_t_hist && cfg->inplace == 1 && cfg->opt != EMG_OPT_SGD),
+                "emg_plan_create: a stateful optimizer's in-place updates under the deferred dense pass need inplace = 2 (Adam's in-kernel replay)");
+    if (cfg->lr_t_hist && cfg->inplace == 2) {   // (what the in-kernel replay and the apply's skip_single = 2 need)
         const bool cplx = cfg->model == EMG_COMPLEX || cfg->model == EMG_HOLE;
         const int n = cplx ? cfg->k_int / 2 : cfg->k_int;
-        EMG_REQUIRE(cfg->fused && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && n % 4 == 0 && n / 4 <= 64 && cfg->k_int > 64,
+        EMG_REQUIRE(cfg->opt == EMG_OPT_ADAM && cfg->fused && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && n % 4 == 0 && n / 4 <= 64 && cfg->k_int > 64,
                     "emg_plan_create: in-place Adam under the deferred dense pass needs the fused step, no regulariser and 16-byte rows of 17 "
                     "... 64 chunks (per half for complex models)");
     }

@@ -37,12 +37,9 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
     else {
         int ip = !P.single_ent ? 0 : (P.opt.opt == EMG_OPT_SGD ? (P.opt.lp_lambda != 0.f ? 3 : 1) : 2);
         const bool fused = pass == Pass::Fused;
-        // stateful optimizers, fused kernels of 16-byte rows at a wave per group: the state rows travel with the table rows (ip 4 / 5;
-        // 6: Adam whose dense pass is deferred — emg_backward_args.lr_hist).  EMG_INPLACE_STATE=0: the chunk-wise form (A/B aid)
-        const char* wenv = getenv("EMG_INPLACE_STATE");   // (read per call: tests flip it)
-        const bool window_env = !(wenv && wenv[0] == '0');
-        if (ip == 2 && fused && W == 4 && NV == 1 && LPG == 64 && window_env)
-            ip = P.lr_hist ? 6 : ((P.opt.opt == EMG_OPT_ADAM || P.opt.opt == EMG_OPT_ADAM_LAZY) ? 5 : 4);
+        // window (emg_backward_args.inplace_window): the window forms — the state rows travel with the table rows (ip 4 / 5; 6: Adam
+        // whose dense pass is deferred, emg_backward_args.lr_hist); run_group_pass has checked the shape
+        if (ip == 2 && P.window) ip = P.lr_hist ? 6 : ((P.opt.opt == EMG_OPT_ADAM || P.opt.opt == EMG_OPT_ADAM_LAZY) ? 5 : 4);
 #define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
         if constexpr (W == 4) {
             if (fused) {   // the fused forms, with or without riders: one translation unit per model
@@ -74,7 +71,7 @@ static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st, 
         // lane reduction's extra levels add zeros.
         static const int wide_env = getenv("EMG_WIDE_GROUPS") ? atoi(getenv("EMG_WIDE_GROUPS")) : -1;   // A/B aid
         // (in-place updates of a stateful optimizer: always a wave per group — the form whose state rows travel with the table rows)
-        const bool stateful_ip = pass == Pass::Fused && P.single_ent && P.opt.opt != EMG_OPT_SGD;
+        const bool stateful_ip = pass == Pass::Fused && P.single_ent && P.window;
         const bool wide = pass != Pass::Forward && (wide_env >= 0 ? wide_env != 0 : (P.B <= 2048 || stateful_ip));
         if (c <= 16 && !wide) launch_group<MODEL, 4, 1, 16>(pass, P, st, riders);
         else if (c <= 32 && !wide) launch_group<MODEL, 4, 1, 32>(pass, P, st, riders);
@@ -114,8 +111,9 @@ static int run_group_pass(Pass pass, int model, GroupParams& P, hipStream_t st, 
     if (pass != Pass::Forward && P.single_ent && P.opt.opt == EMG_OPT_SGD && P.opt.lp_lambda != 0.f && !vec)
         return fail(EMG_ENOSUP, "train backward: in-place updates fold an LP regulariser for 16-byte aligned rows only (k, or k per "
                                 "half for complex models, a multiple of 4); pass single_ent = NULL");
-    if (P.lr_hist && !(vec && pass == Pass::Fused && n / 4 <= 64))
-        return fail(EMG_ENOSUP, "train backward: lagging singletons (lr_hist) need the fused kernel on 16-byte aligned rows of at most 64 chunks");
+    if (P.window && !(vec && pass == Pass::Fused && n / 4 <= 64 && P.single_ent && P.opt.opt != EMG_OPT_SGD))
+        return fail(EMG_ENOSUP, "train backward: inplace_window (a stateful optimizer's state rows travelling with the table rows) needs the "
+                                "fused kernel on 16-byte aligned rows of at most 64 chunks (per half for complex models)");
     if (riders_p) {   // only the fused 16-byte-row kernels carry riders; everything else: the stages alone, first
         const bool can_ride = pass == Pass::Fused && vec && n <= 512;   // (= the train_fused_riders_kernel forms)
         if (!can_ride) {
@@ -419,6 +417,7 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
         if (rc != EMG_OK) return rc;
     }
     P.single_ent = a->single_ent;
+    P.window = a->single_ent && a->inplace_window ? 1 : 0;
     if (a->single_ent) {
         EMG_REQUIRE(a->opt >= EMG_OPT_SGD && a->opt <= EMG_OPT_ADAM_LAZY, "emg_train_backward_ex: unknown optimizer");
         EMG_REQUIRE(!(a->opt == EMG_OPT_MOMENTUM || a->opt == EMG_OPT_ADAGRAD) || a->ent_state0,
@@ -441,7 +440,7 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
         }
     }
     if (a->lr_hist) {   // Adam's dense pass is deferred: singletons among the negatives lag and are replayed in the kernel (ip 6)
-        EMG_REQUIRE(a->single_ent && a->opt == EMG_OPT_ADAM && a->hyper[6] == 0.f && a->tag_ent && fused && a->step >= 1,
+        EMG_REQUIRE(a->single_ent && a->inplace_window && a->opt == EMG_OPT_ADAM && a->hyper[6] == 0.f && a->tag_ent && fused && a->step >= 1,
                     "emg_train_backward_ex: lr_hist (lagging singletons) is for the fused kernel with in-place EMG_OPT_ADAM updates, no regulariser");
         const bool cplx = a->model == EMG_COMPLEX || a->model == EMG_HOLE;
         const int n = cplx ? a->k_int / 2 : a->k_int;

@@ -169,6 +169,7 @@ struct GroupParams {
     double* lp_accum;                                    // IP 3: += sum |w_pre|^p over the rows updated in place
     FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
     const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
+    int32_t window;                                      // stateful in-place updates through the window forms (IP 4 / 5 / 6)
     const float* lr_hist; int32_t upto;                  // IP 6 (Adam, deferred dense pass): learning rate of every step; rows are replayed to step `upto`
 };
 
@@ -181,12 +182,18 @@ struct GroupParams {
 //   6  two state rows, LAGGING (Adam with   }  cache hits, and no load sits under a condition) — the update waits for nothing.
 //      the deferred dense pass): (w, m, v) of a singleton are as of tag[row]; the missed steps tag+1 .. upto are replayed in
 //      registers BEFORE the row is scored (the dense pass's own update with g = 0 and each step's lr_t) — what
-//      emg_deferred_catchup does for the other rows with a pass of its own.  s / o slots are not updated in place in this form.
+//      emg_deferred_catchup does for the other rows with a pass of its own.
+//   The subject / object slots (2 of a group's 22): forms 4 / 5 update their singletons in place at the end of the group, state read
+//   chunk by chunk (form 2's way); form 6 leaves them to the apply (emg_apply_args.skip_single = 2) — their rows would have to be
+//   replayed before the group's queries are built and their replayed state kept to the group's end.  (Measured, C3 + Adagrad: s / o
+//   through the apply in form 4 too — three waves per SIMD instead of two — 0.65 against 0.55-0.60 ms per step: the scoring kernel
+//   no faster, the apply 0.08 ms longer.)
 template <int IP>
 struct ip_traits {
     static constexpr int n_state = IP == 4 ? 1 : ((IP == 5 || IP == 6) ? 2 : 0);
     static constexpr bool window_state = n_state != 0;
     static constexpr bool replay = IP == 6;
+    static constexpr bool so_inplace = IP != 0 && IP != 6;   // the subject / object slots' singletons: in place too, except in the lagging form
     static constexpr int chunkwise = (IP == 4 || IP == 5) ? 2 : IP;   // the form inplace_update runs for the s / o slots
 };
 
@@ -574,7 +581,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         if constexpr (IT::replay) my_tag = (j < P.eta && my_flag) ? P.tag_ent[my_code & 0x7fffffff] : P.upto;
     };
     gather(0);
-    if constexpr (IP != 0 && !IT::replay) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
+    if constexpr (IT::so_inplace) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
     OptParams wopt = P.opt;   // (the window forms know their optimizer family: the update's switch folds away)
     if constexpr (NS == 2) wopt.opt = EMG_OPT_ADAM;
     R qo, qs, Ao, As;
@@ -833,11 +840,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        // (IP 6: the s / o rows' state lags too and their rows were scored at the start — they go through the apply)
-        constexpr int IPC = IT::chunkwise;
-        if (IP != 0 && !IT::replay && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IPC>(P, s, rs, gs, lg, lp_acc);
+        // (form 6: the s / o slots go through the apply)
+        if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, s, rs, gs, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IP != 0 && !IT::replay && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IPC>(P, o, ro, go, lg, lp_acc);
+        if (IT::so_inplace && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, o, ro, go, lg, lp_acc);
         else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
     if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place

@@ -242,6 +242,14 @@ def group_dest(dest, n, n_rows, workspace, single_flags=None):
                                _chk_vec(single_flags, torch.uint8, "single_flags"), _stream()), "emg_group_dest")
 
 
+def group_dest_keyed(dest, order_key, n, n_rows, workspace):
+    """stable grouping of ``dest`` with a destination's contributions in ascending ``order_key`` (int32 >= 0, distinct within a
+    destination); apply with ``apply_grouped(..., factored=True)`` on the buffer the ids index"""
+    lib = L.load()
+    L.check(lib.emg_group_dest_keyed(_chk_vec(dest, torch.int32, "dest"), _chk_vec(order_key, torch.int32, "order_key"), n, n_rows,
+                                     workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()), "emg_group_dest_keyed")
+
+
 def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, n_rel, ws_ent, ws_rel,
                   entities_list=None, seed=0, counter0=0, inj_mask=None, inj_repl=None, n_extra_ent=0, n_extra_rel=0,
                   single_flags=None, B_global=0, row_offset=0, factored=False):

@@ -654,9 +654,13 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             # device copy of the fitted parameters: repeated evaluations of a fitted model do not rebuild it (0.63 M -> 0.75 M
             # ranks/s at |E| = 1M, bench `eval.exact_fast.*.uncached_tables`); a new fit / restore replaces both
             from ..evaluation.ranking import derived_tables
+            # (after fit() the device tables may be the trainer's LIVE ones: keyed on its step count too, so that further steps —
+            # early stopping's evaluations between epochs, a caller driving the trainer — never meet stale half-precision copies)
+            tr = getattr(self, "_trainer", None)
+            stamp = (self._dev, tr.step_count if tr is not None else -1)
             cached = getattr(self, "_derived_cache", None)
-            if cached is None or cached[0] is not self._dev:
-                cached = self._derived_cache = (self._dev, derived_tables(self._model_id(), ent, rel, self.internal_k))
+            if cached is None or cached[0][0] is not stamp[0] or cached[0][1] != stamp[1]:
+                cached = self._derived_cache = (stamp, derived_tables(self._model_id(), ent, rel, self.internal_k))
             tables = cached[1]
         return rank_triples_device(self._model_id(), ent, rel, self.internal_k, self._scale(), X_idx, corrupt_side,
                                    ranking_strategy, filter_triples=filter_idx, entities_subset=corruption_entities,

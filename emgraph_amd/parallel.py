@@ -240,3 +240,113 @@ def allgather_rows(ids, rows, group=None):
 def batch_rows(B, rank, world):
     """rows [r0, r1) of a global batch of B positives that this rank scores"""
     return entity_range(B, rank, world)
+
+
+# ------------------------------------------------------------------------------------------------
+# BATCH sharding, device-resident (round 4): the same exchange with everything that does not depend on the tables settled
+# in a METADATA phase — who sends how many rows to whom, which destinations each owner sums, the order it sums them in,
+# the list of destinations every replica applies — so that the DATA phase between the scoring kernel and the apply is three
+# collectives whose sizes are already on the host: rows -> owners (all_to_all), segmented sum at the owner, sums -> everybody
+# (all_gather).  One host read per step (the W x W matrix of row counts), in the metadata phase, which the Trainer issues a
+# step AHEAD on a side stream (the metadata needs the batch's positives and Philox draws, not the tables).  No torch.unique,
+# no argsort: the bucket order is the local grouping's (emg_prepare_batch), the owner's order a keyed grouping
+# (emg_group_dest_keyed); buffers are allocated once and grow only.
+# ------------------------------------------------------------------------------------------------
+def _staged(t, group):
+    """test harness only (several ranks sharing one GPU over gloo): collectives of CUDA tensors go through the host"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out, inp, group=None):
+    """out (contiguous, world x the size of inp) <- every rank's inp, in rank order (flat views: gloo wants the concatenation shape)"""
+    if _staged(inp, group):
+        ho = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, inp.detach().cpu().contiguous().view(-1), group=group)
+        out.view(-1).copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=group)
+    return out
+
+
+class ExchangePlan:
+    """what the metadata phase of one batch and table leaves behind (see RowExchange)"""
+    __slots__ = ("n", "order", "sc", "rc", "m", "dest_o", "gslot_o", "cap_u", "uniq_local", "ids_all", "sent_bytes", "recv_bytes")
+
+
+class RowExchange:
+    """One table's side of the batch-sharded step.  Owners hold contiguous id ranges (entity_range)."""
+
+    def __init__(self, n_rows, k, device, group=None):
+        self.n_rows, self.k, self.device, self.group = int(n_rows), int(k), device, group
+        self.rank, self.world = rank_world()
+        self.e0, self.e1 = entity_range(self.n_rows, self.rank, self.world)
+        self.bounds = owner_bounds(self.n_rows, self.world).to(device)
+        self.owned = [entity_range(self.n_rows, r, self.world) for r in range(self.world)]
+        self._recv_rows = None       # grow-only buffers of the data phase
+        self._gathered = None
+
+    # ---- metadata phase (table-independent) ----
+    def plan_counts(self, dest_sorted, order, gslot):
+        """dest_sorted int32 [n]: destinations of this rank's contribution slots, ascending; order [n]: the local slot at each sorted
+        position (equal destinations in ascending slot order — the local grouping's keys / vals); gslot int32 [n]: the slot each
+        local slot has in the GLOBAL batch's layout.  Exchanges the row counts (the step's one host read) and the (destination,
+        global slot) pairs; returns the plan with dest_o (owner-local row ids) / gslot_o of the rows this rank will receive."""
+        W = self.world
+        pl = ExchangePlan()
+        pl.n = int(dest_sorted.numel())
+        pl.order = order.to(torch.int64)
+        cuts = torch.searchsorted(dest_sorted.to(torch.int64), self.bounds)
+        send_counts = (cuts[1:] - cuts[:-1]).to(torch.int64)
+        C = torch.empty((W, W), dtype=torch.int64, device=send_counts.device)
+        _all_gather_into(C, send_counts, self.group)
+        Ch = C.cpu()                                              # <- the host read (metadata phase; a step ahead when planned ahead)
+        pl.sc = [int(v) for v in Ch[self.rank]]
+        pl.rc = [int(v) for v in Ch[:, self.rank]]
+        pl.m = sum(pl.rc)
+        totals = [int(Ch[:, p].sum()) for p in range(W)]
+        pl.cap_u = max(1, max(min(self.owned[p][1] - self.owned[p][0], totals[p]) for p in range(W)))
+        meta = torch.stack([dest_sorted.to(torch.int32), gslot.index_select(0, pl.order).to(torch.int32)], 1)
+        meta_r = _split_exchange(torch.empty((pl.m, 2), dtype=torch.int32, device=meta.device), meta, pl.rc, pl.sc, self.group)
+        pl.dest_o = (meta_r[:, 0] - self.e0).contiguous()         # row ids inside this rank's range
+        pl.gslot_o = meta_r[:, 1].contiguous()
+        row_b = self.k * 4
+        pl.sent_bytes = (pl.n - pl.sc[self.rank]) * (row_b + 8)
+        pl.recv_bytes = (W - 1) * pl.cap_u * (row_b + 4)
+        return pl
+
+    def plan_unique(self, pl, keys_sorted_o):
+        """keys_sorted_o int32 [m]: the received owner-local row ids, ascending (the owner grouping's keys).  Compacts the distinct
+        ones (no host read: fixed capacity cap_u, padded with the sentinel n_rows) and all-gathers every owner's list:
+        pl.ids_all int32 [W * cap_u] = the GLOBAL ids every replica applies a summed gradient to (sentinels are dropped by the
+        grouping), pl.uniq_local int64 [cap_u] = this owner's rows (padding -> row 0)."""
+        W, cap = self.world, pl.cap_u
+        dev = keys_sorted_o.device
+        uniq = torch.full((cap + 1,), self.n_rows, dtype=torch.int32, device=dev)          # [cap] = a bin for everything that is no head
+        if pl.m > 0:
+            k64 = keys_sorted_o.to(torch.int64)
+            head = torch.ones(pl.m, dtype=torch.bool, device=dev)
+            head[1:] = k64[1:] != k64[:-1]
+            pos = torch.cumsum(head.to(torch.int64), 0) - 1
+            uniq.index_copy_(0, torch.where(head, pos, torch.full_like(pos, cap)), (keys_sorted_o + self.e0).to(torch.int32))
+            uniq[cap] = self.n_rows
+        mine = uniq[:cap].contiguous()
+        pl.uniq_local = torch.where(mine < self.n_rows, mine.to(torch.int64) - self.e0, torch.zeros_like(mine, dtype=torch.int64))
+        ids_all = torch.empty(W * cap, dtype=torch.int32, device=dev)
+        _all_gather_into(ids_all, mine, self.group)
+        pl.ids_all = ids_all
+        return pl
+
+    # ---- data phase ----
+    def send_rows(self, pl, contrib):
+        """gradient rows -> owners: returns float [m, k], the rows this rank owns the destinations of, in the order of pl.dest_o"""
+        if self._recv_rows is None or self._recv_rows.shape[0] < pl.m:
+            self._recv_rows = torch.empty((int(pl.m * 1.25) + 64, self.k), dtype=contrib.dtype, device=contrib.device)
+        out = self._recv_rows[:pl.m]
+        return _split_exchange(out, contrib.index_select(0, pl.order), pl.rc, pl.sc, self.group)
+
+    def gather_sums(self, pl, sums_compact):
+        """the owners' summed gradient rows float [cap_u, k] (rows of pl.uniq_local) -> everybody: float [W * cap_u, k], row j <-> pl.ids_all[j]"""
+        need = self.world * pl.cap_u
+        if self._gathered is None or self._gathered.shape[0] < need:
+            self._gathered = torch.empty((int(need * 1.25) + 64, self.k), dtype=sums_compact.dtype, device=sums_compact.device)
+        return _all_gather_into(self._gathered[:need], sums_compact, self.group)

@@ -193,6 +193,7 @@ class Trainer:
         # (an LP regulariser is folded into every update: by the apply kernel, and by the in-place form of plain SGD — its
         # own instantiation (IP 3), so that the pow / sign code stays out of the forms that have no regulariser)
         n_cols = self.k_int // 2 if model_id in (L.COMPLEX, L.HOLE) else self.k_int
+        self.inplace_mode = 0   # 0 off | 1 singletons in place | 2 the same through a stateful optimizer's window form (_choose_inplace)
         self.inplace = self._inplace_wanted = inplace and not self.generic and (self.reg is None or (self.opt_id == L.OPT_SGD and self.reg[2] <= 3
                                                                                 and n_cols % 4 == 0))
         # default: on where the dense pass is what a step costs — an entity table of 256 MB or more (C3 with Adam: 2.6 -> 1.65
@@ -220,6 +221,18 @@ class Trainer:
             self.inplace = self.pipeline = pipeline = False
             self.xgmi_bytes = 0          # bytes this rank sent + received over the interconnect (gradient rows + summed rows)
             self._owner_ws = {}
+            # device-resident exchange (parallel.RowExchange; round 4): sizes settled in a table-independent metadata phase, the owner's
+            # order by a keyed counting grouping — which needs a range of at most 2^20 + 16 n rows per owner; EMG_XCHG=host: round 3's
+            # host-driven exchange (argsort / unique, a count exchange and fresh buffers every step)
+            _, world = parallel.rank_world()
+            self._device_exchange = (os.environ.get("EMG_XCHG", "device") != "host" and os.environ.get("EMG_GROUPING") != "sort"
+                                     and -(-max(self.n_ent, self.n_rel) // max(1, world)) <= (1 << 20))
+            self._xchg_objs, self._gslot_cache = {}, {}
+            self._bs_ready = {}          # batches whose metadata phase has been issued ahead: key -> prepared state
+            self._bs_parity = 0
+            self._bs_done = [torch.cuda.Event(), torch.cuda.Event()]   # main-stream work that last used slot / workspaces of a parity
+            self._bs_ahead = self._device_exchange and os.environ.get("EMG_XCHG_AHEAD", "1") != "0"
+            self._bs_stream = torch.cuda.Stream(device=self.device) if self._bs_ahead else None
         # high priority: the many small kernels must not queue behind the big ones.  TWO side streams used
         # alternately: a preparation chain is latency-bound (each small launch waits for a CU slot), so two
         # chains in flight double the rate at which prepared batches arrive
@@ -252,26 +265,31 @@ class Trainer:
         moved the row twelve times.  Results are the same bits either way (one optimizer rule, one summation order:
         tests/test_config_widths.py::test_inplace_choice_does_not_change_bits)."""
         if not self._inplace_wanted or self.batch_sharded:
-            return False
+            return 0
         stateful = self.opt_id != L.OPT_SGD
         n_cols = self.k_int // 2 if self.model_id in (L.COMPLEX, L.HOLE) else self.k_int
         window = self.fused and n_cols % 4 == 0 and n_cols // 4 <= 64 and os.environ.get("EMG_INPLACE_STATE", "1") != "0"
         # what CAN run in place: SGD anything; a stateful optimizer anything (window form or chunk-wise) unless its dense pass is
         # deferred — then only Adam through the window form's replay, finished by the descriptor-driven apply (rows of > 16 chunks)
         can = not (stateful and self.deferred) or (window and self.opt_id == L.OPT_ADAM and self.reg is None and self.k_int > 64)
+        # modes: 1 = singletons in place (SGD; a stateful optimizer's chunk-wise form), 2 = a stateful optimizer's window form
+        mode = 2 if (stateful and window) else 1
         if os.environ.get("EMG_INPLACE") in ("0", "1"):      # A/B aid
-            return os.environ["EMG_INPLACE"] == "1" and can
+            return mode if (os.environ["EMG_INPLACE"] == "1" and can) else 0
         if not stateful or os.environ.get("EMG_INPLACE_ALWAYS"):
-            return can
+            return mode if can else 0
         # small batches (the graph-replay range) stay with the apply: its launch is latency-bound there and does not shrink with its
         # item count, so the in-place work only lengthens the scoring kernel (measured: C1 0.0778 / 0.0747, C2 0.0637 / 0.0585, C5
         # 0.1527 / 0.1319 ms per step in place / through the apply; C3 Adagrad 0.612 / 0.695, C3 Adam 0.90 / 1.15)
-        return can and window and (2 + self.eta_total) * B > GRAPH_MAX_ROWS
+        return 2 if (can and window and (2 + self.eta_total) * B > GRAPH_MAX_ROWS) else 0
 
     def _alloc_scratch(self, B):
         if B <= self._cap:
             return
-        self.inplace = self._choose_inplace(B)
+        self.inplace_mode = self._choose_inplace(B)
+        if self.inplace_mode == 2 and (self.sharded or os.environ.get("EMG_PY_PLAN")):
+            self.inplace_mode = 1      # (the window form is the plan's; host-driven steps keep the chunk-wise form)
+        self.inplace = self.inplace_mode != 0
         torch.cuda.synchronize()
         dev, k, et = self.device, self.k_int, self.eta_total
         ldc = _padded_ld(k)
@@ -285,7 +303,8 @@ class Trainer:
         self.contrib_ent = torch.empty((4 * B if self.factored else n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.contrib_rel = torch.empty((n_cr, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.slots = []
-        for _ in range(1 + self.lookahead):  # current batch + the ones being prepared ahead
+        n_slots = 2 if (self.batch_sharded and getattr(self, "_bs_ahead", False)) else 1 + self.lookahead
+        for _ in range(n_slots):  # current batch + the ones being prepared ahead
             sl = {
                 "codes": torch.empty(B * et, dtype=torch.int32, device=dev),
                 "dest_ent": torch.empty(n_ce, dtype=torch.int32, device=dev),
@@ -332,7 +351,7 @@ class Trainer:
         c.factored = int(self.factored)
         if self.reg is not None:
             c.lp_lambda_ent, c.lp_lambda_rel, c.lp_p = self.reg[0], self.reg[1], self.reg[2]
-        c.fused, c.inplace, c.normalize = int(self.fused), int(self.inplace), int(self.normalize)
+        c.fused, c.inplace, c.normalize = int(self.fused), int(self.inplace_mode), int(self.normalize)
         c.n_slots = len(self.slots)
         for i, sl in enumerate(self.slots):
             ps = c.slots[i]
@@ -489,7 +508,7 @@ class Trainer:
         if B <= 0:
             return
         if self.batch_sharded:
-            return self._step_batch_sharded(start, B, epoch, batch, n_choices, entities_list)
+            return self._step_batch_sharded(start, B, epoch, batch, n_choices, entities_list, prefetch)
         self._alloc_scratch(B)
         if self.plan is not None:
             return self._plan_step(start, B, epoch, batch, n_choices, entities_list, inj_mask, inj_repl, prefetch)
@@ -615,28 +634,65 @@ class Trainer:
             D.clip_rows(self.ent, self.k_int, 1.0)
 
     # ---- batch-sharded step (parallel.py: BATCH sharding) ----
-    def _step_batch_sharded(self, start, B, epoch, batch, n_choices, entities_list):
-        """[start, start + B) is the GLOBAL batch.  This rank scores rows [r0, r1) of it with the negatives the whole
-        batch draws for them, then: gradient rows -> owners (all_to_all) -> summed in global slot order + optimizer at
-        the owner -> updated rows all-gathered into every replica."""
+    def _bs_prepare(self, key, n_choices, entities_list, parity):
+        """Everything of a batch-sharded step that does not read the tables: this rank's rows of the global batch, their Philox
+        negatives and local grouping (emg_prepare_batch) and — device exchange — the exchange's metadata phase for both tables.
+        Issued on the side stream a step ahead when the caller names the next batch (``prefetch``)."""
+        start, B, epoch, batch = key
         rank, world = parallel.rank_world()
         r0, r1 = parallel.batch_rows(B, rank, world)
         Bl = r1 - r0
+        et, eta = self.eta_total, self.eta
+        n_ce = (2 + et) * Bl
+        st = {"key": key, "parity": parity, "r0": r0, "Bl": Bl, "n_ce": n_ce, "pe": None, "pr": None}
+        dev = self.device
+        if Bl > 0:
+            self._alloc_scratch(Bl)
+        sl = self.slots[parity % len(self.slots)]
+        if Bl > 0:
+            pos = self.X[start + r0:start + r1]
+            counter0 = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides
+            D.prepare_batch(pos, eta, self.sides, self.n_ent if n_choices is None else int(n_choices), sl["codes"][:Bl * et],
+                            sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl], self.n_ent, self.n_rel, sl["ws_ent"], sl["ws_rel"],
+                            entities_list=entities_list, seed=self.seed, counter0=counter0, B_global=B, row_offset=r0)
+        if self._device_exchange:
+            if Bl > 0:
+                gslot_e, gslot_r = self._gslots(Bl, B, r0, n_ce)      # slot of the same row in the whole batch's layout
+                sorted_e = D.apply_workspace_views(sl["ws_ent"], n_ce)   # the local grouping: destinations ascending, slots in order
+                sorted_r = D.apply_workspace_views(sl["ws_rel"], Bl)
+            else:
+                z32 = torch.zeros(0, dtype=torch.int32, device=dev)
+                gslot_e = gslot_r = z32
+                sorted_e = sorted_r = (z32, z32)
+            st["pe"] = self._plan_exchange("ent", sorted_e[0], sorted_e[1], gslot_e, parity)
+            st["pr"] = self._plan_exchange("rel", sorted_r[0], sorted_r[1], gslot_r, parity)
+        return st
+
+    def _step_batch_sharded(self, start, B, epoch, batch, n_choices, entities_list, prefetch=None):
+        """[start, start + B) is the GLOBAL batch.  This rank scores rows [r0, r1) of it with the negatives the whole batch draws
+        for them, then: gradient rows -> owners (all_to_all) -> one summed row per destination, added in global slot order ->
+        all-gather -> every replica applies the optimizer (parallel.py: BATCH sharding).  Device exchange (default): the
+        table-independent half — preparation, row counts, (destination, slot) pairs, groupings — is issued for the NEXT batch on a
+        side stream as soon as this step's kernels are enqueued; between the scoring kernel and the apply there is no host read."""
+        key = (start, B, epoch, batch)
         self.step_count += 1
         et, eta, k = self.eta_total, self.eta, self.k_int
         lr = (sgd_learning_rate(self.sgd_params, self.batches_count, epoch, batch) if self.sgd_params is not None
               else self.lr)
         dev = self.device
-        n_ce = (2 + et) * Bl
+        main = torch.cuda.current_stream()
+        st = self._bs_ready.pop(key, None)
+        if st is None:
+            self._bs_ready.clear()                 # (a prefetch list that did not match the steps: nothing prepared is kept)
+            st = self._bs_prepare(key, n_choices, entities_list, self._bs_parity)
+        else:
+            main.wait_event(st["event"])           # the side stream's preparation and metadata phase of this batch
+        self._bs_parity = st["parity"] ^ 1
+        Bl, r0, n_ce = st["Bl"], st["r0"], st["n_ce"]
+        sl = self.slots[st["parity"] % len(self.slots)]
         if Bl > 0:
-            self._alloc_scratch(Bl)
-            sl = self.slots[0]
-            pos = self.X[start + r0:start + r1]
+            pos = self.X[start + r0:start + r0 + Bl]
             codes = sl["codes"][:Bl * et]
-            counter0 = ((epoch - 1) * self.batches_count + (batch - 1)) * self.n_sides
-            D.prepare_batch(pos, eta, self.sides, self.n_ent if n_choices is None else int(n_choices), codes,
-                            sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl], self.n_ent, self.n_rel, sl["ws_ent"], sl["ws_rel"],
-                            entities_list=entities_list, seed=self.seed, counter0=counter0, B_global=B, row_offset=r0)
             ce, cr = self.contrib_ent[:n_ce], self.contrib_rel[:Bl]
             if self.fused:
                 D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr,
@@ -649,22 +705,105 @@ class Trainer:
                 D.loss(self.loss_id, sp, sn, Bl, eta, self.n_sides, self.margin, self.alpha, self.loss_accum, gp, gn)
                 D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
                                     g_pos=gp, g_neg=gn)
-            t = torch.arange(n_ce, dtype=torch.int64, device=dev)
-            gslot_e = (t // Bl) * B + r0 + (t % Bl)          # slot of the same row in the whole batch's layout
-            gslot_r = r0 + torch.arange(Bl, dtype=torch.int64, device=dev)
             dest_e, dest_r = sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl]
             rows_e, rows_r = ce, cr
         else:
-            z32 = torch.zeros(0, dtype=torch.int32, device=dev)
-            z64 = torch.zeros(0, dtype=torch.int64, device=dev)
-            dest_e = dest_r = z32
-            gslot_e = gslot_r = z64
+            dest_e = dest_r = torch.zeros(0, dtype=torch.int32, device=dev)
             rows_e = rows_r = torch.zeros((0, k), dtype=torch.float32, device=dev)
         lp = (self.lp_sum[0:1], self.lp_sum[1:2]) if self.reg is not None else (None, None)
-        self._exchange_apply(self.ent, self.n_ent, self.state_ent, self.tag_ent, dest_e, gslot_e, rows_e, self._hyper(lr, 0), "ent", lp[0])
-        self._exchange_apply(self.rel, self.n_rel, self.state_rel, self.tag_rel, dest_r, gslot_r, rows_r, self._hyper(lr, 1), "rel", lp[1])
+        he, hr = self._hyper(lr, 0), self._hyper(lr, 1)
+        if self._device_exchange:
+            # data phase: rows -> owners, summed in global slot order, sums -> every replica, optimizer
+            self._exchange_apply_planned("ent", st["pe"], rows_e, self.ent, self.state_ent, self.tag_ent, he, lp[0], st["parity"])
+            self._exchange_apply_planned("rel", st["pr"], rows_r, self.rel, self.state_rel, self.tag_rel, hr, lp[1], st["parity"])
+        else:
+            if Bl > 0:
+                gslot_e, gslot_r = self._gslots(Bl, B, r0, n_ce)
+            else:
+                gslot_e = gslot_r = dest_e
+            self._exchange_apply(self.ent, self.n_ent, self.state_ent, self.tag_ent, dest_e, gslot_e.to(torch.int64), rows_e, he, "ent", lp[0])
+            self._exchange_apply(self.rel, self.n_rel, self.state_rel, self.tag_rel, dest_r, gslot_r.to(torch.int64), rows_r, hr, "rel", lp[1])
         if self.normalize:
             D.clip_rows(self.ent, k, 1.0)
+        self._bs_done[st["parity"]].record(main)
+        # the next batch's table-independent half, on the side stream, now: it runs beside this step's exchange and apply
+        if self._bs_ahead and prefetch:
+            nxt = prefetch if isinstance(prefetch, tuple) else next((p for p in prefetch if p is not None and p[1] > 0), None)
+            if nxt is not None and tuple(nxt[:4]) not in self._bs_ready:
+                par = st["parity"] ^ 1
+                side = self._bs_stream
+                side.wait_event(self._bs_done[par])          # the step that last used that slot and those workspaces (two steps back)
+                with torch.cuda.stream(side):
+                    nst = self._bs_prepare(tuple(nxt[:4]), nxt[4] if len(nxt) > 4 else n_choices, nxt[5] if len(nxt) > 5 else entities_list, par)
+                    nst["event"] = torch.cuda.Event()
+                    nst["event"].record(side)
+                for pl in (nst["pe"], nst["pr"]):            # (allocated on the side stream, read by the main stream's data phase)
+                    if pl is not None:
+                        pl.order.record_stream(main)
+                        pl.uniq_local.record_stream(main)
+                self._bs_ready[tuple(nxt[:4])] = nst
+
+    def _gslots(self, Bl, B, r0, n_ce):
+        """global contribution slot of every local slot (int32): local slot t = role block t // Bl, row t % Bl -> block * B + r0 + row"""
+        key = (Bl, B, r0, n_ce)
+        if self._gslot_cache.get("key") != key:
+            t = torch.arange(n_ce, dtype=torch.int64, device=self.device)
+            self._gslot_cache = {"key": key, "e": ((t // Bl) * B + r0 + (t % Bl)).to(torch.int32),
+                                 "r": (r0 + torch.arange(Bl, dtype=torch.int64, device=self.device)).to(torch.int32)}
+        return self._gslot_cache["e"], self._gslot_cache["r"]
+
+    def _xchg(self, which):
+        x = self._xchg_objs.get(which)
+        if x is None:
+            x = parallel.RowExchange(self.n_ent if which == "ent" else self.n_rel, self.k_int, self.device)
+            x.sums = alloc_table(max(1, x.e1 - x.e0), self.k_int, self.device)   # this rank's range: one summed gradient row per owned row
+            x.compact = None
+            x.ws_owner, x.ws_rep = [None, None], [None, None]
+            self._xchg_objs[which] = x
+        return x
+
+    @staticmethod
+    def _grown(buf, need, device):
+        if buf is None or buf.numel() < need:
+            return torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
+        return buf
+
+    def _plan_exchange(self, which, dest_sorted, order, gslot, parity=0):
+        """METADATA phase of one table's exchange (parallel.RowExchange): nothing here reads the tables.  The two grouping
+        workspaces exist twice (``parity``): the next batch's are filled while this batch's are being applied from."""
+        x, k = self._xchg(which), self.k_int
+        pl = x.plan_counts(dest_sorted, order, gslot)
+        owned = max(1, x.e1 - x.e0)
+        if pl.m:
+            # the owner's order: by destination, a destination's rows in GLOBAL slot order (the order one GPU adds them in)
+            x.ws_owner[parity] = self._grown(x.ws_owner[parity], D.apply_workspace_bytes(pl.m, owned, k), self.device)
+            D.group_dest_keyed(pl.dest_o, pl.gslot_o, pl.m, owned, x.ws_owner[parity])
+            keys_o = D.apply_workspace_views(x.ws_owner[parity], pl.m)[0]
+        else:
+            keys_o = pl.dest_o
+        x.plan_unique(pl, keys_o)
+        n_all = x.world * pl.cap_u
+        x.ws_rep[parity] = self._grown(x.ws_rep[parity], D.apply_workspace_bytes(n_all, x.n_rows, k), self.device)
+        D.group_dest(pl.ids_all, n_all, x.n_rows, x.ws_rep[parity])        # (the sentinel ids of the padding are dropped: no row to update)
+        return pl
+
+    def _exchange_apply_planned(self, which, pl, rows, table, state, tag, hyper, lp_accum, parity=0):
+        """DATA phase: gradient rows -> owners (all_to_all) -> one summed row per destination, added in global slot order ("SGD with
+        lr = -1 on a zero row" is 0 - (-1 * g) = g exactly: emg_apply_grouped as a segmented sum) -> all-gather -> every replica
+        applies the optimizer to the same sums with its own (replicated, hence identical) state"""
+        x, k = self._xchg(which), self.k_int
+        recv = x.send_rows(pl, rows)
+        x.sums.index_fill_(0, pl.uniq_local, 0.0)
+        if pl.m:
+            D.apply_grouped(L.OPT_SGD, x.sums, k, None, None, None, 1, recv, pl.m, False, (-1.0, 0, 0, 0, 0, 0), x.ws_owner[parity], factored=True)
+        if x.compact is None or x.compact.shape[0] < pl.cap_u:
+            x.compact = torch.empty((int(pl.cap_u * 1.25) + 64, k), dtype=torch.float32, device=self.device)
+        comp = x.compact[:pl.cap_u]
+        torch.index_select(x.sums, 0, pl.uniq_local, out=comp)
+        g = x.gather_sums(pl, comp)
+        D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, g, x.world * pl.cap_u, False, hyper, x.ws_rep[parity],
+                        lp_accum=lp_accum)
+        self.xgmi_bytes += pl.sent_bytes + pl.recv_bytes
 
     def _exchange_apply(self, table, n_rows, state, tag, dest, gslot, rows, hyper, which, lp_accum=None):
         """gradient rows -> owners (all_to_all) -> per destination ONE summed row, added in global slot order (the order a

@@ -218,13 +218,19 @@ typedef struct emg_backward_args {
     void* fac_ws_ent; int64_t fac_ws_ent_bytes;
     int64_t layout_B; const void* ctl;   /* as in emg_prepare_args: layout of fac_ws_ent; device record, pos = row 0 of the resident set */
     double* lp_accum;   /* folded LP with in-place updates (below): += sum |w|^p (pre-update) over the rows updated in place */
-    /* lr_hist != NULL (EMG_OPT_ADAM in place, fused loss, deferred dense pass — see emg_deferred_catchup): the rows of SINGLETON
+    /* lr_hist != NULL (EMG_OPT_ADAM in place with inplace_window, fused loss, deferred dense pass — see emg_deferred_catchup): the rows of SINGLETON
      * NEGATIVES are as of tag_ent[row]; the kernel fetches (w, m, v) of such a row together, replays the steps tag + 1 .. step - 1 in
      * registers (the dense pass's update with g = 0 and lr_hist[s]), scores the row, applies this step's update and writes
      * (w, m, v, tag = step): one read and one write of the three rows where catch-up + scoring + apply moved twelve.  The subject /
      * object slots are NOT updated in place in this form: finish with emg_apply_grouped_ex(skip_single = 2, single_from_slot =
      * 2 * B) after emg_deferred_catchup(..., skip_single_from = 2 * B) brought every other row of the batch up to date. */
     const float* lr_hist;
+    /* inplace_window != 0 (stateful optimizers; fused loss; 16-byte rows of at most 64 chunks, per half for complex models): a
+     * singleton negative's optimizer state rows are fetched together with its table row in the kernel's rolling window — the update
+     * waits for nothing (0: the state is read chunk by chunk at the update).  Without lr_hist the subject / object singletons are
+     * updated in place too (finish with skip_single = 1); with lr_hist they are not (skip_single = 2, single_from_slot = 2 * B).
+     * Required by lr_hist. */
+    int32_t inplace_window; int32_t reserved2;
 } emg_backward_args;
 /* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
  * only for opt = EMG_OPT_SGD — a singleton row is then updated in place with g + lambda p |w|^(p-1) sign(w), the rule the
@@ -240,6 +246,12 @@ int emg_train_backward_ex(const emg_backward_args* args, void* stream);
  * length-1 segments (already applied in place by emg_train_backward_ex). */
 int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, void* workspace, int64_t workspace_bytes,
                    uint8_t* single_flags, void* stream);
+/* emg_group_dest with an explicit order: a destination's contributions are summed in ascending order_key (distinct within a
+ * destination) instead of ascending index — the batch-sharded multi-GPU step: the owner of a table range receives gradient rows
+ * from every rank and adds them in the order of their slots in the GLOBAL batch.  Counting backend only (EMG_ENOSUP otherwise).
+ * Apply with emg_apply_grouped_factored(contrib = the received rows): it reads row i through the workspace's source array. */
+int emg_group_dest_keyed(const int32_t* dest, const uint32_t* order_key, int64_t n, int64_t n_rows, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 int emg_apply_grouped(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int,
                       float* state0, float* state1, int32_t* tag, int32_t step,
                       const float* contrib, int64_t ldc, int64_t n_contrib, int32_t skip_single,
@@ -612,7 +624,9 @@ typedef struct emg_plan_config {
     double* loss_accum; double* lp_sum;              /* lp_sum[2]: sum |w|^p of the entity / relation table */
     int32_t factored; int32_t reserved0;             /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows */
     float lp_lambda_ent; float lp_lambda_rel; int32_t lp_p;   /* folded LP regulariser (0 = none; excludes inplace) */
-    int32_t fused; int32_t inplace; int32_t normalize;
+    int32_t fused; int32_t inplace; int32_t normalize;   /* inplace: 0 off, 1 singletons in place, 2 the same through a stateful optimizer's
+                                                            window form (emg_backward_args.inplace_window; with lr_t_hist: Adam's singleton
+                                                            negatives replayed inside the scoring kernel, s / o slots through the apply) */
     int32_t n_slots; emg_plan_slot slots[4];
     int64_t aux_min_rows;                            /* entity contribution rows above which apply_rel gets its stream */
     void* ctl_buf; int64_t ctl_bytes;                /* optional device scratch (>= 32 * sizeof(emg_step_ctl)) for emg_plan_run */

@@ -200,6 +200,66 @@ def batch_exchange_worker(rank, world, out_dir):
     np.save(os.path.join(out_dir, "W_%d.npy" % rank), W)
 
 
+def row_exchange_worker(rank, world, out_dir):
+    """the DEVICE-RESIDENT form of the same exchange (parallel.RowExchange, round 4) on CPU tensors over gloo: metadata phase
+    (row counts, (destination, global slot) pairs, every owner's distinct destinations, padded to one capacity) then data phase
+    (rows -> owners, sums -> everybody).  numpy stands in for the two groupings the HIP library does (the local one by destination,
+    the owner's by (destination, global slot)) and for the sequential fp32 sums.  Bit-identical to the single-process result for
+    any rank count; ranks with nothing to send or nothing to own included."""
+    import torch
+
+    from emgraph_amd import parallel
+    rs = np.random.RandomState(11)
+    n_rows, k, B, roles, lr = 37, 6, 23, 5, F32(0.1)
+    W0 = rs.randn(n_rows, k).astype(F32)
+    dest_g = rs.randint(0, n_rows - 4, roles * B).astype(np.int32)
+    dest_g[rs.choice(roles * B, 40, replace=False)] = 7
+    rows_g = rs.randn(roles * B, k).astype(F32)
+    exp = W0.copy()
+    order = np.argsort(dest_g, kind="stable")
+    for seg in np.split(order, np.flatnonzero(np.diff(dest_g[order])) + 1):
+        g = np.zeros(k, F32)
+        for i in seg:
+            g = g + rows_g[i]
+        exp[dest_g[seg[0]]] = W0[dest_g[seg[0]]] - lr * g
+    for trial in range(2):      # twice through the same object: its buffers are reused
+        r0, r1 = parallel.batch_rows(B, rank, world)
+        Bl = r1 - r0
+        t = np.arange(roles * Bl)
+        gslot = ((t // max(Bl, 1)) * B + r0 + (t % max(Bl, 1))).astype(np.int32)
+        dest_l, rows_l = dest_g[gslot], rows_g[gslot]
+        if trial == 0:
+            x = parallel.RowExchange(n_rows, k, torch.device("cpu"))
+        lo = np.argsort(dest_l, kind="stable")                                  # = the local grouping (emg_prepare_batch)
+        pl = x.plan_counts(torch.from_numpy(dest_l[lo]), torch.from_numpy(lo), torch.from_numpy(gslot))
+        d_o, g_o = pl.dest_o.numpy(), pl.gslot_o.numpy()
+        assert ((d_o >= 0) & (d_o < x.e1 - x.e0)).all() and pl.m == len(d_o)
+        oo = np.lexsort((g_o, d_o))                                              # = emg_group_dest_keyed: by destination, then global slot
+        x.plan_unique(pl, torch.from_numpy(d_o[oo].astype(np.int32)))
+        ids_all = pl.ids_all.numpy()
+        assert len(ids_all) == world * pl.cap_u
+        recv = x.send_rows(pl, torch.from_numpy(rows_l)).numpy()
+        sums = np.full((max(1, x.e1 - x.e0), k), np.nan, F32)                   # (stale content must not matter)
+        sums[pl.uniq_local.numpy()] = 0
+        if pl.m:
+            for seg in np.split(oo, np.flatnonzero(np.diff(d_o[oo])) + 1):
+                g = np.zeros(k, F32)
+                for i in seg:
+                    g = g + recv[i]
+                sums[d_o[seg[0]]] = g
+        gathered = x.gather_sums(pl, torch.from_numpy(sums[pl.uniq_local.numpy()])).numpy()
+        W = W0.copy()
+        seen = set()
+        for j, rid in enumerate(ids_all):
+            if rid < n_rows:
+                assert rid not in seen
+                seen.add(int(rid))
+                W[rid] = W0[rid] - lr * gathered[j]
+        np.testing.assert_array_equal(W, exp)
+        assert seen == set(np.unique(dest_g).tolist())
+    np.save(os.path.join(out_dir, "W_%d.npy" % rank), W)
+
+
 def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt, reg=None):
     """the REAL batch-sharded training step (HIP kernels + exchange), two ranks sharing cuda:0 over gloo"""
     import torch

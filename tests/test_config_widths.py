@@ -359,8 +359,8 @@ def test_inplace_choice_does_not_change_bits(monkeypatch, model, k, opt):
         states = [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None]
         return tr.inplace, Et, Rt, states, tr.read_loss()
 
-    # in place with the state rows travelling in the rolling window (round 4: ip 4 / 5) | through the contribution buffer | in place
-    # with the state read chunk by chunk at the update (round 3: ip 2)
+    # singletons in place with the negatives' state rows travelling in the rolling window (round 4: ip 4 / 5) | every row through the
+    # contribution buffer | singletons in place with the state read chunk by chunk at the update (round 3: ip 2)
     a, b, c = run(True), run(False), run(True, window=False)
     assert a[0] and not b[0] and c[0]
     for other in (b, c):

@@ -80,6 +80,16 @@ def test_batch_sharded_exchange_is_rank_count_independent_gloo(tmp_path, world):
         np.testing.assert_array_equal(w, Ws[0])
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_row_exchange_device_resident_form_is_rank_count_independent_gloo(tmp_path, world):
+    """parallel.RowExchange (round 4: metadata phase + data phase, fixed-capacity all-gather, no torch.unique / argsort in the
+    product path): same result as one process, for 2, 3 and 5 ranks (5 ranks over 23 positives and 37 rows: uneven everything)"""
+    _spawn(W.row_exchange_worker, world, tmp_path)
+    Ws = [np.load(os.path.join(tmp_path, "W_%d.npy" % r)) for r in range(world)]
+    for w in Ws[1:]:
+        np.testing.assert_array_equal(w, Ws[0])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,loss,opt,reg", [("ComplEx", "nll", "sgd", None), ("TransE_L2", "pairwise", "adagrad", None),
                                                ("HolE", "multiclass_nll", "momentum", None), ("DistMult", "nll", "adam_lazy", None),

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -x -m gpu 2>&1 | tail -15
-AB_WORKLOADS="C3a C3g C1" bash tools/ab_step.sh "ieee:EMG_X=0" "fast:EMGRAPH_HIP_LIB=$GRAFT_REPO_ROOT/emgraph_amd/lib/variants/libemgraph_hip_fastrecip.so" "ieee2:EMG_X=0" > gpurun_out/r4_e_ab.txt 2>&1
-cat gpurun_out/r4_e_ab.txt
+python -m pytest tests/test_config_widths.py tests/test_graph_step.py tests/test_parallel.py -q -x 2>&1 | tail -6
+python -m pytest tests/test_full_size.py -q -x -k "c3_exact or deferred" 2>&1 | tail -5
+AB_WORKLOADS="C3a C3g" bash tools/ab_step.sh "new:EMG_X=0" "new2:EMG_X=0" > gpurun_out/r4_g_ab.txt 2>&1
+cat gpurun_out/r4_g_ab.txt
