@@ -252,9 +252,6 @@ class StepRunner:
             out["_batch"] = {"unique_ent_rows": n_ue, "singleton_slots": n_single, "unique_rel_rows": n_ur,
                              "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
             ns = N_STATE[self.w["optimizer"]]
-            if getattr(tr, "inplace_mode", 0) == 2 and tr.deferred:   # Adam's lagging form: the s / o slots go through the apply
-                n_single = int(sl["single"][2 * B:n_ce].sum().item())
-                out["_batch"]["singleton_slots_in_place"] = n_single
             for name, v in ms.items():
                 ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns, n_caught_up=(n_ue - n_single) + n_ur)
                 if name == "apply_ent" and "apply_rel" not in ms:   # pair apply: both tables in the same launches
@@ -811,8 +808,6 @@ def main():
                         "every optimizer but SGD.  This block is the same workload with the reference's default optimizer (Adam), which this "
                         "framework does run at that size: singleton negatives replayed + updated inside the scoring kernel, deferred dense pass"}
 
-    if world == 1 and args.workload == "C3" and args.no_others and not args.quick:
-        line["default_optimizer"] = default_optimizer_block(run_other("C3a"))
     if not args.no_others and world == 1 and args.workload == "C3":
         others = {}
         for name in ("C3z", "C3b", "C3p", "C3m", "C3s", "C3r", "C3a", "C3d", "C3g", "C1", "C2", "C5"):

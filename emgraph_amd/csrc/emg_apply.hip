@@ -684,7 +684,7 @@ struct ReplayParams {
     const float* lr_hist; int32_t upto; double* lp_accum;
     int32_t lag;   // 1 (Adam, no regulariser): multi / single destinations get w only; the apply redoes the decay of m, v (ApplyParams.state_lag)
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* keys; const uint32_t* counters; uint32_t task_cap;
-    const uint32_t* vals; int64_t single_from;   // single_from > 0: singletons whose contribution slot is >= it are not this pass's (the scoring kernel replays them)
+    const uint32_t* vals; int64_t single_from;   // single_from >= 0: singletons whose contribution slot is >= it are not this pass's (the scoring kernel replays them)
 };
 
 // one row, steps tag[r]+1 .. upto: what untouched_rows_body does to it in each of them (g = the regulariser's gradient alone).
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void deferred_catchup_kernel(const ReplayParam
             if (i < n_multi) dest = P.multi[i].dest;
             else if (i < n_multi + n_single) {
                 const uint32_t at = P.single[i - n_multi];
-                if (!(P.single_from > 0 && (int64_t)P.vals[at] >= P.single_from)) dest = P.keys[at];
+                if (!(P.single_from >= 0 && (int64_t)P.vals[at] >= P.single_from)) dest = P.keys[at];
             } else {
                 const LongTask tk = P.tasks[i - n_multi - n_single];
                 if (tk.block == 0u) dest = P.keys[tk.head];   // one entry per long segment: its first block's
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const Replay
             if (i < n_multi) dest = (int32_t)P.multi[i].dest;
             else if (i < n_multi + n_single) {
                 const uint32_t at = P.single[i - n_multi];
-                if (!(P.single_from > 0 && (int64_t)P.vals[at] >= P.single_from)) dest = (int32_t)P.keys[at];
+                if (!(P.single_from >= 0 && (int64_t)P.vals[at] >= P.single_from)) dest = (int32_t)P.keys[at];
             } else {
                 const LongTask tk = P.tasks[i - n_multi - n_single];
                 if (tk.block == 0u) dest = (int32_t)P.keys[tk.head];
@@ -1681,7 +1681,7 @@ extern "C" int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64
     if (rc != EMG_OK) return rc;
     EMG_REQUIRE(w.counting, "emg_deferred_catchup: needs the counting grouping (segment descriptors)");
     P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.keys = w.keys; P.counters = w.counters; P.task_cap = w.task_cap;
-    P.vals = w.vals; P.single_from = skip_single_from > 0 ? skip_single_from : 0;
+    P.vals = w.vals; P.single_from = skip_single_from >= 0 ? skip_single_from : -1;
     if (upto_step == 0) return EMG_OK;
     static const int64_t cap_env = getenv("EMG_CATCHUP_WAVES") ? atoll(getenv("EMG_CATCHUP_WAVES")) : 0;   // A/B aid
     const int64_t cap = cap_env >= 256 ? cap_env : 16384;

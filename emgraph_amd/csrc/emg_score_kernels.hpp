@@ -184,16 +184,17 @@ struct GroupParams {
 //      registers BEFORE the row is scored (the dense pass's own update with g = 0 and each step's lr_t) — what
 //      emg_deferred_catchup does for the other rows with a pass of its own.
 //   The subject / object slots (2 of a group's 22): forms 4 / 5 update their singletons in place at the end of the group, state read
-//   chunk by chunk (form 2's way); form 6 leaves them to the apply (emg_apply_args.skip_single = 2) — their rows would have to be
-//   replayed before the group's queries are built and their replayed state kept to the group's end.  (Measured, C3 + Adagrad: s / o
-//   through the apply in form 4 too — three waves per SIMD instead of two — 0.65 against 0.55-0.60 ms per step: the scoring kernel
-//   no faster, the apply 0.08 ms longer.)
+//   chunk by chunk (form 2's way).  Form 6: a singleton subject / object row lags like a singleton negative — its (w, m, v) are
+//   fetched together at the group's START, replayed, the queries are built from the replayed row, and the three replayed rows
+//   wait in LDS (6 rows per wave) for the update at the group's end: no register lives across the loop over the negatives.
+//   (Measured, C3 + Adagrad: s / o through the apply in form 4 — three waves per SIMD instead of two — 0.65 against 0.55-0.60 ms
+//   per step: the scoring kernel no faster, the apply 0.08 ms longer.)
 template <int IP>
 struct ip_traits {
     static constexpr int n_state = IP == 4 ? 1 : ((IP == 5 || IP == 6) ? 2 : 0);
     static constexpr bool window_state = n_state != 0;
     static constexpr bool replay = IP == 6;
-    static constexpr bool so_inplace = IP != 0 && IP != 6;   // the subject / object slots' singletons: in place too, except in the lagging form
+    static constexpr bool so_inplace = IP != 0;              // the subject / object slots' singletons are updated in place too
     static constexpr int chunkwise = (IP == 4 || IP == 5) ? 2 : IP;   // the form inplace_update runs for the s / o slots
 };
 
@@ -588,11 +589,42 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f, lp_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
     R ks, kp, ko;  // live across the loop only when KEEP (dead otherwise: no registers)
+    // form 6: the replayed (w, m, v) of a singleton subject / object row, parked in LDS between the group's start and its end
+    constexpr bool SO6 = IT::replay;
+    float* stash = nullptr;
+    int fso0 = 0, fso1 = 0;
+    if constexpr (SO6) {
+        __shared__ float so_stash_mem[kThreads / 64][6][R::N][64];
+        stash = &so_stash_mem[threadIdx.x >> 6][0][0][0];
+    }
+    auto park = [&](int slot, const R& r) {
+#pragma unroll
+        for (int e = 0; e < R::N; ++e) stash[(slot * R::N + e) * 64 + lg] = r.x[e];
+    };
+    auto unpark = [&](int slot, R& r) {
+#pragma unroll
+        for (int e = 0; e < R::N; ++e) r.x[e] = stash[(slot * R::N + e) * 64 + lg];
+    };
     {
         R rs, rp, ro;
         load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+        if constexpr (SO6) {
+            int my_tag_so = P.upto;
+            if (lg < 2) my_tag_so = P.tag_ent[lg == 0 ? s : o];
+            fso0 = group_lane_value<LPG>(my_flag_so, first, 0); fso1 = group_lane_value<LPG>(my_flag_so, first, 1);
+            R ms, vs, mo, vo;   // (the state rows of a singleton; any other row: its table row again — address selected, load unconditional)
+            load_row<MODEL, W, NV, LPG, false>(ms, fso0 ? P.ent_state0 + (int64_t)s * P.ld_ent : srow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG, false>(vs, fso0 ? P.ent_state1 + (int64_t)s * P.ld_ent : srow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG, false>(mo, fso1 ? P.ent_state0 + (int64_t)o * P.ld_ent : orow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG, false>(vo, fso1 ? P.ent_state1 + (int64_t)o * P.ld_ent : orow, lg, P.nchunks, P.khalf);
+            const int ts = group_lane_value<LPG>(my_tag_so, first, 0), to = group_lane_value<LPG>(my_tag_so, first, 1);
+            const float lrs = P.lr_hist[min(ts + 1 + lg, P.upto)], lro = P.lr_hist[min(to + 1 + lg, P.upto)];
+            if (fso0 && ts > 0 && ts < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, ts, lrs, rs, ms, vs, lg);
+            if (fso1 && to > 0 && to < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, to, lro, ro, mo, vo, lg);
+            park(0, rs); park(1, ms); park(2, vs); park(3, ro); park(4, mo); park(5, vo);
+        }
         make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
         if constexpr (KEEP) { ks = rs; kp = rp; ko = ro; }
         if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
@@ -838,13 +870,23 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
             load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
         }
+        if constexpr (SO6) {   // (a singleton's table row still lags: its replayed row is the parked one)
+            if (fso0) unpark(0, rs);
+            if (fso1) unpark(3, ro);
+        }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        // (form 6: the s / o slots go through the apply)
-        if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, s, rs, gs, lg, lp_acc);
-        else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-        if (IT::so_inplace && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, o, ro, go, lg, lp_acc);
-        else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        if constexpr (SO6) {
+            if (fso0) { R ms, vs; unpark(1, ms); unpark(2, vs); inplace_update_regs<MODEL, W, NV, LPG, 2>(P, wopt, s, rs, gs, ms, vs, lg); }
+            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
+            if (fso1) { R mo, vo; unpark(4, mo); unpark(5, vo); inplace_update_regs<MODEL, W, NV, LPG, 2>(P, wopt, o, ro, go, mo, vo, lg); }
+            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        } else {
+            if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, s, rs, gs, lg, lp_acc);
+            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
+            if (IT::so_inplace && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, o, ro, go, lg, lp_acc);
+            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+        }
     }
     if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place
     if constexpr (FUSED) {
@@ -873,8 +915,11 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
 #ifdef EMG_TRACE   // timing aid (tools/trace_waves.py fused): wall-clock stamps (10 ns) of every wave of the last fused launch
 static __device__ unsigned long long emg_trace_fused_buf[4 * 65536];
 #endif
+#ifndef EMG_IP6_MINWAVES
+#define EMG_IP6_MINWAVES 3   // form 6: three waves per SIMD (168 VGPRs + 64 bytes of scratch for ComplEx k = 200; left alone: 186 VGPRs, two waves)
+#endif
 template <int MODEL, int W, int NV, int LPG, int IP>
-__global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
+__global__ __launch_bounds__(kThreads, (IP == 6 ? EMG_IP6_MINWAVES : EMG_BW_MINWAVES)) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
     unsigned bx;
     if (run_riders(riders, &bx)) return;
 #ifdef EMG_TRACE

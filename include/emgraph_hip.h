@@ -221,15 +221,15 @@ typedef struct emg_backward_args {
     /* lr_hist != NULL (EMG_OPT_ADAM in place with inplace_window, fused loss, deferred dense pass — see emg_deferred_catchup): the rows of SINGLETON
      * NEGATIVES are as of tag_ent[row]; the kernel fetches (w, m, v) of such a row together, replays the steps tag + 1 .. step - 1 in
      * registers (the dense pass's update with g = 0 and lr_hist[s]), scores the row, applies this step's update and writes
-     * (w, m, v, tag = step): one read and one write of the three rows where catch-up + scoring + apply moved twelve.  The subject /
-     * object slots are NOT updated in place in this form: finish with emg_apply_grouped_ex(skip_single = 2, single_from_slot =
-     * 2 * B) after emg_deferred_catchup(..., skip_single_from = 2 * B) brought every other row of the batch up to date. */
+     * (w, m, v, tag = step): one read and one write of the three rows where catch-up + scoring + apply moved twelve.  The same for
+     * singleton subject / object rows (replayed before the group's queries are built).  Finish with emg_apply_grouped_ex(skip_single
+     * = 1) after emg_deferred_catchup(..., skip_single_from = 0) brought every other row of the batch up to date. */
     const float* lr_hist;
     /* inplace_window != 0 (stateful optimizers; fused loss; 16-byte rows of at most 64 chunks, per half for complex models): a
      * singleton negative's optimizer state rows are fetched together with its table row in the kernel's rolling window — the update
-     * waits for nothing (0: the state is read chunk by chunk at the update).  Without lr_hist the subject / object singletons are
-     * updated in place too (finish with skip_single = 1); with lr_hist they are not (skip_single = 2, single_from_slot = 2 * B).
-     * Required by lr_hist. */
+     * waits for nothing (0: the state is read chunk by chunk at the update).  The subject / object singletons are updated in place too
+     * (without lr_hist: at the group's end, state read chunk by chunk; with lr_hist: replayed at the group's start, parked in LDS,
+     * updated at its end): finish with skip_single = 1.  Required by lr_hist. */
     int32_t inplace_window; int32_t reserved2;
 } emg_backward_args;
 /* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
@@ -297,8 +297,8 @@ int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, voi
  * and tag[row] stay as of the row's last write, and the apply redoes their decay over the missed steps in registers
  * (two multiplications per element and step) instead of this call writing and the apply re-reading both state rows.
  * Same bits.
- * skip_single_from > 0: singleton destinations whose contribution slot is >= it are left alone — the scoring kernel replays them
- * itself as it gathers them (emg_backward_args.lr_hist). */
+ * skip_single_from >= 0: singleton destinations whose contribution slot is >= it are left alone — the scoring kernel replays them
+ * itself as it gathers them (emg_backward_args.lr_hist: 0 = every singleton); < 0: none are. */
 int emg_deferred_catchup(int opt, float* table, int64_t n_rows, int64_t ld, int32_t k_int, float* state0, float* state1,
                          int32_t* tag, const float* hyper, const float* lr_hist, int32_t upto_step, double* lp_accum,
                          const void* workspace, int64_t workspace_bytes, int64_t layout_n, int32_t w_only, int64_t skip_single_from,
