@@ -182,7 +182,6 @@ class ApplyArgs(C.Structure):
         ("factored", _i32), ("table_index", _i32),
         ("layout_n", _i64), ("ctl", _p),
         ("deferred_dense", _i32), ("reserved1", _i32),
-        ("single_from_slot", _i64),
     ]
 
 

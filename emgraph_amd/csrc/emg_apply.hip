@@ -29,8 +29,7 @@ struct ApplyParams {
     int32_t state_lag;   // 1 (Adam, deferred dense pass): m, v of a multi / single destination are as of tag[row], w is current (below)
     const float* contrib; int64_t ldc;
     const uint32_t* keys; const uint32_t* vals; int64_t n;
-    int32_t skip_single;   // 1: singletons were updated in place; 2: those whose contribution slot is >= single_from were
-    int64_t single_from;
+    int32_t skip_single;   // 1: singletons were updated in place by the scoring kernel
     int32_t win;  // sorted positions per wave
     OptParams opt;
     // segments longer than `defer` rows leave the window kernel as BLOCK TASKS (apply_long_kernel): 64-row blocks of
@@ -192,7 +191,7 @@ __device__ __forceinline__ void apply_rows_body(const ApplyParams& P, int64_t bl
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
-    unsigned long long todo = __ballot(head && !(P.skip_single == 1 && last));
+    unsigned long long todo = __ballot(head && !(P.skip_single && last));
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     float lp_acc = 0.f;
@@ -492,7 +491,7 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
     const bool head = in && (t0 == 0 || P.keys[t0 - 1] != mykey);
     const bool last = in && (t0 + 1 == P.n || P.keys[t0 + 1] != mykey);
     const unsigned long long heads = __ballot(head);
-    const unsigned long long todo = __ballot(head && !(P.skip_single == 1 && last));
+    const unsigned long long todo = __ballot(head && !(P.skip_single && last));
     const int64_t wend = min(w0 + (int64_t)P.win, P.n);  // end of this window
     const int nchunks = P.k_int / W;
     const int ntodo = __popcll(todo);
@@ -766,7 +765,8 @@ __global__ __launch_bounds__(256) void deferred_catchup_kernel(const ReplayParam
     float lp_acc = 0.f;
     const int lane = threadIdx.x & 63;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.counters[GC_SINGLE];
+    // (single_from == 0: every singleton is the scoring kernel's — none in this pass's item list, so that the waves' shares hold real items)
+    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.single_from == 0 ? 0 : P.counters[GC_SINGLE];
     const int64_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
     const int64_t total = n_multi + n_single + n_tasks;
     const int64_t share = (total + nw - 1) / nw;
@@ -867,7 +867,8 @@ __global__ __launch_bounds__(256) void deferred_catchup_rows_kernel(const Replay
     const int lane = threadIdx.x & 63;
     const int nchunks = P.k_int / 4;
     const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.counters[GC_SINGLE];
+    // (single_from == 0: every singleton is the scoring kernel's — none in this pass's item list, so that the waves' shares hold real items)
+    const int64_t n_multi = P.counters[GC_MULTI], n_single = P.single_from == 0 ? 0 : P.counters[GC_SINGLE];
     const int64_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
     const int64_t total = n_multi + n_single + n_tasks;
     const int64_t share = (total + nw - 1) / nw;
@@ -1167,9 +1168,8 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     }
     const int nchunks = P.k_int / 4;
     const uint32_t n_multi = P.counters[GC_MULTI];
-    const uint32_t n_single = P.skip_single == 1 ? 0u : P.counters[GC_SINGLE];
+    const uint32_t n_single = P.skip_single ? 0u : P.counters[GC_SINGLE];
     const uint32_t n_tasks = min(P.counters[GC_TASKS], P.task_cap);
-    const int64_t single_from = (P.ctl && P.skip_single == 2) ? 2 * (int64_t)P.ctl->B : P.single_from;   // (graph node: the batch size is the record's)
     float lp_acc = 0.f;
     if (n_tasks && partial) {
         const unsigned per = waves_per_task(P, nchunks);
@@ -1193,29 +1193,14 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     } else {
         i0 = gw * share; i1 = min(total, i0 + share);
     }
-    // skip_single = 2: most singletons are no items (the scoring kernel updated them) — one contiguous share of [multi | single]
-    // would give the waves at the front every multi-row segment and the others next to nothing (C3 + Adam: 0.44 ms, all of it
-    // the first sixth of the grid).  Every wave takes its share of EACH list: two stretches.
-    int64_t j0 = 0, j1 = 0;
-    if (P.skip_single == 2) {
-        const int64_t sm = ((int64_t)n_multi + nw - 1) / nw, ss = ((int64_t)n_single + nw - 1) / nw;
-        i0 = min(gw * sm, (int64_t)n_multi); i1 = min(i0 + sm, (int64_t)n_multi);
-        j0 = (int64_t)n_multi + min(gw * ss, (int64_t)n_single); j1 = min(j0 + ss, total);
-    }
     static_assert(kDeferSegment <= 32, "segment_update_half keeps a segment's sources in 32 lanes");
     constexpr bool halves = HALF;   // (its own instantiation: both forms in one kernel cost the wide rows a wave per SIMD)
-    for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) { i0 = j0; i1 = j1; }
     for (int64_t base = i0; base < i1; base += 64) {
         const int64_t it = base + lane;
         Seg sg{0u, 0u, 0u};
         if (it < i1) {
             if (it < (int64_t)n_multi) sg = P.multi[it];
-            else {
-                const uint32_t at = P.single[it - n_multi];
-                sg = Seg{at, 1u, P.keys[at]};
-                if (P.skip_single == 2 && (int64_t)P.vals[at] >= single_from) sg.len = 0u;   // updated in place by the scoring kernel: no item
-            }
+            else { const uint32_t at = P.single[it - n_multi]; sg = Seg{at, 1u, P.keys[at]}; }
         }
         const int cnt = (int)min((int64_t)64, i1 - base);
         if constexpr (halves) {   // two items at a time, one per half of the wave (segment_update_half)
@@ -1226,7 +1211,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                 len = (uint32_t)__shfl((int)sg.len, from_lane, 64);
                 dest = (uint32_t)__shfl((int)sg.dest, from_lane, 64);
                 const uint32_t start = (uint32_t)__shfl((int)sg.start, from_lane, 64);
-                on = kk < cnt && (int64_t)dest < P.n_rows && len != 0u;   // (defensive: never write outside the table; len 0: no item)
+                on = kk < cnt && (int64_t)dest < P.n_rows;   // (defensive: never write outside the table)
                 return (on && (uint32_t)l < len) ? contrib_src(P, (int64_t)start + l) : Src{0u, 0.f};
             };
             uint32_t len_n, dest_n;
@@ -1248,11 +1233,10 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             if (k + 1 < cnt)
                 nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, k + 1),
                                       (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
-            if ((int64_t)dest >= P.n_rows || len == 0u) continue;   // defensive: never write outside the table; len 0: no item
+            if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
             segment_update<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
         }
         }
-    }
     }
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
@@ -1286,7 +1270,7 @@ __global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunc
     int64_t heavy = 0, relief = 0;
     if (K.n_tables == 2 && K.relief) {
         const ApplyParams& R = K.P[1];
-        const int64_t n_multi = R.counters[GC_MULTI], n_single = R.skip_single == 1 ? 0 : R.counters[GC_SINGLE];
+        const int64_t n_multi = R.counters[GC_MULTI], n_single = R.skip_single ? 0 : R.counters[GC_SINGLE];
         const int64_t rows = (int64_t)R.counters[GC_VALID] - (int64_t)R.counters[GC_SINGLE];
         const int64_t items = n_multi + n_single;
         if (items > 0 && items <= nw) {
@@ -1350,15 +1334,14 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     A = ApplyLaunch{};
     P.table = a->table; P.n_rows = n_rows; P.ld = ld; P.k_int = k_int;
     P.state0 = a->state0; P.state1 = a->state1; P.tag = a->tag; P.step = a->step;
-    P.contrib = a->contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = a->skip_single; P.single_from = a->single_from_slot;
-    EMG_REQUIRE(a->skip_single >= 0 && a->skip_single <= 2 && (a->skip_single != 2 || a->single_from_slot > 0),
-                "emg_apply_grouped: skip_single is 0, 1 or 2 (2: with single_from_slot > 0)");
+    P.contrib = a->contrib; P.ldc = ldc; P.n = n_contrib; P.skip_single = a->skip_single ? 1 : 0;
     P.opt = make_opt_params(opt, hyper);
     P.lp_accum = a->lp_accum;
     P.ctl = (const StepCtl*)a->ctl; P.which = a->table_index;
     A.dense = (opt == EMG_OPT_ADAM || P.opt.lp_lambda != 0.f) && !a->deferred_dense;
-    EMG_REQUIRE(a->deferred_dense != 2 || (opt == EMG_OPT_ADAM && P.opt.lp_lambda == 0.f && a->tag && a->skip_single != 1),
-                "emg_apply_grouped: deferred_dense = 2 (m, v lag behind w) is Adam's, without a regulariser or in-place singletons");
+    // (skip_single = 1 with deferred_dense = 2: the scoring kernel replayed and updated every singleton itself — emg_backward_args.lr_hist)
+    EMG_REQUIRE(a->deferred_dense != 2 || (opt == EMG_OPT_ADAM && P.opt.lp_lambda == 0.f && a->tag),
+                "emg_apply_grouped: deferred_dense = 2 (m, v lag behind w) is Adam's, without a regulariser");
     EMG_REQUIRE(a->deferred_dense != 2 || segments_path_enabled(), "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply");
     P.state_lag = a->deferred_dense == 2 ? 1 : 0;
     { const char* e = getenv("EMG_APPLY_HALF"); P.half_rows = (e && e[0] == '0') ? 0 : 1; }   // A/B aid (read per call: tests flip it)
@@ -1381,8 +1364,6 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     A.segs = w.counting && A.vec && !A.skinny && segments_path_enabled();
     EMG_REQUIRE(!P.state_lag || A.segs, "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply (counting grouping, "
                                         "16-byte aligned rows of more than 16 chunks)");
-    EMG_REQUIRE(P.skip_single != 2 || A.segs, "emg_apply_grouped: skip_single = 2 needs the descriptor-driven apply (counting grouping, "
-                                              "16-byte aligned rows of more than 16 chunks)");
     EMG_REQUIRE(!P.ctl || A.segs, "emg_apply_grouped: a device-side step record needs the descriptor-driven apply (counting "
                                   "grouping, 16-byte aligned rows of more than 16 chunks)");
     if (A.segs) {

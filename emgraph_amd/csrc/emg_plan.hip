@@ -171,7 +171,6 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     // of such a row together, replays its missed steps in registers and updates it (emg_backward_args.lr_hist); the catch-up and
     // the apply handle every other destination of the batch (s / o slots, rows hit more than once)
     const bool lag_ip = c.lr_t_hist && c.inplace == 2 && c.opt == EMG_OPT_ADAM;
-    const bool neg_only = false;   // (skip_single = 2: the apply finishing the s / o slots of a form that leaves them — none does since form 6 parks them in LDS)
     const int32_t w_only = (c.lr_t_hist && c.opt == EMG_OPT_ADAM && !lp && (!c.inplace || lag_ip) && seg_rows && lag_env) ? 1 : 0;
     if (lag_ip) ba.lr_hist = c.lr_t_hist;
     if (c.lr_t_hist) {   // deferred dense pass (Keras Adam / LP): bring the rows this batch reads and updates up to step - 1
@@ -225,7 +224,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         for (int i = 0; i < 8; ++i) aa.hyper[i] = h[i];
         if (ent_table) {
             aa.table = c.ent; aa.n_rows = c.n_ent; aa.ld = c.ld_ent; aa.state0 = c.ent_state0; aa.state1 = c.ent_state1;
-            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? (neg_only ? 2 : 1) : 0; aa.single_from_slot = neg_only ? 2 * B : 0;
+            aa.tag = c.tag_ent; aa.skip_single = c.inplace ? 1 : 0;
             aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
             aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
             aa.factored = c.factored; aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
@@ -310,7 +309,7 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
     EMG_REQUIRE(cfg->inplace != 2 || (cfg->opt != EMG_OPT_SGD && cfg->fused), "emg_plan_create: inplace = 2 is for stateful optimizers in the fused step");
     EMG_REQUIRE(!(cfg->lr_t_hist && cfg->inplace == 1 && cfg->opt != EMG_OPT_SGD),
                 "emg_plan_create: a stateful optimizer's in-place updates under the deferred dense pass need inplace = 2 (Adam's in-kernel replay)");
-    if (cfg->lr_t_hist && cfg->inplace == 2) {   // (what the in-kernel replay and the apply's skip_single = 2 need)
+    if (cfg->lr_t_hist && cfg->inplace == 2) {   // (what the in-kernel replay needs; the apply that finishes the other rows is the descriptor-driven one)
         const bool cplx = cfg->model == EMG_COMPLEX || cfg->model == EMG_HOLE;
         const int n = cplx ? cfg->k_int / 2 : cfg->k_int;
         EMG_REQUIRE(cfg->opt == EMG_OPT_ADAM && cfg->fused && cfg->lp_lambda_ent == 0.f && cfg->lp_lambda_rel == 0.f && n % 4 == 0 && n / 4 <= 64 && cfg->k_int > 64,

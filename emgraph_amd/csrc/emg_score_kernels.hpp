@@ -589,12 +589,14 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     float pos_nrm = 0.f, pos_score = 0.f, gpos = 0.f, loss_acc = 0.f, lp_acc = 0.f;
     constexpr bool KEEP = keep_rows<MODEL, W, NV, FUSED, IP>::value;
     R ks, kp, ko;  // live across the loop only when KEEP (dead otherwise: no registers)
-    // form 6: the replayed (w, m, v) of a singleton subject / object row, parked in LDS between the group's start and its end
-    constexpr bool SO6 = IT::replay;
+    // window forms: the state rows of a singleton subject / object row are fetched with the row at the group's START (form 6: and
+    // the row replayed to the current step before the queries are built from it) and wait, with the row, in LDS for the update at
+    // the group's end — nothing of it lives in registers across the loop over the negatives
+    constexpr bool SOP = IT::window_state;
     float* stash = nullptr;
     int fso0 = 0, fso1 = 0;
-    if constexpr (SO6) {
-        __shared__ float so_stash_mem[kThreads / 64][6][R::N][64];
+    if constexpr (SOP) {
+        __shared__ float so_stash_mem[kThreads / 64][2 * (1 + NS)][R::N][64];
         stash = &so_stash_mem[threadIdx.x >> 6][0][0][0];
     }
     auto park = [&](int slot, const R& r) {
@@ -610,20 +612,25 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
         load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
-        if constexpr (SO6) {
-            int my_tag_so = P.upto;
-            if (lg < 2) my_tag_so = P.tag_ent[lg == 0 ? s : o];
+        if constexpr (SOP) {
+            int my_tag_so = 0;
+            if constexpr (IT::replay) { my_tag_so = P.upto; if (lg < 2) my_tag_so = P.tag_ent[lg == 0 ? s : o]; }
             fso0 = group_lane_value<LPG>(my_flag_so, first, 0); fso1 = group_lane_value<LPG>(my_flag_so, first, 1);
             R ms, vs, mo, vo;   // (the state rows of a singleton; any other row: its table row again — address selected, load unconditional)
             load_row<MODEL, W, NV, LPG, false>(ms, fso0 ? P.ent_state0 + (int64_t)s * P.ld_ent : srow, lg, P.nchunks, P.khalf);
-            load_row<MODEL, W, NV, LPG, false>(vs, fso0 ? P.ent_state1 + (int64_t)s * P.ld_ent : srow, lg, P.nchunks, P.khalf);
             load_row<MODEL, W, NV, LPG, false>(mo, fso1 ? P.ent_state0 + (int64_t)o * P.ld_ent : orow, lg, P.nchunks, P.khalf);
-            load_row<MODEL, W, NV, LPG, false>(vo, fso1 ? P.ent_state1 + (int64_t)o * P.ld_ent : orow, lg, P.nchunks, P.khalf);
-            const int ts = group_lane_value<LPG>(my_tag_so, first, 0), to = group_lane_value<LPG>(my_tag_so, first, 1);
-            const float lrs = P.lr_hist[min(ts + 1 + lg, P.upto)], lro = P.lr_hist[min(to + 1 + lg, P.upto)];
-            if (fso0 && ts > 0 && ts < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, ts, lrs, rs, ms, vs, lg);
-            if (fso1 && to > 0 && to < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, to, lro, ro, mo, vo, lg);
-            park(0, rs); park(1, ms); park(2, vs); park(3, ro); park(4, mo); park(5, vo);
+            if constexpr (NS == 2) {
+                load_row<MODEL, W, NV, LPG, false>(vs, fso0 ? P.ent_state1 + (int64_t)s * P.ld_ent : srow, lg, P.nchunks, P.khalf);
+                load_row<MODEL, W, NV, LPG, false>(vo, fso1 ? P.ent_state1 + (int64_t)o * P.ld_ent : orow, lg, P.nchunks, P.khalf);
+            }
+            if constexpr (IT::replay) {
+                const int ts = group_lane_value<LPG>(my_tag_so, first, 0), to = group_lane_value<LPG>(my_tag_so, first, 1);
+                const float lrs = P.lr_hist[min(ts + 1 + lg, P.upto)], lro = P.lr_hist[min(to + 1 + lg, P.upto)];
+                if (fso0 && ts > 0 && ts < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, ts, lrs, rs, ms, vs, lg);
+                if (fso1 && to > 0 && to < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, to, lro, ro, mo, vo, lg);
+            }
+            park(0, rs); park(1, ms); park(1 + NS, ro); park(2 + NS, mo);
+            if constexpr (NS == 2) { park(2, vs); park(5, vo); }
         }
         make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
         if constexpr (KEEP) { ks = rs; kp = rp; ko = ro; }
@@ -870,16 +877,16 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
             load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
         }
-        if constexpr (SO6) {   // (a singleton's table row still lags: its replayed row is the parked one)
+        if constexpr (IT::replay) {   // (a singleton's table row still lags: its replayed row is the parked one)
             if (fso0) unpark(0, rs);
-            if (fso1) unpark(3, ro);
+            if (fso1) unpark(1 + NS, ro);
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
-        if constexpr (SO6) {
-            if (fso0) { R ms, vs; unpark(1, ms); unpark(2, vs); inplace_update_regs<MODEL, W, NV, LPG, 2>(P, wopt, s, rs, gs, ms, vs, lg); }
+        if constexpr (SOP) {
+            if (fso0) { R ms, vs; unpark(1, ms); if constexpr (NS == 2) unpark(2, vs); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, s, rs, gs, ms, vs, lg); }
             else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-            if (fso1) { R mo, vo; unpark(4, mo); unpark(5, vo); inplace_update_regs<MODEL, W, NV, LPG, 2>(P, wopt, o, ro, go, mo, vo, lg); }
+            if (fso1) { R mo, vo; unpark(2 + NS, mo); if constexpr (NS == 2) unpark(5, vo); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, o, ro, go, mo, vo, lg); }
             else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
         } else {
             if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, s, rs, gs, lg, lp_acc);
@@ -916,10 +923,10 @@ __global__ __launch_bounds__(kThreads, EMG_BW_MINWAVES) void train_backward_kern
 static __device__ unsigned long long emg_trace_fused_buf[4 * 65536];
 #endif
 #ifndef EMG_IP6_MINWAVES
-#define EMG_IP6_MINWAVES 3   // form 6: three waves per SIMD (168 VGPRs + 64 bytes of scratch for ComplEx k = 200; left alone: 186 VGPRs, two waves)
-#endif
+#define EMG_IP6_MINWAVES 3   // window forms: three waves per SIMD (form 6, ComplEx k = 200: 168 VGPRs + 64 bytes of scratch; left alone 186 VGPRs, two waves:
+#endif                       // C3 + Adam 0.86 against 0.93 ms per step)
 template <int MODEL, int W, int NV, int LPG, int IP>
-__global__ __launch_bounds__(kThreads, (IP == 6 ? EMG_IP6_MINWAVES : EMG_BW_MINWAVES)) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
+__global__ __launch_bounds__(kThreads, (ip_traits<IP>::window_state ? EMG_IP6_MINWAVES : EMG_BW_MINWAVES)) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
     unsigned bx;
     if (run_riders(riders, &bx)) return;
 #ifdef EMG_TRACE

@@ -277,8 +277,6 @@ typedef struct emg_apply_args {
     int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
     int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below;
                                                   * 2: the same, and the catch-up ran with w_only (m, v of the destinations lag behind w) */
-    int64_t single_from_slot;            /* skip_single = 2: only the singletons whose contribution slot is >= this were updated in place (the
-                                          * negatives' slots start at 2 * B: emg_backward_args.lr_hist); the others are applied here */
 } emg_apply_args;
 int emg_apply_grouped_ex(const emg_apply_args* args, void* stream);
 int emg_apply_grouped_pair(const emg_apply_args* a, const emg_apply_args* b, void* stream);
