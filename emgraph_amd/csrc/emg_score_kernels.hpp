@@ -655,7 +655,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     }
 
     // rows in flight per wave: U table rows — with their state rows (IP 4 / 5 / 6) U * (1 + NS) rows, held to ~48 registers
-    constexpr int U = !IT::window_state ? EMG_BW_U : (R::N * (1 + NS) * 4 <= 48 ? 4 : (R::N * (1 + NS) * 3 <= 48 ? 3 : 2));
+#ifndef EMG_WIN_BUDGET
+#define EMG_WIN_BUDGET 48
+#endif
+    constexpr int U = !IT::window_state ? EMG_BW_U : (R::N * (1 + NS) * 4 <= EMG_WIN_BUDGET ? 4 : (R::N * (1 + NS) * 3 <= EMG_WIN_BUDGET ? 3 : 2));
     int chunk0 = 0, chunk1 = min(P.eta, LPG);   // the negatives [chunk0, chunk1) are the ones my_code / my_flag / my_pos describe
     auto code_of = [&](int j) -> int32_t { return group_lane_value<LPG>(my_code, first, j - chunk0); };
     auto flag_of = [&](int j) -> int {   // negative j of the current chunk
