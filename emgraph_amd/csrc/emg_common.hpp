@@ -194,7 +194,7 @@ __device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float
 // range.  ONE function for every path (dense pass, catch-up, apply, in-place forms): their results stay bit-identical to each
 // other; against Keras' CPU arithmetic (parity unpinned) the difference is the one TF's own GPU kernels have.
 #ifndef EMG_OPT_FAST_RECIP
-#define EMG_OPT_FAST_RECIP 0
+#define EMG_OPT_FAST_RECIP 1
 #endif
 __device__ __forceinline__ float opt_ratio(float num, float root, float eps) {
 #pragma clang fp contract(off)
