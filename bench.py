@@ -404,7 +404,9 @@ def run_eval(r, args):
     def timed(T_, **kw):
         # untimed warm-up on enough triples (> 128 query rows) to take the same kernels as the timed call: a kernel's first
         # launch loads its code object and sets its LDS attribute (~30 ms once per process for the prefilter + re-scoring pair)
-        rank_triples_device(mid, ent, rel, k_int, r.scale, T_[:192], "s+o", "worst", filter_triples=F, shard=shard, **kw)
+        # (half of the test set: long enough segments for the segment-wise re-scoring kernel too — with 192 triples it was sometimes
+        # first launched inside the timed call: 164 k instead of 406 k ranks/s in one run of round 4)
+        rank_triples_device(mid, ent, rel, k_int, r.scale, T_[:max(192, len(T_) // 2)], "s+o", "worst", filter_triples=F, shard=shard, **kw)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()

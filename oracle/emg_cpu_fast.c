@@ -6,8 +6,9 @@
  *   - one OpenMP thread per positive group: the group's s, p, o rows are read once, its two hoisted query vectors
  *     (object side from (s, p), subject side from (p, o)) built once, and every negative is ONE SIMD dot product /
  *     distance of a query with the replacement row (the same algebra the GPU kernel uses, SURVEY B-2);
- *   - `omp simd reduction` inner loops (AVX2 / AVX-512 FMA under -O3 -march=native), software prefetch of the next
- *     negatives' rows (the gather is DRAM-latency bound on a 1.6 GB table).
+ *   - `omp simd reduction` inner loops (AVX2 / AVX-512 FMA under -O3 -march=native), software prefetch of EVERY cache line of
+ *     the next CPUFAST_PF negatives' rows and of the next group's rows (the gather is DRAM-latency bound on a 1.6 GB table;
+ *     round 3 prefetched one line of a 25-line row).
  * Results agree with the checker within fp32 reassociation (tests/test_oracle_golden.py). */
 #include <math.h>
 #include <stdint.h>
@@ -25,6 +26,14 @@ int cpufast_num_threads(void) {
     return 1;
 #endif
 }
+
+/* every cache line of a k_int-float row: a 1600-byte row is 25 lines, and the hardware prefetcher does not follow a gather */
+static inline void prefetch_row(const float* row, int k_int) {
+    for (int c = 0; c < k_int; c += 16) __builtin_prefetch(row + c, 0, 0);
+}
+#ifndef CPUFAST_PF
+#define CPUFAST_PF 6   /* negatives' rows in flight per thread ahead of the one being scored */
+#endif
 
 static inline float dot(const float* restrict a, const float* restrict b, int n) {
     float acc = 0.f;
@@ -60,8 +69,12 @@ void cpufast_train_forward(int model, const float* ent, int64_t ld_ent, const fl
             const float* rs = ent + (int64_t)pos[3 * g] * ld_ent;
             const float* rp = rel + (int64_t)pos[3 * g + 1] * ld_rel;
             const float* ro = ent + (int64_t)pos[3 * g + 2] * ld_ent;
-            for (int j = 0; j < eta && j < 4; ++j)
-                __builtin_prefetch(ent + (int64_t)(codes[(int64_t)j * B + g] & 0x7fffffff) * ld_ent, 0, 0);
+            for (int j = 0; j < eta && j < CPUFAST_PF; ++j)
+                prefetch_row(ent + (int64_t)(codes[(int64_t)j * B + g] & 0x7fffffff) * ld_ent, k_int);
+            if (g + 1 < B) {   /* the next group's own rows (this thread's next iteration under the static schedule) */
+                prefetch_row(ent + (int64_t)pos[3 * (g + 1)] * ld_ent, k_int);
+                prefetch_row(ent + (int64_t)pos[3 * (g + 1) + 2] * ld_ent, k_int);
+            }
             /* hoisted queries: a negative that keeps the subject scores <qo, e>, one that keeps the object <qs, e> */
             if (model <= TRANSE_L2) {
 #pragma omp simd
@@ -83,7 +96,9 @@ void cpufast_train_forward(int model, const float* ent, int64_t ld_ent, const fl
             else sp = dot(qo, ro, k_int) * (model == HOLE ? scale : 1.f);
             scores_pos[g] = sp;
             for (int j = 0; j < eta; ++j) {
-                if (j + 4 < eta) __builtin_prefetch(ent + (int64_t)(codes[(int64_t)(j + 4) * B + g] & 0x7fffffff) * ld_ent, 0, 0);
+                if (j + CPUFAST_PF < eta) prefetch_row(ent + (int64_t)(codes[(int64_t)(j + CPUFAST_PF) * B + g] & 0x7fffffff) * ld_ent, k_int);
+                else if (g + 1 < B && j + CPUFAST_PF - eta < eta)   /* past this group's end: the next group's first negatives */
+                    prefetch_row(ent + (int64_t)(codes[(int64_t)(j + CPUFAST_PF - eta) * B + g + 1] & 0x7fffffff) * ld_ent, k_int);
                 const int32_t code = codes[(int64_t)j * B + g];
                 const float* re = ent + (int64_t)(code & 0x7fffffff) * ld_ent;
                 const float* q = code < 0 ? qo : qs;

@@ -58,6 +58,31 @@ def test_graph_steps_equal_single_steps_bit_for_bit(monkeypatch, name, k, loss, 
     np.testing.assert_array_equal(np.array(mg.trained_model_params[0]), Eg)
 
 
+@pytest.mark.parametrize("name,k,loss,opt", [("DistMult", 72, "nll", "adam"), ("ComplEx", 100, "nll", "adagrad"), ("TransE", 100, "pairwise", "momentum")])
+def test_graph_steps_with_the_window_forms_in_place(monkeypatch, name, k, loss, opt):
+    """a stateful optimizer's singletons updated inside the scoring kernel (window forms 4 / 5, round 4) are not the default for
+    batches this small — forced here (EMG_INPLACE=1): as graph replays (per-step values from the device records) == single steps
+    == every row through the apply, bit for bit"""
+    n_ent, n_rel, n = 3000, 7, 2003
+    X = synth_graph(n_ent, n_rel, n, seed=3)
+    rs = np.random.RandomState(5)
+    ki = 2 * k if name in ("ComplEx", "HolE") else k
+    ent0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    rel0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    kw = dict(eta=5, epochs=2, batches_count=6, seed=11, loss=loss, optimizer=opt, optimizer_params={"lr": 0.02})
+    monkeypatch.setenv("EMG_INPLACE", "1")
+    Eg, Rg, Lg, mg = _fit(monkeypatch, True, name, k, X, ent0, rel0, **kw)
+    assert mg._trainer.inplace_mode == 2
+    Es, Rs, Ls, _ = _fit(monkeypatch, False, name, k, X, ent0, rel0, **kw)
+    monkeypatch.setenv("EMG_INPLACE", "0")
+    Ea, Ra, La, ma = _fit(monkeypatch, True, name, k, X, ent0, rel0, **kw)
+    assert ma._trainer.inplace_mode == 0
+    for E, R, Ls_ in ((Es, Rs, Ls), (Ea, Ra, La)):
+        np.testing.assert_array_equal(Eg, E)
+        np.testing.assert_array_equal(Rg, R)
+        assert Lg == Ls_
+
+
 def test_graph_fit_matches_oracle_training_loop(monkeypatch):
     """the graph path against the oracle loop directly (same Philox draws, Keras Adam), at a width the graph path covers"""
     name, k, eta, epochs, bc, seed, lr = "DistMult", 72, 3, 2, 5, 7, 0.05
