@@ -86,7 +86,6 @@ class BackwardArgs(C.Structure):
         ("lp_accum", _p),
         ("lr_hist", _p),
         ("inplace_window", _i32), ("reserved2", _i32),
-        ("fac_sign_row0", _i64),
     ]
 
 
@@ -182,7 +181,6 @@ class ApplyArgs(C.Structure):
         ("hyper", _f32 * 8), ("lp_accum", _p), ("workspace", _p), ("workspace_bytes", _i64),
         ("factored", _i32), ("table_index", _i32),
         ("layout_n", _i64), ("ctl", _p),
-        ("fac_sign_row0", _i64),
         ("deferred_dense", _i32), ("reserved1", _i32),
     ]
 

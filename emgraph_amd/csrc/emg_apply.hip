@@ -46,10 +46,6 @@ struct ApplyParams {
     //   grouping (mark_single_kernel: the codes are known there), coef[t] is written by the backward kernel straight
     //   into sorted order (pos_of_slot) — so a window's sources are ONE coalesced load each, like its keys.
     const uint32_t* srcrow; const float* coef;
-    //   PACKED (TransE-L1; emg_backward_args.fac_sign_row0): srcrow[t] = kPackedSrc | negative index for the negatives' slots — their
-    //   row is coef[t] * s, s in {-1, 0, +1} per coordinate, stored as one byte per coordinate: chunk c of negative i is the dword
-    //   signs[i * (k_int / 4) + c].  coef * (+-1 | 0) is exact: the same bits as adding the stored row.
-    const uint32_t* signs;
     // segment descriptors of the counting grouping (apply_segments_kernel): see emg_group.hpp
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* counters; uint32_t task_cap;
     int32_t which;             // 0: entity table, 1: relation table (which hyper-parameters of a StepCtl apply)
@@ -59,20 +55,6 @@ struct ApplyParams {
 struct Src { uint32_t row; float coef; };
 __device__ __forceinline__ Src contrib_src(const ApplyParams& P, int64_t t) {
     return Src{P.srcrow[t], P.coef ? P.coef[t] : 1.f};
-}
-// 16-byte chunk c of a source row, RAW: a float4 of the contribution buffer — or, for a packed row, the chunk's four sign bytes in .x
-__device__ __forceinline__ float4 src_chunk_raw(const ApplyParams& P, uint32_t row, int c, int nchunks) {
-    if (row & kPackedSrc) {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        r.x = __uint_as_float(P.signs[(int64_t)(row & ~kPackedSrc) * nchunks + c]);
-        return r;
-    }
-    return *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c);
-}
-__device__ __forceinline__ float4 src_chunk_value(uint32_t row, const float4& raw) {
-    if (!(row & kPackedSrc)) return raw;
-    const uint32_t b = __float_as_uint(raw.x);
-    return make_float4((float)(int)(int8_t)(b), (float)(int)(int8_t)(b >> 8), (float)(int)(int8_t)(b >> 16), (float)(int)(int8_t)(b >> 24));
 }
 // acc += coef * v, the product rounded on its own (never contracted into an fma): the same bits as adding a row the
 // backward kernel stored as coef * q
@@ -283,24 +265,22 @@ __device__ __forceinline__ void sum_block(const ApplyParams& P, int64_t u0, int6
         float4 acc = carry ? make_float4(out[0], out[1], out[2], out[3]) : make_float4(0.f, 0.f, 0.f, 0.f);   // carry: continue a running sum
         const int n = (int)(u1 - u0);
         int j0 = 0;
-        const int nch = P.k_int / 4;
         for (; j0 + RIF <= n; j0 += RIF) {
             float4 v[RIF];
             float cf[RIF];
-            uint32_t rw[RIF];
 #pragma unroll
             for (int j = 0; j < RIF; ++j) {
-                rw[j] = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0 + j);
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0 + j);
                 cf[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), j0 + j));
-                v[j] = src_chunk_raw(P, rw[j], c, nch);
+                v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c);
             }
 #pragma unroll
-            for (int j = 0; j < RIF; ++j) add_scaled(acc, src_chunk_value(rw[j], v[j]), cf[j]);
+            for (int j = 0; j < RIF; ++j) add_scaled(acc, v[j], cf[j]);
         }
         for (; j0 < n; ++j0) {
             const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, j0);
             const float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_coef), j0));
-            add_scaled(acc, src_chunk_value(row, src_chunk_raw(P, row, c, nch)), cf);
+            add_scaled(acc, *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * c), cf);
         }
         out[0] = acc.x; out[1] = acc.y; out[2] = acc.z; out[3] = acc.w;
     } else {
@@ -1023,22 +1003,22 @@ __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptPa
         for (int u = 0; u < len; u += DEPTH) {
             float4 va[DEPTH], vb[DEPTH];
             float cf[DEPTH];
-            uint32_t rw[DEPTH];
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
-                va[j] = zero; vb[j] = zero; cf[j] = 0.f; rw[j] = 0u;
+                va[j] = zero; vb[j] = zero; cf[j] = 0.f;
                 if (u + j < len) {
-                    rw[j] = (uint32_t)__builtin_amdgcn_readlane((int)mine.row, u + j);
+                    const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)mine.row, u + j);
                     cf[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.coef), u + j));
-                    if (oa) va[j] = src_chunk_raw(P, rw[j], ca, nchunks);
-                    if (ob) vb[j] = src_chunk_raw(P, rw[j], cb, nchunks);
+                    const float* rj = P.contrib + (int64_t)row * P.ldc;
+                    if (oa) va[j] = *reinterpret_cast<const float4*>(rj + 4 * ca);
+                    if (ob) vb[j] = *reinterpret_cast<const float4*>(rj + 4 * cb);
                 }
             }
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {   // added in contribution order
                 if (u + j < len) {
-                    if (oa) add_scaled(accA, src_chunk_value(rw[j], va[j]), cf[j]);
-                    if (ob) add_scaled(accB, src_chunk_value(rw[j], vb[j]), cf[j]);
+                    if (oa) add_scaled(accA, va[j], cf[j]);
+                    if (ob) add_scaled(accB, vb[j], cf[j]);
                 }
             }
         }
@@ -1103,18 +1083,17 @@ __device__ __forceinline__ void segment_update_half(const ApplyParams& P, const 
     for (int u = 0; u < maxlen; u += DEPTH) {
         float4 v[DEPTH];
         float cf[DEPTH];
-        uint32_t rw[DEPTH];
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             v[j] = zero;
             const int from_lane = hb + min(u + j, 31);
-            rw[j] = (uint32_t)__shfl((int)mine.row, from_lane, 64);
+            const uint32_t row = (uint32_t)__shfl((int)mine.row, from_lane, 64);
             cf[j] = __shfl(mine.coef, from_lane, 64);
-            if (oc && u + j < len) v[j] = src_chunk_raw(P, rw[j], l, nchunks);
+            if (oc && u + j < len) v[j] = *reinterpret_cast<const float4*>(P.contrib + (int64_t)row * P.ldc + 4 * l);
         }
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {   // added in contribution order
-            if (oc && u + j < len) add_scaled(acc, src_chunk_value(rw[j], v[j]), cf[j]);
+            if (oc && u + j < len) add_scaled(acc, v[j], cf[j]);
         }
     }
     if (oc) {
@@ -1379,17 +1358,12 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
     P.vals = w.vals;
     P.srcrow = a->factored ? w.srcrow : w.vals;
     P.coef = a->factored ? w.coef : nullptr;
-    EMG_REQUIRE(a->fac_sign_row0 == 0 || (a->factored && k_int % 4 == 0 && ldc % 4 == 0 && aligned16(a->contrib) && a->fac_sign_row0 > 0),
-                "emg_apply_grouped: fac_sign_row0 (TransE-L1's packed contributions) needs the factored form on 16-byte aligned rows");
-    P.signs = a->fac_sign_row0 > 0 ? reinterpret_cast<const uint32_t*>(a->contrib + a->fac_sign_row0 * ldc) : nullptr;
     P.arrive = w.arrive;
     const int nch = A.vec ? k_int / 4 : k_int;
     A.skinny = nch <= 16;
     A.segs = w.counting && A.vec && !A.skinny && segments_path_enabled();
     EMG_REQUIRE(!P.state_lag || A.segs, "emg_apply_grouped: deferred_dense = 2 needs the descriptor-driven apply (counting grouping, "
                                         "16-byte aligned rows of more than 16 chunks)");
-    EMG_REQUIRE(!P.signs || A.segs, "emg_apply_grouped: packed contributions need the descriptor-driven apply (counting grouping, 16-byte "
-                                    "aligned rows of more than 16 chunks)");
     EMG_REQUIRE(!P.ctl || A.segs, "emg_apply_grouped: a device-side step record needs the descriptor-driven apply (counting "
                                   "grouping, 16-byte aligned rows of more than 16 chunks)");
     if (A.segs) {

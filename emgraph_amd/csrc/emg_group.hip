@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void prepare_ids_kernel(const PrepParams P, co
 // SORT backend epilogue: flags[original index] = 1 iff its destination occurs exactly once; factored source rows
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ counters,
-                                   const int32_t* __restrict__ fac_codes, uint32_t fac_B, int fac_packed, uint32_t* __restrict__ srcrow,
+                                   const int32_t* __restrict__ fac_codes, uint32_t fac_B, uint32_t* __restrict__ srcrow,
                                    uint32_t* __restrict__ pos_of_slot, float* __restrict__ coef,
                                    int32_t* __restrict__ arrive) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,7 +164,7 @@ __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint
             coef[t] = 1.f;
         } else {
             const uint32_t i = slot - 2u * fac_B;
-            srcrow[t] = fac_packed ? (kPackedSrc | i) : (fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
+            srcrow[t] = (fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
             pos_of_slot[i] = (uint32_t)t;
         }
     }
@@ -204,7 +204,7 @@ static int counting_tail(GroupLaunch& G, int64_t cap_n0, int64_t cap_n1, hipStre
 
 // stable grouping of n destination ids into the workspace (SORT backend)
 static int sort_group(const int32_t* dest, int64_t n, int64_t n_rows, const GroupWs& w, uint8_t* single_flags, hipStream_t st,
-                      const int32_t* fac_codes, int64_t fac_B, int fac_packed = 0) {
+                      const int32_t* fac_codes, int64_t fac_B) {
     int end_bit = 1;
     while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
     size_t tmp = w.sort_tmp_bytes;
@@ -213,7 +213,7 @@ static int sort_group(const int32_t* dest, int64_t n, int64_t n_rows, const Grou
                                                   rocprim::counting_iterator<uint32_t>(0u), w.vals, (size_t)n, 0,
                                                   end_bit, st, false));
     hipLaunchKernelGGL(mark_single_kernel, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, st, w.keys, w.vals, n,
-                       single_flags, w.counters, fac_codes, (uint32_t)fac_B, fac_packed, w.srcrow, w.pos_of_slot, w.coef, w.arrive);
+                       single_flags, w.counters, fac_codes, (uint32_t)fac_B, w.srcrow, w.pos_of_slot, w.coef, w.arrive);
     EMG_LAUNCH_CHECK();
     return EMG_OK;
 }
@@ -337,8 +337,6 @@ int prepare_stages(const emg_prepare_args* a, PrepStages* o) {
     GroupLaunch& G = o->G;
     G.n_tables = 2; G.B = a->B; G.ctl = ctl;
     fill_table(G.t[0], o->we, a->dest_ent, a->n_extra_ent, 2 + et, a->n_ent, a->single_flags, a->factored ? a->codes : nullptr);
-    EMG_REQUIRE(a->factored >= 0 && a->factored <= 2, "emg_prepare_batch: factored is 0, 1 (bilinear models) or 2 (TransE-L1: packed signs)");
-    G.t[0].fac_packed = a->factored == 2 ? 1 : 0;
     fill_table(G.t[1], o->wr, a->dest_rel, a->n_extra_rel, 1, a->n_rel, nullptr, nullptr);
     o->both = o->we.counting && o->wr.counting;
     // the histogram rides in the id kernel unless caller-filled extra rows come first (the ids of those are in memory)
@@ -393,7 +391,7 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
         const int64_t n = ti ? S.n_cr : S.n_ce, R = ti ? a->n_rel : a->n_ent;
         uint8_t* flags = ti ? nullptr : a->single_flags;
         const int32_t* fc = (ti == 0 && a->factored) ? a->codes : nullptr;
-        if (!w.counting) { rc = sort_group(dest, n, R, w, flags, st, fc, a->B, a->factored == 2 ? 1 : 0); if (rc != EMG_OK) return rc; continue; }
+        if (!w.counting) { rc = sort_group(dest, n, R, w, flags, st, fc, a->B); if (rc != EMG_OK) return rc; continue; }
         if (!a->ws_clean) { rc = clean_ws(w, ti ? a->ws_rel : a->ws_ent, st); if (rc != EMG_OK) return rc; }
         GroupLaunch G1{};
         G1.n_tables = 1; G1.B = a->B;

@@ -22,9 +22,7 @@ struct TableGroup {
     // optional (emg_group_dest_keyed): the order of a destination's contributions is ascending order_key[i] instead of ascending
     // input index i; vals[q] then holds the key and srcrow[q] the input index (coef[q] = 1): the apply reads rows through srcrow
     const uint32_t* order_key;
-    int32_t fac_packed;    // with fac_codes: 1 = TransE-L1's packed form — a negative's source is its own sign row (srcrow = kPackedSrc | negative index)
 };
-constexpr uint32_t kPackedSrc = 0x80000000u;
 struct GroupLaunch {
     TableGroup t[2]; int32_t n_tables; int32_t pad0;
     int64_t B; const StepCtl* ctl;
@@ -242,7 +240,7 @@ __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned 
             T.coef[q] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
         } else {
             const uint32_t i = mine - 2u * fac_B;
-            T.srcrow[q] = T.fac_packed ? (kPackedSrc | i) : (T.fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
+            T.srcrow[q] = (T.fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
             T.pos_of_slot[i] = q;
         }
     }

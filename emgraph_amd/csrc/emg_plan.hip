@@ -157,7 +157,6 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     if (c.inplace && c.lp_lambda_ent != 0.f) { ba.hyper[6] = he[6]; ba.hyper[7] = he[7]; ba.lp_accum = c.lp_sum; }   // (plain SGD: checked at creation)
     ba.ent_state0 = c.ent_state0; ba.ent_state1 = c.ent_state1; ba.tag_ent = c.tag_ent;
     if (c.factored) { ba.fac_ws_ent = sl.buf.ws_ent; ba.fac_ws_ent_bytes = sl.buf.ws_ent_bytes; }
-    if (c.factored == 2) ba.fac_sign_row0 = 2 * c.cap_B;   // TransE-L1's packed signs: behind the subject / object rows of the plan's capacity
     ba.layout_B = c.cap_B;
     if (P->ctl) { ba.pos = c.X; ba.B = c.cap_B; ba.ctl = P->ctl; }
     int rc;
@@ -228,8 +227,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
             aa.tag = c.tag_ent; aa.skip_single = c.inplace ? 1 : 0;
             aa.contrib = c.contrib_ent; aa.n_contrib = n_ce;
             aa.lp_accum = lp ? c.lp_sum : nullptr; aa.workspace = sl.buf.ws_ent; aa.workspace_bytes = sl.buf.ws_ent_bytes;
-            aa.factored = c.factored ? 1 : 0; aa.fac_sign_row0 = c.factored == 2 ? 2 * c.cap_B : 0;
-            aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
+            aa.factored = c.factored; aa.layout_n = (2 + (int64_t)et) * c.cap_B; aa.table_index = 0;
         } else {
             aa.table = c.rel; aa.n_rows = c.n_rel; aa.ld = c.ld_rel; aa.state0 = c.rel_state0; aa.state1 = c.rel_state1;
             aa.tag = c.tag_rel; aa.skip_single = 0; aa.contrib = c.contrib_rel; aa.n_contrib = B;
@@ -306,9 +304,6 @@ extern "C" int emg_plan_create(const emg_plan_config* cfg, void** out) {
                 "emg_plan_create: a deferred dense pass needs the counting grouping for both tables (emg_plan_deferred_ok): "
                 "n_ent = %lld, n_rel = %lld against %lld gradient rows per batch", (long long)cfg->n_ent, (long long)cfg->n_rel,
                 (long long)((2 + (int64_t)cfg->eta * cfg->n_sides) * cfg->cap_B));
-    EMG_REQUIRE(cfg->factored >= 0 && cfg->factored <= 2 && (cfg->factored != 2 || cfg->model == EMG_TRANSE_L1) &&
-                    (cfg->factored != 1 || !(cfg->model == EMG_TRANSE_L1 || cfg->model == EMG_TRANSE_L2)),
-                "emg_plan_create: factored is 0, 1 (bilinear models: 4 * cap_B contribution rows) or 2 (EMG_TRANSE_L1: packed signs behind 2 * cap_B rows)");
     EMG_REQUIRE(cfg->inplace >= 0 && cfg->inplace <= 2, "emg_plan_create: inplace is 0 (off), 1 (singletons in place) or 2 (a stateful optimizer's "
                                                         "window form)");
     EMG_REQUIRE(cfg->inplace != 2 || (cfg->opt != EMG_OPT_SGD && cfg->fused), "emg_plan_create: inplace = 2 is for stateful optimizers in the fused step");

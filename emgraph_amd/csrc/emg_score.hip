@@ -409,15 +409,9 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
     P.scores_pos = a->scores_pos_out; P.scores_neg = a->scores_neg_out;
     P.contrib_ent = a->contrib_ent; P.contrib_rel = a->contrib_rel; P.ldc = a->ldc;
     if (a->fac_ws_ent) {
-        const bool packed = a->model == EMG_TRANSE_L1 && a->fac_sign_row0 > 0;
-        EMG_REQUIRE(packed || !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
-                    "emg_train_backward_ex: factored contributions need a bilinear model (a factor times a query row of the group) or "
-                    "EMG_TRANSE_L1 with fac_sign_row0 (a factor times the signs of the difference)");
-        EMG_REQUIRE(!packed || (a->k_int % 4 == 0 && a->k_int / 4 > 16 && a->k_int / 4 <= 64 && a->ldc % 4 == 0 && aligned16(a->contrib_ent) &&
-                                a->ld_ent % 4 == 0 && a->ld_rel % 4 == 0 && aligned16(a->ent) && aligned16(a->rel) && a->fac_sign_row0 >= 2 * a->B),
-                    "emg_train_backward_ex: TransE-L1's packed contributions need 16-byte aligned rows of 17 .. 64 chunks and a sign area behind "
-                    "the 2 B subject / object rows");
-        P.fac_sign_row0 = packed ? a->fac_sign_row0 : 0;
+        EMG_REQUIRE(!(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2),
+                    "emg_train_backward_ex: factored contributions need a bilinear model — a TransE gradient row depends "
+                    "on the replacement entity");
         const int64_t Bl = a->layout_B > 0 ? a->layout_B : a->B;
         int rc = factor_view(a->fac_ws_ent, a->fac_ws_ent_bytes, (2 + (int64_t)a->eta) * Bl, a->n_ent, &P.fac);
         if (rc != EMG_OK) return rc;

@@ -170,7 +170,6 @@ struct GroupParams {
     FactorView fac;                                      // fac.coef != nullptr: FACTORED contributions (bilinear models), see emg_backward_args
     const StepCtl* ctl;                                  // graph node: batch rows, step number and learning rates from the device record
     int32_t window;                                      // stateful in-place updates through the window forms (IP 4 / 5 / 6)
-    int64_t fac_sign_row0;                               // TransE-L1, factored: row of contrib_ent where the negatives' packed signs start (0: off)
     const float* lr_hist; int32_t upto;                  // IP 6 (Adam, deferred dense pass): learning rate of every step; rows are replayed to step `upto`
 };
 
@@ -578,7 +577,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     auto gather = [&](int c0) {
         const int j = c0 + lg;
         my_code = j < P.eta ? P.codes[(int64_t)j * B + g] : 0;
-        if ((kBilinear || MODEL == EMG_TRANSE_L1) && P.fac.coef) my_pos = j < P.eta ? (int)P.fac.pos_of_slot[(int64_t)j * B + g] : 0;
+        if (kBilinear && P.fac.coef) my_pos = j < P.eta ? (int)P.fac.pos_of_slot[(int64_t)j * B + g] : 0;
         if constexpr (IP != 0) my_flag = j < P.eta ? (int)P.single_ent[2 * B + (int64_t)j * B + g] : 0;
         if constexpr (IT::replay) my_tag = (j < P.eta && my_flag) ? P.tag_ent[my_code & 0x7fffffff] : P.upto;
     };
@@ -831,21 +830,6 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
                 else if (kBilinear && P.fac.coef) {   // row = gi * q: q is stored once, below; gi goes where the apply reads it
                     const int at = group_lane_value<LPG>(my_pos, first, j - chunk0);
                     if (lg == 0) P.fac.coef[at] = gi;
-                }
-                else if (MODEL == EMG_TRANSE_L1 && W == 4 && NV == 1 && P.fac.coef) {
-                    // TransE-L1: row = gi * s, s = +-sgn(d) in {-1, 0, +1} per coordinate — gi goes where the apply reads it, the signs as
-                    // one byte per coordinate (a quarter of the row; gi * (+-1 | 0) is exact, so the apply adds the same bits)
-                    const int at = group_lane_value<LPG>(my_pos, first, j - chunk0);
-                    if (lg == 0) P.fac.coef[at] = gi;
-                    uint32_t bits = 0u;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float d = keep_s ? qo.x[w] - re[u].x[w] : re[u].x[w] - qs.x[w];
-                        const int sg = (d > 0.f) - (d < 0.f);
-                        bits |= (uint32_t)((keep_s ? sg : -sg) & 0xff) << (8 * w);
-                    }
-                    if (lg < P.nchunks)
-                        reinterpret_cast<uint32_t*>(P.contrib_ent + P.fac_sign_row0 * P.ldc)[((int64_t)j * B + g) * P.nchunks + lg] = bits;
                 }
                 else store_row<MODEL, W, NV, LPG>(row, P.contrib_ent + slot * P.ldc, lg, P.nchunks, P.khalf);
             }

@@ -183,16 +183,12 @@ def build_dest(pos, eta, codes, dest_ent, dest_rel):
 def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
                       margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
                       scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
-                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None, lp_accum=None, fac_sign_row0=0,
-                      inplace_window=False, lr_hist=None):
+                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None, lp_accum=None):
     """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
     singleton updates (single_ent flags from group_dest).  ``fac_ws_ent`` (bilinear models): FACTORED entity
     contributions — the entity workspace of ``prepare_batch(..., factored=True)`` for this batch; ``contrib_ent`` then
     holds 4*B rows (see include/emgraph_hip.h) and the entity apply is ``apply_grouped(..., factored=True)``.
-    ``hyper`` of 8 values + ``lp_accum`` (plain SGD only): the LP regulariser folded into the in-place updates.
-    ``fac_sign_row0`` (TransE-L1 with ``fac_ws_ent`` of ``prepare_batch(..., factored=2)``): the negatives' rows as a factor and one
-    sign byte per coordinate, in the area of ``contrib_ent`` that starts at that row (>= 2 B).  ``inplace_window`` / ``lr_hist``:
-    a stateful optimizer's window form / Adam's lagging singletons (include/emgraph_hip.h)."""
+    ``hyper`` of 8 values + ``lp_accum`` (plain SGD only): the LP regulariser folded into the in-place updates."""
     lib = L.load()
     B = pos.shape[0]
     a = L.BackwardArgs()
@@ -211,15 +207,8 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     a.scores_neg_out = _chk_vec(scores_neg_out, torch.float32, "scores_neg_out", B * eta if scores_neg_out is not None else None)
     pce, nce, ldc = _chk_table(contrib_ent, "contrib_ent")
     pcr, ncr, ldc2 = _chk_table(contrib_rel, "contrib_rel")
-    if fac_sign_row0:
-        need = fac_sign_row0 + -(-(eta * B * (k_int // 4)) // ldc)
-    else:
-        need = (4 if fac_ws_ent is not None else 2 + eta) * B
-    if ldc != ldc2 or nce < need or ncr < B:
+    if ldc != ldc2 or nce < (4 if fac_ws_ent is not None else 2 + eta) * B or ncr < B:
         raise ValueError("contribution buffers have the wrong shape")
-    a.fac_sign_row0 = int(fac_sign_row0)
-    a.inplace_window = 1 if inplace_window else 0
-    a.lr_hist = _chk_vec(lr_hist, torch.float32, "lr_hist") if lr_hist is not None else None
     a.contrib_ent, a.contrib_rel, a.ldc = pce, pcr, ldc
     a.single_ent = _chk_vec(single_ent, torch.uint8, "single_ent", (2 + eta) * B if single_ent is not None else None)
     a.opt, a.step = opt_id, step
@@ -288,7 +277,7 @@ def prepare_batch(pos, eta, sides, n_choices, codes, dest_ent, dest_rel, n_ent, 
     a.ws_rel, a.ws_rel_bytes = ws_rel.data_ptr(), ws_rel.numel() * ws_rel.element_size()
     a.single_flags = _chk_vec(single_flags, torch.uint8, "single_flags")
     a.B_global, a.row_offset = int(B_global), int(row_offset)
-    a.factored = int(factored)          # 0 | 1 (bilinear models) | 2 (TransE-L1: packed signs)
+    a.factored = 1 if factored else 0
     L.check(lib.emg_prepare_batch(C.byref(a), _stream()), "emg_prepare_batch")
 
 
@@ -311,7 +300,7 @@ def apply_grouped(opt_id, table, k_int, state0, state1, tag, step, contrib, n_co
 
 
 def _apply_args(opt_id, table, k_int, state0, state1, tag, step, contrib, n_contrib, skip_single, hyper, workspace,
-                lp_accum=None, factored=False, fac_sign_row0=0):
+                lp_accum=None, factored=False):
     a = L.ApplyArgs()
     a.opt, a.k_int = opt_id, k_int
     a.table, a.n_rows, a.ld = _chk_table(table, "table")
@@ -326,14 +315,7 @@ def _apply_args(opt_id, table, k_int, state0, state1, tag, step, contrib, n_cont
     a.lp_accum = _chk_vec(lp_accum, torch.float64, "lp_accum", 1) if lp_accum is not None else None
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     a.factored = 1 if factored else 0
-    a.fac_sign_row0 = int(fac_sign_row0)
     return a
-
-
-def apply_grouped_ex(**kw):
-    """emg_apply_grouped_ex: apply_grouped with every argument of the struct (``fac_sign_row0``: TransE-L1's packed contributions)"""
-    a = _apply_args(**kw)
-    L.check(L.load().emg_apply_grouped_ex(C.byref(a), _stream()), "emg_apply_grouped_ex")
 
 
 def apply_grouped_pair(first, second):

@@ -211,10 +211,6 @@ class Trainer:
         #            rows) instead of eta full rows per group (emg_backward_args.fac_ws_ent); EMG_FACTORED=0 = A/B switch
         self.factored = (model_id not in (L.TRANSE_L1, L.TRANSE_L2, L.TRANSE_P) and not self.batch_sharded
                          and os.environ.get("EMG_FACTORED", "1") != "0")
-        #  packed   : TransE-L1 writes a negative's gradient row  +-g * sgn(d)  as one float and a sign byte per coordinate (a quarter
-        #             of the row; emg_backward_args.fac_sign_row0) — through the plan, rows of 17 .. 64 sixteen-byte chunks
-        self.packed = (model_id == L.TRANSE_L1 and not self.batch_sharded and not self.sharded and self.k_int % 4 == 0
-                       and 16 < self.k_int // 4 <= 64 and os.environ.get("EMG_FACTORED", "1") != "0" and not os.environ.get("EMG_PY_PLAN"))
         self.pipeline = pipeline
         if self.batch_sharded:
             # a destination's contributions come from several ranks: no rank may update a row in place, and the
@@ -290,8 +286,6 @@ class Trainer:
     def _alloc_scratch(self, B):
         if B <= self._cap:
             return
-        if self.packed and not L.load().emg_plan_deferred_ok(B, self.eta_total, self.n_ent, self.n_rel):
-            self.packed = False     # (packed rows are summed by the descriptor-driven apply: the counting grouping's)
         self.inplace_mode = self._choose_inplace(B)
         if self.inplace_mode == 2 and (self.sharded or os.environ.get("EMG_PY_PLAN")):
             self.inplace_mode = 1      # (the window form is the plan's; host-driven steps keep the chunk-wise form)
@@ -306,10 +300,7 @@ class Trainer:
         self.g_all = torch.empty(B * (1 + et), dtype=torch.float32, device=dev)       # dL/dscore, same layout
         self.g_pos, self.g_neg = self.g_all[:B], self.g_all[B:]
         # factored: subject rows | object rows | query rows (object side) | query rows (subject side)
-        rows_ce = 4 * B if self.factored else n_ce
-        if self.packed:      # subject / object rows in full, then the negatives' sign bytes (k bytes each)
-            rows_ce = 2 * B + -(-(et * B * (k // 4)) // ldc)
-        self.contrib_ent = torch.empty((rows_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
+        self.contrib_ent = torch.empty((4 * B if self.factored else n_ce, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.contrib_rel = torch.empty((n_cr, ldc), dtype=torch.float32, device=dev)[:, :k]
         self.slots = []
         n_slots = 2 if (self.batch_sharded and getattr(self, "_bs_ahead", False)) else 1 + self.lookahead
@@ -357,7 +348,7 @@ class Trainer:
         c.scores, c.g = self.scores_all.data_ptr(), self.g_all.data_ptr()
         c.contrib_ent, c.contrib_rel, c.ldc = self.contrib_ent.data_ptr(), self.contrib_rel.data_ptr(), self.contrib_ent.stride(0)
         c.loss_accum, c.lp_sum = self.loss_accum.data_ptr(), self.lp_sum.data_ptr()
-        c.factored = 2 if self.packed else int(self.factored)
+        c.factored = int(self.factored)
         if self.reg is not None:
             c.lp_lambda_ent, c.lp_lambda_rel, c.lp_p = self.reg[0], self.reg[1], self.reg[2]
         c.fused, c.inplace, c.normalize = int(self.fused), int(self.inplace_mode), int(self.normalize)

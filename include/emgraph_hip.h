@@ -170,8 +170,7 @@ typedef struct emg_prepare_args {
     void* ws_ent; int64_t ws_ent_bytes; void* ws_rel; int64_t ws_rel_bytes;  /* emg_apply_workspace_bytes */
     uint8_t* single_flags;                                   /* optional out, per entity contribution row */
     int64_t B_global; int64_t row_offset;                    /* batch-sharded draws (see above); 0, 0 = whole batch */
-    /* factored = 2: TransE-L1's packed form — a negative's source is its own sign row (emg_backward_args.fac_sign_row0).
-     * factored != 0 (bilinear models, n_extra_ent = 0): the entity workspace also receives, per sorted position, the
+    /* factored != 0 (bilinear models, n_extra_ent = 0): the entity workspace also receives, per sorted position, the
      * row of the 4*B-row contribution buffer its slot points at, and per negative slot its sorted position — what
      * emg_train_backward_ex (fac_ws_ent) and emg_apply_grouped_factored work from. */
     int32_t factored;
@@ -232,13 +231,6 @@ typedef struct emg_backward_args {
      * (without lr_hist: at the group's end, state read chunk by chunk; with lr_hist: replayed at the group's start, parked in LDS,
      * updated at its end): finish with skip_single = 1.  Required by lr_hist. */
     int32_t inplace_window; int32_t reserved2;
-    /* fac_sign_row0 > 0 (EMG_TRANSE_L1 with fac_ws_ent; 16-byte rows of 17 .. 64 chunks; emg_prepare_args.factored = 2): the gradient
-     * row of a negative's replacement entity is  +-g * sgn(d)  — one float and a sign per coordinate.  Negatives that are not
-     * updated in place write the float where the apply reads it (as the bilinear models' factored form) and their signs as one
-     * byte per coordinate (-1, 0, +1), k_int bytes at dword offset (negative index) * (k_int / 4) of the area that starts at row
-     * fac_sign_row0 of contrib_ent — 1/4 of a full row (a third of the scoring kernel's writes and most of the apply's reads are
-     * such rows).  contrib_ent: rows [0, 2B) subject / object rows in full, then the sign area.  Same bits: coef * (+-1 | 0) is exact. */
-    int64_t fac_sign_row0;
 } emg_backward_args;
 /* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
  * only for opt = EMG_OPT_SGD — a singleton row is then updated in place with g + lambda p |w|^(p-1) sign(w), the rule the
@@ -283,7 +275,6 @@ typedef struct emg_apply_args {
     int32_t factored;
     int32_t table_index;                 /* 0 entity / 1 relation table: which hyper-parameters of `ctl` apply */
     int64_t layout_n; const void* ctl;   /* layout_n > 0: contribution slots the workspace was laid out for (>= n_contrib); device record */
-    int64_t fac_sign_row0;               /* factored, TransE-L1's packed form (emg_backward_args.fac_sign_row0): the row of `contrib` its sign area starts at */
     int32_t deferred_dense; int32_t reserved1;   /* 1: no dense pass (Keras Adam's decay, the LP regulariser's): the caller runs emg_deferred_catchup, below;
                                                   * 2: the same, and the catch-up ran with w_only (m, v of the destinations lag behind w) */
 } emg_apply_args;
@@ -629,9 +620,7 @@ typedef struct emg_plan_config {
     int64_t cap_B;
     float* scores; float* g; float* contrib_ent; float* contrib_rel; int64_t ldc;
     double* loss_accum; double* lp_sum;              /* lp_sum[2]: sum |w|^p of the entity / relation table */
-    int32_t factored; int32_t reserved0;             /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows;
-                                                        2 (EMG_TRANSE_L1): packed signs (emg_backward_args.fac_sign_row0 = 2 * cap_B): contrib_ent needs
-                                                        2 * cap_B + ceil(eta_total * cap_B * (k_int / 4) / ldc) rows */
+    int32_t factored; int32_t reserved0;             /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows */
     float lp_lambda_ent; float lp_lambda_rel; int32_t lp_p;   /* folded LP regulariser (0 = none; excludes inplace) */
     int32_t fused; int32_t inplace; int32_t normalize;   /* inplace: 0 off, 1 singletons in place, 2 the same through a stateful optimizer's
                                                             window form (emg_backward_args.inplace_window; with lr_t_hist: Adam's singleton

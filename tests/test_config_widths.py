@@ -239,28 +239,24 @@ def _run_steps(factored, inplace, model, k, eta, loss, opt, n_ent, n_rel, B, kin
     n_single = 0
     for step in range(1, steps + 1):
         pos = Xt[(step - 1) * B:step * B]
-        packed = factored and model == "TransE_L1"
-        sign_row0 = 2 * B if packed else 0
         d.prepare_batch(pos, eta, [L.SIDE_SO], n_ent, codes, de, dr, n_ent, n_rel, we, wr, seed=seed, counter0=step - 1,
-                        single_flags=single if inplace else None, factored=2 if packed else factored)
+                        single_flags=single if inplace else None, factored=factored)
         # poison: nothing may be read that this step did not write
-        rows_ce = 2 * B + -(-(eta * B * (ki // 4)) // Et.stride(0)) if packed else (4 * B if factored else n_ce)
-        ce = torch.full((rows_ce, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
+        ce = torch.full((4 * B if factored else n_ce, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
         cr = torch.full((B, Et.stride(0)), float("nan"), dtype=torch.float32, device=dev)[:, :ki]
         hyper = _hyper(0.002, step)
         d.train_backward_ex(MID[model], Et, Rt, ki, sc, pos, eta, codes, ce, cr, fused_loss=L.LOSS_IDS[loss], margin=1.0,
                             loss_accum=acc, single_ent=single if inplace else None, opt_id=L.OPT_IDS[opt], step=step,
-                            hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, fac_ws_ent=we if factored else None,
-                            fac_sign_row0=sign_row0)
+                            hyper=hyper, ent_state0=se[0], ent_state1=se[1], tag_ent=tag_e, fac_ws_ent=we if factored else None)
         if pair:   # both tables through shared launches (what emg_plan_step does for large batches)
             d.apply_grouped_pair(
                 dict(opt_id=L.OPT_IDS[opt], table=Et, k_int=ki, state0=se[0], state1=se[1], tag=tag_e, step=step, contrib=ce,
-                     n_contrib=n_ce, skip_single=inplace, hyper=hyper, workspace=we, factored=factored, fac_sign_row0=sign_row0),
+                     n_contrib=n_ce, skip_single=inplace, hyper=hyper, workspace=we, factored=factored),
                 dict(opt_id=L.OPT_IDS[opt], table=Rt, k_int=ki, state0=sr[0], state1=sr[1], tag=tag_r, step=step, contrib=cr,
                      n_contrib=B, skip_single=0, hyper=hyper, workspace=wr))
         else:
-            d.apply_grouped_ex(opt_id=L.OPT_IDS[opt], table=Et, k_int=ki, state0=se[0], state1=se[1], tag=tag_e, step=step, contrib=ce,
-                               n_contrib=n_ce, skip_single=inplace, hyper=hyper, workspace=we, factored=factored, fac_sign_row0=sign_row0)
+            d.apply_grouped(L.OPT_IDS[opt], Et, ki, se[0], se[1], tag_e, step, ce, n_ce, inplace, hyper, we,
+                            factored=factored)
             d.apply_grouped(L.OPT_IDS[opt], Rt, ki, sr[0], sr[1], tag_r, step, cr, B, 0, hyper, wr)
         if inplace:
             n_single += int(single.sum().item())
@@ -279,11 +275,6 @@ FACTORED_CASES = {
     "k32-momentum": ("DistMult", 32, 5, "pairwise", "momentum", 3000, 7, 2048, "uniform"),       # skinny rows: sub-wave segments
     "k50-sgd": ("DistMult", 50, 8, "pairwise", "sgd", 4000, 7, 2048, "uniform"),                 # k % 4 != 0: scalar path
     "k512-adam": ("ComplEx", 256, 4, "nll", "adam", 5000, 20, 1024, "uniform"),                  # two 16-byte chunks per lane
-    # TransE-L1, PACKED: a negative's row = one float x a sign byte per coordinate (emg_backward_args.fac_sign_row0; round 4)
-    "C3p-sgd": ("TransE_L1", 200, 20, "pairwise", "sgd", 60000, 1000, 4096, "uniform"),
-    "C1-adam": ("TransE_L1", 100, 20, "pairwise", "adam", 38600, 11, 1725, "uniform"),          # 25 chunks: two segments per wave
-    "C1-zipf-adagrad": ("TransE_L1", 100, 20, "pairwise", "adagrad", 3000, 11, 4096, "zipf"),   # hub rows: block-tree sums of packed rows
-    "k256-momentum": ("TransE_L1", 256, 7, "pairwise", "momentum", 9000, 5, 2048, "uniform"),   # 64 chunks
 }
 
 
@@ -315,7 +306,7 @@ def test_factored_contributions_refused_for_transe():
     codes = torch.zeros(8, dtype=torch.int32, device=dev)
     ce, cr = alloc_table(16, 8, dev), alloc_table(4, 8, dev)
     ws = torch.empty(d.apply_workspace_bytes(16, 50, 8), dtype=torch.uint8, device=dev)
-    with pytest.raises(RuntimeError, match="bilinear"):   # (TransE-L1 has a factored form of its own: with fac_sign_row0, rows of 17 .. 64 chunks)
+    with pytest.raises(RuntimeError, match="bilinear"):
         d.train_backward_ex(MID["TransE_L1"], Et, Rt, 8, 1.0, pos, 2, codes, ce, cr, fused_loss=L.LOSS_IDS["pairwise"],
                             loss_accum=torch.zeros(1, dtype=torch.float64, device=dev), fac_ws_ent=ws)
 

@@ -63,7 +63,7 @@ def test_graph_steps_with_the_window_forms_in_place(monkeypatch, name, k, loss, 
     """a stateful optimizer's singletons updated inside the scoring kernel (window forms 4 / 5, round 4) are not the default for
     batches this small — forced here (EMG_INPLACE=1): as graph replays (per-step values from the device records) == single steps
     == every row through the apply, bit for bit"""
-    n_ent, n_rel, n = 3000, 7, 2003
+    n_ent, n_rel, n = 1500, 7, 2003          # (mostly singletons: 2003 triples over 1500 entities, 6 batches)
     X = synth_graph(n_ent, n_rel, n, seed=3)
     rs = np.random.RandomState(5)
     ki = 2 * k if name in ("ComplEx", "HolE") else k
