@@ -274,7 +274,8 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     float* sn = sp + a->B;
     float* gp = (float*)(ws + L.g);
     float* gn = gp + a->B;
-    const bool inplace = a->inplace != 0;
+    const bool generic = a->model == EMG_TRANSE_P;   // TransE with an order of the norm other than 1 / 2: generic kernels, unfused, every row through the apply
+    const bool inplace = a->inplace != 0 && !generic;
 
     emg_prepare_args pa{};
     pa.pos = a->pos; pa.B = a->B; pa.eta = a->eta; pa.n_sides = a->n_sides;
@@ -288,7 +289,7 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     // bilinear models: a negative's gradient row stays factored (one float x a query row of its group) between the
     // backward pass and the apply, as in emg_plan_step; rows wider than the register-tiled kernels take the separate
     // forward / loss / backward path (column blocks)
-    const bool factored = !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2);
+    const bool factored = !(a->model == EMG_TRANSE_L1 || a->model == EMG_TRANSE_L2 || generic);
     const bool cplx = a->model == EMG_COMPLEX || a->model == EMG_HOLE;
     const bool wide = (cplx ? a->k_int / 2 : a->k_int) > 512;
     pa.factored = factored;
@@ -305,7 +306,7 @@ extern "C" int emg_train_step(const emg_step_args* a, void* stream) {
     ba.ent_state0 = a->ent_state0; ba.ent_state1 = a->ent_state1; ba.tag_ent = a->tag_ent;
     if (factored) { ba.fac_ws_ent = ws + L.ws_ent; ba.fac_ws_ent_bytes = L.ws_ent_bytes; }
     const bool pair_local = a->loss == EMG_LOSS_PAIRWISE || a->loss == EMG_LOSS_NLL || a->loss == EMG_LOSS_ABSOLUTE_MARGIN;
-    if (pair_local && !wide) {
+    if (pair_local && !wide && !generic) {
         ba.fused_loss = a->loss;
     } else {  // softmax-coupled losses: scores, then the loss kernel, then backward with external dL/dscore
         rc = emg_train_forward(a->model, a->ent, a->n_ent, a->ld_ent, a->rel, a->n_rel, a->ld_rel, a->k_int, a->scale, a->pos,

@@ -975,6 +975,36 @@ def test_train_step_one_call_matches_trainer(model, loss, opt, sides):
     assert tr.read_loss() == tr2.read_loss()
 
 
+@pytest.mark.parametrize("order,loss,opt", [(3.0, "pairwise", "adagrad"), (float("inf"), "nll", "sgd")])
+def test_train_step_one_call_transe_any_norm(order, loss, opt):
+    """emg_train_step with EMG_TRANSE_P (the order of the norm in `scale`): the generic unfused step — same tables, state and loss as
+    the Trainer's step (which goes through emg_plan_step)"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    d = dev()
+    k, n_ent, n_rel, B, eta = 20, 300, 6, 128, 3
+    E, R, ki = make_tables("TransE_L1", k, n_ent, n_rel, seed=12)
+    rs = np.random.RandomState(3)
+    X = np.stack([rs.randint(0, n_ent, 3 * B), rs.randint(0, n_rel, 3 * B), rs.randint(0, n_ent, 3 * B)], 1).astype(np.int32)
+    mk = lambda: Trainer(L.TRANSE_P, ki, order, E, R, eta, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05}, batches_count=3, seed=5)  # noqa: E731
+    tr, tr2 = mk(), mk()
+    tr.set_training_set(X, B)
+    assert tr.generic and not tr.fused and not tr.inplace
+    ws = torch.empty(d.train_step_workspace_bytes(B, eta, ki, n_ent, n_rel), dtype=torch.uint8, device="cuda")
+    Xt = cu(X)
+    for b in range(3):
+        tr.step(b * B, B, epoch=1, batch=b + 1)
+        tr2.step_count += 1
+        d.train_step(L.TRANSE_P, tr2.ent, tr2.rel, ki, order, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum,
+                     tr2.opt_id, tr2.step_count, tr2._hyper(tr2.lr), ws, margin=tr2.margin, alpha=tr2.alpha,
+                     states=(tr2.state_ent[0], tr2.state_ent[1], tr2.state_rel[0], tr2.state_rel[1]),
+                     tags=(tr2.tag_ent, tr2.tag_rel), n_choices=n_ent, seed=5, counter0=b, inplace=True)   # (inplace is ignored for this model)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.ent, tr2.ent) and torch.equal(tr.rel, tr2.rel)
+    assert not torch.equal(tr.ent[:, :ki].cpu(), torch.from_numpy(E))
+    assert tr.read_loss() == tr2.read_loss()
+
+
 # ------------------------------------------------------------------------------------------------
 # the rank path against the reference's own execution (tests/golden/ranks.npz, see make_golden.py::gen_ranks)
 # ------------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_graph_step.py tests/test_config_widths.py -q 2>&1 | tail -4
-AB_WORKLOADS="C1 C3 C3p" bash tools/ab_step.sh "now:EMG_X=0" > gpurun_out/r4_r_ab.txt 2>&1
-cat gpurun_out/r4_r_ab.txt
+python -m pytest tests/test_hip_kernels.py -q -k "one_call" 2>&1 | tail -3
+EMG_INPLACE=1 EMG_ADAM_DEFERRED=1 EMG_FUZZ_SEEDS=400 python -m pytest tests/test_api.py -q -x -k "random_configurations" 2>&1 | tail -15
+EMG_INPLACE=1 EMG_FUZZ_SEEDS=200 python -m pytest tests/test_api.py -q -x -k "random_configurations" 2>&1 | tail -8
