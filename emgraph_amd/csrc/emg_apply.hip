@@ -50,6 +50,10 @@ struct ApplyParams {
     const Seg* multi; const uint32_t* single; const LongTask* tasks; const uint32_t* counters; uint32_t task_cap;
     int32_t which;             // 0: entity table, 1: relation table (which hyper-parameters of a StepCtl apply)
     const StepCtl* ctl;        // graph node: step number and learning rates from the device record
+    // dense_here = 1: the rows no contribution touches (Keras Adam's dense-equivalent update) are visited by apply_segments_kernel's
+    // own waves after their items — a row is untouched when the grouping counted nothing for it (off[r + 1] == off[r]) — instead of
+    // by a launch of their own afterwards (untouched_rows_kernel, which asks tag[r] != step)
+    const uint32_t* off; int32_t dense_here;
 };
 
 struct Src { uint32_t row; float coef; };
@@ -625,6 +629,43 @@ __global__ __launch_bounds__(256) void apply_rows_sub_kernel(const ApplyParams P
 //     EmbeddingModel.py:818-820): an untouched row still has g = lambda * p * |w|^(p-1) * sign(w), and its |w|^p
 //     belongs to the loss.  Touched rows got the same term folded into their update (lp_fold), so the regulariser
 //     costs ONE pass over the rows nothing else visited instead of n_rows extra contribution rows.
+// one untouched row: the optimizer's update with g = 0 (+ the regulariser's gradient), a wave per row
+__device__ __forceinline__ void untouched_row_update(const ApplyParams& P, int64_t r, int lane, bool vec, float& lp_acc) {
+    float* w = P.table + r * P.ld;
+    float* s0 = P.state0 ? P.state0 + r * P.ld : nullptr;
+    float* s1 = P.state1 ? P.state1 + r * P.ld : nullptr;
+    if (vec) {   // 16-byte chunks: table row and state rows as float4 (the pass is pure bandwidth)
+        for (int c = lane; 4 * c < P.k_int; c += 64) {
+            float4 wv = *reinterpret_cast<const float4*>(w + 4 * c);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (s0) a = *reinterpret_cast<const float4*>(s0 + 4 * c);
+            if (s1) b = *reinterpret_cast<const float4*>(s1 + 4 * c);
+            float ww[4] = {wv.x, wv.y, wv.z, wv.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g = 0.f;
+                lp_fold(P.opt, ww[j], g, lp_acc);
+                opt_update_elem(P.opt, ww[j], g, &aa[j], &bb[j]);
+            }
+            *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+            if (s0) *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+            if (s1) *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        }
+        return;
+    }
+    for (int c = lane; c < P.k_int; c += 64) {
+        float wv = w[c], g = 0.f;
+        lp_fold(P.opt, wv, g, lp_acc);
+        opt_update_elem(P.opt, wv, g, s0 ? s0 + c : nullptr, s1 ? s1 + c : nullptr);
+        w[c] = wv;
+    }
+}
+__device__ __forceinline__ bool untouched_vec(const ApplyParams& P) {
+    return (P.k_int % 4 == 0) && (P.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(P.table) & 15u) == 0) &&
+           (!P.state0 || (reinterpret_cast<uintptr_t>(P.state0) & 15u) == 0) &&
+           (!P.state1 || (reinterpret_cast<uintptr_t>(P.state1) & 15u) == 0);
+}
+
 __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64_t block, int64_t n_blocks) {
     const int lane = threadIdx.x & 63;
     float lp_acc = 0.f;
@@ -637,39 +678,10 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
     // double that accumulates sum |w|^p — 9 ms per step of the LP-regularised C3 before; now one atomic per wave of a
     // few thousand)
     const int64_t nw = (n_blocks * blockDim.x) >> 6;
-    const bool vec = (P.k_int % 4 == 0) && (P.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(P.table) & 15u) == 0) &&
-                     (!P.state0 || (reinterpret_cast<uintptr_t>(P.state0) & 15u) == 0) &&
-                     (!P.state1 || (reinterpret_cast<uintptr_t>(P.state1) & 15u) == 0);
+    const bool vec = untouched_vec(P);
     for (int64_t r = (block * blockDim.x + threadIdx.x) >> 6; r < P.n_rows; r += nw) {
         if (P.tag[r] == P.step) continue;
-        float* w = P.table + r * P.ld;
-        float* s0 = P.state0 ? P.state0 + r * P.ld : nullptr;
-        float* s1 = P.state1 ? P.state1 + r * P.ld : nullptr;
-        if (vec) {   // 16-byte chunks: table row and state rows as float4 (the pass is pure bandwidth)
-            for (int c = lane; 4 * c < P.k_int; c += 64) {
-                float4 wv = *reinterpret_cast<const float4*>(w + 4 * c);
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                if (s0) a = *reinterpret_cast<const float4*>(s0 + 4 * c);
-                if (s1) b = *reinterpret_cast<const float4*>(s1 + 4 * c);
-                float ww[4] = {wv.x, wv.y, wv.z, wv.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float g = 0.f;
-                    lp_fold(P.opt, ww[j], g, lp_acc);
-                    opt_update_elem(P.opt, ww[j], g, &aa[j], &bb[j]);
-                }
-                *reinterpret_cast<float4*>(w + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-                if (s0) *reinterpret_cast<float4*>(s0 + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
-                if (s1) *reinterpret_cast<float4*>(s1 + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
-            }
-            continue;
-        }
-        for (int c = lane; c < P.k_int; c += 64) {
-            float wv = w[c], g = 0.f;
-            lp_fold(P.opt, wv, g, lp_acc);
-            opt_update_elem(P.opt, wv, g, s0 ? s0 + c : nullptr, s1 ? s1 + c : nullptr);
-            w[c] = wv;
-        }
+        untouched_row_update(P, r, lane, vec, lp_acc);
     }
     if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
@@ -1238,6 +1250,23 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
         }
         }
     }
+    if constexpr (!PLAIN) if (P.dense_here) {   // the rows nothing touched: 64 rows' counts in one load, then a wave per untouched row
+        ApplyParams Q = P;
+        Q.opt = opt;
+        const bool vec = untouched_vec(P);
+        const int64_t per = (P.n_rows + nw - 1) / nw;
+        const int64_t r0 = gw * per, r1 = min(P.n_rows, r0 + per);
+        for (int64_t base = r0; base < r1; base += 64) {
+            const int64_t r = base + lane;
+            const bool idle = r < r1 && P.off[r + 1] == P.off[r];
+            unsigned long long todo = __ballot(idle);
+            while (todo) {
+                const int k = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                untouched_row_update(Q, base + k, lane, vec, lp_acc);
+            }
+        }
+    }
     if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
 }
 
@@ -1368,6 +1397,7 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
                                   "grouping, 16-byte aligned rows of more than 16 chunks)");
     if (A.segs) {
         P.multi = w.multi; P.single = w.single; P.tasks = w.tasks; P.counters = w.counters; P.task_cap = w.task_cap;
+        P.off = w.off;
         A.partial = w.partial;
         // persistent grid: enough waves to fill the chip at 8 per SIMD, fewer for small batches (every wave of the launch
         // reads the list counters and its descriptors before it has anything to do)
@@ -1435,7 +1465,18 @@ static unsigned segments_grid(unsigned wanted, bool plain, bool ride, bool half)
     return fixed || wanted <= cap ? wanted : cap;
 }
 
-static int apply_launch(const ApplyParams& P, const ApplyLaunch& A, hipStream_t st) {
+// the dense pass inside the descriptor-driven launch (ApplyParams.dense_here): small tables, where a launch of its own costs more
+// than its rows (the reference's own configurations: 12 of a 73 us step); EMG_DENSE_FUSED = 0 / 1 forces it off / on (A/B aid)
+static bool dense_in_segments(const ApplyParams& P, const ApplyLaunch& A) {
+    static const int env = getenv("EMG_DENSE_FUSED") ? atoi(getenv("EMG_DENSE_FUSED")) : -1;
+    if (!(A.any && A.segs && A.dense) || P.opt.lp_lambda != 0.f) return false;
+    return env >= 0 ? env != 0 : P.n_rows <= 131072;
+}
+
+static int apply_launch(const ApplyParams& P0, const ApplyLaunch& A0, hipStream_t st) {
+    ApplyParams P = P0;
+    ApplyLaunch A = A0;
+    if (dense_in_segments(P, A)) { P.dense_here = 1; A.dense = false; }
     if (A.any && A.segs) {
         SegmentsLaunch K{};
         K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
@@ -1508,6 +1549,7 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         return rc != EMG_OK ? rc : apply_launch(P1, A1, st);
     }
     if (share_segs) {
+        if (dense_in_segments(P0, A0) && dense_in_segments(P1, A1)) { P0.dense_here = P1.dense_here = 1; A0.dense = A1.dense = false; }
         SegmentsLaunch K{};
         K.P[0] = P0; K.partial[0] = A0.partial; K.ldp[0] = A0.ldp;
         K.P[1] = P1; K.partial[1] = A1.partial; K.ldp[1] = A1.ldp; K.n_tables = 2;

@@ -542,7 +542,7 @@ struct keep_rows {
 #endif
     static constexpr bool value = EMG_BW_KEEP != 0 && W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
 };
-template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP>
+template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP, int UW = EMG_BW_U>
 __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
     using R = Row<MODEL, W, NV>;
     GroupParams P = P0;
@@ -658,7 +658,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
 #ifndef EMG_WIN_BUDGET
 #define EMG_WIN_BUDGET 48
 #endif
-    constexpr int U = !IT::window_state ? EMG_BW_U : (R::N * (1 + NS) * 4 <= EMG_WIN_BUDGET ? 4 : (R::N * (1 + NS) * 3 <= EMG_WIN_BUDGET ? 3 : 2));
+    constexpr int U = !IT::window_state ? UW : (R::N * (1 + NS) * 4 <= EMG_WIN_BUDGET ? 4 : (R::N * (1 + NS) * 3 <= EMG_WIN_BUDGET ? 3 : 2));
     int chunk0 = 0, chunk1 = min(P.eta, LPG);   // the negatives [chunk0, chunk1) are the ones my_code / my_flag / my_pos describe
     auto code_of = [&](int j) -> int32_t { return group_lane_value<LPG>(my_code, first, j - chunk0); };
     auto flag_of = [&](int j) -> int {   // negative j of the current chunk
@@ -928,7 +928,14 @@ static __device__ unsigned long long emg_trace_fused_buf[4 * 65536];
 #ifndef EMG_IP6_MINWAVES
 #define EMG_IP6_MINWAVES 3   // window forms: three waves per SIMD (form 6, ComplEx k = 200: 168 VGPRs + 64 bytes of scratch; left alone 186 VGPRs, two waves:
 #endif                       // C3 + Adam 0.86 against 0.93 ms per step)
-template <int MODEL, int W, int NV, int LPG, int IP>
+// UW: replacement rows in flight per wave.  EMG_BW_U where the launch fills the chip several times over; a SMALL batch (fewer waves
+// than the SIMDs can hold at once: the reference's own configurations, 1.7 - 4.7 waves per SIMD) has registers to spare and a
+// kernel time that is one wave's chain of dependent round trips — a deeper window (EMG_BW_U_DEEP) shortens the chain.  Same bits:
+// the negatives are consumed in the same order.
+#ifndef EMG_BW_U_DEEP
+#define EMG_BW_U_DEEP 10
+#endif
+template <int MODEL, int W, int NV, int LPG, int IP, int UW = EMG_BW_U>
 __global__ __launch_bounds__(kThreads, (ip_traits<IP>::window_state ? EMG_IP6_MINWAVES : EMG_BW_MINWAVES)) void train_fused_riders_kernel(const GroupParams P, const Riders riders) {
     unsigned bx;
     if (run_riders(riders, &bx)) return;
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(kThreads, (ip_traits<IP>::window_state ? EMG_IP6_MI
     const unsigned tw = (bx * kThreads + threadIdx.x) >> 6;
     if ((threadIdx.x & 63) == 0 && tw < 65536) emg_trace_fused_buf[4 * tw] = wall_clock64();
 #endif
-    train_backward_body<MODEL, W, NV, LPG, true, IP>(P, bx);
+    train_backward_body<MODEL, W, NV, LPG, true, IP, UW>(P, bx);
 #ifdef EMG_TRACE
     if ((threadIdx.x & 63) == 0 && tw < 65536) emg_trace_fused_buf[4 * tw + 1] = wall_clock64();
 #endif
