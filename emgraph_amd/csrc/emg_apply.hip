@@ -1260,6 +1260,45 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             const int64_t r = base + lane;
             const bool idle = r < r1 && P.off[r + 1] == P.off[r];
             unsigned long long todo = __ballot(idle);
+            if (vec && nchunks <= 64 && P.state0 && P.state1) {
+                // FOUR rows in flight (one row at a time is a chain of load -> update -> store round trips: 5 untouched rows per wave
+                // of C1's launch took as long as its 8 destinations).  Past the list's end: the last row again, its stores skipped.
+                while (todo) {
+                    int64_t row[4];
+                    bool live[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        live[q] = todo != 0ull;
+                        const int k = live[q] ? __ffsll((long long)todo) - 1 : 0;
+                        row[q] = live[q] ? base + k : (q ? row[q - 1] : base);
+                        todo &= todo - 1ull;   // (0 stays 0)
+                    }
+                    const int c = min(lane, nchunks - 1);
+                    float4 wv[4], av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        wv[q] = *reinterpret_cast<const float4*>(P.table + row[q] * P.ld + 4 * c);
+                        av[q] = *reinterpret_cast<const float4*>(P.state0 + row[q] * P.ld + 4 * c);
+                        bv[q] = *reinterpret_cast<const float4*>(P.state1 + row[q] * P.ld + 4 * c);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float ww[4] = {wv[q].x, wv[q].y, wv[q].z, wv[q].w}, aa[4] = {av[q].x, av[q].y, av[q].z, av[q].w},
+                              bb[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float g = 0.f;
+                            opt_update_elem(opt, ww[j], g, &aa[j], &bb[j]);
+                        }
+                        if (live[q] && lane < nchunks) {
+                            *reinterpret_cast<float4*>(P.table + row[q] * P.ld + 4 * c) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+                            *reinterpret_cast<float4*>(P.state0 + row[q] * P.ld + 4 * c) = make_float4(aa[0], aa[1], aa[2], aa[3]);
+                            *reinterpret_cast<float4*>(P.state1 + row[q] * P.ld + 4 * c) = make_float4(bb[0], bb[1], bb[2], bb[3]);
+                        }
+                    }
+                }
+                continue;
+            }
             while (todo) {
                 const int k = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;

@@ -130,11 +130,39 @@ __device__ __forceinline__ void store_tile(const RowTile<W, NV>& t, float* __res
     }
 }
 
+// Sum over the LPG lanes of a group, the same bits in every lane.  A butterfly, lowest lane bit first: lanes (i, i ^ 1), (i, i ^ 2),
+// (i, i ^ 4), (i, i ^ 8) as DPP operands of the adds themselves (quad_perm; row_half_mirror / row_mirror reach the other quad /
+// the other half of the row, whose lanes all hold the same partial sum by then), the four rows of 16 through v_readlane:
+// (r0 + r1) + (r2 + r3).  __shfl_xor is ds_bpermute_b32 — six dependent trips through the LDS crossbar, ~0.5 us per negative of a
+// wave's chain: nothing where 12 waves per SIMD wait in line (C3), the whole kernel time where there are 1.7 (the reference's own
+// batch sizes; tools/sweep_small.py: fused time = 16 us + 0.55 us per negative whatever the depth of the row window).
+// A group narrower than the wave: the missing levels would add zeros, so every LPG gives the same bits for the same row.
+#ifndef EMG_DPP_SUM
+#define EMG_DPP_SUM 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 template <int LPG>
 __device__ __forceinline__ float group_sum(float v) {
+#if EMG_DPP_SUM
+    static_assert(LPG == 16 || LPG == 32 || LPG == 64, "a group is 16, 32 or 64 lanes");
+    v += dpp_lane_f<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_lane_f<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_lane_f<0x141>(v);   // row_half_mirror
+    v += dpp_lane_f<0x140>(v);   // row_mirror
+    if constexpr (LPG == 16) return v;
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    const float a = r0 + r1, b = r2 + r3;
+    if constexpr (LPG == 32) return (__lane_id() & 32) ? b : a;
+    return a + b;
+#else
 #pragma unroll
-    for (int off = LPG / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = 1; off < LPG; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
+#endif
 }
 
 __device__ __forceinline__ float sgnf(float d) { return (float)(d > 0.f) - (float)(d < 0.f); }

@@ -499,6 +499,9 @@ __device__ __forceinline__ void finish_grads(const Row<MODEL, W, NV>& s, const R
 #ifndef EMG_BW_U
 #define EMG_BW_U 4
 #endif
+#ifndef EMG_BW_ROLL
+#define EMG_BW_ROLL 1   // 0: A/B aid — U rows per trip, none in flight across trips
+#endif
 
 // ASYNC replacement rows (EMG_BW_ASYNC, bilinear fused forms with 16-byte rows): the row loads of the rolling window are
 // inline assembly, so hipcc neither counts nor waits for them; the wait before a row's first use is written by hand:
@@ -686,6 +689,16 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     float lrv[IT::replay ? U : 1];
     emg_f4 aw[IT::window_state ? U : 1][IT::window_state ? PIECES_S : 1], a0[IT::window_state ? U : 1][IT::window_state ? PIECES_S : 1],
            a1[NS == 2 ? U : 1][NS == 2 ? PIECES_S : 1];
+    // TransE sums |q - e| over every lane, so lanes past the row's end must hold zeros.  The select sits at the row's USE, not at its
+    // load: a select behind the load makes hipcc wait for the refill it has just issued (ISA of the first form: four
+    // s_waitcnt vmcnt(0) at the end of every trip — the window went U -> 0 -> U, one exposed round trip per U negatives:
+    // tools/sweep_small.py, C1: 0.4 - 0.55 us per negative whatever U)
+    constexpr bool kZeroAtLoad = !kBilinear && EMG_BW_ROLL == 0;
+    constexpr bool kZeroAtUse = !kBilinear && !kZeroAtLoad;
+    auto zero_tail = [&](R& r) {
+#pragma unroll
+        for (int e = 0; e < R::N; ++e) r.x[e] = (lg + ((e % (W * NV)) / W) * LPG < P.nchunks) ? r.x[e] : 0.f;
+    };
     auto issue_slot = [&](int u, int jn, int32_t repl) {
         if constexpr (IT::window_state) {
             const bool f = flag_of(jn) != 0;
@@ -733,16 +746,13 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         for (int u = 0; u < U; ++u) {
             const int32_t repl = code[u] & 0x7fffffff;
             if constexpr (IT::window_state) issue_slot(u, min(j0 + u, chunk1 - 1), repl);
-            else load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
+            else load_row<MODEL, W, NV, LPG, kZeroAtLoad>(re[u], P.ent + (int64_t)repl * P.ld_ent, lg, P.nchunks, P.khalf);
         }
     };
     // ROLLING window of U replacement rows: as soon as a negative's row has been consumed (score, gradient, in-place
     // update or contribution), ITS registers take the load of the negative U places later — the wave keeps U rows in flight
     // through the whole loop instead of U -> 0 -> U per trip, with no register beyond the U rows (at 3 waves per SIMD it is
     // the bytes in flight per wave that bound this kernel: tools/hbm_ceiling's bare mix runs 8 waves deep)
-#ifndef EMG_BW_ROLL
-#define EMG_BW_ROLL 1
-#endif
     int32_t code[U];
     float gj[U];
     R re[U];
@@ -797,6 +807,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             const int32_t repl = code[u] & 0x7fffffff;
             if constexpr (kAsync) take_row(pa[u], re[u]);
             if constexpr (IT::window_state) take_slot(u, re[u]);
+            if constexpr (kZeroAtUse && !IT::window_state) zero_tail(re[u]);
             if constexpr (IT::replay) {   // a singleton behind the table's step: replay the steps it missed, THEN score it
                 if (flag_of(j) && tg[u] > 0 && tg[u] < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, tg[u], lrv[u], re[u], st0[u], st1[u], lg);
             }
@@ -841,7 +852,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
                 code[u] = code_of(jn);
                 if constexpr (kAsync) issue_row(pa[u], code[u] & 0x7fffffff);
                 else if constexpr (IT::window_state) issue_slot(u, jn, code[u] & 0x7fffffff);
-                else load_row<MODEL, W, NV, LPG, !kBilinear>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
+                else load_row<MODEL, W, NV, LPG, kZeroAtLoad>(re[u], P.ent + (int64_t)(code[u] & 0x7fffffff) * P.ld_ent, lg, P.nchunks, P.khalf);
                 if constexpr (!FUSED) gj[u] = P.g_neg[(int64_t)jn * B + g];
             }
         }
