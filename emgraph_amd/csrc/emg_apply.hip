@@ -855,9 +855,13 @@ __device__ __forceinline__ void replay_finish(const ReplayParams& P, ReplayRegs<
         for (int t = 0; t < T; ++t) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float g = 0.f;
-                if constexpr (LPK == 1) lp_fold_p123(opt, ww[t][j], g, acc[t]);
-                opt_update_elem(opt, ww[t][j], g, &aa[t][j], &bb[t][j]);
+                if constexpr (OPT == EMG_OPT_ADAM && LPK == 0) {
+                    adam_zero_grad_elem(opt, ww[t][j], aa[t][j], bb[t][j]);
+                } else {
+                    float g = 0.f;
+                    if constexpr (LPK == 1) lp_fold_p123(opt, ww[t][j], g, acc[t]);
+                    opt_update_elem(opt, ww[t][j], g, &aa[t][j], &bb[t][j]);
+                }
             }
         }
     }

@@ -254,14 +254,31 @@ __device__ __forceinline__ void opt_update_elem(const OptParams& P, float& w, fl
     }
 }
 
-// Adam's m, v after a step whose gradient is zero: opt_update_elem's own expressions with g = 0 (opaque to the compiler: the
-// same instructions, the same roundings — b1 m + (1 - b1) 0 is not b1 m when b1 m is -0)
+// Adam's step with a ZERO gradient (the dense pass on a row no triple touched, replayed by the deferred pass): opt_update_elem's
+// values with g = +0, in 9 instructions per element instead of 13 — the replay is arithmetic, and the kernels that carry it
+// (catch-up, the scoring kernel's form 6) are bound by instruction issue (PMC, C3 + Adam: 12.3 k VALU instructions per wave, the
+// SIMDs issuing 79 % of the time).
+//   m: b1 m + (1 - b1) 0 = b1 m + (+0): the ADDITION stays — it turns a product that is -0 into +0, as the dense pass's own does;
+//   v: b2 v + (1 - b2) 0 0 = b2 v + (+0) = b2 v exactly (v is a sum of squares: never -0, never negative).
+#ifndef EMG_ZERO_GRAD_TRIM
+#define EMG_ZERO_GRAD_TRIM 1   // 0: A/B aid — opt_update_elem's expressions with a zero the compiler cannot see through
+#endif
 __device__ __forceinline__ void adam_decay_elem(const OptParams& P, float& m, float& v) {
 #pragma clang fp contract(off)
+#if EMG_ZERO_GRAD_TRIM
+    m = P.beta1 * m + 0.0f;
+    v = P.beta2 * v;
+#else
     float g = 0.f;
     asm volatile("" : "+v"(g));
     m = P.beta1 * m + (1.f - P.beta1) * g;
     v = P.beta2 * v + (1.f - P.beta2) * g * g;
+#endif
+}
+__device__ __forceinline__ void adam_zero_grad_elem(const OptParams& P, float& w, float& m, float& v) {
+#pragma clang fp contract(off)
+    adam_decay_elem(P, m, v);
+    w = w - opt_ratio(P.lr_t * m, v, P.eps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,6 +298,24 @@ __device__ __forceinline__ float relu_nan(float v) { return (v >= 0.f || v != v)
 struct PosTerms {
     float loss, grad;
 };
+
+// The per-negative NLL terms with the hardware's 1-ulp transcendental instructions (v_exp_f32, v_log_f32, v_rcp_f32) instead of
+// libm's expf / logf and an IEEE division: 14 instructions instead of 45, in a loop whose cost at the reference's batch sizes is
+// the instruction stream of ONE wave per SIMD (tools/sweep_small.py: ~0.4 us per negative).  exp(x), |x| <= 75: 2^(x log2 e) with the
+// product's rounding error carried into a first-order correction (<= 2 ulp); sigmoid = e rcp(1 + e) (<= 2 ulp); the loss VALUE's
+// log(1 + e) = ln 2 log2(1 + e) (absolute error ~1e-7 per term, summed in double).  EMG_LOSS_FAST = 0 (default): libm / IEEE forms —
+// measured on one box, ms per step, fast against libm: C2 0.0519 / 0.0530, C5 0.1191 / 0.1202, C3 0.3478 / 0.3437 (the large batch is
+// memory-bound): a microsecond where it helps, so the accurate forms stay.
+#ifndef EMG_LOSS_FAST
+#define EMG_LOSS_FAST 0
+#endif
+__device__ __forceinline__ float exp75_fast(float x) {
+    const float t = x * 1.44269502f;                         // log2(e) = 1.44269502 + 1.92596299e-8
+    float r = fmaf(x, 1.44269502f, -t);                      // the product's rounding error, exact
+    r = fmaf(x, 1.92596299e-8f, r);
+    const float e0 = __builtin_amdgcn_exp2f(t);
+    return fmaf(e0 * r, 0.693147181f, e0);                   // 2^(t + r) = 2^t (1 + r ln 2 + ...)
+}
 
 __device__ __forceinline__ PosTerms local_loss_pos(int loss, float pos) {
     PosTerms t;
@@ -304,10 +339,18 @@ __device__ __forceinline__ float local_loss_neg(int loss, float pos, const PosTe
         return act;
     }
     if (loss == EMG_LOSS_NLL) {
+#if EMG_LOSS_FAST
+        const float e = exp75_fast(clip75(neg));
+        const float one_e = 1.0f + e;
+        loss_acc += t.loss + 0.693147181f * __builtin_amdgcn_logf(one_e);   // nll.py:59 literal log(1+exp(x))
+        gpos_acc += t.grad;
+        return in75(neg) * (e * __builtin_amdgcn_rcpf(one_e));              // sigmoid(clip(neg))
+#else
         const float e = expf(clip75(neg));    // <= e^75 = 3.7e32, finite in f32
         loss_acc += t.loss + logf(1.0f + e);  // nll.py:59 literal log(1+exp(x))
         gpos_acc += t.grad;
         return in75(neg) * (e / (1.0f + e));  // sigmoid(clip(neg))
+#endif
     }
     const float v = margin + neg;  // absolute_margin
     loss_acc += relu_nan(v) - pos;

@@ -193,8 +193,8 @@ static int counting_tail(GroupLaunch& G, int64_t cap_n0, int64_t cap_n1, hipStre
     hipLaunchKernelGGL(group_scan_kernel, dim3(scan_blocks), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     // (+1: the order kernel also resets arrive[0 .. n / 64], and thread 0 / 1 the window path's task counters)
-    G.split_n = (unsigned)cdiv(cap_n0 + 1, 256);
-    const unsigned nb = G.split_n + (G.n_tables > 1 ? (unsigned)cdiv(cap_n1 + 1, 256) : 0u);
+    G.split_n = (unsigned)cdiv(cap_n0 + 1, kPrepBlock);
+    const unsigned nb = G.split_n + (G.n_tables > 1 ? (unsigned)cdiv(cap_n1 + 1, kPrepBlock) : 0u);
     hipLaunchKernelGGL(group_scatter_kernel, dim3(nb), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     hipLaunchKernelGGL(group_order_kernel, dim3(nb), dim3(256), 0, st, G);
@@ -246,7 +246,7 @@ extern "C" int emg_group_dest(const int32_t* dest, int64_t n, int64_t n_rows, vo
     G.n_tables = 1; G.B = 0;
     fill_table(G.t[0], w, dest, n, 0, n_rows, single_flags, nullptr);
     G.t[1] = G.t[0];
-    G.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, 256);
+    G.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, kPrepBlock);
     hipLaunchKernelGGL(group_hist_kernel, dim3(G.split_n), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     return counting_tail(G, n, 0, st);
@@ -274,7 +274,7 @@ extern "C" int emg_group_dest_keyed(const int32_t* dest, const uint32_t* order_k
     fill_table(G.t[0], w, dest, n, 0, n_rows, nullptr, nullptr);
     G.t[0].order_key = order_key;
     G.t[1] = G.t[0];
-    G.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, 256);
+    G.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, kPrepBlock);
     hipLaunchKernelGGL(group_hist_kernel, dim3(G.split_n), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     return counting_tail(G, n, 0, st);
@@ -344,12 +344,12 @@ int prepare_stages(const emg_prepare_args* a, PrepStages* o) {
     P.hist = o->fused_hist ? 1 : 0;
     int64_t threads = n_neg > Bl ? n_neg : Bl;
     if (o->fused_hist) { const int64_t sb = o->we.scan_blocks > o->wr.scan_blocks ? o->we.scan_blocks : o->wr.scan_blocks; if (sb > threads) threads = sb; }
-    o->nb_ids = (unsigned)cdiv(threads, 256);
+    o->nb_ids = (unsigned)cdiv(threads, kPrepBlock);
     if (o->both) {   // launch geometry of scan / scatter / order (as counting_tail)
         G.split_scan = (unsigned)G.t[0].scan_blocks;
         o->nb_scan = G.split_scan + (unsigned)G.t[1].scan_blocks;
-        G.split_n = (unsigned)cdiv(o->cap_ce + 1, 256);
-        o->nb_n = G.split_n + (unsigned)cdiv(o->cap_cr + 1, 256);
+        G.split_n = (unsigned)cdiv(o->cap_ce + 1, kPrepBlock);
+        o->nb_n = G.split_n + (unsigned)cdiv(o->cap_cr + 1, kPrepBlock);
     }
     return EMG_OK;
 }
@@ -376,8 +376,8 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
     if (S.both) {
         if (!S.fused_hist) {
             GroupLaunch H = S.G;
-            H.split_n = (unsigned)cdiv(S.cap_ce > S.we.scan_blocks ? S.cap_ce : S.we.scan_blocks, 256);
-            const unsigned nb = H.split_n + (unsigned)cdiv(S.cap_cr > S.wr.scan_blocks ? S.cap_cr : S.wr.scan_blocks, 256);
+            H.split_n = (unsigned)cdiv(S.cap_ce > S.we.scan_blocks ? S.cap_ce : S.we.scan_blocks, kPrepBlock);
+            const unsigned nb = H.split_n + (unsigned)cdiv(S.cap_cr > S.wr.scan_blocks ? S.cap_cr : S.wr.scan_blocks, kPrepBlock);
             hipLaunchKernelGGL(group_hist_kernel, dim3(nb), dim3(256), 0, st, H);
             EMG_LAUNCH_CHECK();
         }
@@ -396,7 +396,7 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
         GroupLaunch G1{};
         G1.n_tables = 1; G1.B = a->B;
         G1.t[0] = S.G.t[ti]; G1.t[1] = S.G.t[ti];
-        G1.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, 256);
+        G1.split_n = (unsigned)cdiv(n > w.scan_blocks ? n : w.scan_blocks, kPrepBlock);
         hipLaunchKernelGGL(group_hist_kernel, dim3(G1.split_n), dim3(256), 0, st, G1);
         EMG_LAUNCH_CHECK();
         rc = counting_tail(G1, n, 0, st);

@@ -43,6 +43,16 @@ struct GroupWs {
 };
 
 constexpr int kScanTile = 4096;                  // rows per scan workgroup (256 threads x 16)
+// Contributions per THREAD of the per-contribution stages (ids + histogram, scatter, order), taken 256 apart so that every load
+// of a wave stays coalesced, each stage written in phases (all loads of a phase issued before anything waits).  These kernels
+// stream beside the scoring kernel, which holds its SIMDs' register files: a preparation wave gets a slot only when a scoring
+// wave leaves and keeps a scoring wave out for as long as it lives — a chain of dependent round trips per contribution (id ->
+// offsets -> cursor -> store).  Four chains per thread: a quarter of the waves, each living little longer.
+#ifndef EMG_PREP_ITEMS
+#define EMG_PREP_ITEMS 4
+#endif
+constexpr int kPrepItems = EMG_PREP_ITEMS;
+constexpr int kPrepBlock = 256 * kPrepItems;     // contributions per workgroup of those stages
 
 bool group_backend_counting(int64_t N, int64_t R);
 int64_t group_ws_bytes(int64_t N, int64_t R, int64_t ldp);

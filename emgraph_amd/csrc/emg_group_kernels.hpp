@@ -48,9 +48,17 @@ __device__ __forceinline__ void hist_add(const TableGroup& T, int32_t d) {
 __device__ __forceinline__ void group_hist_body(const GroupLaunch& G, unsigned bx) {
     const int ti = bx < G.split_n ? 0 : 1;
     const TableGroup& T = G.t[ti];
-    const int64_t i = (int64_t)(bx - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
-    group_reset(T, i);
-    if (i < table_n(G, ti)) hist_add(T, T.dest[i]);
+    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock + threadIdx.x;
+    const int64_t n = table_n(G, ti);
+    int32_t d[kPrepItems];
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {
+        const int64_t i = base + q * 256;
+        group_reset(T, i);
+        d[q] = i < n ? T.dest[i] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) hist_add(T, d[q]);
 }
 
 // 2. scan over the table rows.  Tile = 4096 rows = 256 threads x 16; tiles are taken in ticket order, so every
@@ -176,21 +184,42 @@ __device__ __forceinline__ void group_scan_body(const GroupLaunch& G, unsigned b
 __device__ __forceinline__ void group_scatter_body(const GroupLaunch& G, unsigned bx) {
     const int ti = bx < G.split_n ? 0 : 1;
     const TableGroup& T = G.t[ti];
-    const int64_t i = (int64_t)(bx - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
-    if (i >= table_n(G, ti)) return;
-    const int32_t d = T.dest[i];
-    const bool ok = d >= 0 && (int64_t)d < T.R;
-    bool single = false;
-    if (ok) {
-        const uint32_t start = T.off[d];
-        single = T.off[d + 1] - start == 1u;
-        // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
-        const uint32_t pos = single ? start : (uint32_t)atomicAdd(T.cnt + d, 1);
-        T.tmpv[pos] = T.order_key ? T.order_key[i] : (uint32_t)i;
-        if (T.order_key) T.pos_of_slot[pos] = (uint32_t)i;
-        T.keys[pos] = (uint32_t)d;
+    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock + threadIdx.x;
+    const int64_t n = table_n(G, ti);
+    if (base >= n) return;
+    int32_t d[kPrepItems];
+    bool ok[kPrepItems], single[kPrepItems];
+    uint32_t start[kPrepItems], next[kPrepItems], pos[kPrepItems], key[kPrepItems];
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 1: the ids (an index past the end: the last one again, nothing stored for it)
+        const int64_t i = base + q * 256;
+        d[q] = T.dest[i < n ? i : n - 1];
+        key[q] = T.order_key ? T.order_key[i < n ? i : n - 1] : (uint32_t)i;
     }
-    if (T.flags) T.flags[i] = single ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 2: their segments
+        ok[q] = base + q * 256 < n && d[q] >= 0 && (int64_t)d[q] < T.R;
+        const int32_t dd = ok[q] ? d[q] : 0;
+        start[q] = T.off[dd];
+        next[q] = T.off[dd + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 3: a contribution takes the next free position of its destination's segment
+        single[q] = ok[q] && next[q] - start[q] == 1u;
+        // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
+        pos[q] = start[q];
+        if (ok[q] && !single[q]) pos[q] = (uint32_t)atomicAdd(T.cnt + d[q], 1);
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {
+        const int64_t i = base + q * 256;
+        if (ok[q]) {
+            T.tmpv[pos[q]] = key[q];
+            if (T.order_key) T.pos_of_slot[pos[q]] = (uint32_t)i;
+            T.keys[pos[q]] = (uint32_t)d[q];
+        }
+        if (T.flags && i < n) T.flags[i] = single[q] ? 1 : 0;
+    }
 }
 
 // 4. order: rank of a contribution among the slots of its segment = its place in the stable order.
@@ -200,48 +229,81 @@ __device__ __forceinline__ void group_scatter_body(const GroupLaunch& G, unsigne
 __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned bx) {
     const int ti = bx < G.split_n ? 0 : 1;
     const TableGroup& T = G.t[ti];
-    const int64_t t = (int64_t)(bx - (ti ? G.split_n : 0u)) * 256 + threadIdx.x;
+    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock + threadIdx.x;
     const int64_t n = table_n(G, ti);
-    if (t < 2) T.counters[GC_LONG_COUNT + t] = 0u;          // window-path task list (apply_rows_kernel) starts empty
-    if (t <= n / kLongSegment) T.arrive[t] = 0;             // per-segment block counters of the long-segment reduction
-    if (t >= (int64_t)T.off[T.R]) return;
-    const uint32_t d = T.keys[t];
-    const uint32_t start = T.off[d], len = T.off[d + 1] - start;
-    const uint32_t mine = T.tmpv[t];
-    uint32_t rank = 0u;
-    {
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {
+        const int64_t t = base + q * 256;
+        if (t < 2) T.counters[GC_LONG_COUNT + t] = 0u;          // window-path task list (apply_rows_kernel) starts empty
+        if (t <= n / kLongSegment) T.arrive[t] = 0;             // per-segment block counters of the long-segment reduction
+    }
+    const int64_t total = (int64_t)T.off[T.R];
+    if (base >= total) return;
+    uint32_t d[kPrepItems], mine[kPrepItems], start[kPrepItems], len[kPrepItems], rank[kPrepItems];
+    bool on[kPrepItems];
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 1 (a position past the end: the last one again, nothing stored for it)
+        const int64_t t = base + q * 256;
+        on[q] = t < total;
+        const int64_t tt = on[q] ? t : total - 1;
+        d[q] = T.keys[tt];
+        mine[q] = T.tmpv[tt];
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 2
+        start[q] = T.off[d[q]];
+        len[q] = T.off[d[q] + 1] - start[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 3: the rank among the segment's slots (a singleton: nothing to read)
         // A hub row's segment is thousands of slots and every one of its threads walks all of them: 16-byte loads, sixteen
         // values per trip (the scalar loop took 130 us alone / 510 us beside the scoring kernel on the Zipf batch, most of
         // the preparation; short segments never leave the head / tail loops)
-        const uint32_t* seg = T.tmpv + start;
-        uint32_t j = 0u;
-        const uint32_t head = min(len, (4u - (start & 3u)) & 3u);   // up to the first 16-byte boundary
-        for (; j < head; ++j) rank += seg[j] < mine ? 1u : 0u;
-        for (; j + 16u <= len; j += 16u) {
-            const uint4 a = *reinterpret_cast<const uint4*>(seg + j), b = *reinterpret_cast<const uint4*>(seg + j + 4),
-                        c = *reinterpret_cast<const uint4*>(seg + j + 8), d = *reinterpret_cast<const uint4*>(seg + j + 12);
-            rank += (a.x < mine) + (a.y < mine) + (a.z < mine) + (a.w < mine) + (b.x < mine) + (b.y < mine) + (b.z < mine) + (b.w < mine)
-                  + (c.x < mine) + (c.y < mine) + (c.z < mine) + (c.w < mine) + (d.x < mine) + (d.y < mine) + (d.z < mine) + (d.w < mine);
+        uint32_t r = 0u;
+        if (on[q] && len[q] > 1u) {
+            const uint32_t* seg = T.tmpv + start[q];
+            const uint32_t m = mine[q], ln = len[q];
+            uint32_t j = 0u;
+            const uint32_t head = min(ln, (4u - (start[q] & 3u)) & 3u);   // up to the first 16-byte boundary
+            for (; j < head; ++j) r += seg[j] < m ? 1u : 0u;
+            for (; j + 16u <= ln; j += 16u) {
+                const uint4 a = *reinterpret_cast<const uint4*>(seg + j), b = *reinterpret_cast<const uint4*>(seg + j + 4),
+                            c = *reinterpret_cast<const uint4*>(seg + j + 8), e = *reinterpret_cast<const uint4*>(seg + j + 12);
+                r += (a.x < m) + (a.y < m) + (a.z < m) + (a.w < m) + (b.x < m) + (b.y < m) + (b.z < m) + (b.w < m)
+                   + (c.x < m) + (c.y < m) + (c.z < m) + (c.w < m) + (e.x < m) + (e.y < m) + (e.z < m) + (e.w < m);
+            }
+            for (; j + 4u <= ln; j += 4u) {
+                const uint4 a = *reinterpret_cast<const uint4*>(seg + j);
+                r += (a.x < m) + (a.y < m) + (a.z < m) + (a.w < m);
+            }
+            for (; j < ln; ++j) r += seg[j] < m ? 1u : 0u;
         }
-        for (; j + 4u <= len; j += 4u) {
-            const uint4 a = *reinterpret_cast<const uint4*>(seg + j);
-            rank += (a.x < mine) + (a.y < mine) + (a.z < mine) + (a.w < mine);
-        }
-        for (; j < len; ++j) rank += seg[j] < mine ? 1u : 0u;
+        rank[q] = r;
     }
-    const uint32_t q = start + rank;
-    T.vals[q] = mine;
-    if (T.order_key) { T.srcrow[q] = T.pos_of_slot[t]; T.coef[q] = 1.f; }   // (pos_of_slot: the scatter's second payload here)
-    if ((uint32_t)t == start) T.cnt[d] = 0;                 // the cursor has done its work: the histogram is zero again
-    if (T.fac_codes) {
-        const uint32_t fac_B = (uint32_t)(G.ctl ? G.ctl->B : G.B);
-        if (mine < 2u * fac_B) {
-            T.srcrow[q] = mine;
-            T.coef[q] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
-        } else {
-            const uint32_t i = mine - 2u * fac_B;
-            T.srcrow[q] = (T.fac_codes[i] < 0 ? 2u : 3u) * fac_B + i % fac_B;
-            T.pos_of_slot[i] = q;
+    const uint32_t fac_B = (uint32_t)(G.ctl ? G.ctl->B : G.B);
+    int32_t fcode[kPrepItems];
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {   // phase 4 (factored contributions): the codes of the negatives' slots
+        fcode[q] = 0;
+        if (T.fac_codes && on[q] && mine[q] >= 2u * fac_B) fcode[q] = T.fac_codes[mine[q] - 2u * fac_B];
+    }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {
+        if (!on[q]) continue;
+        const int64_t t = base + q * 256;
+        const uint32_t at = start[q] + rank[q];
+        T.vals[at] = mine[q];
+        if (T.order_key) { T.srcrow[at] = T.pos_of_slot[t]; T.coef[at] = 1.f; }   // (pos_of_slot: the scatter's second payload here)
+        if ((uint32_t)t == start[q]) T.cnt[d[q]] = 0;          // the cursor has done its work: the histogram is zero again
+        if (T.fac_codes) {
+            if (mine[q] < 2u * fac_B) {
+                T.srcrow[at] = mine[q];
+                T.coef[at] = 1.f;   // subject / object rows are stored in full (the negatives' factors come from the backward kernel)
+            } else {
+                const uint32_t i = mine[q] - 2u * fac_B;
+                T.srcrow[at] = (fcode[q] < 0 ? 2u : 3u) * fac_B + i % fac_B;
+                T.pos_of_slot[i] = at;
+            }
         }
     }
 }
@@ -259,7 +321,6 @@ struct PrepParams {
 };
 
 __device__ __forceinline__ void prepare_ids_body(const PrepParams& P, const GroupLaunch& G, unsigned bx) {
-    const int64_t j = (int64_t)bx * blockDim.x + threadIdx.x;
     int64_t B = P.B;
     const int32_t* pos = P.pos;
     uint64_t counter0 = P.counter0, n_choices = P.n_choices;
@@ -268,36 +329,40 @@ __device__ __forceinline__ void prepare_ids_body(const PrepParams& P, const Grou
         B = P.ctl->B; pos += 3 * P.ctl->start; counter0 = P.ctl->draw_counter0;
         if (P.ctl->n_choices > 0) { n_choices = (uint64_t)P.ctl->n_choices; elist = P.ctl->entities_list; }
     }
-    if (P.hist) { group_reset(G.t[0], j); group_reset(G.t[1], j); }
     const int64_t per_side = (int64_t)P.eta * B;
-    if (j < B) {
-        const int32_t s = pos[3 * j + 0], p = pos[3 * j + 1], o = pos[3 * j + 2];
-        P.dest_ent[j] = s;
-        P.dest_ent[B + j] = o;
-        P.dest_rel[j] = p;
-        if (P.hist) { hist_add(G.t[0], s); hist_add(G.t[0], o); hist_add(G.t[1], p); }
+#pragma unroll
+    for (int q = 0; q < kPrepItems; ++q) {
+        const int64_t j = ((int64_t)bx * kPrepItems + q) * 256 + threadIdx.x;
+        if (P.hist) { group_reset(G.t[0], j); group_reset(G.t[1], j); }
+        if (j < B) {
+            const int32_t s = pos[3 * j + 0], p = pos[3 * j + 1], o = pos[3 * j + 2];
+            P.dest_ent[j] = s;
+            P.dest_ent[B + j] = o;
+            P.dest_rel[j] = p;
+            if (P.hist) { hist_add(G.t[0], s); hist_add(G.t[0], o); hist_add(G.t[1], p); }
+        }
+        if (j >= per_side * P.n_sides) continue;
+        const int sd = (int)(j / per_side);
+        int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
+        if (!P.ctl && P.B_global != B) {  // this batch is rows [row_offset, row_offset + B) of a larger one: draw what IT would
+            const int64_t je = jj / B;
+            jj = je * P.B_global + P.row_offset + (jj - je * B);
+        }
+        const int side = P.sides[sd];
+        uint32_t keep, idx;
+        if (P.inj_repl) {
+            idx = (uint32_t)P.inj_repl[j];
+            keep = P.inj_mask ? (uint32_t)(P.inj_mask[j] != 0) : 0u;
+        } else {
+            corruption_draw(P.seed, counter0 + (uint64_t)sd, (uint64_t)jj, n_choices, &keep, &idx);
+        }
+        if (side == EMG_SIDE_O) keep = 1u;
+        else if (side == EMG_SIDE_S) keep = 0u;
+        const uint32_t repl = elist ? (uint32_t)elist[idx] : idx;
+        P.codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
+        P.dest_ent[2 * B + j] = (int32_t)(repl & 0x7fffffffu);
+        if (P.hist) hist_add(G.t[0], (int32_t)(repl & 0x7fffffffu));
     }
-    if (j >= per_side * P.n_sides) return;
-    const int sd = (int)(j / per_side);
-    int64_t jj = j - sd * per_side;  // the draw index restarts per side (one emg_corrupt_codes call each)
-    if (!P.ctl && P.B_global != B) {  // this batch is rows [row_offset, row_offset + B) of a larger one: draw what IT would
-        const int64_t je = jj / B;
-        jj = je * P.B_global + P.row_offset + (jj - je * B);
-    }
-    const int side = P.sides[sd];
-    uint32_t keep, idx;
-    if (P.inj_repl) {
-        idx = (uint32_t)P.inj_repl[j];
-        keep = P.inj_mask ? (uint32_t)(P.inj_mask[j] != 0) : 0u;
-    } else {
-        corruption_draw(P.seed, counter0 + (uint64_t)sd, (uint64_t)jj, n_choices, &keep, &idx);
-    }
-    if (side == EMG_SIDE_O) keep = 1u;
-    else if (side == EMG_SIDE_S) keep = 0u;
-    const uint32_t repl = elist ? (uint32_t)elist[idx] : idx;
-    P.codes[j] = (int32_t)((repl & 0x7fffffffu) | (keep << 31));
-    P.dest_ent[2 * B + j] = (int32_t)(repl & 0x7fffffffu);
-    if (P.hist) hist_add(G.t[0], (int32_t)(repl & 0x7fffffffu));
 }
 
 

@@ -372,9 +372,8 @@ __device__ __forceinline__ void replay_in_window(const GroupParams& P, const Opt
 #pragma unroll
         for (int e = 0; e < Row<MODEL, W, NV>::N; ++e) {
             const bool on = lg + ((e % E) / W) * LPG < P.nchunks;
-            float g = 0.f, wv = w.x[e];
-            asm volatile("" : "+v"(g));   // (opaque zero: opt_update_elem's own instructions and roundings, as the dense pass executes them)
-            opt_update_elem(opt, wv, g, &m.x[e], &v.x[e]);
+            float wv = w.x[e];
+            adam_zero_grad_elem(opt, wv, m.x[e], v.x[e]);   // (the dense pass's update of a row with no gradient: the same values)
             w.x[e] = on ? wv : w.x[e];
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -757,7 +756,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     float gj[U];
     R re[U];
     constexpr int PIECES = NV * (is_complex<MODEL>::value ? 2 : 1);   // 16-byte loads per row and lane
-    constexpr bool kAsync = EMG_BW_ASYNC != 0 && EMG_BW_ROLL != 0 && kBilinear && W == 4 && FUSED && (PIECES == 1 || PIECES == 2 || PIECES == 4) &&
+    constexpr bool kAsync = EMG_BW_ASYNC != 0 && EMG_BW_ROLL != 0 && W == 4 && FUSED && (PIECES == 1 || PIECES == 2 || PIECES == 4) &&
                             (U - 1) * PIECES <= 15 && !IT::window_state;
     static_assert(!IT::window_state || EMG_BW_ROLL != 0, "IP 4 / 5 / 6 use the rolling window");
     emg_f4 pa[kAsync ? U : 1][kAsync ? PIECES : 1];

@@ -1,10 +1,12 @@
 source tools/ab_env.sh
-for w in C1 C2 C5; do
-  run "$w" --workload $w
-  run "$w" --workload $w
+V=emgraph_amd/lib/variants
+python -m pytest tests/test_graph_step.py tests/test_hip_kernels.py -x -q -m gpu 2>&1 | tail -3
+for i in 1 2 3; do
+run "C3 main(prep4)" --workload C3
+EMGRAPH_HIP_LIB=$V/libemgraph_hip_prep1.so run "C3 prep1" --workload C3
 done
-EMG_WIDE_GROUPS=0 run "C1 narrow" --workload C1
-EMG_WIDE_GROUPS=0 run "C1 narrow" --workload C1
-EMG_WIDE_GROUPS=0 run "C3p narrow" --workload C3p
-run "C3p" --workload C3p
-python -m pytest tests/test_graph_step.py tests/test_config_widths.py tests/test_api.py tests/test_hip_kernels.py -x -q -m gpu 2>&1 | tail -3
+for w in C3a C1 C2 C5; do
+run "$w main(prep4)" --workload $w
+EMGRAPH_HIP_LIB=$V/libemgraph_hip_prep1.so run "$w prep1" --workload $w
+done
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
