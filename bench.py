@@ -139,7 +139,8 @@ def pmc_traffic(stage, name, B, world, args):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
             k = [v for n, v in d["kernels"].items()
-                 if "train_fused_riders_kernel<3, 4, 1, 64, 1>" in n or "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
+                 if "train_fused_riders_kernel<3, 4, 1, 64, 1>" in n or "train_fused_riders_kernel<3, 4, 1, 64, 1, " in n   # (, window depth> since round 4)
+                 or "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
             if k:
                 return k[0]["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc pass of this command, not measured in this run)" % fn
         except (OSError, ValueError, KeyError):
@@ -256,9 +257,13 @@ class StepRunner:
                 ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns, n_caught_up=(n_ue - n_single) + n_ur)
                 if name == "apply_ent" and "apply_rel" not in ms:   # pair apply: both tables in the same launches
                     ab += algorithmic_bytes("apply_rel", B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns)
+                dense_here = name == "apply_ent" and self.w["optimizer"] == "adam" and not tr.deferred
+                if dense_here:   # Keras Adam's dense-equivalent pass: every row the batch did NOT touch is read and written too (w, m, v),
+                    ab += ((self.w["n_ent"] - n_ue) + (self.w["n_rel"] - n_ur)) * 2 * (1 + ns) * 4 * self.k_local   # inside this stage's launches
                 out[name] = {"ms": round(v, 4), "alg_bytes": ab, "GBps": round(ab / (v * 1e-3) / 1e9, 1) if ab else None}
                 if name == "apply_ent" and "apply_rel" not in ms:
-                    out[name]["note"] = "entity + relation table through shared launches (emg_apply_grouped_pair)"
+                    out[name]["note"] = "entity + relation table through shared launches (emg_apply_grouped_pair)" + (
+                        "; bytes include Adam's dense pass over the untouched rows (same launch for tables of <= 131072 rows)" if dense_here else "")
                 if name == "catchup":
                     out[name]["note"] = ("emg_deferred_catchup of both tables; bytes = an upper bound (every destination the apply finishes; rows "
                                          "already at the current step are skipped)")
@@ -771,7 +776,7 @@ def main():
                 line["roofline"]["mix_ceiling"] = {"what": "the fused kernel's own access mix as a bare microkernel (23 random 1600-B rows read per "
                                                    "group, 16 written back in place, 5 streamed out non-temporally), same byte count",
                                                    "ms": ceilings["mix23_nt_ms"], "frac_of_mix_ceiling": round(ceilings["mix23_nt_ms"] / stages[dom]["ms"], 4)}
-        prof = profiled_avg_us("train_fused_riders_kernel<3, 4, 1, 64, 1>" if dom == "fused" else "apply_segments_kernel")
+        prof = profiled_avg_us("train_fused_riders_kernel<3, 4, 1, 64, 1" if dom == "fused" else "apply_segments_kernel")
         if prof and args.workload == "C3":
             line["roofline"]["profiled"] = dict(prof, frac=round(stages[dom]["alg_bytes"] / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                 note="rocprofv3 --kernel-trace --stats of `bench.py --no-others --no-eval` (this workload only), committed")

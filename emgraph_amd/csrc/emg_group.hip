@@ -137,9 +137,16 @@ int factor_view(void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, 
 
 __global__ __launch_bounds__(256) void group_hist_kernel(const GroupLaunch G) { group_hist_body(G, blockIdx.x); }
 __global__ __launch_bounds__(256) void group_scan_kernel(const GroupLaunch G) { group_scan_body(G, blockIdx.x); }
-__global__ __launch_bounds__(256) void group_scatter_kernel(const GroupLaunch G) { group_scatter_body(G, blockIdx.x); }
-__global__ __launch_bounds__(256) void group_order_kernel(const GroupLaunch G) { group_order_body(G, blockIdx.x); }
-__global__ __launch_bounds__(256) void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) { prepare_ids_body(P, G, blockIdx.x); }
+// EMG_PREP_VGPRS (A/B aid): a register cap for the per-contribution stages — the scoring kernel of C3 allocates 160 of a SIMD's 512
+// registers per wave, three waves leave 32: a preparation wave that fits there would not keep a scoring wave out
+#ifdef EMG_PREP_VGPRS
+#define EMG_PREP_CAP __attribute__((amdgpu_num_vgpr(EMG_PREP_VGPRS)))
+#else
+#define EMG_PREP_CAP
+#endif
+__global__ __launch_bounds__(256) EMG_PREP_CAP void group_scatter_kernel(const GroupLaunch G) { group_scatter_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) EMG_PREP_CAP void group_order_kernel(const GroupLaunch G) { group_order_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) EMG_PREP_CAP void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) { prepare_ids_body(P, G, blockIdx.x); }
 
 // SORT backend epilogue: flags[original index] = 1 iff its destination occurs exactly once; factored source rows
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
@@ -193,8 +200,8 @@ static int counting_tail(GroupLaunch& G, int64_t cap_n0, int64_t cap_n1, hipStre
     hipLaunchKernelGGL(group_scan_kernel, dim3(scan_blocks), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     // (+1: the order kernel also resets arrive[0 .. n / 64], and thread 0 / 1 the window path's task counters)
-    G.split_n = (unsigned)cdiv(cap_n0 + 1, kPrepBlock);
-    const unsigned nb = G.split_n + (G.n_tables > 1 ? (unsigned)cdiv(cap_n1 + 1, kPrepBlock) : 0u);
+    G.split_n = (unsigned)cdiv(cap_n0 + 1, kPrepBlock2);
+    const unsigned nb = G.split_n + (G.n_tables > 1 ? (unsigned)cdiv(cap_n1 + 1, kPrepBlock2) : 0u);
     hipLaunchKernelGGL(group_scatter_kernel, dim3(nb), dim3(256), 0, st, G);
     EMG_LAUNCH_CHECK();
     hipLaunchKernelGGL(group_order_kernel, dim3(nb), dim3(256), 0, st, G);
@@ -348,8 +355,8 @@ int prepare_stages(const emg_prepare_args* a, PrepStages* o) {
     if (o->both) {   // launch geometry of scan / scatter / order (as counting_tail)
         G.split_scan = (unsigned)G.t[0].scan_blocks;
         o->nb_scan = G.split_scan + (unsigned)G.t[1].scan_blocks;
-        G.split_n = (unsigned)cdiv(o->cap_ce + 1, kPrepBlock);
-        o->nb_n = G.split_n + (unsigned)cdiv(o->cap_cr + 1, kPrepBlock);
+        G.split_n = (unsigned)cdiv(o->cap_ce + 1, kPrepBlock2);
+        o->nb_n = G.split_n + (unsigned)cdiv(o->cap_cr + 1, kPrepBlock2);
     }
     return EMG_OK;
 }

@@ -52,7 +52,14 @@ constexpr int kScanTile = 4096;                  // rows per scan workgroup (256
 #define EMG_PREP_ITEMS 4
 #endif
 constexpr int kPrepItems = EMG_PREP_ITEMS;
-constexpr int kPrepBlock = 256 * kPrepItems;     // contributions per workgroup of those stages
+constexpr int kPrepBlock = 256 * kPrepItems;     // contributions per workgroup of the id / histogram stages
+// scatter and order: as many as still leave the kernel within 32 registers — the scoring kernel of a large batch allocates 160 of a
+// SIMD's 512 per wave, three waves leave 32, and a preparation wave that fits THERE keeps no scoring wave out
+#ifndef EMG_PREP_ITEMS2
+#define EMG_PREP_ITEMS2 EMG_PREP_ITEMS
+#endif
+constexpr int kPrepItems2 = EMG_PREP_ITEMS2;
+constexpr int kPrepBlock2 = 256 * kPrepItems2;   // contributions per workgroup of the scatter / order stages
 
 bool group_backend_counting(int64_t N, int64_t R);
 int64_t group_ws_bytes(int64_t N, int64_t R, int64_t ldp);

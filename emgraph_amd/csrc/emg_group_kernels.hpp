@@ -184,34 +184,34 @@ __device__ __forceinline__ void group_scan_body(const GroupLaunch& G, unsigned b
 __device__ __forceinline__ void group_scatter_body(const GroupLaunch& G, unsigned bx) {
     const int ti = bx < G.split_n ? 0 : 1;
     const TableGroup& T = G.t[ti];
-    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock + threadIdx.x;
+    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock2 + threadIdx.x;
     const int64_t n = table_n(G, ti);
     if (base >= n) return;
-    int32_t d[kPrepItems];
-    bool ok[kPrepItems], single[kPrepItems];
-    uint32_t start[kPrepItems], next[kPrepItems], pos[kPrepItems], key[kPrepItems];
+    int32_t d[kPrepItems2];
+    bool ok[kPrepItems2], single[kPrepItems2];
+    uint32_t start[kPrepItems2], next[kPrepItems2], pos[kPrepItems2], key[kPrepItems2];
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 1: the ids (an index past the end: the last one again, nothing stored for it)
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 1: the ids (an index past the end: the last one again, nothing stored for it)
         const int64_t i = base + q * 256;
         d[q] = T.dest[i < n ? i : n - 1];
         key[q] = T.order_key ? T.order_key[i < n ? i : n - 1] : (uint32_t)i;
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 2: their segments
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 2: their segments
         ok[q] = base + q * 256 < n && d[q] >= 0 && (int64_t)d[q] < T.R;
         const int32_t dd = ok[q] ? d[q] : 0;
         start[q] = T.off[dd];
         next[q] = T.off[dd + 1];
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 3: a contribution takes the next free position of its destination's segment
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 3: a contribution takes the next free position of its destination's segment
         single[q] = ok[q] && next[q] - start[q] == 1u;
         // (a destination hit once — most of them, for uniform negatives on a large table — needs no cursor)
         pos[q] = start[q];
         if (ok[q] && !single[q]) pos[q] = (uint32_t)atomicAdd(T.cnt + d[q], 1);
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {
+    for (int q = 0; q < kPrepItems2; ++q) {
         const int64_t i = base + q * 256;
         if (ok[q]) {
             T.tmpv[pos[q]] = key[q];
@@ -229,20 +229,20 @@ __device__ __forceinline__ void group_scatter_body(const GroupLaunch& G, unsigne
 __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned bx) {
     const int ti = bx < G.split_n ? 0 : 1;
     const TableGroup& T = G.t[ti];
-    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock + threadIdx.x;
+    const int64_t base = (int64_t)(bx - (ti ? G.split_n : 0u)) * kPrepBlock2 + threadIdx.x;
     const int64_t n = table_n(G, ti);
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {
+    for (int q = 0; q < kPrepItems2; ++q) {
         const int64_t t = base + q * 256;
         if (t < 2) T.counters[GC_LONG_COUNT + t] = 0u;          // window-path task list (apply_rows_kernel) starts empty
         if (t <= n / kLongSegment) T.arrive[t] = 0;             // per-segment block counters of the long-segment reduction
     }
     const int64_t total = (int64_t)T.off[T.R];
     if (base >= total) return;
-    uint32_t d[kPrepItems], mine[kPrepItems], start[kPrepItems], len[kPrepItems], rank[kPrepItems];
-    bool on[kPrepItems];
+    uint32_t d[kPrepItems2], mine[kPrepItems2], start[kPrepItems2], len[kPrepItems2], rank[kPrepItems2];
+    bool on[kPrepItems2];
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 1 (a position past the end: the last one again, nothing stored for it)
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 1 (a position past the end: the last one again, nothing stored for it)
         const int64_t t = base + q * 256;
         on[q] = t < total;
         const int64_t tt = on[q] ? t : total - 1;
@@ -250,12 +250,12 @@ __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned 
         mine[q] = T.tmpv[tt];
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 2
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 2
         start[q] = T.off[d[q]];
         len[q] = T.off[d[q] + 1] - start[q];
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 3: the rank among the segment's slots (a singleton: nothing to read)
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 3: the rank among the segment's slots (a singleton: nothing to read)
         // A hub row's segment is thousands of slots and every one of its threads walks all of them: 16-byte loads, sixteen
         // values per trip (the scalar loop took 130 us alone / 510 us beside the scoring kernel on the Zipf batch, most of
         // the preparation; short segments never leave the head / tail loops)
@@ -281,14 +281,14 @@ __device__ __forceinline__ void group_order_body(const GroupLaunch& G, unsigned 
         rank[q] = r;
     }
     const uint32_t fac_B = (uint32_t)(G.ctl ? G.ctl->B : G.B);
-    int32_t fcode[kPrepItems];
+    int32_t fcode[kPrepItems2];
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {   // phase 4 (factored contributions): the codes of the negatives' slots
+    for (int q = 0; q < kPrepItems2; ++q) {   // phase 4 (factored contributions): the codes of the negatives' slots
         fcode[q] = 0;
         if (T.fac_codes && on[q] && mine[q] >= 2u * fac_B) fcode[q] = T.fac_codes[mine[q] - 2u * fac_B];
     }
 #pragma unroll
-    for (int q = 0; q < kPrepItems; ++q) {
+    for (int q = 0; q < kPrepItems2; ++q) {
         if (!on[q]) continue;
         const int64_t t = base + q * 256;
         const uint32_t at = start[q] + rank[q];

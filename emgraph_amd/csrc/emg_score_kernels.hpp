@@ -322,6 +322,11 @@ __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row
     if (P.tag_ent && lg == 0) P.tag_ent[row] = P.step;
 }
 
+// EMG_OPT_GROUP: elements whose update chains (mul -> v_sqrt -> add -> v_rcp -> mul -> sub) the scheduler may interleave in the window
+// forms — one at a time leaves every transcendental's wait states as s_nop (56 of the ~600 instructions per negative of form 6)
+#ifndef EMG_OPT_GROUP
+#define EMG_OPT_GROUP 1
+#endif
 // The same update with the state rows ALREADY IN REGISTERS (IP 4 / 5 / 6: they arrived with the table row): nothing is waited for.
 template <int MODEL, int W, int NV, int LPG, int NS>
 __device__ __forceinline__ void inplace_update_regs(const GroupParams& P, const OptParams& opt, int64_t row, const Row<MODEL, W, NV>& cur,
@@ -343,7 +348,7 @@ __device__ __forceinline__ void inplace_update_regs(const GroupParams& P, const 
                 const int e = h * E + it * W + w;
                 wv[w] = cur.x[e];
                 opt_update_elem(opt, wv[w], grad.x[e], &s0.x[e], NS == 2 ? &s1.x[e] : nullptr);
-                __builtin_amdgcn_sched_barrier(0);   // (one sqrt / divide expansion at a time: see inplace_update)
+                if (w % EMG_OPT_GROUP == EMG_OPT_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // (EMG_OPT_GROUP sqrt / reciprocal chains at a time: see inplace_update)
             }
             if (c < P.nchunks) {
                 const int off = h * P.khalf + c * W;
@@ -375,7 +380,7 @@ __device__ __forceinline__ void replay_in_window(const GroupParams& P, const Opt
             float wv = w.x[e];
             adam_zero_grad_elem(opt, wv, m.x[e], v.x[e]);   // (the dense pass's update of a row with no gradient: the same values)
             w.x[e] = on ? wv : w.x[e];
-            __builtin_amdgcn_sched_barrier(0);
+            if (e % EMG_OPT_GROUP == EMG_OPT_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // the first 64 steps: learning rates from the lane register — NO memory operation in this loop (a load here, even one never
@@ -938,10 +943,10 @@ static __device__ unsigned long long emg_trace_fused_buf[4 * 65536];
 #ifndef EMG_IP6_MINWAVES
 #define EMG_IP6_MINWAVES 3   // window forms: three waves per SIMD (form 6, ComplEx k = 200: 168 VGPRs + 64 bytes of scratch; left alone 186 VGPRs, two waves:
 #endif                       // C3 + Adam 0.86 against 0.93 ms per step)
-// UW: replacement rows in flight per wave.  EMG_BW_U where the launch fills the chip several times over; a SMALL batch (fewer waves
-// than the SIMDs can hold at once: the reference's own configurations, 1.7 - 4.7 waves per SIMD) has registers to spare and a
-// kernel time that is one wave's chain of dependent round trips — a deeper window (EMG_BW_U_DEEP) shortens the chain.  Same bits:
-// the negatives are consumed in the same order.
+// UW: replacement rows in flight per wave (EMG_BW_U).  A/B aid (EMG_DEEP_B): a SMALL batch (fewer waves than the SIMDs can hold at
+// once: the reference's own configurations, 1.7 - 4.7 waves per SIMD) has registers to spare, and a deeper window (EMG_BW_U_DEEP)
+// was expected to shorten a wave's chain of round trips.  Measured: C1 / C2 +-0, C5 slower — those kernels are one wave's
+// instruction stream, not its row loads.  Same bits: the negatives are consumed in the same order.
 #ifndef EMG_BW_U_DEEP
 #define EMG_BW_U_DEEP 10
 #endif
