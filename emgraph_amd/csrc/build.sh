@@ -6,7 +6,7 @@ OUT="${HERE}/../lib"
 OBJ="${HERE}/_obj"
 mkdir -p "${OUT}" "${OBJ}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function -Wno-array-bounds)
 pids=()
 for f in emg_abi emg_score emg_fused_m0 emg_fused_m1 emg_fused_m2 emg_fused_m3 emg_fused_m4 emg_train emg_group emg_apply emg_rank emg_rank_bf16 emg_rank_sad emg_api emg_plan; do
   src="${HERE}/${f}.hip"; obj="${OBJ}/${f}.o"

@@ -1322,8 +1322,11 @@ __device__ unsigned long long emg_trace_buf[4 * 65536];
 #define EMG_STAMP(slot) do { } while (0)
 #endif
 
+#ifndef EMG_SEG_MINWAVES
+#define EMG_SEG_MINWAVES 1   // A/B aid: waves per SIMD the stateful instantiations are compiled for (a register cap)
+#endif
 template <bool PLAIN, bool RIDE, bool HALF = false>   // HALF: rows of 17..32 chunks, two items per wave (segment_update_half)
-__global__ __launch_bounds__(256) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
+__global__ __launch_bounds__(256, (PLAIN ? 1 : EMG_SEG_MINWAVES)) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
     // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
     unsigned bx = blockIdx.x, nbx = gridDim.x;
     if constexpr (RIDE) {
