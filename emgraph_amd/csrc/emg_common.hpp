@@ -165,7 +165,22 @@ __device__ __forceinline__ float group_sum(float v) {
 #endif
 }
 
-__device__ __forceinline__ float sgnf(float d) { return (float)(d > 0.f) - (float)(d < 0.f); }
+// sign(d) in {-1, 0, +1} (-0 for d = -0).  Two compares, two selects and a subtraction — with their wait states eight issues per
+// element, a third of TransE-L1's instructions per negative — or: d 2^100 2^100 saturates every nonzero d (denormals included)
+// far beyond +-1, and the median of (that, -1, 1) clamps it: three instructions, the multiplications packed two elements each.
+// (A NaN gives -1 / +1 / NaN instead of 0: a diverged model either way.)
+#ifndef EMG_SGN_MED3
+#define EMG_SGN_MED3 1
+#endif
+__device__ __forceinline__ float sgnf(float d) {
+#if EMG_SGN_MED3
+#pragma clang fp contract(off)
+    const float h = 0x1p+100f;
+    return __builtin_amdgcn_fmed3f((d * h) * h, -1.f, 1.f);
+#else
+    return (float)(d > 0.f) - (float)(d < 0.f);
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // Optimizer element update (Keras / TF-2.2 rules; training/{sgd,momentum,adagrad,adam}.py).

@@ -1,6 +1,9 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python -c "
-import __graft_entry__ as g
-g.smoke(); print('smoke ok')" 2>&1 | tail -2
 source tools/ab_env.sh
-for w in C3 C1 C2 C5; do run "$w" --workload $w; done
+V=emgraph_amd/lib/variants
+for i in 1 2; do
+for w in C1 C3p; do
+run "$w main" --workload $w
+EMGRAPH_HIP_LIB=$V/libemgraph_hip_sgnold.so run "$w sgnold" --workload $w
+done
+done
+python -m pytest tests/test_graph_step.py tests/test_config_widths.py tests/test_api.py tests/test_hip_kernels.py tests/test_full_size.py -x -q -m gpu 2>&1 | tail -3
