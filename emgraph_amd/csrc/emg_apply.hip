@@ -1169,13 +1169,25 @@ __device__ __forceinline__ void long_segment_serial(const ApplyParams& P, const 
     if (P.tag && lane == 0) P.tag[key] = step;
 }
 
+#ifdef EMG_TRACE   // timing aid (tools/trace_waves.py): wall-clock stamps (10 ns) of every wave of the last launch
+__device__ unsigned long long emg_trace_buf[4 * 65536];
+#define EMG_STAMP(slot) do { if (lane == 0 && gw < 65536) emg_trace_buf[4 * gw + (slot)] = wall_clock64(); } while (0)
+#else
+#define EMG_STAMP(slot) do { } while (0)
+#endif
+
 // heavy / relief: the last `heavy` waves of the grid take `relief` items fewer each (they carry the other table's long
 // segments, see apply_segments_kernel); the others share what that leaves
-template <bool PLAIN, bool HALF>
+// FIX: the optimizer known at compile time for the stateful instantiations (0: run-time switch; EMG_OPT_ADAM / EMG_OPT_ADAGRAD: that
+// rule, no regulariser).  The run-time form walks opt_update_elem's four branches and lp_fold's test for EVERY element — scalar
+// compares and branches that a wave issues in line with its vector work: per-wave stamps put an item of C1 / C2 at 4 - 5 us where
+// its round trips are 0.3 us each (TCP->TCC latency counters), i.e. at the SIMD's instruction issue.
+template <bool PLAIN, bool HALF, int FIX = 0>
 __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
                                                      int64_t nw, int lane, int64_t heavy = 0, int64_t relief = 0) {
     OptParams opt = P.opt;
     if constexpr (PLAIN) { opt.opt = EMG_OPT_SGD; opt.lp_lambda = 0.f; }   // (known at compile time: the update folds to w - lr g)
+    if constexpr (FIX != 0) { opt.opt = FIX; opt.lp_lambda = 0.f; }
     int32_t step = P.step;
     if (P.ctl) {   // the step's number and learning rates from the device record (a captured graph cannot bake them)
         const float* h = P.which ? P.ctl->hyper_rel : P.ctl->hyper_ent;
@@ -1254,6 +1266,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
         }
         }
     }
+    if (P.which == 0) EMG_STAMP(3);   // (trace builds: the entity table's items done, its untouched rows next)
     if constexpr (!PLAIN) if (P.dense_here) {   // the rows nothing touched: 64 rows' counts in one load, then a wave per untouched row
         ApplyParams Q = P;
         Q.opt = opt;
@@ -1315,17 +1328,11 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
 
 struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; int32_t relief; };
 
-#ifdef EMG_TRACE   // timing aid (tools/trace_waves.py): wall-clock stamps (10 ns) of every wave of the last launch
-__device__ unsigned long long emg_trace_buf[4 * 65536];
-#define EMG_STAMP(slot) do { if (lane == 0 && gw < 65536) emg_trace_buf[4 * gw + (slot)] = wall_clock64(); } while (0)
-#else
-#define EMG_STAMP(slot) do { } while (0)
-#endif
 
 #ifndef EMG_SEG_MINWAVES
 #define EMG_SEG_MINWAVES 1   // A/B aid: waves per SIMD the stateful instantiations are compiled for (a register cap)
 #endif
-template <bool PLAIN, bool RIDE, bool HALF = false>   // HALF: rows of 17..32 chunks, two items per wave (segment_update_half)
+template <bool PLAIN, bool RIDE, bool HALF = false, int FIX = 0>   // HALF: rows of 17..32 chunks, two items per wave (segment_update_half)
 __global__ __launch_bounds__(256, (PLAIN ? 1 : EMG_SEG_MINWAVES)) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
     // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
     unsigned bx = blockIdx.x, nbx = gridDim.x;
@@ -1353,10 +1360,10 @@ __global__ __launch_bounds__(256, (PLAIN ? 1 : EMG_SEG_MINWAVES)) void apply_seg
             heavy = items; relief = trips;
         }
     }
-    apply_segments_table<PLAIN, HALF>(K.P[0], K.partial[0], K.ldp[0], gw, nw, lane, heavy, relief);
+    apply_segments_table<PLAIN, HALF, FIX>(K.P[0], K.partial[0], K.ldp[0], gw, nw, lane, heavy, relief);
     EMG_STAMP(1);
     if (K.n_tables == 2) {
-        apply_segments_table<PLAIN, HALF>(K.P[1], K.partial[1], K.ldp[1], nw - 1 - gw, nw, lane);
+        apply_segments_table<PLAIN, HALF, FIX>(K.P[1], K.partial[1], K.ldp[1], nw - 1 - gw, nw, lane);
         EMG_STAMP(2);
     }
 }
@@ -1481,23 +1488,38 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
 // tools/trace_waves.py, C3: 5120 of 8192 waves start at 0 and live 38 us, the other 3072 start at 34-41 us: 78 us for
 // 1.6 rounds of work) — so never launch more than fit.
 typedef void (*SegmentsKernel)(const SegmentsLaunch, const Riders);
-static SegmentsKernel segments_kernel(bool plain, bool ride, bool half) {
+// fix: 0 run-time optimizer switch, 1 Adam without regulariser, 2 Adagrad without regulariser (compile-time forms of the stateful kernel)
+static SegmentsKernel segments_kernel(bool plain, bool ride, bool half, int fix = 0) {
     static const SegmentsKernel fns[8] = {
         apply_segments_kernel<false, false, false>, apply_segments_kernel<false, false, true>,
         apply_segments_kernel<false, true, false>,  apply_segments_kernel<false, true, true>,
         apply_segments_kernel<true, false, false>,  apply_segments_kernel<true, false, true>,
         apply_segments_kernel<true, true, false>,   apply_segments_kernel<true, true, true>};
+    static const SegmentsKernel adam[4] = {
+        apply_segments_kernel<false, false, false, EMG_OPT_ADAM>, apply_segments_kernel<false, false, true, EMG_OPT_ADAM>,
+        apply_segments_kernel<false, true, false, EMG_OPT_ADAM>,  apply_segments_kernel<false, true, true, EMG_OPT_ADAM>};
+    static const SegmentsKernel adagrad[4] = {
+        apply_segments_kernel<false, false, false, EMG_OPT_ADAGRAD>, apply_segments_kernel<false, false, true, EMG_OPT_ADAGRAD>,
+        apply_segments_kernel<false, true, false, EMG_OPT_ADAGRAD>,  apply_segments_kernel<false, true, true, EMG_OPT_ADAGRAD>};
+    if (!plain && fix == 1) return adam[(ride ? 2 : 0) + (half ? 1 : 0)];
+    if (!plain && fix == 2) return adagrad[(ride ? 2 : 0) + (half ? 1 : 0)];
     return fns[(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)];
 }
 static bool segments_half(const ApplyParams& P) { return P.half_rows && P.k_int / 4 <= 32; }
-static unsigned segments_capacity(bool plain, bool ride, bool half) {
-    static std::atomic<unsigned> cached[8][64];
+// which compile-time optimizer form serves this table (EMG_APPLY_FIX = 0: the run-time switch everywhere — A/B aid)
+static int segments_fix(const ApplyParams& P) {
+    static const bool off = getenv("EMG_APPLY_FIX") && atoi(getenv("EMG_APPLY_FIX")) == 0;
+    if (off || P.opt.lp_lambda != 0.f) return 0;
+    return P.opt.opt == EMG_OPT_ADAM ? 1 : (P.opt.opt == EMG_OPT_ADAGRAD ? 2 : 0);
+}
+static unsigned segments_capacity(bool plain, bool ride, bool half, int fix) {
+    static std::atomic<unsigned> cached[3][8][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024u;
-    std::atomic<unsigned>& c = cached[(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)][dev & 63];
+    std::atomic<unsigned>& c = cached[plain ? 0 : fix][(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)][dev & 63];
     unsigned v = c.load(std::memory_order_relaxed);
     if (v) return v;
-    const void* fn = (const void*)segments_kernel(plain, ride, half);
+    const void* fn = (const void*)segments_kernel(plain, ride, half, fix);
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -1505,9 +1527,9 @@ static unsigned segments_capacity(bool plain, bool ride, bool half) {
     c.store(v, std::memory_order_relaxed);
     return v;
 }
-static unsigned segments_grid(unsigned wanted, bool plain, bool ride, bool half) {
+static unsigned segments_grid(unsigned wanted, bool plain, bool ride, bool half, int fix) {
     static const bool fixed = getenv("EMG_SEG_BLOCKS") != nullptr;   // A/B aid: the grid as given
-    const unsigned cap = segments_capacity(plain, ride, half);
+    const unsigned cap = segments_capacity(plain, ride, half, fix);
     return fixed || wanted <= cap ? wanted : cap;
 }
 
@@ -1528,8 +1550,9 @@ static int apply_launch(const ApplyParams& P0, const ApplyLaunch& A0, hipStream_
         K.P[0] = P; K.partial[0] = A.partial; K.ldp[0] = A.ldp; K.n_tables = 1;
         static const Riders none{};
         const bool half = segments_half(P);
-        const unsigned g1 = segments_grid(A.grid, plain_sgd(P), false, half);
-        hipLaunchKernelGGL(segments_kernel(plain_sgd(P), false, half), dim3(g1), dim3(256), 0, st, K, none);
+        const int fix = segments_fix(P);
+        const unsigned g1 = segments_grid(A.grid, plain_sgd(P), false, half, fix);
+        hipLaunchKernelGGL(segments_kernel(plain_sgd(P), false, half, fix), dim3(g1), dim3(256), 0, st, K, none);
         EMG_LAUNCH_CHECK();
     } else if (A.any) {
         const dim3 grid(A.grid), block(256);
@@ -1603,13 +1626,14 @@ int emg::apply_pair_impl(const emg_apply_args* a, const emg_apply_args* b, const
         K.relief = no_relief ? 0 : 1;
         const bool plain = plain_sgd(P0) && plain_sgd(P1);
         const bool half = segments_half(P0) && segments_half(P1);   // (one width for both tables)
+        const int fix = segments_fix(P0) == segments_fix(P1) ? segments_fix(P0) : 0;   // (one optimizer form for both tables)
         if (riders && riders->total) {
-            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true, half) + riders->total);
-            hipLaunchKernelGGL(segments_kernel(plain, true, half), grid, dim3(256), 0, st, K, *riders);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, true, half, fix) + riders->total);
+            hipLaunchKernelGGL(segments_kernel(plain, true, half, fix), grid, dim3(256), 0, st, K, *riders);
         } else {
             static const Riders none{};
-            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, false, half));
-            hipLaunchKernelGGL(segments_kernel(plain, false, half), grid, dim3(256), 0, st, K, none);
+            const dim3 grid(segments_grid(A0.grid > A1.grid ? A0.grid : A1.grid, plain, false, half, fix));
+            hipLaunchKernelGGL(segments_kernel(plain, false, half, fix), grid, dim3(256), 0, st, K, none);
         }
         EMG_LAUNCH_CHECK();
     } else {

@@ -1,9 +1,8 @@
 source tools/ab_env.sh
-V=emgraph_amd/lib/variants
-for i in 1 2; do
-for w in C1 C3p; do
-run "$w main" --workload $w
-EMGRAPH_HIP_LIB=$V/libemgraph_hip_sgnold.so run "$w sgnold" --workload $w
+for w in C1 C2 C5 C3a C3g; do
+run "$w fix" --workload $w
+EMG_APPLY_FIX=0 run "$w nofix" --workload $w
+run "$w fix" --workload $w
+EMG_APPLY_FIX=0 run "$w nofix" --workload $w
 done
-done
-python -m pytest tests/test_graph_step.py tests/test_config_widths.py tests/test_api.py tests/test_hip_kernels.py tests/test_full_size.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests/test_graph_step.py tests/test_config_widths.py tests/test_api.py tests/test_hip_kernels.py -x -q -m gpu 2>&1 | tail -3
