@@ -1,2 +1,1 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-bash tools/profile_round4.sh r4_z
+python -m pytest tests/test_library_switches.py -x -q -m gpu 2>&1 | tail -5
