@@ -60,6 +60,27 @@ def gen_scores():
     return out
 
 
+def gen_scores_transe_p():
+    """TransE._fn with orders of the norm other than 1 / 2 (TransE.py:208-216 hands `norm` to tf.norm as `ord`): the path
+    the product serves through its generic kernels (EMG_TRANSE_P), training included since round 4"""
+    out = {}
+    cases = []
+    for k in (3, 10, 100, 200):
+        for n in (1, 7):
+            for p in (3.0, 1.5, 4.0, float("inf")):
+                cases.append((k, n, p))
+    out["cases"] = np.array(cases, dtype=np.float64)
+    for ci, (k, n, p) in enumerate(cases):
+        rs = np.random.RandomState(7000 + ci)
+        scale = 1.0 if k <= 10 else 0.1
+        es, ep, eo = [(rs.randn(n, k) * scale).astype(F32) for _ in range(3)]
+        m = TransE(k=k, embedding_model_params={"norm": p})
+        y = np.asarray(m._fn(es, ep, eo), dtype=F32)
+        tag = "c%d" % ci
+        out[tag + "_es"], out[tag + "_ep"], out[tag + "_eo"], out[tag + "_y"] = es, ep, eo, y
+    return out
+
+
 def gen_losses():
     out = {}
     cases = []
@@ -388,8 +409,8 @@ def gen_model_selection():
 
 def main():
     gen_model_selection()
-    for name, fn in (("scores", gen_scores), ("losses", gen_losses), ("corruptions", gen_corruptions),
-                     ("misc", gen_misc), ("ranks", gen_ranks), ("checkpoints", gen_checkpoints)):
+    for name, fn in (("scores", gen_scores), ("scores_transe_p", gen_scores_transe_p), ("losses", gen_losses),
+                     ("corruptions", gen_corruptions), ("misc", gen_misc), ("ranks", gen_ranks), ("checkpoints", gen_checkpoints)):
         data = fn()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)

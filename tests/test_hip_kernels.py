@@ -91,6 +91,23 @@ def test_score_triples_golden_fixtures(model, golden):
         assert np.all(np.abs(got - g[tag + "_y"]) <= tol), (tag, np.abs(got - g[tag + "_y"]).max())
 
 
+def test_score_triples_transe_any_norm_golden_fixtures(golden):
+    """the reference-executed TransE._fn with norm = 3, 1.5, 4, inf (tests/golden/scores_transe_p.npz) through the generic
+    kernels (EMG_TRANSE_P, the order of the norm in `scale`): 1e-4 relative to the score, the bar of north_star"""
+    from emgraph_amd import _lib as L
+    d = dev()
+    g = golden("scores_transe_p")
+    for ci, (k, n, p) in enumerate(g["cases"]):
+        tag = "c%d" % ci
+        es, ep, eo = g[tag + "_es"], g[tag + "_ep"], g[tag + "_eo"]
+        n = es.shape[0]
+        E = np.concatenate([es, eo], 0)
+        x = np.stack([np.arange(n), np.arange(n), n + np.arange(n)], 1).astype(np.int32)
+        got = d.score_triples(L.TRANSE_P, cu(E), cu(ep), es.shape[1], float(p), cu(x)).cpu().numpy()
+        want = g[tag + "_y"]
+        assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want) + 1e-7), (tag, float(p), np.abs(got - want).max())
+
+
 def test_score_triples_strided_and_odd_layouts():
     """row stride > k_int, unaligned (odd) strides -> scalar path; huge k -> generic fallback"""
     d = dev()

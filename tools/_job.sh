@@ -1,1 +1,1 @@
-python -m pytest tests/test_library_switches.py -x -q -m gpu 2>&1 | tail -5
+python -m pytest tests/test_hip_kernels.py -x -q -m gpu -k "any_norm" 2>&1 | tail -30
