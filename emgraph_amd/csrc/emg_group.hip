@@ -137,16 +137,9 @@ int factor_view(void* workspace, int64_t workspace_bytes, int64_t N, int64_t R, 
 
 __global__ __launch_bounds__(256) void group_hist_kernel(const GroupLaunch G) { group_hist_body(G, blockIdx.x); }
 __global__ __launch_bounds__(256) void group_scan_kernel(const GroupLaunch G) { group_scan_body(G, blockIdx.x); }
-// EMG_PREP_VGPRS (A/B aid): a register cap for the per-contribution stages — the scoring kernel of C3 allocates 160 of a SIMD's 512
-// registers per wave, three waves leave 32: a preparation wave that fits there would not keep a scoring wave out
-#ifdef EMG_PREP_VGPRS
-#define EMG_PREP_CAP __attribute__((amdgpu_num_vgpr(EMG_PREP_VGPRS)))
-#else
-#define EMG_PREP_CAP
-#endif
-__global__ __launch_bounds__(256) EMG_PREP_CAP void group_scatter_kernel(const GroupLaunch G) { group_scatter_body(G, blockIdx.x); }
-__global__ __launch_bounds__(256) EMG_PREP_CAP void group_order_kernel(const GroupLaunch G) { group_order_body(G, blockIdx.x); }
-__global__ __launch_bounds__(256) EMG_PREP_CAP void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) { prepare_ids_body(P, G, blockIdx.x); }
+__global__ __launch_bounds__(256) void group_scatter_kernel(const GroupLaunch G) { group_scatter_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void group_order_kernel(const GroupLaunch G) { group_order_body(G, blockIdx.x); }
+__global__ __launch_bounds__(256) void prepare_ids_kernel(const PrepParams P, const GroupLaunch G) { prepare_ids_body(P, G, blockIdx.x); }
 
 // SORT backend epilogue: flags[original index] = 1 iff its destination occurs exactly once; factored source rows
 __global__ void mark_single_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,

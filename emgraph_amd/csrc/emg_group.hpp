@@ -45,16 +45,17 @@ struct GroupWs {
 constexpr int kScanTile = 4096;                  // rows per scan workgroup (256 threads x 16)
 // Contributions per THREAD of the per-contribution stages (ids + histogram, scatter, order), taken 256 apart so that every load
 // of a wave stays coalesced, each stage written in phases (all loads of a phase issued before anything waits).  These kernels
-// stream beside the scoring kernel, which holds its SIMDs' register files: a preparation wave gets a slot only when a scoring
-// wave leaves and keeps a scoring wave out for as long as it lives — a chain of dependent round trips per contribution (id ->
-// offsets -> cursor -> store).  Four chains per thread: a quarter of the waves, each living little longer.
+// stream beside the scoring kernel; a contribution is a chain of dependent round trips (id -> offsets -> cursor -> store) and a
+// wave is alive for as long as its chain.  Four chains per thread: a quarter of the waves, each living little longer — measured,
+// C3: step 0.3633 -> 0.3555 ms (scoring kernel 0.280 -> 0.274 with the preparation beside it); eight: 0.3551, but the small
+// batches' riders then are their launch's long pole (C1 0.062 -> 0.071).  (Not a matter of registers: the scoring kernel of C3
+// holds 2 x 200 of a SIMD's 512, a preparation wave of <= 56 fits beside it in either form.)
 #ifndef EMG_PREP_ITEMS
 #define EMG_PREP_ITEMS 4
 #endif
 constexpr int kPrepItems = EMG_PREP_ITEMS;
 constexpr int kPrepBlock = 256 * kPrepItems;     // contributions per workgroup of the id / histogram stages
-// scatter and order: as many as still leave the kernel within 32 registers — the scoring kernel of a large batch allocates 160 of a
-// SIMD's 512 per wave, three waves leave 32, and a preparation wave that fits THERE keeps no scoring wave out
+// scatter and order can take a count of their own (A/B aid; default: the same)
 #ifndef EMG_PREP_ITEMS2
 #define EMG_PREP_ITEMS2 EMG_PREP_ITEMS
 #endif
