@@ -1,1 +1,6 @@
-python -m pytest tests/test_hip_kernels.py -x -q -m gpu -k "any_norm" 2>&1 | tail -30
+source tools/ab_env.sh
+V=emgraph_amd/lib/variants
+for i in 1 2 3; do
+run "C3a main" --workload C3a
+EMGRAPH_HIP_LIB=$V/libemgraph_hip_fastloss.so run "C3a fastloss" --workload C3a
+done
