@@ -1,6 +1,3 @@
-source tools/ab_env.sh
-V=emgraph_amd/lib/variants
-for i in 1 2 3; do
-run "C3a main" --workload C3a
-EMGRAPH_HIP_LIB=$V/libemgraph_hip_fastloss.so run "C3a fastloss" --workload C3a
-done
+# scratch job script for `gpurun -- 'bash tools/_job.sh'` (the round's last content: the full GPU suite + the evidence run)
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+bash tools/profile_round4.sh r4_z
