@@ -659,6 +659,106 @@ def cpu_baseline(r, args):
     return out
 
 
+SUMMARY_MAX_BYTES = 4096
+DETAIL_FILE = "bench_detail.json"
+
+
+def _finite(x):
+    """strict JSON has no NaN / Infinity: non-finite floats become null (recursively)"""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return _finite(x.item())
+    if isinstance(x, np.bool_):
+        return bool(x)
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def summary_line(line, detail_file=DETAIL_FILE):
+    """The ONE stdout line of the contract, <= SUMMARY_MAX_BYTES of strict JSON, built from the full result `line` (which goes to
+    `detail_file`): the contract's keys, the dominant kernel's roofline, the default-optimizer block, ranks/s of the three
+    evaluation modes, ms/step of the secondary workloads and the CPU baseline — numbers only, no prose."""
+    s = _pick(line, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data")
+    cfg = line.get("config", {})
+    s["config"] = dict(_pick(cfg, "B_per_gpu", "global_batch", "eta", "k_int", "k_int_per_gpu", "n_ent", "n_rel"),
+                       workload=str(cfg.get("workload", ""))[:120], parallelism=str(cfg.get("parallelism", ""))[:80])
+    if "sustained" in line:
+        s["sustained"] = _pick(line["sustained"], "value", "ms_per_step", "steps")
+    st = line.get("stages", {})
+    s["stages_ms"] = {k: v["ms"] for k, v in st.items() if isinstance(v, dict) and "ms" in v}
+    rf = line.get("roofline")
+    if rf:
+        r = _pick(rf, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms")
+        r["traffic_source"] = (rf.get("traffic_source") or None) and str(rf["traffic_source"])[:72]
+        if "profiled" in rf:
+            r["profiled"] = _pick(rf["profiled"], "file", "avg_us", "frac")
+        if "mix_ceiling" in rf:
+            r["mix_ceiling_ms"] = rf["mix_ceiling"].get("ms")
+        s["roofline"] = r
+    do = line.get("default_optimizer")
+    if do:
+        s["default_optimizer"] = dict(_pick(do, "value", "ms_per_step", "steps", "stages_ms"), workload="C3a: C3 with Keras Adam (the reference's default)",
+                                      roofline=_pick(do.get("roofline", {}), "kernel", "frac", "achieved", "alg_bytes_per_launch", "avg_launch_ms"))
+    if "others" in line:
+        s["others_ms_per_step"] = {k: v.get("ms_per_step") for k, v in line["others"].items()}
+    ev = line.get("eval")
+    if ev:
+        e = {"unit": "ranks/s", "test_triples": ev.get("test_triples"),
+             "exact": {"value": ev.get("value"), "frac": ev.get("roofline", {}).get("frac"), "peak_TF": MFMA_F32_PEAK_TF}}
+        if "bf16" in ev:
+            b = ev["bf16"]
+            e["bf16"] = {"value": b.get("value"), "frac": b.get("roofline", {}).get("frac"), "peak_TF": MFMA_BF16_PEAK_TF}
+            sw = b.get("query_tile_sweep")
+            if sw:
+                e["bf16"]["frac_by_query_tile"] = {k.replace("B_q=", ""): v.get("MFMA_frac") for k, v in sw.items()}
+        for label, short in (("random_positives", "exact_fast_random"), ("planted_positives", "exact_fast_planted")):
+            x = ev.get("exact_fast", {}).get(label)
+            if x:
+                e[short] = _pick(x, "value", "equal_to_exact_f32_ranks", "undecided_fraction", "kernel_ms")
+        s["eval"] = e
+    cpu = line.get("cpu_baseline")
+    if cpu:
+        s["cpu_baseline"] = dict(_pick(cpu, "value", "unit", "cores", "kind", "cpu", "seconds"), scope=cpu.get("scope", "forward only"),
+                                 sample=str(cpu.get("sample", ""))[:160])
+    for k in ("xgmi_bytes_per_step_per_rank", "plans"):
+        if k in line:
+            s[k] = line[k]
+    s["detail_file"] = detail_file
+    s = _finite(s)
+    out = json.dumps(s, allow_nan=False, separators=(",", ":"))
+    if len(out) > SUMMARY_MAX_BYTES:            # never print an unparseably long line: drop the optional blocks, largest first
+        for k in ("others_ms_per_step", "stages_ms", "sustained", "eval", "default_optimizer"):
+            s.pop(k, None)
+            out = json.dumps(s, allow_nan=False, separators=(",", ":"))
+            if len(out) <= SUMMARY_MAX_BYTES:
+                break
+    return out
+
+
+def emit(line):
+    """full result -> bench_detail.json (repo root, and gpurun_out/ when it exists); the summary -> the ONE stdout line"""
+    detail = json.dumps(_finite(line), allow_nan=False, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    print(summary_line(line), flush=True)
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` started as a plain process: start the N ranks as CHILD processes (torch.distributed.run)
     BEFORE anything here touches the GPU, pass their output through and exit with their code."""
@@ -824,7 +924,7 @@ def main():
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
