@@ -8,7 +8,7 @@ mkdir -p "${OUT}" "${OBJ}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function -Wno-array-bounds)
 pids=()
-for f in emg_abi emg_score emg_fused_m0 emg_fused_m1 emg_fused_m2 emg_fused_m3 emg_fused_m4 emg_train emg_group emg_apply emg_rank emg_rank_bf16 emg_rank_sad emg_api emg_plan; do
+for f in emg_abi emg_score emg_fused_m0 emg_fused_m1 emg_fused_m2 emg_fused_m3 emg_fused_m4 emg_train emg_group emg_group_bucket emg_apply emg_rank emg_rank_bf16 emg_rank_sad emg_api emg_plan; do
   src="${HERE}/${f}.hip"; obj="${OBJ}/${f}.o"
   if [[ ! -f "${obj}" || "${src}" -nt "${obj}" || "${HERE}/emg_common.hpp" -nt "${obj}" || "${HERE}/emg_group.hpp" -nt "${obj}" || "${HERE}/emg_group_kernels.hpp" -nt "${obj}" || "${HERE}/emg_score_kernels.hpp" -nt "${obj}" || "${HERE}/emg_fused_inst.inc" -nt "${obj}" || "${HERE}/../../include/emgraph_hip.h" -nt "${obj}" ]]; then
     "${HIPCC}" "${FLAGS[@]}" -c "${src}" -o "${obj}" &

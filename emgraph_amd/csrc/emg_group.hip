@@ -42,6 +42,28 @@ bool group_backend_counting(int64_t N, int64_t R) {
     return R <= 16 * N + ((int64_t)1 << 20);
 }
 
+BucketGeo bucket_geometry(int64_t N, int64_t R) {
+    BucketGeo g{0, 0, 0, false};
+    if (N <= 0 || R <= 0) return g;
+    // ~1024 contributions per bucket on average: rows per bucket = 1024 R / N, a power of two in [1, kBucketRowsMax]
+    int64_t want = (1024 * R) / N;
+    if (want < 1) want = 1;
+    int sh = 0;
+    while (sh < 11 && ((int64_t)2 << sh) <= want) ++sh;
+    while (sh < 11 && cdiv(R, (int64_t)1 << sh) > kBucketMaxNB) ++sh;
+    const int64_t nb = cdiv(R, (int64_t)1 << sh);
+    const int64_t nchunks = cdiv(N, kBucketChunk);
+    if (nb > kBucketMaxNB || nchunks * (nb + 1) > ((int64_t)8 << 20)) return g;
+    g.sh = sh; g.nb = (int)nb; g.nchunks = (int)nchunks; g.ok = true;
+    return g;
+}
+
+bool group_backend_bucket(int64_t n_ent) {
+    const char* e = getenv("EMG_GROUPING");   // (read per call: tests switch it inside one process)
+    if (e && e[0]) return strcmp(e, "bucket") == 0;   // count / sort: never
+    return n_ent >= kBucketMinRows;
+}
+
 // force Onesweep (histogram + scan + one pass per 8-bit digit) above 4096 items: the default picks a
 // block sort + ~13 merge launches below 1M items, which is launch-bound at our sizes
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
@@ -85,7 +107,8 @@ static int layout_impl(char* ws, int64_t ws_bytes, int64_t N, int64_t R, int64_t
     o->clean_offset = at;
     const size_t arrive = take(4 * ((size_t)N / kLongSegment + 2));
     const size_t counters = take(4 * GC_WORDS);
-    size_t status = 0, cnt = 0, off = 0, stmp = 0;
+    size_t status = 0, cnt = 0, off = 0, stmp = 0, tmpv2 = 0, bmat = 0;
+    const BucketGeo geo = bucket_geometry(N, R);
     o->scan_blocks = 0; o->sort_tmp_bytes = 0;
     if (o->counting) {
         o->scan_blocks = (int)cdiv(R + 1, kScanTile);
@@ -93,6 +116,7 @@ static int layout_impl(char* ws, int64_t ws_bytes, int64_t N, int64_t R, int64_t
         cnt = take(4 * ((size_t)R + 1));
         o->clean_bytes = at - o->clean_offset;
         off = take(4 * ((size_t)R + 1));
+        if (geo.ok) { tmpv2 = take(o->kb); bmat = take(4 * (size_t)geo.nchunks * ((size_t)geo.nb + 1)); }
     } else {
         o->clean_bytes = at - o->clean_offset;
         int rc = sort_temp_bytes(N, &o->sort_tmp_bytes);
@@ -112,6 +136,8 @@ static int layout_impl(char* ws, int64_t ws_bytes, int64_t N, int64_t R, int64_t
     o->cnt = o->counting ? (int32_t*)(ws + cnt) : nullptr;
     o->off = o->counting ? (uint32_t*)(ws + off) : nullptr;
     o->sort_tmp = o->counting ? nullptr : (void*)(ws + stmp);
+    o->tmpv2 = (o->counting && geo.ok) ? (uint32_t*)(ws + tmpv2) : nullptr;
+    o->bmat = (o->counting && geo.ok) ? (uint32_t*)(ws + bmat) : nullptr;
     o->partial = (need > 0 && (int64_t)(base + need) <= ws_bytes) ? (float*)(ws + base) : nullptr;
     return EMG_OK;
 }
@@ -371,6 +397,7 @@ extern "C" int emg_prepare_batch(const emg_prepare_args* a, void* stream) {
         if (rc == EMG_OK) rc = clean_ws(S.wr, a->ws_rel, st);
         if (rc != EMG_OK) return rc;
     }
+    if (bucket_eligible(a, S)) return bucket_prepare(a, S, st);
     hipLaunchKernelGGL(prepare_ids_kernel, dim3(S.nb_ids), dim3(256), 0, st, S.prep, S.G);
     EMG_LAUNCH_CHECK();
     if (S.both) {

@@ -37,6 +37,7 @@ struct GroupWs {
     unsigned long long* status; int scan_blocks;
     int32_t* cnt; uint32_t* off;                 // counting backend: per-row count / cursor, exclusive offsets [R + 1]
     void* sort_tmp; size_t sort_tmp_bytes;       // sort backend
+    uint32_t *tmpv2, *bmat;                      // bucket grouping: second half of the chunk-ordered pairs; chunk x bucket offset matrix
     float* partial;                              // block sums of the long-segment reduction (nullptr: no room)
     size_t clean_offset, clean_bytes;            // the control region that must be zero before the first grouping
     uint32_t task_cap;
@@ -61,6 +62,22 @@ constexpr int kPrepBlock = 256 * kPrepItems;     // contributions per workgroup 
 #endif
 constexpr int kPrepItems2 = EMG_PREP_ITEMS2;
 constexpr int kPrepBlock2 = 256 * kPrepItems2;   // contributions per workgroup of the scatter / order stages
+
+// BUCKET grouping (emg_group_bucket.hip; round 5): the counting grouping for tables far larger than L2.  The table-sized
+// histogram / offset arrays of the counting backend are random 4-byte accesses into 4 MB arrays per contribution (the 117 MB
+// per step of profiles/r4_z beside the scoring kernel); here a contribution is bucketed by its destination's high bits inside
+// the id kernel's workgroup (LDS histogram of <= 4096 bins, chunk-ordered pairs + one offset row per chunk), and ONE workgroup
+// per bucket of <= 2048 table rows does histogram, scan, scatter, in-segment ordering and the segment descriptors in LDS.
+// Two launches for both tables, no global atomics but the three list stretches per bucket, nothing table-sized.
+constexpr int kBucketChunk = 4096;     // contribution slots per workgroup of the id kernel (= per row of the offset matrix)
+constexpr int kBucketRowsMax = 2048;   // table rows per bucket (the LDS row table of the bucket kernel)
+constexpr int kBucketMaxNB = 4096;     // buckets per table (the LDS histogram of the id kernel)
+constexpr int kBucketCap = 8192;       // contributions of a bucket sorted in LDS; a fuller bucket is sorted through global memory
+constexpr int64_t kBucketMinRows = 65536;  // smaller tables keep the counting grouping: their row arrays live in L2
+struct BucketGeo { int sh, nb, nchunks; bool ok; };   // bucket = row >> sh; nb buckets; nchunks rows of the offset matrix
+BucketGeo bucket_geometry(int64_t N, int64_t R);
+// 0: counting grouping as ever; 1: bucket grouping where eligible (default); EMG_GROUPING=count|bucket|sort
+bool group_backend_bucket(int64_t n_ent);
 
 bool group_backend_counting(int64_t N, int64_t R);
 int64_t group_ws_bytes(int64_t N, int64_t R, int64_t ldp);

@@ -374,6 +374,9 @@ struct PrepStages {
     int64_t n_ce, n_cr, cap_ce, cap_cr;
 };
 int prepare_stages(const emg_prepare_args* a, PrepStages* out);
+// the bucket form of the same preparation (emg_group_bucket.hip): two launches, nothing table-sized
+bool bucket_eligible(const emg_prepare_args* a, const PrepStages& S);
+int bucket_prepare(const emg_prepare_args* a, const PrepStages& S, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------------------
 // riders: up to two preparation stages in front of a launch's own workgroups

@@ -861,10 +861,11 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             }
         }
     }
-    }
     if constexpr (kAsync) {
-        // the refills issued past the end are never taken: their registers must stay theirs until the loads have landed
-        // (hipcc does not know they are being written) — one wait for everything, with every row as its operand
+        // the refills issued past the chunk's end are never taken: their registers must stay theirs until the loads have landed
+        // (hipcc does not know they are being written) — one wait for everything, with every row as its operand.  At the end of
+        // EVERY chunk trip (eta > LPG): on the back edge the next fetch() redefines these registers with pure outputs, so the
+        // compiler may hand them to gather()'s address arithmetic while the loads are still landing (round-4 advisor finding)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (PIECES == 1) vm_wait<0>(pa[u][0]);
@@ -880,6 +881,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             for (int q = 0; q < PIECES_S; ++q) { vm_landed(aw[u][q]); vm_landed(a0[u][q]); if constexpr (NS == 2) vm_landed(a1[u][q]); }
             if constexpr (IT::replay) vm_landed(lrv[u]);
         }
+    }
     }
     if (kBilinear && P.fac.coef && active) {   // the two query rows every factored negative of this group points at
         store_row<MODEL, W, NV, LPG>(qo, P.contrib_ent + (2 * B + g) * P.ldc, lg, P.nchunks, P.khalf);

@@ -1,0 +1,207 @@
+"""The BUCKET form of emg_prepare_batch (csrc/emg_group_bucket.hip: tables of >= 65536 rows) against the counting form
+(EMG_GROUPING=count) on the same inputs: Philox codes, destination arrays, sorted keys, the stable order, singleton flags,
+factored source rows and positions must be IDENTICAL, the segment descriptors (singleton / segment / block-task lists) equal as
+sets — and an apply from either grouping gives the same table bits.  Shapes: C3's own (1M x 1k, B 16384, eta 20), hub rows,
+a restricted corruption pool (a few rows hit thousands of times: rows longer than 32 and buckets beyond the LDS capacity),
+every bucket through the global-memory form (EMG_BUCKET_CAP), ids outside the table, rows of a larger (sharded) batch,
+injected draws.  Reference behaviour being restated: the sparse gradient aggregation of EmbeddingModel.py:1388-1440."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+
+
+def dev():
+    from emgraph_amd import device as d
+    d.require_gpu()
+    return d
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def al(x):
+    return (x + 255) // 256 * 256
+
+
+def regions(ws, N):
+    """views of a grouping workspace (csrc/emg_group.hip::layout_impl)"""
+    kb = al(4 * N)
+    at = 0
+    out = {}
+    w = ws.cpu().numpy()
+    for name in ("keys", "vals", "tmpv", "srcrow", "pos_of_slot", "coef"):
+        out[name] = w[at:at + 4 * N].view(np.float32 if name == "coef" else np.uint32)
+        at += kb
+    n_multi = N // 2 + 1
+    out["multi"] = w[at:at + 12 * n_multi].view(np.uint32).reshape(-1, 3)
+    at += al(12 * n_multi)
+    out["single"] = w[at:at + 4 * N].view(np.uint32)
+    at += kb
+    task_cap = N // 8 + 2
+    out["tasks"] = w[at:at + 12 * task_cap].view(np.uint32).reshape(-1, 3)
+    at += al(12 * task_cap)
+    out["arrive"] = w[at:at + 4 * (N // 64 + 2)].view(np.int32)
+    at += al(4 * (N // 64 + 2))
+    out["counters"] = w[at:at + 256].view(np.uint32)
+    return out
+
+
+def run_prepare(d, mode, pos, eta, sides, n_ent, n_rel, factored, cap=None, **kw):
+    B = pos.shape[0]
+    et = eta * len(sides)
+    n_ce = (2 + et) * B
+    os.environ["EMG_GROUPING"] = mode
+    if cap:
+        os.environ["EMG_BUCKET_CAP"] = str(cap)
+    try:
+        codes = torch.full((B * et,), -7, dtype=torch.int32, device="cuda")
+        de = torch.full((n_ce,), -7, dtype=torch.int32, device="cuda")
+        dr = torch.full((B,), -7, dtype=torch.int32, device="cuda")
+        we = torch.zeros(d.apply_workspace_bytes(n_ce, n_ent), dtype=torch.uint8, device="cuda")
+        wr = torch.zeros(d.apply_workspace_bytes(B, n_rel), dtype=torch.uint8, device="cuda")
+        flags = torch.full((n_ce,), 9, dtype=torch.uint8, device="cuda")
+        d.prepare_batch(cu(pos), eta, list(sides), kw.pop("n_choices", n_ent), codes, de, dr, n_ent, n_rel, we, wr, seed=5, counter0=3,
+                        single_flags=flags, factored=factored, **kw)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("EMG_GROUPING", None)
+        os.environ.pop("EMG_BUCKET_CAP", None)
+    return dict(codes=codes.cpu().numpy(), de=de.cpu().numpy(), dr=dr.cpu().numpy(), flags=flags.cpu().numpy(),
+                we=we, wr=wr, E=regions(we, n_ce), R=regions(wr, B), n_ce=n_ce)
+
+
+def compare(a, b, B, factored, n_ent, n_rel):
+    for k in ("codes", "de", "dr"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for tab, n, rows, dest in (("E", a["n_ce"], n_ent, a["de"]), ("R", B, n_rel, a["dr"])):
+        x, y = a[tab], b[tab]
+        valid = (dest >= 0) & (dest < rows)
+        nv = int(valid.sum())
+        assert x["counters"][3] == nv == y["counters"][3], (tab, "GC_VALID")
+        order = np.argsort(np.where(valid, dest, np.iinfo(np.int32).max), kind="stable")[:nv]
+        np.testing.assert_array_equal(y["keys"][:nv], dest[order].astype(np.uint32), err_msg=tab + " keys vs numpy")
+        np.testing.assert_array_equal(y["vals"][:nv], order.astype(np.uint32), err_msg=tab + " vals vs numpy")
+        np.testing.assert_array_equal(x["keys"][:nv], y["keys"][:nv], err_msg=tab + " keys")
+        np.testing.assert_array_equal(x["vals"][:nv], y["vals"][:nv], err_msg=tab + " vals")
+        for c in range(3):   # list lengths
+            assert x["counters"][c] == y["counters"][c], (tab, "counter", c, x["counters"][:4], y["counters"][:4])
+        assert x["counters"][8] == 0 and y["counters"][8] == 0 and not x["arrive"].any() and not y["arrive"].any()
+        nm, ns, nt = (int(v) for v in x["counters"][:3])
+        for name, m in (("multi", nm), ("tasks", nt)):
+            ax, ay = x[name][:m], y[name][:m]
+            np.testing.assert_array_equal(ax[np.lexsort(ax.T[::-1])], ay[np.lexsort(ay.T[::-1])], err_msg=tab + " " + name)
+        np.testing.assert_array_equal(np.sort(x["single"][:ns]), np.sort(y["single"][:ns]), err_msg=tab + " single")
+        cnt = np.bincount(dest[valid], minlength=rows)
+        assert ns == int((cnt == 1).sum()) and nm == int(((cnt >= 2) & (cnt <= 32)).sum())
+    np.testing.assert_array_equal(a["flags"], b["flags"], err_msg="flags")
+    if factored:
+        x, y = a["E"], b["E"]
+        nv = int(x["counters"][3])
+        np.testing.assert_array_equal(x["srcrow"][:nv], y["srcrow"][:nv], err_msg="srcrow")
+        n_neg = a["n_ce"] - 2 * B
+        np.testing.assert_array_equal(x["pos_of_slot"][:n_neg], y["pos_of_slot"][:n_neg], err_msg="pos_of_slot")
+        so = x["vals"][:nv] < 2 * B
+        np.testing.assert_array_equal(x["coef"][:nv][so], y["coef"][:nv][so], err_msg="coef of the subject / object positions")
+
+
+CASES = {
+    # name: B, eta, sides, n_ent, n_rel, what
+    "c3_shape": (16384, 20, (2,), 1_000_000, 1000, "uniform"),
+    "two_sides": (4096, 5, (0, 1), 200_000, 300, "uniform"),
+    "hubs": (16384, 6, (2,), 500_000, 50, "zipf"),
+    "restricted_pool": (8192, 10, (2,), 300_000, 7, "pool"),
+    "tiny_batch_big_table": (37, 1, (1,), 2_000_000, 3, "uniform"),
+    "one_relation": (5000, 2, (2,), 70_000, 1, "uniform"),
+    "dense_small_rows": (20000, 30, (2,), 65_536, 2000, "uniform"),
+}
+
+
+@pytest.mark.parametrize("factored", [False, True])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_bucket_grouping_equals_counting_grouping(case, factored):
+    d = dev()
+    B, eta, sides, n_ent, n_rel, what = CASES[case]
+    rs = np.random.RandomState(len(case) * 7 + B)
+    if what == "zipf":
+        wts = 1.0 / np.arange(1, n_ent + 1)
+        perm = rs.permutation(n_ent)
+        s, o = perm[rs.choice(n_ent, B, p=wts / wts.sum())], perm[rs.choice(n_ent, B, p=wts / wts.sum())]
+        s[: B // 2] = perm[0]           # one subject in half of the batch: a row of 8192 + contributions
+    else:
+        s, o = rs.randint(0, n_ent, B), rs.randint(0, n_ent, B)
+    pos = np.stack([s, rs.randint(0, n_rel, B), o], 1).astype(np.int32)
+    kw = {}
+    if what == "pool":     # negatives from 40 entities of one neighbourhood: ~2000 contributions per row, one bucket holds them all
+        kw = dict(entities_list=cu((123_000 + 3 * np.arange(40)).astype(np.int32)), n_choices=40)
+    ref = run_prepare(d, "count", pos, eta, sides, n_ent, n_rel, factored, **dict(kw))
+    got = run_prepare(d, "bucket", pos, eta, sides, n_ent, n_rel, factored, **dict(kw))
+    compare(got, ref, B, factored, n_ent, n_rel)
+    if case in ("c3_shape", "hubs", "two_sides"):       # every bucket through the global-memory form
+        got2 = run_prepare(d, "bucket", pos, eta, sides, n_ent, n_rel, factored, cap=48, **dict(kw))
+        compare(got2, ref, B, factored, n_ent, n_rel)
+
+
+def test_bucket_grouping_drops_ids_outside_the_table_and_follows_sharded_and_injected_draws():
+    d = dev()
+    rs = np.random.RandomState(11)
+    B, eta, n_ent, n_rel = 3000, 4, 100_000, 20
+    pos = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    pos[::17, 0] = n_ent + 5          # ids outside the table (subject / relation): dropped, their flags 0
+    pos[::29, 1] = n_rel + 1
+    ref = run_prepare(d, "count", pos, eta, (2,), n_ent, n_rel, False)
+    got = run_prepare(d, "bucket", pos, eta, (2,), n_ent, n_rel, False)
+    compare(got, ref, B, False, n_ent, n_rel)
+    pos = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    ref = run_prepare(d, "count", pos, eta, (2,), n_ent, n_rel, True, B_global=4 * B, row_offset=B)
+    got = run_prepare(d, "bucket", pos, eta, (2,), n_ent, n_rel, True, B_global=4 * B, row_offset=B)
+    compare(got, ref, B, True, n_ent, n_rel)
+    inj_repl = cu(rs.randint(0, n_ent, B * eta).astype(np.int32))
+    inj_mask = cu(rs.randint(0, 2, B * eta).astype(np.int32))
+    ref = run_prepare(d, "count", pos, eta, (2,), n_ent, n_rel, True, inj_repl=inj_repl, inj_mask=inj_mask)
+    got = run_prepare(d, "bucket", pos, eta, (2,), n_ent, n_rel, True, inj_repl=inj_repl, inj_mask=inj_mask)
+    compare(got, ref, B, True, n_ent, n_rel)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_apply_from_the_bucket_grouping_gives_the_counting_grouping_bits(opt):
+    """the descriptor-driven apply (segments, singletons, block tasks) from either grouping: same table and state bits"""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(3)
+    B, eta, n_ent, n_rel, k = 6000, 8, 150_000, 11, 72
+    pos = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+    pos[:3000, 0] = 777                # a row of 3000 contributions: block tasks
+    n_ce = (2 + eta) * B
+    contrib = cu(rs.randn(n_ce, k).astype(F32))
+    W0 = rs.randn(n_ent, k).astype(F32)
+    out = {}
+    for mode in ("count", "bucket"):
+        g = run_prepare(d, mode, pos, eta, (2,), n_ent, n_rel, False)
+        # a workspace with room for the long-segment partial sums: group again into it
+        os.environ["EMG_GROUPING"] = mode
+        try:
+            ws = torch.zeros(d.apply_workspace_bytes(n_ce, n_ent, k), dtype=torch.uint8, device="cuda")
+            wr = torch.zeros(d.apply_workspace_bytes(B, n_rel, k), dtype=torch.uint8, device="cuda")
+            codes = torch.empty(B * eta, dtype=torch.int32, device="cuda")
+            de = torch.empty(n_ce, dtype=torch.int32, device="cuda")
+            dr = torch.empty(B, dtype=torch.int32, device="cuda")
+            d.prepare_batch(cu(pos), eta, [2], n_ent, codes, de, dr, n_ent, n_rel, ws, wr, seed=5, counter0=3)
+        finally:
+            os.environ.pop("EMG_GROUPING", None)
+        np.testing.assert_array_equal(de.cpu().numpy(), g["de"])
+        W = cu(W0.copy())
+        st = [torch.full_like(W, 0.1), None] if opt == "adagrad" else [None, None]
+        oid = L.OPT_ADAGRAD if opt == "adagrad" else L.OPT_SGD
+        d.apply_grouped(oid, W, k, st[0], st[1], None, 1, contrib, n_ce, 0, (0.01, 0.0, 0.9, 0.999, 1e-7, 0.01), ws)
+        torch.cuda.synchronize()
+        out[mode] = [W.cpu().numpy()] + [s.cpu().numpy() for s in st if s is not None]
+    for x, y in zip(out["count"], out["bucket"]):
+        np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert not np.array_equal(out["count"][0], W0)

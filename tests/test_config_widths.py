@@ -421,6 +421,48 @@ def test_adam_replayed_in_the_scoring_kernel_gives_the_dense_pass_bits(monkeypat
     assert not np.array_equal(a[0], E0)
 
 
+@pytest.mark.parametrize("form", ["adagrad", "momentum", "adam_dense", "adam_deferred", "sgd"])
+@pytest.mark.parametrize("model,k,eta", [("ComplEx", 100, 70), ("DistMult", 200, 130), ("TransE", 100, 65)])
+def test_window_forms_with_more_than_64_negatives_keep_the_bits(monkeypatch, model, k, eta, form):
+    """more negatives per positive than the wave has lanes (eta > 64): the group's codes / flags / positions are gathered 64 at a
+    time and the loop over the rolling window runs once per gather.  The refills issued past a chunk's end are never taken; they
+    must have LANDED before the next gather reuses registers (round-4 advisor finding: the drain sat behind the whole loop).
+    Window forms (ip 4: Adagrad / momentum, ip 5: Adam with its dense pass, ip 6: Adam under the deferred pass) and the plain
+    in-place form (ip 1) against every row through the contribution buffer: tables, optimizer state and loss bit for bit."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": L.TRANSE_L1}[model]
+    n_ent, n_rel, B, nb = 60000, 9, 256, 3             # most slots are singletons
+    ki = 2 * k if model == "ComplEx" else k
+    rs = np.random.RandomState(eta)
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, nb * B), rs.randint(0, n_rel, nb * B), rs.randint(0, n_ent, nb * B)], 1).astype(np.int32)
+    opt = {"adam_dense": "adam", "adam_deferred": "adam"}.get(form, form)
+    deferred = {"adam_dense": False, "adam_deferred": True}.get(form)
+
+    def run(inplace):
+        monkeypatch.setenv("EMG_INPLACE", "1" if inplace else "0")
+        monkeypatch.setenv("EMG_INPLACE_STATE", "1")
+        tr = Trainer(mid, ki, 1.0, E0, R0, eta, loss="pairwise" if model == "TransE" else "nll", optimizer=opt, optimizer_params={"lr": 0.01},
+                     batches_count=nb, seed=3, deferred_dense=deferred if inplace or deferred is None else False)
+        tr.set_training_set(X, B)
+        assert bool(tr.inplace) == inplace
+        for ep in (1, 2):
+            for b in range(nb):
+                tr.step(b * B, B, epoch=ep, batch=b + 1)
+        Et, Rt = tr.tables_numpy()
+        return Et, Rt, [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None], tr.read_loss()
+
+    a, b = run(True), run(False)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    assert a[3] == b[3]
+    assert not np.array_equal(a[0], E0)
+
+
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
 @pytest.mark.parametrize("model,k", [("ComplEx", 100), ("DistMult", 200), ("TransE", 100)])
 def test_inplace_sgd_folds_the_lp_regulariser(monkeypatch, model, k, p):
