@@ -729,7 +729,7 @@ def summary_line(line, detail_file=DETAIL_FILE):
     if cpu:
         s["cpu_baseline"] = dict(_pick(cpu, "value", "unit", "cores", "kind", "cpu", "seconds"), scope=cpu.get("scope", "forward only"),
                                  sample=str(cpu.get("sample", ""))[:160])
-    for k in ("xgmi_bytes_per_step_per_rank", "plans"):
+    for k in ("xgmi_bytes_per_step_per_rank", "plans", "plan"):
         if k in line:
             s[k] = line[k]
     s["detail_file"] = detail_file
@@ -776,9 +776,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--sharding", default="k", choices=["k", "batch"],
+    ap.add_argument("--sharding", default="both", choices=["both", "k", "batch"],
                     help="multi-GPU training plan: k = column slabs + all-reduce of partial scores; batch = batch rows split, "
-                         "sparse gradient-row exchange to the owning rank, updated rows all-gathered (emgraph_amd/parallel.py)")
+                         "sparse gradient-row exchange to the owning rank, summed rows all-gathered (emgraph_amd/parallel.py); "
+                         "both (default) = each is timed, the line carries both and `value` is the better one")
     ap.add_argument("--eval-triples", type=int, default=4096)
     ap.add_argument("--sustained-seconds", type=float, default=1.2, help="length of the extra sustained window (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work timed for cpu_baseline")
@@ -813,13 +814,41 @@ def main():
         dist.init_process_group("gloo" if os.environ.get("EMG_BENCH_ONE_DEVICE") else "nccl")
 
     ceilings = hbm_ceilings() if (rank == 0 and not args.no_ceilings) else None   # (a child process; also brings the clocks up)
-    r = StepRunner(args.workload, args, rank, world, sharding=args.sharding, batch=args.batch)
+
+    def run_plan(sharding, timed=True):
+        """W warm-up steps + EXACTLY K timed steps (barrier + synchronize on both sides, max over ranks) of one multi-GPU plan"""
+        rr = StepRunner(args.workload, args, rank, world, sharding=sharding, batch=args.batch)
+        if not timed:
+            rr.run(args.warmup)
+            return rr, None, None, None
+        rr.run(args.warmup)
+        dt_, ti_ = rr.timed(args.steps)
+        hd = step_summary(rr, dt_, ti_, args.steps)
+        ls = rr.tr.read_loss()
+        assert math.isfinite(ls), "loss is not finite"
+        if world > 1:   # bytes each rank puts on the links per step
+            if sharding == "batch":
+                hd["xgmi_bytes_per_step_per_rank"] = int(rr.tr.xgmi_bytes / max(1, rr.tr.step_count))
+            else:       # ring all-reduce of the (1 + eta) * B_global partial scores: 2 (N - 1) / N of the buffer out, as much in
+                hd["xgmi_bytes_per_step_per_rank"] = int(2 * (world - 1) / world * 4 * (1 + rr.eta) * rr.B)
+        return rr, hd, ls, (dt_, ti_)
+
+    # N > 1: BOTH training plans are timed (K steps each) and the line carries both; `value` is the better one — so a scaling run
+    # records north_star's split (batch rows over the ranks, RCCL exchange of gradient rows) whatever wins
+    plan_names = [None] if world == 1 else (["k", "batch"] if args.sharding == "both" else [args.sharding])
+    plans = {}
+    r = None
+    for pn in plan_names:
+        if r is not None:
+            r.close()
+        r, hd, ls, tm = run_plan(pn)
+        plans[pn] = {"head": hd, "loss": ls, "tm": tm}
+    best = max(plan_names, key=lambda n: plans[n]["head"]["value"])
+    if best != plan_names[-1]:   # the stage / evaluation sections below run on the better plan's runner
+        r.close()
+        r, _, _, _ = run_plan(best, timed=False)
+    head, loss, (dt, t_issue) = plans[best]["head"], plans[best]["loss"], plans[best]["tm"]
     w = r.w
-    r.run(args.warmup)
-    dt, t_issue = r.timed(args.steps)                              # THE contract's number
-    head = step_summary(r, dt, t_issue, args.steps)
-    loss = r.tr.read_loss()
-    assert math.isfinite(loss), "loss is not finite"
     line = {
         "metric": "positive+negative triples scored/sec at k=200, eta=20; filtered ranks/sec",
         "value": head["value"], "unit": "triples scored/s", "n_gpus": world, "steps": args.steps,
@@ -839,8 +868,12 @@ def main():
                                     "batch-sharded x%d: sparse gradient rows to owners, updated rows all-gathered" % world))},
         "loss_sum": loss,
     }
+    if world > 1:
+        line["xgmi_bytes_per_step_per_rank"] = head["xgmi_bytes_per_step_per_rank"]
+        line["plans"] = {n: dict(_pick(plans[n]["head"], "value", "ms_per_step", "xgmi_bytes_per_step_per_rank"), loss_sum=plans[n]["loss"])
+                         for n in plan_names}
+        line["plan"] = best
     if world > 1 and r.sharding == "batch":
-        line["xgmi_bytes_per_step_per_rank"] = int(r.tr.xgmi_bytes / max(1, r.tr.step_count))
         # what the two forms of the gradient exchange put on the links per step and rank (uniform destinations; the sums' all-gather
         # is the same for both): FULL ROWS (implemented: every gradient row travels to the owner of its destination) against the
         # FACTORED form of the bilinear models (not implemented: a negative's row is g * q, so a group would send its subject /

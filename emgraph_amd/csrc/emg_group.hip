@@ -52,9 +52,10 @@ BucketGeo bucket_geometry(int64_t N, int64_t R) {
     while (sh < 11 && ((int64_t)2 << sh) <= want) ++sh;
     while (sh < 11 && cdiv(R, (int64_t)1 << sh) > kBucketMaxNB) ++sh;
     const int64_t nb = cdiv(R, (int64_t)1 << sh);
-    const int64_t nchunks = cdiv(N, kBucketChunk);
-    if (nb > kBucketMaxNB || nchunks * (nb + 1) > ((int64_t)8 << 20)) return g;
-    g.sh = sh; g.nb = (int)nb; g.nchunks = (int)nchunks; g.ok = true;
+    int cl = 10;
+    while (cl < 30 && cdiv(N, (int64_t)1 << cl) > kBucketChunksMax) ++cl;
+    if (nb > kBucketMaxNB || cl > 16) return g;   // (a workgroup of the id kernel walks at most 65536 slots)
+    g.sh = sh; g.nb = (int)nb; g.chunk_log = cl; g.ok = true;
     return g;
 }
 
@@ -116,7 +117,7 @@ static int layout_impl(char* ws, int64_t ws_bytes, int64_t N, int64_t R, int64_t
         cnt = take(4 * ((size_t)R + 1));
         o->clean_bytes = at - o->clean_offset;
         off = take(4 * ((size_t)R + 1));
-        if (geo.ok) { tmpv2 = take(o->kb); bmat = take(4 * (size_t)geo.nchunks * ((size_t)geo.nb + 1)); }
+        if (geo.ok) { tmpv2 = take(o->kb); bmat = take(4 * (size_t)kBucketChunksMax * ((size_t)geo.nb + 1)); }
     } else {
         o->clean_bytes = at - o->clean_offset;
         int rc = sort_temp_bytes(N, &o->sort_tmp_bytes);

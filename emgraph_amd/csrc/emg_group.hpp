@@ -69,12 +69,13 @@ constexpr int kPrepBlock2 = 256 * kPrepItems2;   // contributions per workgroup 
 // the id kernel's workgroup (LDS histogram of <= 4096 bins, chunk-ordered pairs + one offset row per chunk), and ONE workgroup
 // per bucket of <= 2048 table rows does histogram, scan, scatter, in-segment ordering and the segment descriptors in LDS.
 // Two launches for both tables, no global atomics but the three list stretches per bucket, nothing table-sized.
-constexpr int kBucketChunk = 4096;     // contribution slots per workgroup of the id kernel (= per row of the offset matrix)
+constexpr int kBucketChunkMin = 1024;  // contribution slots per workgroup of the id kernel (doubled until a batch is <= 512 chunks)
+constexpr int kBucketChunksMax = 512;  // chunks per batch = entries of a row of the offset matrix (bmat[bucket][chunk])
 constexpr int kBucketRowsMax = 2048;   // table rows per bucket (the LDS row table of the bucket kernel)
 constexpr int kBucketMaxNB = 4096;     // buckets per table (the LDS histogram of the id kernel)
-constexpr int kBucketCap = 8192;       // contributions of a bucket sorted in LDS; a fuller bucket is sorted through global memory
+constexpr int kBucketCap = 4096;       // contributions of a bucket sorted in LDS; a fuller bucket is sorted through global memory
 constexpr int64_t kBucketMinRows = 65536;  // smaller tables keep the counting grouping: their row arrays live in L2
-struct BucketGeo { int sh, nb, nchunks; bool ok; };   // bucket = row >> sh; nb buckets; nchunks rows of the offset matrix
+struct BucketGeo { int sh, nb, chunk_log; bool ok; };   // bucket = row >> sh; nb buckets; chunks of 1 << chunk_log slots
 BucketGeo bucket_geometry(int64_t N, int64_t R);
 // 0: counting grouping as ever; 1: bucket grouping where eligible (default); EMG_GROUPING=count|bucket|sort
 bool group_backend_bucket(int64_t n_ent);

@@ -120,6 +120,7 @@ CASES = {
     "tiny_batch_big_table": (37, 1, (1,), 2_000_000, 3, "uniform"),
     "one_relation": (5000, 2, (2,), 70_000, 1, "uniform"),
     "dense_small_rows": (20000, 30, (2,), 65_536, 2000, "uniform"),
+    "big_batch_wide_chunks": (70000, 12, (2,), 400_000, 100, "uniform"),      # 980 k contributions: chunks of 2048 slots
 }
 
 

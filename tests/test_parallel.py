@@ -6,6 +6,7 @@ GPU: the real k-sharded training + range-sharded evaluation (HIP kernels) with t
 over gloo must match a single-process run."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ torch = pytest.importorskip("torch")
 import torch.multiprocessing as mp  # noqa: E402
 
 from tests import _dist_workers as W  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -215,3 +218,32 @@ print("rccl ok")
 ''' % _free_port()
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sharding", ["both", "batch"])
+def test_bench_runs_at_two_ranks_and_prints_both_plans(sharding):
+    """`bench.py --gpus 2` as the driver starts it for a scaling run (here: both ranks on ONE device over gloo,
+    EMG_BENCH_ONE_DEVICE=1): the N > 1 branch must start, time both training plans (k-slabs + score all-reduce; batch rows +
+    gradient-row exchange — north_star's split) and end with ONE parseable stdout line carrying n_gpus, both plans and the bytes
+    each rank puts on the links per step.  No scaling number is asserted: one device cannot give one."""
+    import json
+    import subprocess
+    env = dict(os.environ, EMG_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-eval", "--no-cpu",
+           "--no-ceilings", "--sustained-seconds", "0", "--sharding", sharding]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    want = {"k", "batch"} if sharding == "both" else {sharding}
+    assert set(d["plans"]) == want and d["plan"] in want
+    for name in want:
+        pl = d["plans"][name]
+        assert pl["value"] > 0 and pl["ms_per_step"] > 0 and pl["xgmi_bytes_per_step_per_rank"] > 0
+    assert d["value"] == max(pl["value"] for pl in d["plans"].values())
+    assert d["xgmi_bytes_per_step_per_rank"] == d["plans"][d["plan"]]["xgmi_bytes_per_step_per_rank"]
+    assert d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"]

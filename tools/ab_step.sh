@@ -1,11 +1,13 @@
 #!/usr/bin/env bash
 # A/B of the C3 / C3b / C2 step under environment switches: bash tools/ab_step.sh "LABEL:ENV=VAL ENV2=VAL2" ...
+# (BENCH_ARGS=--no-pipeline among the switches adds bench.py arguments; the numbers come from bench_detail.json)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 for spec in "$@"; do
   label="${spec%%:*}"; envs="${spec#*:}"
   for wl in ${AB_WORKLOADS:-C3 C3b C2}; do
     steps=300; [[ $wl == C3b ]] && steps=60
-    out=$(env $envs python3 bench.py --workload $wl --no-cpu --no-eval --no-others --sustained-seconds 0 --no-ceilings --steps $steps --warmup 20 2>/dev/null | tail -1)
+    env $envs bash -c 'python3 bench.py $BENCH_ARGS "$@"' _ --workload $wl --no-cpu --no-eval --no-others --sustained-seconds 0 --no-ceilings --steps $steps --warmup 20 >/dev/null 2>&1
+    out=$(cat bench_detail.json)
     python3 - "$label" "$wl" "$out" <<'PY'
 import json, sys
 label, wl, out = sys.argv[1:4]
