@@ -128,23 +128,47 @@ def moved_bytes_model(stage, B, eta, k_int, n_single_neg, n_single_so, n_ns_rows
     return 0
 
 
+def lib_source_hash():
+    """hash of the kernel sources libemgraph_hip.so was built from (csrc/build.sh -> emg_source_hash)"""
+    try:
+        from emgraph_amd import _lib
+        return _lib.load().emg_source_hash().decode()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def profile_files(pattern):
+    """committed profiles/ files matching `pattern`, newest first by (round number, tag) parsed from r<round>_<tag>_..."""
+    import glob
+    import re
+
+    def key(fn):
+        m = re.match(r"r(\d+)_([A-Za-z0-9]+)_", os.path.basename(fn))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=key, reverse=True)
+
+
 def pmc_traffic(stage, name, B, world, args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this command
     (profiles/r2_d_pmc_traffic.json; separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
     STATIC: read from the file, not measured in this run; only for the configuration it was collected on."""
     if stage != "fused" or name != "C3" or B != 16384 or world != 1 or args.no_inplace or args.no_fused:
         return None, None
-    import glob
-    for fn in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))), reverse=True):   # newest round first
+    h = lib_source_hash()
+    for path in profile_files("r*_pmc_traffic.json"):   # newest round first; only a pass of THIS binary counts
+        fn = os.path.basename(path)
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            d = json.load(open(path))
+            if d.get("source_hash") != h:
+                continue
             k = [v for n, v in d["kernels"].items()
                  if "train_fused_riders_kernel<3, 4, 1, 64, 1>" in n or "train_fused_riders_kernel<3, 4, 1, 64, 1, " in n   # (, window depth> since round 4)
                  or "train_backward_kernel<3, 4, 1, 64, true, 1>" in n]
             if k:
-                return k[0]["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc pass of this command, not measured in this run)" % fn
+                return k[0]["hbm_bytes_per_launch"], "static: profiles/%s (rocprofv3 --pmc pass of this command and binary %s, not measured in this run)" % (fn, h)
         except (OSError, ValueError, KeyError):
             pass
+    return None, "none: no committed rocprofv3 --pmc pass of this binary (source hash %s) under profiles/" % h
     return None, None
 
 
@@ -302,19 +326,21 @@ def hbm_ceilings():
 def profiled_avg_us(kernel_substr, tag_glob="r*_c3_kernel_stats.md"):
     """average duration (us) of a kernel in the newest committed rocprofv3 --kernel-trace --stats table of THIS workload
     (profiles/): printed next to the live HIP-event figure so that `frac` can be re-derived from profiles/ alone"""
-    import glob
-    best = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob))):
-        for line in open(fn):
+    h = lib_source_hash()
+    for fn in profile_files(tag_glob):   # newest first; only a table of THIS binary (its first line names the source hash)
+        lines = open(fn).read().splitlines()
+        if not lines or ("source_hash: %s" % h) not in lines[0]:
+            continue
+        for line in lines:
             if kernel_substr in line and line.startswith("|"):
                 cells = [c.strip() for c in line.strip().strip("|").split("|")]
                 try:
-                    best = {"file": "profiles/" + os.path.basename(fn), "kernel": cells[0], "calls": int(cells[1]), "avg_us": float(cells[3]),
-                            "min_us": float(cells[4])}
+                    return {"file": "profiles/" + os.path.basename(fn), "kernel": cells[0], "calls": int(cells[1]), "avg_us": float(cells[3]),
+                            "min_us": float(cells[4]), "source_hash": h}
                 except (ValueError, IndexError):
                     pass
                 break
-    return best
+    return None
 
 
 def copy_rate(torch):
@@ -361,14 +387,15 @@ def score_kernel_alone(r, reps=50):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     ab = algorithmic_bytes("forward", B, eta, tr.k_int)
-    traffic = None
+    traffic, fn = None, None
     try:
-        import glob
-        for fn in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))), reverse=True):
-            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        for path in profile_files("r*_pmc_traffic.json"):
+            d = json.load(open(path))
+            if d.get("source_hash") != lib_source_hash():
+                continue
             k = [v for n, v in d["kernels"].items() if "train_forward_kernel<0, 4, 1, 64>" in n and "16384 groups" in n]
             if k:
-                traffic = k[0]["hbm_bytes_per_launch"]
+                traffic, fn = k[0]["hbm_bytes_per_launch"], os.path.basename(path)
                 break
     except (OSError, ValueError, KeyError):
         pass

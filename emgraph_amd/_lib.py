@@ -41,6 +41,7 @@ SIGNATURES = {
     "emg_version": (_int, []),
     "emg_last_error": (C.c_char_p, []),
     "emg_target": (C.c_char_p, []),
+    "emg_source_hash": (C.c_char_p, []),
     "emg_score_triples": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _i32, _p, _p]),
     "emg_finalize_scores": (_int, [_int, _f32, _p, _i64, _p]),
     "emg_corrupt_codes": (_int, [_i64, _i32, _int, _i64, _p, _u64, _u64, _p, _p, _p, _p]),

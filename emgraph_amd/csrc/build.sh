@@ -6,12 +6,15 @@ OUT="${HERE}/../lib"
 OBJ="${HERE}/_obj"
 mkdir -p "${OUT}" "${OBJ}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function -Wno-array-bounds)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function)
+# the hash of every kernel source goes into the library (emg_source_hash): profiles/ name the binary they measured
+SRC_HASH="$(cd "${HERE}" && cat emg_*.hip emg_*.hpp emg_*.inc ../../include/emgraph_hip.h | sha256sum | cut -c1-16)"
+if [[ ! -f "${OBJ}/src_hash.txt" || "$(cat "${OBJ}/src_hash.txt")" != "${SRC_HASH}" ]]; then rm -f "${OBJ}/emg_abi.o"; echo "${SRC_HASH}" > "${OBJ}/src_hash.txt"; fi
 pids=()
 for f in emg_abi emg_score emg_fused_m0 emg_fused_m1 emg_fused_m2 emg_fused_m3 emg_fused_m4 emg_train emg_group emg_group_bucket emg_apply emg_rank emg_rank_bf16 emg_rank_sad emg_api emg_plan; do
   src="${HERE}/${f}.hip"; obj="${OBJ}/${f}.o"
   if [[ ! -f "${obj}" || "${src}" -nt "${obj}" || "${HERE}/emg_common.hpp" -nt "${obj}" || "${HERE}/emg_group.hpp" -nt "${obj}" || "${HERE}/emg_group_kernels.hpp" -nt "${obj}" || "${HERE}/emg_score_kernels.hpp" -nt "${obj}" || "${HERE}/emg_fused_inst.inc" -nt "${obj}" || "${HERE}/../../include/emgraph_hip.h" -nt "${obj}" ]]; then
-    "${HIPCC}" "${FLAGS[@]}" -c "${src}" -o "${obj}" &
+    "${HIPCC}" "${FLAGS[@]}" -DEMG_SRC_HASH="\"${SRC_HASH}\"" -c "${src}" -o "${obj}" &
     pids+=($!)
   fi
 done

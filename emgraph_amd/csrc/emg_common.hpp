@@ -242,7 +242,9 @@ __device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float
 __device__ __forceinline__ float opt_ratio(float num, float root, float eps) {
 #pragma clang fp contract(off)
 #if EMG_OPT_FAST_RECIP
-    return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(root) + eps);
+    // (the max changes nothing for eps >= 1e-7 — Keras' value, the only one the package passes; with a denormal or zero eps from a
+    // C-ABI caller and root == 0 (an untouched row of the dense pass) v_rcp_f32 would return inf and 0 * inf poison the table)
+    return num * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(root) + eps, 1.17549435e-38f));
 #else
     return num / (sqrtf(root) + eps);
 #endif

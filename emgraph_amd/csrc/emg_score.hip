@@ -72,7 +72,9 @@ static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st, 
         static const int wide_env = getenv("EMG_WIDE_GROUPS") ? atoi(getenv("EMG_WIDE_GROUPS")) : -1;   // A/B aid
         // (in-place updates of a stateful optimizer: always a wave per group — the form whose state rows travel with the table rows)
         const bool stateful_ip = pass == Pass::Fused && P.single_ent && P.window;
-        const bool wide = pass != Pass::Forward && (wide_env >= 0 ? wide_env != 0 : (P.B <= 2048 || stateful_ip));
+        // (stateful_ip wins over the A/B switch: forms 4 / 5 / 6 exist for LPG = 64 only — with EMG_WIDE_GROUPS=0 a narrow row would
+        // otherwise reach a shape that launches nothing)
+        const bool wide = pass != Pass::Forward && (stateful_ip || (wide_env >= 0 ? wide_env != 0 : P.B <= 2048));
         if (c <= 16 && !wide) launch_group<MODEL, 4, 1, 16>(pass, P, st, riders);
         else if (c <= 32 && !wide) launch_group<MODEL, 4, 1, 32>(pass, P, st, riders);
         else if (c <= 64) launch_group<MODEL, 4, 1, 64>(pass, P, st, riders);

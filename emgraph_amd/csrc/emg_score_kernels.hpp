@@ -547,7 +547,9 @@ struct keep_rows {
 #ifndef EMG_BW_KEEP
 #define EMG_BW_KEEP 1   // 0: A/B aid — never keep s, p, o across the loop
 #endif
-    static constexpr bool value = EMG_BW_KEEP != 0 && W == 4 && NV == 1 && (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
+    // (not with two state rows per window slot — forms 5 / 6: the three kept rows are the registers DistMult's form 5 spilled)
+    static constexpr bool value = EMG_BW_KEEP != 0 && W == 4 && NV == 1 && ip_traits<IP>::n_state != 2 &&
+                                  (!is_complex<MODEL>::value || (FUSED && (IP == 1 || IP == 2)));
 };
 template <int MODEL, int W, int NV, int LPG, bool FUSED, int IP, int UW = EMG_BW_U>
 __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsigned bx) {
@@ -775,6 +777,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
                 dst[h * NV + it] = vm_load16_async(base + h * P.khalf + 4 * c);
             }
     };
+    // (the body indexes src[1 .. 3] under `if constexpr` on PIECES; where kAsync is off the array has one entry and the lambda is
+    // never called, but it is still instantiated: the diagnostic is silenced HERE, not for the translation unit)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Warray-bounds"
     auto take_row = [&](emg_f4 (&src)[kAsync ? PIECES : 1], R& r) {   // wait for THIS row (the U - 1 younger ones may fly on)
         if constexpr (PIECES == 1) vm_wait<(U - 1) * PIECES>(src[0]);
         else if constexpr (PIECES == 2) vm_wait<(U - 1) * PIECES>(src[0], src[1]);
@@ -782,6 +788,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) { r.x[4 * q + 0] = src[q].x; r.x[4 * q + 1] = src[q].y; r.x[4 * q + 2] = src[q].z; r.x[4 * q + 3] = src[q].w; }
     };
+#pragma clang diagnostic pop
     for (; chunk0 < P.eta; chunk0 += LPG) {   // (one trip unless eta > LPG)
     chunk1 = min(P.eta, chunk0 + LPG);
     if (chunk0 > 0) gather(chunk0);
@@ -887,32 +894,41 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         store_row<MODEL, W, NV, LPG>(qo, P.contrib_ent + (2 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
         store_row<MODEL, W, NV, LPG>(qs, P.contrib_ent + (3 * B + g) * P.ldc, lg, P.nchunks, P.khalf);
     }
+    // The epilogue's row addresses are formed from the ids HERE.  Window forms: from an OPAQUE copy of the ids — left to hipcc the
+    // addresses are computed in the prologue and live across the whole loop over the negatives as 64-bit pairs, registers the cap
+    // of three waves per SIMD does not have (round 4: 12 .. 84 bytes of scratch per lane in every window-form kernel)
+    int32_t es = s, ep = p, eo = o;
+    int64_t eg = g;
+    if constexpr (IT::window_state) asm volatile("" : "+v"(es), "+v"(ep), "+v"(eo), "+v"(eg));
+    const float* srow_e = P.ent + (int64_t)es * P.ld_ent;
+    const float* prow_e = P.rel + (int64_t)ep * P.ld_rel;
+    const float* orow_e = P.ent + (int64_t)eo * P.ld_ent;
     if (active) {
         // kept rows: form their gradients from the accumulators
         R rs, rp, ro, gs, gp, go;
         if constexpr (KEEP) {
             rs = ks; rp = kp; ro = ko;
         } else {  // re-load s, p, o (read a moment ago) instead of holding three more rows per group
-            load_row<MODEL, W, NV, LPG>(rs, srow, lg, P.nchunks, P.khalf);
-            load_row<MODEL, W, NV, LPG>(rp, prow, lg, P.nchunks, P.khalf);
-            load_row<MODEL, W, NV, LPG>(ro, orow, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(rs, srow_e, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(rp, prow_e, lg, P.nchunks, P.khalf);
+            load_row<MODEL, W, NV, LPG>(ro, orow_e, lg, P.nchunks, P.khalf);
         }
         if constexpr (IT::replay) {   // (a singleton's table row still lags: its replayed row is the parked one)
             if (fso0) unpark(0, rs);
             if (fso1) unpark(1 + NS, ro);
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
-        store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + g * P.ldc, lg, P.nchunks, P.khalf);
+        store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + eg * P.ldc, lg, P.nchunks, P.khalf);
         if constexpr (SOP) {
-            if (fso0) { R ms, vs; unpark(1, ms); if constexpr (NS == 2) unpark(2, vs); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, s, rs, gs, ms, vs, lg); }
-            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-            if (fso1) { R mo, vo; unpark(2 + NS, mo); if constexpr (NS == 2) unpark(5, vo); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, o, ro, go, mo, vo, lg); }
-            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+            if (fso0) { R ms, vs; unpark(1, ms); if constexpr (NS == 2) unpark(2, vs); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, es, rs, gs, ms, vs, lg); }
+            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + eg * P.ldc, lg, P.nchunks, P.khalf);
+            if (fso1) { R mo, vo; unpark(2 + NS, mo); if constexpr (NS == 2) unpark(5, vo); inplace_update_regs<MODEL, W, NV, LPG, NS>(P, wopt, eo, ro, go, mo, vo, lg); }
+            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + eg) * P.ldc, lg, P.nchunks, P.khalf);
         } else {
-            if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, s, rs, gs, lg, lp_acc);
-            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + g * P.ldc, lg, P.nchunks, P.khalf);
-            if (IT::so_inplace && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, o, ro, go, lg, lp_acc);
-            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + g) * P.ldc, lg, P.nchunks, P.khalf);
+            if (IT::so_inplace && flag_so(0)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, es, rs, gs, lg, lp_acc);
+            else store_row<MODEL, W, NV, LPG>(gs, P.contrib_ent + eg * P.ldc, lg, P.nchunks, P.khalf);
+            if (IT::so_inplace && flag_so(1)) inplace_update<MODEL, W, NV, LPG, IT::chunkwise>(P, eo, ro, go, lg, lp_acc);
+            else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + eg) * P.ldc, lg, P.nchunks, P.khalf);
         }
     }
     if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place

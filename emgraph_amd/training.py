@@ -283,9 +283,22 @@ class Trainer:
         # 0.1527 / 0.1319 ms per step in place / through the apply; C3 Adagrad 0.612 / 0.695, C3 Adam 0.90 / 1.15)
         return 2 if (can and window and (2 + self.eta_total) * B > GRAPH_MAX_ROWS) else 0
 
+    def _settle_deferred(self, B):
+        """decide, BEFORE the in-place form is chosen from it, whether the deferred dense pass can go on with scratch for B positives
+        (it lives in the plan's step and walks the counting / bucket grouping's descriptors); if it ends after steps have run, the
+        lagging rows and their state are brought up to date first"""
+        if not self.deferred:
+            return
+        ok = not (self.sharded or self.batch_sharded or self.X is None or os.environ.get("EMG_PY_PLAN"))
+        ok = ok and bool(L.load().emg_plan_deferred_ok(B, self.eta_total, self.n_ent, self.n_rel))
+        if not ok:
+            self.materialize()
+            self.deferred = False
+
     def _alloc_scratch(self, B):
         if B <= self._cap:
             return
+        self._settle_deferred(B)
         self.inplace_mode = self._choose_inplace(B)
         if self.inplace_mode == 2 and (self.sharded or os.environ.get("EMG_PY_PLAN")):
             self.inplace_mode = 1      # (the window form is the plan's; host-driven steps keep the chunk-wise form)
@@ -330,6 +343,7 @@ class Trainer:
             L.check(L.load().emg_plan_destroy(self.plan), "emg_plan_destroy")
             self.plan = None
         if self.sharded or self.batch_sharded or self.X is None or os.environ.get("EMG_PY_PLAN"):
+            self.materialize()      # (no-op unless deferred steps have run)
             self.deferred = False   # (the deferred dense decay lives in the plan's step)
             return   # multi-GPU steps have a collective in the middle: driven from the host (see step / _compute)
         c = L.PlanConfig()
@@ -365,6 +379,7 @@ class Trainer:
         if self.deferred and not L.load().emg_plan_deferred_ok(self._cap, self.eta_total, self.n_ent, self.n_rel):
             # the catch-up walks the counting grouping's segment descriptors; a table far longer than a batch has gradient
             # rows (or EMG_GROUPING=sort) is grouped by the radix-sort backend: keep the dense pass there
+            self.materialize()
             self.deferred = False
         if self.deferred:
             if self._lr_t_hist is None:

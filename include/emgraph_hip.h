@@ -77,6 +77,8 @@ int emg_version(void);
 const char* emg_last_error(void);
 /* name of the compiled GPU target ("gfx950") */
 const char* emg_target(void);
+/* hash of the kernel sources the library was built from (the rocprofv3 evidence under profiles/ names the binary it measured) */
+const char* emg_source_hash(void);
 
 /* ---- K1+K2: fused embedding gather + score (replaces EmbeddingModel._lookup_embeddings
  * :490-533 followed by Model._fn; the predict() path :2132-2133). out[n] f32. */

@@ -10,7 +10,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${c}_score -o p -- $CMD2 > $OUT/${c}_score.log 2>&1
 done
 python3 - "$OUT" "${1:-gpurun_out/pmc_traffic.json}" "$CMD" "$CMD2" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections, os
+sys.path.insert(0, os.getcwd())
 out, dst, cmd, cmd2 = sys.argv[1:5]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -27,7 +28,7 @@ for k, v in agg.items():
     w = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
     res[k] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1), "dispatches": len(v["FETCH_SIZE"]),
               "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s` (C3, B=16384) and of "
+json.dump({"source_hash": __import__("emgraph_amd._lib", fromlist=["x"]).load().emg_source_hash().decode(), "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s` (C3, B=16384) and of "
            "`%s` (gather+score kernels alone on the 1M-entity table).  Values are KB per dispatch averaged over dispatches. "
            "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a "
            "wide coalesced 16 B/lane read); calibration kernel: prepare_ids_kernel reads 3*4*B = 196,608 B of triples and "
