@@ -32,13 +32,11 @@ namespace emg {
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 bool group_backend_counting(int64_t N, int64_t R) {
-    static const int forced = [] {
-        const char* e = getenv("EMG_GROUPING");   // A/B aid: "sort" = the radix-sort backend + window apply everywhere
-        if (!e) return 0;
-        return strcmp(e, "sort") == 0 ? 1 : (strcmp(e, "count") == 0 ? 2 : 0);
-    }();
-    if (forced == 1) return false;
-    if (forced == 2) return R < ((int64_t)1 << 31);
+    // A/B aid, read per call (tests switch it inside one process): "sort" = the radix-sort backend + window apply everywhere,
+    // "count" = the counting grouping whatever the table's size; anything else (unset, "bucket"): by size
+    const char* e = getenv("EMG_GROUPING");
+    if (e && strcmp(e, "sort") == 0) return false;
+    if (e && strcmp(e, "count") == 0) return R < ((int64_t)1 << 31);
     return R <= 16 * N + ((int64_t)1 << 20);
 }
 

@@ -117,7 +117,7 @@ CASES = {
     "two_sides": (4096, 5, (0, 1), 200_000, 300, "uniform"),
     "hubs": (16384, 6, (2,), 500_000, 50, "zipf"),
     "restricted_pool": (8192, 10, (2,), 300_000, 7, "pool"),
-    "tiny_batch_big_table": (37, 1, (1,), 2_000_000, 3, "uniform"),
+    "tiny_batch_big_table": (37, 1, (1,), 1_000_000, 3, "uniform"),      # (the largest table the counting layout takes for 111 rows)
     "one_relation": (5000, 2, (2,), 70_000, 1, "uniform"),
     "dense_small_rows": (20000, 30, (2,), 65_536, 2000, "uniform"),
     "big_batch_wide_chunks": (70000, 12, (2,), 400_000, 100, "uniform"),      # 980 k contributions: chunks of 2048 slots

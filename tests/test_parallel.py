@@ -236,8 +236,9 @@ def test_bench_runs_at_two_ranks_and_prints_both_plans(sharding):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    # (gloo announces its connections on stdout; RCCL does not — the contract's line is the LAST one, and the only JSON one)
+    assert len([ln for ln in lines if ln.startswith("{")]) == 1 and lines[-1].startswith("{") and len(lines[-1]) < 4096, out.stdout[-2000:]
+    d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     want = {"k", "batch"} if sharding == "both" else {sharding}
     assert set(d["plans"]) == want and d["plan"] in want
