@@ -512,6 +512,90 @@ def test_training_steps_vs_oracle_at_c3_exact_shape(world, opt):
         Ep, Rp = E1, R1
 
 
+@pytest.mark.parametrize("form", ["adagrad", "momentum", "sgd_lp2_deferred", "sgd_b131072"])
+def test_training_steps_vs_oracle_at_c3_shape_stateful_lp_and_large_batch(world, form):
+    """the seams round 4's review named: the WINDOW forms of Adagrad / momentum (ip 4: state rows of singleton negatives
+    travelling with their table rows in the scoring kernel, adagrad.py:30-46 / momentum.py:51-69), SGD + the LP regulariser with
+    its dense pass DEFERRED (C3r: lp.py:107-113 folded into the step, singletons in place, emg_deferred_catchup for the rest) and
+    one step at B = 131 072 (SURVEY 8d's second batch size; the bucket grouping's wide-chunk form) — each against
+    orc.train_grads_sparse (float64 gradient rows of EmbeddingModel.py:614-822's loss, grouped by destination) and the optimizer
+    rules restated from the reference, at |E| = 1M, k = 200, eta = 20.  Loss rtol 2e-5, gradients rtol 1e-4 (+ 1e-5 of the largest)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import ADAGRAD_INIT_ACC, DEFAULT_MOMENTUM, Trainer
+    from oracle import emgraph_oracle as orc
+    ent, rel, _, pos = world
+    E0, R0 = ent[:, :K_INT].cpu().numpy(), rel[:, :K_INT].cpu().numpy()
+    rs = np.random.RandomState(33)
+    Bt = 131072 if form == "sgd_b131072" else B
+    n_steps = 1 if form == "sgd_b131072" else 2
+    X = np.stack([rs.randint(0, N_ENT, n_steps * Bt), rs.randint(0, N_REL, n_steps * Bt), rs.randint(0, N_ENT, n_steps * Bt)], 1).astype(np.int32)
+    opt = form if form in ("adagrad", "momentum") else "sgd"
+    lam, lp_p = 1e-5, 2
+    lr = {"adagrad": 0.05, "momentum": 0.02}.get(form, 0.05)
+    kw = dict(regularizer="LP", regularizer_params={"lambda": lam, "p": lp_p}) if form == "sgd_lp2_deferred" else {}
+    tr = Trainer(L.COMPLEX, K_INT, 1.0, E0, R0, ETA, loss="nll", optimizer=opt, optimizer_params={"lr": lr}, batches_count=n_steps, seed=0, **kw)
+    tr.set_training_set(X, Bt)
+    assert tr.fused and tr.inplace, (tr.fused, tr.inplace)
+    if form in ("adagrad", "momentum"):
+        assert tr.inplace_mode == 2            # the window form (ip 4)
+    if form == "sgd_lp2_deferred":
+        assert tr.deferred                     # the dense regulariser pass is replayed on demand (C3r)
+    ulp = 2.0 ** -23
+    Ep, Rp = E0, R0
+    state_prev = {"ent": None, "rel": None}
+    for b in range(n_steps):
+        xb = X[b * Bt:(b + 1) * Bt]
+        xneg = orc.generate_corruptions_for_fit_philox(xb, eta=ETA, corrupt_side="s,o", entities_size=N_ENT, seed=0, counter=b)
+        if opt != "sgd":
+            for tab, st in (("ent", tr.state_ent), ("rel", tr.state_rel)):
+                state_prev[tab] = st[0].cpu().numpy()[:, :K_INT].copy()
+        tr.step(b * Bt, Bt, epoch=1, batch=b + 1, prefetch=[(Bt, Bt, 1, 2)] if (b == 0 and n_steps > 1) else None)
+        loss = tr.read_loss()
+        E1, R1 = tr.tables_numpy()
+        ue, ge, ur, gr, oloss = orc.train_grads_sparse("ComplEx", Ep, Rp, xb, ETA, "nll", None, [xneg])
+        if form == "sgd_lp2_deferred":       # + lambda * sum |w|^p over the FULL tables as they were before the step (lp.py:107-113)
+            oloss += lam * (float(np.sum(np.abs(Ep.astype(np.float64)) ** lp_p)) + float(np.sum(np.abs(Rp.astype(np.float64)) ** lp_p)))
+        assert loss == pytest.approx(oloss, rel=2e-5), (b, loss, oloss)
+        for tab, ids, g, W0, W1, state in (("ent", ue, ge, Ep, E1, tr.state_ent), ("rel", ur, gr, Rp, R1, tr.state_rel)):
+            gmax = np.abs(g).max()
+            gtol = 1e-4 * np.abs(g) + 1e-5 * gmax
+            untouched = np.ones(W0.shape[0], bool)
+            untouched[ids] = False
+            w0 = W0[ids].astype(np.float64)
+            if form == "sgd_lp2_deferred":
+                # every row moves by the regulariser's gradient lambda p |w|^(p-1) sgn(w); touched rows by the loss's as well
+                reg_g = lam * lp_p * np.abs(w0) ** (lp_p - 1) * np.sign(w0)
+                want = w0 - lr * (g + reg_g)
+                assert np.all(np.abs(W1[ids] - want) <= lr * gtol + 2 * ulp * np.abs(w0)), (tab, b)
+                wu = W0[untouched].astype(np.float64)
+                want_u = wu - lr * lam * lp_p * np.abs(wu) ** (lp_p - 1) * np.sign(wu)
+                assert np.all(np.abs(W1[untouched] - want_u) <= 2 * ulp * np.abs(wu) + 1e-12), (tab, b)
+                assert not untouched.any() or not np.array_equal(W1[untouched], W0[untouched])
+                continue
+            np.testing.assert_array_equal(W1[untouched], W0[untouched])
+            if opt == "sgd":
+                want = w0 - lr * g
+                assert np.all(np.abs(W1[ids] - want) <= lr * gtol + ulp * np.abs(w0)), (tab, b, float(np.max(np.abs(W1[ids] - want))))
+                continue
+            s0 = state_prev[tab][ids].astype(np.float64)
+            s1 = state[0].cpu().numpy()[:, :K_INT]
+            np.testing.assert_array_equal(s1[untouched], state_prev[tab][untouched])      # row-sparse state: untouched rows keep theirs
+            s1 = s1[ids].astype(np.float64)
+            if opt == "momentum":    # Keras SGD(momentum): v = mu v - lr g ; w += v   (momentum.py:51-69)
+                want_s = DEFAULT_MOMENTUM * s0 - lr * g
+                assert np.all(np.abs(s1 - want_s) <= lr * gtol + 2 * ulp * np.abs(want_s) + 2 * ulp * np.abs(s0)), (tab, b)
+                assert np.all(np.abs(W1[ids] - (w0 + s1)) <= ulp * (np.abs(w0) + np.abs(s1))), (tab, b)
+            else:                    # Adagrad: acc += g^2 ; w -= lr g / (sqrt(acc) + eps)   (adagrad.py:30-46)
+                if b == 0:
+                    assert np.all(s0 == np.float32(ADAGRAD_INIT_ACC))
+                want_s = s0 + g * g
+                assert np.all(np.abs(s1 - want_s) <= 2 * np.abs(g) * gtol + 2 * ulp * want_s), (tab, b)
+                step = lr * g / (np.sqrt(s1) + 1e-7)           # from the device's accumulator: the step is a smooth function of g
+                tol = lr * gtol / (np.sqrt(s1) + 1e-7) + 4 * ulp * np.abs(step) + ulp * np.abs(w0)
+                assert np.all(np.abs(W1[ids] - (w0 - step)) <= tol), (tab, b, float(np.max(np.abs(W1[ids] - (w0 - step)) / tol)))
+        Ep, Rp = E1, R1
+
+
 def test_ranks_assembled_by_the_literal_oracle_at_one_million_entities(world):
     """the rank ASSEMBLY of the reference (EmbeddingModel.py:1856-1986: eval corruptions, filter lookups, perform_comparision, rank =
     cmp(all) + 1 - cmp(filter_s) - cmp(filter_o)) done by oracle.emgraph_oracle.rank_triple — its own generate_corruptions_for_eval,
