@@ -135,6 +135,8 @@ SIGNATURES.update({
     "emg_eval_prefilter_max_cols": (_i32, []),
     "emg_eval_rescore_pairs_rows": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _i32, _i32, _p, _p, _p]),
     "emg_eval_prefilter_ld": (_i64, [_i32]),
+    "emg_eval_rescore_tiles_ws_bytes": (_i64, [_i64]),
+    "emg_eval_rescore_pairs_tiles": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "emg_eval_rescore_pairs": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _p, _p, _p]),
     "emg_eval_rescore_pairs_ex": (_int, [_int, _p, _i64, _p, _p, _i64, _i64, _i32, _f32, _p, _i64, _p, _i64, _i32, _p, _p, _p]),
     "emg_to_f16_l2": (_int, [_p, _i64, _i64, _i32, _int, _p, _i64, _p, _p, _p]),

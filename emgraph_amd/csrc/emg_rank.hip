@@ -693,12 +693,30 @@ __global__ __launch_bounds__(256) void rescore_pairs_kernel(const RescoreParams 
 #ifndef RQ_ABLATE
 #define RQ_ABLATE 0   // timing experiments only (wrong results): 1 no entity loads, 2 no LDS staging / chain
 #endif
+#ifndef RQ_NPF
+#define RQ_NPF 2
+#endif
 constexpr int RQ_ROWS = 32;        // query rows of a segment (one wave of count_mfma_bf16_v3_kernel)
 constexpr int RQ_MIN_PAIRS = 512;  // shorter segments go to rescore_pairs_kernel: a workgroup's eight waves need a batch of 64 each
 constexpr int RQ_KC = 32, RQ_LD = RQ_KC + 4;   // 32-float slices: every request a whole 128-byte line (16-float slices: PMC 77 B / request)
 
 // RQ_WAVES = 8 up to ~570 columns; 4 where the image of wider rows leaves room for four staging regions only (<= 830)
 static inline size_t rescore_segment_lds(int k_int, int waves) { return ((size_t)RQ_ROWS * (k_int + 4) + (size_t)waves * 64 * RQ_LD) * sizeof(float); }
+
+// Asynchronous 16-byte row loads with a hand-counted wait (as emg_score_kernels.hpp's rolling window): compiler-visible loads under
+// the slice loop's conditions made every wait s_waitcnt vmcnt(0) — the ISA of round 4's kernels: ONE slice in flight per wave, each
+// slice a full L2 round trip (1.4 us at C4's size: 13 slices x 221 batches per wave = the kernel's 4 ms).  Here the loads are
+// inline assembly, unconditional (past the row's end: its last piece again), every consumed slice issues exactly one refill, and
+// the wait before slice j is vmcnt(8 (NPF - 1)): only the NPF - 1 younger slices may still be in flight.
+typedef float rq_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rq_f4 rq_load16(const float* p) {
+    rq_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void rq_wait(rq_f4 (&a)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "n"(N) : "memory");
+}
 
 template <int KIND, int RQ_WAVES>
 __global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const RescoreParams P) {
@@ -751,7 +769,7 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const Re
     __syncthreads();
 
     const int sub = lane >> 3, part = lane & 7;   // loader role: pair (8 it + sub) of the wave's 64, 16-byte piece `part` of a slice
-    constexpr int NPF = 2;                        // entity slices in flight per wave beside the one being multiplied
+    constexpr int NPF = RQ_NPF;                   // entity slices in flight per wave beside the one being multiplied
     for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n; c0 += RQ_THREADS) {
         const bool live = c0 + lane < n;
         int64_t row = rmin, e = 0;
@@ -767,26 +785,41 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const Re
         for (int it = 0; it < 8; ++it) ep[it] = P.ent + __shfl(e, 8 * it + sub, 64) * P.ld_ent + 4 * part;
         const float* const ql = qrows + (int)(row - rmin) * ldq_s;   // staged: this pair's query row in the LDS image
         const float* const qg = P.Q + row * P.ldq;                   // otherwise (rows outside one 32-row span): read in place
-        float4 ev[NPF][8];
-        auto fetch = [&](int k0, float4 (&evs)[8]) {   // k_int % 4 == 0: a 4-float piece is whole or absent
-            const bool pin = k0 + 4 * part < P.k_int;
+        static_assert(8 * (NPF - 1) <= 63, "vmcnt is a 6-bit counter");
+        rq_f4 ev[NPF][8];
+        const int k_last = ((P.k_int - 1) / RQ_KC) * RQ_KC;   // start of the row's last slice
+        auto fetch = [&](int k0, rq_f4 (&evs)[8]) {   // k_int % 4 == 0; past the row's end: its last piece again (never multiplied)
+            const int kk = min(min(k0, k_last) + 4 * part, P.k_int - 4) - 4 * part;   // (the row pointers carry the lane's piece already)
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                evs[it] = (pin && !(RQ_ABLATE & 1)) ? *reinterpret_cast<const float4*>(ep[it] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < 8; ++it) evs[it] = rq_load16(ep[it] + kk);
         };
         float acc = 0.f;
-        auto slice = [&](int k0, float4 (&evs)[8]) {
-            if (RQ_ABLATE & 2) {
-                acc += evs[0].x + evs[1].y + evs[2].z + evs[3].w + evs[4].x + evs[5].y + evs[6].z + evs[7].w;
-                if (k0 + NPF * RQ_KC < P.k_int) fetch(k0 + NPF * RQ_KC, evs);
-                return;
-            }
+        auto slice = [&](int k0, rq_f4 (&evs)[8]) {
+            rq_wait<8 * (NPF - 1)>(evs);   // this slice has landed; the NPF - 1 younger ones fly on
             wave_lds_sync();   // the previous slice has been consumed by every lane
 #pragma unroll
-            for (int it = 0; it < 8; ++it) *reinterpret_cast<float4*>(mye + (8 * it + sub) * RQ_LD + 4 * part) = evs[it];
+            for (int it = 0; it < 8; ++it) *reinterpret_cast<rq_f4*>(mye + (8 * it + sub) * RQ_LD + 4 * part) = evs[it];
             wave_lds_sync();
-            if (k0 + NPF * RQ_KC < P.k_int) fetch(k0 + NPF * RQ_KC, evs);   // NPF slices ahead of the chain
+            fetch(k0 + NPF * RQ_KC, evs);   // the refill, unconditional: NPF slices ahead of the chain
             const int kn = min(RQ_KC, P.k_int - k0);
+            // A whole slice (all but a row's last): straight-line code — its sixteen LDS reads are issued together and waited for
+            // ONCE.  With the per-chunk guard below hipcc put a branch and an s_waitcnt lgkmcnt(0) in front of every four chain
+            // steps: eight exposed LDS round trips per slice, which was the kernel's time (round 5: neither deeper prefetch nor
+            // conflict-free reads nor L2-resident rows changed it)
+            if (kn == RQ_KC && staged) {
+                float4 a[RQ_KC / 4], b2[RQ_KC / 4];
+#pragma unroll
+                for (int c = 0; c < RQ_KC / 4; ++c) {
+                    a[c] = *reinterpret_cast<const float4*>(ql + k0 + 4 * c);
+                    b2[c] = *reinterpret_cast<const float4*>(mye + lane * RQ_LD + 4 * c);
+                }
+#pragma unroll
+                for (int c = 0; c < RQ_KC / 4; ++c) {
+                    acc = chain_step<KIND>(a[c].x, b2[c].x, acc); acc = chain_step<KIND>(a[c].y, b2[c].y, acc);
+                    acc = chain_step<KIND>(a[c].z, b2[c].z, acc); acc = chain_step<KIND>(a[c].w, b2[c].w, acc);
+                }
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < RQ_KC / 4; ++c) {
                 if (4 * c < kn) {
@@ -798,13 +831,14 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const Re
             }
         };
 #pragma unroll
-        for (int u = 0; u < NPF; ++u)
-            if (u * RQ_KC < P.k_int) fetch(u * RQ_KC, ev[u]);
+        for (int u = 0; u < NPF; ++u) fetch(u * RQ_KC, ev[u]);
         for (int k0 = 0; k0 < P.k_int; k0 += NPF * RQ_KC) {
 #pragma unroll
             for (int u = 0; u < NPF; ++u)
                 if (k0 + u * RQ_KC < P.k_int) slice(k0 + u * RQ_KC, ev[u]);
         }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) rq_wait<0>(ev[u]);   // refills never taken: their registers stay theirs until the loads have landed
         if (live) {
             if (!staged) rescore_finish(P, row, acc);
             else {
@@ -822,6 +856,188 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void rescore_segment_kernel(const Re
             if (s_gt[tid]) atomicAdd(&P.cnt_gt[rmin + tid], s_gt[tid]);
             if (s_eq[tid]) atomicAdd(&P.cnt_eq[rmin + tid], s_eq[tid]);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ENTITY-TILE-MAJOR re-scoring (round 5).  The segment form above keeps 32 query rows in LDS and streams an entity row per pair:
+// 59 M pairs x 1600 B at C4's size, of which 22 % miss L2 (the table is 1.6 GB) — 20 GB from HBM per 8192 query rows.  Here the
+// pairs are first bucketed by TILE of 32 entity rows (the prefilter's segments list them tile by tile, so runs of a tile take
+// ONE atomic: histogram | scan | scatter, 0.5 GB read and written), then one workgroup per tile keeps the tile's 32 entity rows
+// in LDS and streams the QUERY rows of its pairs — the query matrix of a call is 13 MB: every streamed byte comes from L2 / MALL.
+// Same chain, same comparison; counters are integers, so the order of the additions is free.
+// ---------------------------------------------------------------------------------------------
+constexpr int RT_TILE_LOG = 5;   // 32 entity rows per tile = RQ_ROWS (the LDS image)
+struct TileParams {
+    RescoreParams R; int64_t n_local; uint32_t n_tiles;
+    uint32_t *tcnt, *toff, *cursor; uint64_t* sorted; uint64_t sorted_cap;
+};
+
+// runs of equal tile among the 64 pairs a wave holds (a segment lists its pairs tile by tile): the run's first lane acts for it
+__device__ __forceinline__ void tile_runs(bool live, uint32_t tile, int lane, bool* head, int* head_lane, uint32_t* run) {
+    const uint32_t prev = __shfl_up(tile, 1, 64);
+    const bool prev_live = __shfl_up((int)live, 1, 64) != 0;
+    *head = live && (lane == 0 || !prev_live || tile != prev);
+    const unsigned long long hm = __ballot(*head), lm = __ballot(live);
+    const unsigned long long below = hm & ((2ull << lane) - 1ull);            // heads at or below this lane
+    *head_lane = below ? 63 - __clzll((long long)below) : 0;
+    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+    // the run ends at the next head, or at the first dead lane above (live lanes need not be a prefix: a short last batch is)
+    const unsigned long long dead_above = lane == 63 ? 0ull : ((~lm) >> (lane + 1));
+    const unsigned long long stop = above | dead_above;
+    *run = (uint32_t)(stop ? __ffsll((long long)stop) : 64 - lane);
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void tile_sort_kernel(const TileParams T) {
+    const RescoreParams& P = T.R;
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= P.n_seg) return;
+    const uint32_t n = min(P.seg_count[seg], P.cap);
+    const uint64_t* sp = P.pairs + (uint64_t)seg * P.cap;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const bool live = c0 + lane < n;
+        const uint64_t pr = live ? sp[c0 + lane] : 0ull;
+        const uint32_t el = (uint32_t)pr - (uint32_t)P.ent_offset;
+        const uint32_t tile = live ? el >> RT_TILE_LOG : 0xffffffffu;
+        bool head; int head_lane; uint32_t run;
+        tile_runs(live, tile, lane, &head, &head_lane, &run);
+        if constexpr (!SCATTER) {
+            if (head) atomicAdd(T.tcnt + tile, run);
+        } else {
+            uint32_t base = 0u;
+            if (head) base = atomicAdd(T.cursor + tile, run);
+            base = __shfl(base, head_lane, 64);
+            const uint64_t at = (uint64_t)base + (uint32_t)(lane - head_lane);
+            if (live && at < T.sorted_cap) T.sorted[at] = ((uint64_t)el << 32) | (pr >> 32);   // (local entity row, query row)
+        }
+    }
+}
+
+// exclusive offsets of the tiles' stretches (one workgroup: the tile counts of 1M entities are 31 k words)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const TileParams T) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < T.n_tiles; base += 1024u * 8u) {
+        uint32_t c[8], sum = 0u;
+        const uint32_t i0 = base + threadIdx.x * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c[j] = i0 + j < T.n_tiles ? T.tcnt[i0 + j] : 0u; sum += c[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t pre = s_carry, tot = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t v = s_w[w]; if (w < wv) pre += v; tot += v; }
+        uint32_t run = pre + inc - sum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i0 + j < T.n_tiles) { T.toff[i0 + j] = run; T.cursor[i0 + j] = run; T.tcnt[i0 + j] = 0u; }   // (the counts return to zero)
+            run += c[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) T.toff[T.n_tiles] = s_carry;
+}
+
+template <int KIND, int RQ_WAVES>
+__global__ __launch_bounds__(64 * RQ_WAVES) void rescore_tile_kernel(const TileParams T) {
+    constexpr int RQ_THREADS = 64 * RQ_WAVES;
+    const RescoreParams& P = T.R;
+    extern __shared__ __attribute__((aligned(16))) float rq_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lde_s = P.k_int + 4;
+    float* const erows = rq_lds;
+    float* const myq = rq_lds + RQ_ROWS * lde_s + wave * (64 * RQ_LD);
+    const uint32_t tile = blockIdx.x;
+    const uint64_t p0 = T.toff[tile], p1 = min((uint64_t)T.toff[tile + 1], T.sorted_cap);
+    if (p1 <= p0) return;
+    const uint32_t n = (uint32_t)(p1 - p0);
+    const uint64_t* sp = T.sorted + p0;
+    const int64_t e_first = (int64_t)tile << RT_TILE_LOG;
+    const int nrows = (int)min((int64_t)RQ_ROWS, T.n_local - e_first);
+    {   // the tile's entity rows: read once
+        const int pieces = P.k_int >> 2;
+        for (int t = tid; t < nrows * pieces; t += RQ_THREADS) {
+            const int r = t / pieces, c = t - r * pieces;
+            *reinterpret_cast<float4*>(erows + r * lde_s + 4 * c) = *reinterpret_cast<const float4*>(P.ent + (e_first + r) * P.ld_ent + 4 * c);
+        }
+    }
+    __syncthreads();
+    const int sub = lane >> 3, part = lane & 7;   // loader role: pair (8 it + sub) of the wave's 64, 16-byte piece `part` of a slice
+    constexpr int NPF = RQ_NPF;                   // query slices in flight per wave beside the one being multiplied
+    for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n; c0 += RQ_THREADS) {
+        const bool live = c0 + lane < n;
+        int64_t row = 0;
+        int er = 0;
+        if (live) {
+            const uint64_t pr = sp[c0 + lane];
+            row = (int64_t)(uint32_t)pr;
+            er = (int)((pr >> 32) - (uint64_t)e_first);
+        }
+        const float* qp[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) qp[it] = P.Q + __shfl(row, 8 * it + sub, 64) * P.ldq + 4 * part;
+        const float* const el = erows + er * lde_s;   // this pair's entity row in the LDS image
+        static_assert(8 * (NPF - 1) <= 63, "vmcnt is a 6-bit counter");
+        rq_f4 qv[NPF][8];
+        const int k_last = ((P.k_int - 1) / RQ_KC) * RQ_KC;   // start of the row's last slice
+        auto fetch = [&](int k0, rq_f4 (&qs)[8]) {   // k_int % 4 == 0; past the row's end: its last piece again (never multiplied)
+            const int kk = min(min(k0, k_last) + 4 * part, P.k_int - 4) - 4 * part;   // (the row pointers carry the lane's piece already)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) qs[it] = rq_load16(qp[it] + kk);
+        };
+        float acc = 0.f;
+        auto slice = [&](int k0, rq_f4 (&qs)[8]) {
+            rq_wait<8 * (NPF - 1)>(qs);   // this slice has landed; the NPF - 1 younger ones fly on
+            wave_lds_sync();   // the previous slice has been consumed by every lane
+#pragma unroll
+            for (int it = 0; it < 8; ++it) *reinterpret_cast<rq_f4*>(myq + (8 * it + sub) * RQ_LD + 4 * part) = qs[it];
+            wave_lds_sync();
+            fetch(k0 + NPF * RQ_KC, qs);   // the refill, unconditional: NPF slices ahead of the chain
+            const int kn = min(RQ_KC, P.k_int - k0);
+            if (kn == RQ_KC) {   // a whole slice: sixteen LDS reads issued together, one wait (see rescore_segment_kernel)
+                float4 a[RQ_KC / 4], b2[RQ_KC / 4];
+#pragma unroll
+                for (int c = 0; c < RQ_KC / 4; ++c) {
+                    a[c] = *reinterpret_cast<const float4*>(myq + lane * RQ_LD + 4 * c);
+                    b2[c] = *reinterpret_cast<const float4*>(el + k0 + 4 * c);
+                }
+#pragma unroll
+                for (int c = 0; c < RQ_KC / 4; ++c) {
+                    acc = chain_step<KIND>(a[c].x, b2[c].x, acc); acc = chain_step<KIND>(a[c].y, b2[c].y, acc);
+                    acc = chain_step<KIND>(a[c].z, b2[c].z, acc); acc = chain_step<KIND>(a[c].w, b2[c].w, acc);
+                }
+                return;
+            }
+#pragma unroll
+            for (int c = 0; c < RQ_KC / 4; ++c) {
+                if (4 * c < kn) {
+                    const float4 a = *reinterpret_cast<const float4*>(myq + lane * RQ_LD + 4 * c);
+                    const float4 b2 = *reinterpret_cast<const float4*>(el + k0 + 4 * c);
+                    acc = chain_step<KIND>(a.x, b2.x, acc); acc = chain_step<KIND>(a.y, b2.y, acc);
+                    acc = chain_step<KIND>(a.z, b2.z, acc); acc = chain_step<KIND>(a.w, b2.w, acc);
+                }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) fetch(u * RQ_KC, qv[u]);
+        for (int k0 = 0; k0 < P.k_int; k0 += NPF * RQ_KC) {
+#pragma unroll
+            for (int u = 0; u < NPF; ++u)
+                if (k0 + u * RQ_KC < P.k_int) slice(k0 + u * RQ_KC, qv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) rq_wait<0>(qv[u]);   // refills never taken: their registers stay theirs until the loads have landed
+        if (live) rescore_finish(P, row, acc);
     }
 }
 
@@ -1370,6 +1586,70 @@ extern "C" int emg_eval_rescore_pairs_rows(int model, const float* Q, int64_t ld
     } else {
         if (vec) hipLaunchKernelGGL((rescore_pairs_kernel<true, 0>), grid, block, 0, st, P);
         else hipLaunchKernelGGL((rescore_pairs_kernel<false, 0>), grid, block, 0, st, P);
+    }
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
+extern "C" int64_t emg_eval_rescore_tiles_ws_bytes(int64_t n_local) {
+    if (n_local <= 0) return 256;
+    const int64_t n_tiles = cdiv(n_local, (int64_t)1 << RT_TILE_LOG);
+    return 3 * 4 * (n_tiles + 64) + 256;
+}
+
+extern "C" int emg_eval_rescore_pairs_tiles(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                            int64_t ld_ent, int64_t ent_offset, int64_t n_local, int32_t k_int, float scale,
+                                            const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count,
+                                            int64_t n_segments, uint64_t* sorted, int64_t sorted_capacity, void* tile_ws,
+                                            int64_t tile_ws_bytes, int32_t* cnt_gt, int32_t* cnt_eq, void* stream) {
+    EMG_REQUIRE(model >= EMG_TRANSE_L1 && model <= EMG_HOLE, "emg_eval_rescore_pairs_tiles: unknown model id %d", model);
+    EMG_REQUIRE(Q && pos_int && ent && pairs && pair_count && cnt_gt && cnt_eq && sorted && tile_ws, "emg_eval_rescore_pairs_tiles: null pointer");
+    if (n_segments <= 0 || n_local <= 0) return EMG_OK;
+    EMG_REQUIRE(pairs_capacity >= n_segments && sorted_capacity >= pairs_capacity, "emg_eval_rescore_pairs_tiles: pair buffers too small");
+    EMG_REQUIRE(tile_ws_bytes >= emg_eval_rescore_tiles_ws_bytes(n_local), "emg_eval_rescore_pairs_tiles: tile workspace too small (must be zero on first use)");
+    EMG_REQUIRE(n_local < ((int64_t)1 << 32), "emg_eval_rescore_pairs_tiles: too many entities");
+    const bool vec = (k_int % 4 == 0) && (ldq % 4 == 0) && (ld_ent % 4 == 0) && aligned16(Q) && aligned16(ent);
+    const int waves = rescore_segment_lds(k_int, 8) <= 144 * 1024 ? 8 : (rescore_segment_lds(k_int, 4) <= 144 * 1024 ? 4 : 0);
+    if (!vec || !waves) return fail(EMG_ENOSUP, "emg_eval_rescore_pairs_tiles: needs 16-byte aligned rows whose 32-row image fits LDS");
+    TileParams T{};
+    RescoreParams& P = T.R;
+    P.model = model; P.Q = Q; P.ldq = ldq; P.pos_int = pos_int; P.ent = ent; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
+    P.k_int = k_int; P.scale = scale; P.pairs = pairs; P.cap = (uint32_t)(pairs_capacity / n_segments);
+    P.seg_count = pair_count; P.n_seg = (uint32_t)n_segments; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq;
+    T.n_local = n_local; T.n_tiles = (uint32_t)cdiv(n_local, (int64_t)1 << RT_TILE_LOG);
+    T.tcnt = (uint32_t*)tile_ws; T.toff = T.tcnt + T.n_tiles + 64; T.cursor = T.toff + T.n_tiles + 64;
+    T.sorted = sorted; T.sorted_cap = (uint64_t)sorted_capacity;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 sgrid((unsigned)cdiv(n_segments, 4)), sblock(256);
+    hipLaunchKernelGGL(tile_sort_kernel<false>, sgrid, sblock, 0, st, T);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, T);
+    hipLaunchKernelGGL(tile_sort_kernel<true>, sgrid, sblock, 0, st, T);
+    EMG_LAUNCH_CHECK();
+    const size_t lds = rescore_segment_lds(k_int, waves);
+    const int kind = model == EMG_TRANSE_L1 ? 1 : (model == EMG_TRANSE_L2 ? 2 : 0);
+    static std::atomic<uint64_t> done[6];
+    const void* fn8[3] = {(const void*)rescore_tile_kernel<0, 8>, (const void*)rescore_tile_kernel<1, 8>, (const void*)rescore_tile_kernel<2, 8>};
+    const void* fn4[3] = {(const void*)rescore_tile_kernel<0, 4>, (const void*)rescore_tile_kernel<1, 4>, (const void*)rescore_tile_kernel<2, 4>};
+    const void* fn = waves == 8 ? fn8[kind] : fn4[kind];
+    if (lds > 48 * 1024) {   // opt in to > 64 KB of dynamic LDS once per device and kernel
+        int dev = 0;
+        EMG_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        std::atomic<uint64_t>& flag = done[kind + (waves == 8 ? 0 : 3)];
+        if (!(flag.load(std::memory_order_acquire) & bit)) {
+            EMG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            flag.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    const dim3 tgrid(T.n_tiles), tblock(64 * waves);
+    if (waves == 8) {
+        if (kind == 1) hipLaunchKernelGGL((rescore_tile_kernel<1, 8>), tgrid, tblock, lds, st, T);
+        else if (kind == 2) hipLaunchKernelGGL((rescore_tile_kernel<2, 8>), tgrid, tblock, lds, st, T);
+        else hipLaunchKernelGGL((rescore_tile_kernel<0, 8>), tgrid, tblock, lds, st, T);
+    } else {
+        if (kind == 1) hipLaunchKernelGGL((rescore_tile_kernel<1, 4>), tgrid, tblock, lds, st, T);
+        else if (kind == 2) hipLaunchKernelGGL((rescore_tile_kernel<2, 4>), tgrid, tblock, lds, st, T);
+        else hipLaunchKernelGGL((rescore_tile_kernel<0, 4>), tgrid, tblock, lds, st, T);
     }
     EMG_LAUNCH_CHECK();
     return EMG_OK;

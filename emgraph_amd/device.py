@@ -604,6 +604,26 @@ def eval_rescore_pairs(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pair
                                             _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs_rows")
 
 
+def eval_rescore_pairs_tiles(model_id, Q, pos_int, ent, ent_offset, k_int, scale, pairs, pair_count, n_seg, sorted_pairs, tile_ws,
+                             cnt_gt, cnt_eq):
+    """entity-tile-major re-scoring of the prefilter's undecided pairs (include/emgraph_hip.h): pairs bucketed by tile of 32
+    entity rows, the tile's rows in LDS, query rows streamed; ``sorted_pairs``: int64 scratch of pairs.numel() entries,
+    ``tile_ws``: uint8 scratch of rescore_tiles_ws_bytes(rows of ent), zero before its first use"""
+    lib = L.load()
+    pq, n_rows, ldq = _chk_table(Q, "Q")
+    pe, ne, lde = _chk_table(ent, "ent")
+    L.check(lib.emg_eval_rescore_pairs_tiles(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows), pe, lde, ent_offset, ne,
+                                             k_int, scale, _chk_vec(pairs, torch.int64, "pairs"), pairs.numel(),
+                                             _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1), n_seg,
+                                             _chk_vec(sorted_pairs, torch.int64, "sorted_pairs"), sorted_pairs.numel(),
+                                             tile_ws.data_ptr(), tile_ws.numel(), _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                             _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows), _stream()), "emg_eval_rescore_pairs_tiles")
+
+
+def rescore_tiles_ws_bytes(n_local):
+    return int(L.load().emg_eval_rescore_tiles_ws_bytes(n_local))
+
+
 def to_f16_l2(src, k_int, is_query, ld_dst=None):
     """half rows of the TransE-L2 contraction (include/emgraph_hip.h): entity rows [e | n_hi | n_lo] -> (rows, residual
     max as 1 float64 on the device); query rows [2q | -1 | -1] -> (rows, the f32 rows 2q)"""

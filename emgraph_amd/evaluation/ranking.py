@@ -323,6 +323,38 @@ def _pair_buffer(device, n_seg):
     return buf[0][:cap], buf[1][:n_seg + 1]
 
 
+_tile_buffers = {}
+
+
+def _tile_buffers_for(device, pairs, n_local):
+    """(sorted pairs int64 [pairs.numel()], tile workspace uint8) scratch of the tile-major re-scoring, cached per device; the
+    workspace is zero between calls (the library leaves it so)"""
+    key = (device.type, device.index)
+    buf = _tile_buffers.get(key)
+    need = D.rescore_tiles_ws_bytes(n_local)
+    if buf is None or buf[0].numel() < pairs.numel() or buf[1].numel() < need:
+        buf = (torch.empty(pairs.numel(), dtype=torch.int64, device=device), torch.zeros(need, dtype=torch.uint8, device=device))
+        _tile_buffers[key] = buf
+    return buf[0][:pairs.numel()], buf[1]
+
+
+def _rescore(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt, waves, rows):
+    """exact re-scoring of the prefilter's undecided pairs: segment-wise with the query rows in LDS (the default), or
+    entity-tile-major (EMG_RESCORE=tiles: the pairs bucketed by tile of 32 entity rows, the tile's rows in LDS, query rows
+    streamed).  Measured at C4's size (round 5, profiles/r5_*_pmc_rescore.txt): the segment form already finds 88 % of its
+    rows in L2 and both forms are bound by LDS instruction issue (4800 bytes through LDS per pair), so the tile form's L2
+    hits buy nothing: 19.2 against 17.1 ms per 8192 query rows."""
+    mode = os.environ.get("EMG_RESCORE", "segments")
+    if mode == "tiles" and rows == 32:
+        sorted_pairs, tile_ws = _tile_buffers_for(Q.device, pairs, slab.shape[0])
+        try:
+            D.eval_rescore_pairs_tiles(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, sorted_pairs, tile_ws, cnt[0], cnt[1])
+            return
+        except L.EmgError:   # rows that are not 16-byte aligned / an image that does not fit LDS: the segment form
+            pass
+    D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], waves, rows)
+
+
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
                         filter_triples=None, entities_subset=None, query_chunk=4096, precision=0, shard=None,
                         ent_bf16=None, stats=None, ent_f16=None):
@@ -460,8 +492,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1],
-                                     D.prefilter_waves(k_int + 2), 32)
+                _rescore(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt, D.prefilter_waves(k_int + 2), 32)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         elif precision == 2 and have_cands:
@@ -479,8 +510,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:
-                D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1],
-                                     D.prefilter_waves(k_int), 32)
+                _rescore(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt, D.prefilter_waves(k_int), 32)
                 _ev_stop(stats, ev)
                 pre = (torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]), count)
         if have_cands and pre is None:

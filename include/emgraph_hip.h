@@ -495,6 +495,19 @@ int emg_eval_rescore_pairs_rows(int model, const float* Q, int64_t ldq, const in
                                 int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments,
                                 int32_t segments_per_block, int32_t rows_per_segment, int32_t* cnt_gt, int32_t* cnt_eq,
                                 void* stream);
+/* ENTITY-TILE-MAJOR form of the re-scoring (round 5): the undecided pairs of all segments are bucketed by tile of 32 entity rows
+ * (histogram | scan | scatter into `sorted`, capacity >= pairs_capacity), then one workgroup per tile holds the tile's f32 rows in
+ * LDS and streams the query rows of its pairs — the query matrix of a call fits L2 / MALL where the entity table does not.  Same
+ * chain and comparison as emg_eval_rescore_pairs; n_local = rows of `ent`; tile_ws: emg_eval_rescore_tiles_ws_bytes(n_local)
+ * bytes, ZERO before its first use (the call leaves it zero).  EMG_ENOSUP for rows that are not 16-byte aligned or whose
+ * 32-row image does not fit LDS: use emg_eval_rescore_pairs_rows.  Replaces the same reference lines as emg_eval_rescore_pairs
+ * (EmbeddingModel.py:1856-1866, 2010-2033). */
+int64_t emg_eval_rescore_tiles_ws_bytes(int64_t n_local);
+int emg_eval_rescore_pairs_tiles(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
+                                 int64_t ld_ent, int64_t ent_offset, int64_t n_local, int32_t k_int, float scale,
+                                 const uint64_t* pairs, int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments,
+                                 uint64_t* sorted, int64_t sorted_capacity, void* tile_ws, int64_t tile_ws_bytes,
+                                 int32_t* cnt_gt, int32_t* cnt_eq, void* stream);
 int emg_eval_scores_dense_bf16(int model, const void* q_bf16, int64_t ldq, int64_t n_rows, const void* ent_bf16,
                                int64_t n_cand, int64_t ld_ent, const int32_t* cand, int32_t k_pad, float scale,
                                float* S, int64_t lds, void* stream);

@@ -283,8 +283,11 @@ def test_ranking_full_size_invariants(world):
     assert fast.min() >= 1
 
 
-def test_exact_fast_ranking_full_size_equals_exact(world):
-    """precision 2 (half-precision MFMA prefilter with a rigorous error band + exact re-scoring of the undecided
+@pytest.mark.parametrize("rescore", ["segments", "tiles"])
+def test_exact_fast_ranking_full_size_equals_exact(world, monkeypatch, rescore):
+    """(both forms of the exact re-scoring: segment-wise with the query rows in LDS — the default —, and entity-tile-major with
+    the pairs bucketed by tile of 32 entity rows, EMG_RESCORE=tiles)
+    precision 2 (half-precision MFMA prefilter with a rigorous error band + exact re-scoring of the undecided
     candidates) at |E| = 1M: ranks BIT-equal to the exact f32 path for all three strategies, filtered and raw, on
     the Glorot-scale tables of the training world (scores ~1e-4: most comparison integers tie at 0, the hardest case
     for a band-based prefilter — hundreds of thousands of undecided pairs) and on trained-scale tables."""
@@ -292,6 +295,7 @@ def test_exact_fast_ranking_full_size_equals_exact(world):
     from emgraph_amd.evaluation import FilterIndex, PrefilterTables, rank_triples_device
     from emgraph_amd.training import alloc_table
     ent, rel, pos_t, pos = world
+    monkeypatch.setenv("EMG_RESCORE", rescore)
     T = pos[:512]
     F = FilterIndex(pos[:200000])
     rs = np.random.RandomState(3)
