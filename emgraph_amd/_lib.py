@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE, TRANSE_P = range(6)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)

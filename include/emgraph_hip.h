@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 6
+#define EMG_ABI_VERSION 7
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */

@@ -1,14 +1,15 @@
 #!/usr/bin/env bash
-# Round 4's judged evidence in one call on the GPU box:  bash tools/profile_round4.sh TAG
+# Round 5's judged evidence in one call on the GPU box:  bash tools/profile_round5.sh TAG
 #   gpurun_out/TAG_bench.json                 python3 bench.py --gpus 1 --steps 20 --warmup 5          (the driver's command)
 #   gpurun_out/TAG_<wl>_kernel_stats.md       rocprofv3 --kernel-trace --stats of each workload ALONE (C3 C3a C3g C1 C2 C5)
 #   gpurun_out/TAG_pmc_traffic.json           tools/pmc_traffic.sh (C3: the file bench.py's roofline.traffic reads)
 #   gpurun_out/TAG_pmc_traffic_all.json       tools/pmc_traffic_all.sh (FETCH_SIZE / WRITE_SIZE of every kernel of C3 C3a C3g C1 C2 C5)
-TAG="${1:-r4_x}"
+TAG="${1:-r5_x}"
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-for wl in C3 C3a C3g C1 C2 C5; do
+cp bench_detail.json gpurun_out/${TAG}_bench_detail.json
+for wl in C3 C3a C3g C3r C1 C2 C5; do
   lw=$(echo $wl | tr 'A-Z' 'a-z')
   steps=100; [[ $wl == C1 || $wl == C2 || $wl == C5 ]] && steps=300
   bash tools/prof_quick.sh ${TAG}_$lw --workload $wl --steps $steps --warmup 20
