@@ -105,9 +105,13 @@ __device__ __forceinline__ IdOut slot_ids(const PrepParams& P, int64_t i, int64_
 // SMALL: chunks of kBucketChunkMin slots — a thread's four ids stay in registers between the histogram and the placement
 template <bool SMALL>
 __global__ __launch_bounds__(kBT) void bucket_ids_kernel(const PrepParams P, const BucketLaunch L) {
-    __shared__ uint32_t s_he[kBucketMaxNB + 1], s_hr[kBucketMaxNB + 1];
+    // dynamic LDS, sized for THIS batch's bucket counts (C3: 2 KB, not the 33 KB of two 4097-bin histograms): the workgroups start
+    // beside scoring workgroups that hold most of a CU's LDS (the window forms' stash)
+    extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_part[kBT / 64];
     const BucketTable &TE = L.t[0], &TR = L.t[1];
+    uint32_t* const s_he = s_hist;
+    uint32_t* const s_hr = s_hist + TE.nb + 1;
     const int64_t B = P.B, n_ce = L.n_ce;
     const int64_t per_side = (int64_t)P.eta * B;
     const unsigned c = blockIdx.x;
@@ -468,8 +472,9 @@ int bucket_prepare(const emg_prepare_args* a, const PrepStages& S, hipStream_t s
     L.B = a->B; L.n_ce = S.n_ce; L.cap_lds = cap_env; L.chunk_log = ge.chunk_log;   // (both tables in the entity table's chunks)
     const PrepParams P = S.prep;
     const unsigned nchunks = (unsigned)cdiv(S.n_ce, (int64_t)1 << ge.chunk_log);
-    if (ge.chunk_log == 10) hipLaunchKernelGGL(bucket_ids_kernel<true>, dim3(nchunks), dim3(kBT), 0, st, P, L);
-    else hipLaunchKernelGGL(bucket_ids_kernel<false>, dim3(nchunks), dim3(kBT), 0, st, P, L);
+    const size_t hist_lds = (size_t)(ge.nb + gr.nb + 2) * sizeof(uint32_t);   // (<= 2 x 4097 words: below the 64 KB that need no opt-in)
+    if (ge.chunk_log == 10) hipLaunchKernelGGL(bucket_ids_kernel<true>, dim3(nchunks), dim3(kBT), hist_lds, st, P, L);
+    else hipLaunchKernelGGL(bucket_ids_kernel<false>, dim3(nchunks), dim3(kBT), hist_lds, st, P, L);
     EMG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bucket_sort_kernel, dim3((unsigned)(ge.nb + gr.nb)), dim3(kBT), 0, st, L);
     EMG_LAUNCH_CHECK();
