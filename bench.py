@@ -278,7 +278,11 @@ class StepRunner:
                              "longest_segment": int(cnt.max().item()), "segments_over_64_rows": int((cnt > 64).sum().item())}
             ns = N_STATE[self.w["optimizer"]]
             for name, v in ms.items():
-                ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns, n_caught_up=(n_ue - n_single) + n_ur)
+                # rows the deferred catch-up brings up to date: every destination of the batch — except the singleton negatives' and
+                # singleton s / o rows under Adam's window form, which the scoring kernel replays itself (emg_plan.hip: lag_ip)
+                replayed_in_kernel = self.w["optimizer"] == "adam" and getattr(tr, "inplace_mode", 0) == 2
+                n_cu = ((n_ue - n_single) if replayed_in_kernel else n_ue) + n_ur
+                ab = algorithmic_bytes(name, B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns, n_caught_up=n_cu)
                 if name == "apply_ent" and "apply_rel" not in ms:   # pair apply: both tables in the same launches
                     ab += algorithmic_bytes("apply_rel", B, eta, self.k_local, n_ue, n_ur, n_single, ns=ns)
                 dense_here = name == "apply_ent" and self.w["optimizer"] == "adam" and not tr.deferred
@@ -289,8 +293,9 @@ class StepRunner:
                     out[name]["note"] = "entity + relation table through shared launches (emg_apply_grouped_pair)" + (
                         "; bytes include Adam's dense pass over the untouched rows (same launch for tables of <= 131072 rows)" if dense_here else "")
                 if name == "catchup":
-                    out[name]["note"] = ("emg_deferred_catchup of both tables; bytes = an upper bound (every destination the apply finishes; rows "
-                                         "already at the current step are skipped)")
+                    out[name]["note"] = ("emg_deferred_catchup of both tables; bytes = an upper bound (every destination it walks: all of the batch's, "
+                                         "minus the singletons Adam's window form replays in the scoring kernel; rows already at the current step "
+                                         "— ~30 % at C3 — are skipped)")
                 if getattr(tr, "factored", False) and tr.inplace and ns == 0 and name in ("fused", "apply_ent"):
                     flags = sl["single"][:n_ce]
                     n_s_so, n_s_neg = int(flags[:2 * B].sum().item()), int(flags[2 * B:].sum().item())

@@ -699,7 +699,7 @@ struct ReplayParams {
 };
 
 // one row, steps tag[r]+1 .. upto: what untouched_rows_body does to it in each of them (g = the regulariser's gradient alone).
-// OPT / LPK (0: no regulariser, 1: p in {1, 2, 3}, 2: any p) are compile-time: the replay is ALU work — as many row-steps as
+// OPT / LPK (0: no regulariser, 1: p in {1, 2, 3}, 2: any p, 3: p == 2 — two multiplications per step, same bits) are compile-time: the replay is ALU work — as many row-steps as
 // the dense pass visits, only without their memory traffic — and the generic optimizer switch / powf cost it twice the time
 template <int OPT, int LPK>
 __device__ __forceinline__ void replay_row(const ReplayParams& P, int64_t r, int lane, float& lp_acc) {
@@ -736,6 +736,7 @@ __device__ __forceinline__ void replay_row(const ReplayParams& P, int64_t r, int
                 if (j < n) {
                     float g = 0.f;
                     if constexpr (LPK == 1) lp_fold_p123(opt, ww[j], g, lp_acc);
+                    else if constexpr (LPK == 3) lp_fold_p2(opt, ww[j], g, lp_acc);
                     else if constexpr (LPK == 2) lp_fold(opt, ww[j], g, lp_acc);
                     opt_update_elem(opt, ww[j], g, &aa[j], &bb[j]);
                 }
@@ -860,6 +861,7 @@ __device__ __forceinline__ void replay_finish(const ReplayParams& P, ReplayRegs<
                 } else {
                     float g = 0.f;
                     if constexpr (LPK == 1) lp_fold_p123(opt, ww[t][j], g, acc[t]);
+                    else if constexpr (LPK == 3) lp_fold_p2(opt, ww[t][j], g, acc[t]);
                     opt_update_elem(opt, ww[t][j], g, &aa[t][j], &bb[t][j]);
                 }
             }
@@ -1726,7 +1728,8 @@ static void launch_replay(bool catchup, const ReplayParams& P, dim3 grid, hipStr
     if (catchup && lpk != 2 && P.k_int % 4 == 0 && P.ld % 4 == 0 && P.k_int <= 1024 && aligned && env_replay_rows()) {
         const int trips = (int)cdiv((int64_t)P.k_int / 4, 64);
         if (P.lag) { launch_catchup_rows_lag(trips, P, grid, st); return; }
-#define EMG_RR(O_) do { if (lpk == 0) launch_catchup_rows<O_, 0>(trips, P, grid, st); else launch_catchup_rows<O_, 1>(trips, P, grid, st); } while (0)
+#define EMG_RR(O_) do { if (lpk == 0) launch_catchup_rows<O_, 0>(trips, P, grid, st); else if (P.opt.lp_p == 2) launch_catchup_rows<O_, 3>(trips, P, grid, st); \
+                        else launch_catchup_rows<O_, 1>(trips, P, grid, st); } while (0)
         switch (P.opt.opt) {
             case EMG_OPT_SGD: EMG_RR(EMG_OPT_SGD); break;
             case EMG_OPT_MOMENTUM: EMG_RR(EMG_OPT_MOMENTUM); break;

@@ -216,6 +216,15 @@ __device__ __forceinline__ void lp_fold_p123(const OptParams& P, float w, float&
     g += P.lp_lambda * (float)P.lp_p * pm1 * sgnf(w);
     lp_acc += P.lp_p == 1 ? a : (P.lp_p == 2 ? a2 : a2 * a);
 }
+// p == 2 at compile time (the reference's default, regularizers/_regularizer_constants.py): lambda * 2 * |w| * sgn(w) is fl(2 lambda * w)
+// — the product with the sign is exact and rounding is sign-symmetric, signed zeros included — and |w|^2 is fl(w * w): two
+// multiplications where the generic form spends an abs, a square, two selects, three multiplications and the sign's med3.  SAME bits
+// as lp_fold / lp_fold_p123 at p = 2 (the deferred replay is bound by exactly this arithmetic: DESIGN 7)
+__device__ __forceinline__ void lp_fold_p2(const OptParams& P, float w, float& g, float& lp_acc) {
+#pragma clang fp contract(off)
+    g += (P.lp_lambda * 2.f) * w;
+    lp_acc += w * w;
+}
 // every row's update sees the gradient of the WHOLE loss: data term (summed contributions, 0 for a row no triple of
 // the batch touches) + the regulariser's, both evaluated at the pre-update value (EmbeddingModel.py:786-820)
 __device__ __forceinline__ void lp_fold(const OptParams& P, float w, float& g, float& lp_acc) {
