@@ -221,7 +221,7 @@ print("rccl ok")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sharding", ["both", "batch"])
+@pytest.mark.parametrize("sharding", ["both"])
 def test_bench_runs_at_two_ranks_and_prints_both_plans(sharding):
     """`bench.py --gpus 2` as the driver starts it for a scaling run (here: both ranks on ONE device over gloo,
     EMG_BENCH_ONE_DEVICE=1): the N > 1 branch must start, time both training plans (k-slabs + score all-reduce; batch rows +
