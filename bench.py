@@ -861,6 +861,11 @@ def main():
         if world > 1:   # bytes each rank puts on the links per step
             if sharding == "batch":
                 hd["xgmi_bytes_per_step_per_rank"] = int(rr.tr.xgmi_bytes / max(1, rr.tr.step_count))
+                # rows a rank's optimizer updates per step (upper bounds from the count matrix): state replicated (what ran) against
+                # state sharded by owner (Trainer(shard_state=True): SGD / momentum / Adagrad; same bits, same bytes on the links)
+                hd["optimizer_rows_per_step_per_rank"] = {
+                    "replicated_state": int(rr.tr.opt_rows_replicated_form / max(1, rr.tr.step_count)),
+                    "owner_sharded_state": int(rr.tr.opt_rows_owner_form / max(1, rr.tr.step_count))}
             else:       # ring all-reduce of the (1 + eta) * B_global partial scores: 2 (N - 1) / N of the buffer out, as much in
                 hd["xgmi_bytes_per_step_per_rank"] = int(2 * (world - 1) / world * 4 * (1 + rr.eta) * rr.B)
         return rr, hd, ls, (dt_, ti_)
@@ -902,7 +907,8 @@ def main():
     }
     if world > 1:
         line["xgmi_bytes_per_step_per_rank"] = head["xgmi_bytes_per_step_per_rank"]
-        line["plans"] = {n: dict(_pick(plans[n]["head"], "value", "ms_per_step", "xgmi_bytes_per_step_per_rank"), loss_sum=plans[n]["loss"])
+        line["plans"] = {n: dict(_pick(plans[n]["head"], "value", "ms_per_step", "xgmi_bytes_per_step_per_rank", "optimizer_rows_per_step_per_rank"),
+                                 loss_sum=plans[n]["loss"])
                          for n in plan_names}
         line["plan"] = best
     if world > 1 and r.sharding == "batch":

@@ -57,6 +57,7 @@ SIGNATURES = {
     "emg_lp_regularizer": (_int, [_p, _i64, _i64, _i32, _f32, _i32, _f32, _p, _p]),
     "emg_lp_grad_rows": (_int, [_p, _i64, _i64, _i32, _f32, _i32, _p, _i64, _p, _p, _p]),
     "emg_clip_rows": (_int, [_p, _i64, _i64, _i32, _f32, _p]),
+    "emg_scatter_rows": (_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _i64, _p]),
     "emg_eval_build_queries": (_int, [_int, _p, _i64, _i64, _p, _i64, _i64, _i32, _f32, _p, _i64, _int, _p, _i64,
                                       _p, _p]),
     "emg_eval_count": (_int, [_int, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i32, _f32, _int, _p, _i64, _p, _p, _p]),

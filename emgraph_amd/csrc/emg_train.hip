@@ -297,6 +297,28 @@ extern "C" int emg_init_table(int kind, float* table, int64_t n_rows, int64_t ld
     return EMG_OK;
 }
 
+// rows[j] -> table[ids[j]] for the ids inside the table (a wave per row; the batch-sharded step with the optimizer state sharded by
+// owner: every replica takes the owners' UPDATED rows; ids are distinct, the padding of the fixed-capacity all-gather is >= n_rows)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ table, int64_t n_rows, int64_t ld, int k_int,
+                                                           const float* __restrict__ rows, int64_t ldr, const int32_t* __restrict__ ids, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    const int64_t id = ids[j];
+    if (id < 0 || id >= n_rows) return;
+    for (int c = lane; c < k_int; c += 64) table[id * ld + c] = rows[j * ldr + c];
+}
+
+extern "C" int emg_scatter_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, const float* rows, int64_t ldr,
+                                const int32_t* ids, int64_t n, void* stream) {
+    EMG_REQUIRE(table && rows && ids && n_rows >= 0 && ld >= k_int && ldr >= k_int && k_int > 0 && n >= 0, "emg_scatter_rows: bad arguments");
+    if (n == 0) return EMG_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cdiv(n * 64, 256)), dim3(256), 0, (hipStream_t)stream, table, n_rows, ld,
+                       (int)k_int, rows, ldr, ids, n);
+    EMG_LAUNCH_CHECK();
+    return EMG_OK;
+}
+
 extern "C" int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream) {
     EMG_REQUIRE(table && n_rows >= 0 && ld >= k_int && k_int > 0, "emg_clip_rows: bad arguments");
     if (n_rows == 0) return EMG_OK;

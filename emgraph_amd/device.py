@@ -373,6 +373,14 @@ def lp_grad_rows(table, k_int, lam, p, contrib, dest, loss_accum):
                                  _chk_vec(loss_accum, torch.float64, "loss_accum", 1), _stream()), "emg_lp_grad_rows")
 
 
+def scatter_rows(table, k_int, rows, ids):
+    """rows[j] -> table[ids[j]] for the ids inside the table (distinct; others skipped)"""
+    lib = L.load()
+    pt, nrows, ld = _chk_table(table, "table")
+    pr, n, ldr = _chk_table(rows, "rows")
+    L.check(lib.emg_scatter_rows(pt, nrows, ld, k_int, pr, ldr, _chk_vec(ids, torch.int32, "ids", n), n, _stream()), "emg_scatter_rows")
+
+
 def clip_rows(table, k_int, max_norm=1.0):
     lib = L.load()
     pt, nrows, ld = _chk_table(table, "table")

@@ -371,7 +371,8 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
                      loss_params=self.loss_params, optimizer=self.optimizer, optimizer_params=self.optimizer_params,
                      corrupt_sides=self._corrupt_sides(), batches_count=self.batches_count, seed=self.seed,
                      regularizer=self.regularizer, regularizer_params=self.regularizer_params,
-                     normalize_ent_emb=normalize, sharded=sharding or False)
+                     normalize_ent_emb=normalize, sharded=sharding or False,
+                     shard_state=bool(self.embedding_model_params.get("shard_state", False)) and sharding == "batch")
         tr.set_training_set(X_idx, batch_size)
         n_choices, fixed_list, batch_lists = self._negative_pool(X_idx, batch_size)
         if normalize:  # EmbeddingModel.py:1371-1380: both tables clipped once before the loop

@@ -270,7 +270,8 @@ def _all_gather_into(out, inp, group=None):
 
 class ExchangePlan:
     """what the metadata phase of one batch and table leaves behind (see RowExchange)"""
-    __slots__ = ("n", "order", "sc", "rc", "m", "dest_o", "gslot_o", "cap_u", "uniq_local", "ids_all", "sent_bytes", "recv_bytes")
+    __slots__ = ("n", "order", "sc", "rc", "m", "dest_o", "gslot_o", "cap_u", "uniq_local", "ids_all", "mine", "sent_bytes", "recv_bytes",
+                 "rows_mine", "rows_all")
 
 
 class RowExchange:
@@ -304,7 +305,9 @@ class RowExchange:
         pl.rc = [int(v) for v in Ch[:, self.rank]]
         pl.m = sum(pl.rc)
         totals = [int(Ch[:, p].sum()) for p in range(W)]
-        pl.cap_u = max(1, max(min(self.owned[p][1] - self.owned[p][0], totals[p]) for p in range(W)))
+        bound = [min(self.owned[p][1] - self.owned[p][0], totals[p]) for p in range(W)]   # distinct destinations per owner, at most
+        pl.cap_u = max(1, max(bound))
+        pl.rows_mine, pl.rows_all = bound[self.rank], sum(bound)   # rows an optimizer updates: state sharded by owner / replicated
         meta = torch.stack([dest_sorted.to(torch.int32), gslot.index_select(0, pl.order).to(torch.int32)], 1)
         meta_r = _split_exchange(torch.empty((pl.m, 2), dtype=torch.int32, device=meta.device), meta, pl.rc, pl.sc, self.group)
         pl.dest_o = (meta_r[:, 0] - self.e0).contiguous()         # row ids inside this rank's range
@@ -334,6 +337,7 @@ class RowExchange:
         ids_all = torch.empty(W * cap, dtype=torch.int32, device=dev)
         _all_gather_into(ids_all, mine, self.group)
         pl.ids_all = ids_all
+        pl.mine = mine            # this owner's GLOBAL ids (padding: n_rows)
         return pl
 
     # ---- data phase ----

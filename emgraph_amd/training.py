@@ -95,11 +95,16 @@ class Trainer:
     def __init__(self, model_id, k_int, scale, ent_init, rel_init, eta, loss="nll", loss_params=None,
                  optimizer="adam", optimizer_params=None, corrupt_sides=("s,o",), batches_count=1, seed=0,
                  regularizer=None, regularizer_params=None, normalize_ent_emb=False, device="cuda", fused=True,
-                 inplace=True, pipeline=True, sharded=False, deferred_dense=None):
+                 inplace=True, pipeline=True, sharded=False, deferred_dense=None, shard_state=False):
         """``sharded=True`` / ``"k"``: ent_init / rel_init are this rank's COLUMN slabs (emgraph_amd.parallel.shard_columns)
         and k_int is the local width; every step all-reduces the partial scores.
         ``sharded="batch"``: full tables on every rank; each rank scores its rows of the global batch, gradient rows
         travel to the owner of their destination, which applies them and all-gathers the updated rows (parallel.py).
+        ``shard_state=True`` (with ``sharded="batch"``; SGD / momentum / Adagrad without regulariser): the optimizer state is
+        sharded by OWNER — each rank holds the state rows of its own id range only, applies the optimizer to the summed gradients of
+        ITS rows and all-gathers the UPDATED rows (the same bytes as the summed gradients), which every replica copies into its
+        table: 1/N of the state and of the update arithmetic, same bits.  Keras Adam cannot take this form (every row moves every
+        step: the replicas would need the whole table back), nor can a folded LP regulariser.
         ``deferred_dense`` (one GPU, Adam and / or an LP regulariser; default: tables of >= 256 MB, or env EMG_ADAM_DEFERRED=0/1):
         the dense pass (Keras Adam's decay, the regulariser's gradient) is replayed only for the rows a batch reads and
         updates (emg_deferred_catchup) instead of passing over the whole table every step — same bits; ``materialize()``
@@ -228,11 +233,25 @@ class Trainer:
             self._device_exchange = (os.environ.get("EMG_XCHG", "device") != "host" and os.environ.get("EMG_GROUPING") != "sort"
                                      and -(-max(self.n_ent, self.n_rel) // max(1, world)) <= (1 << 20))
             self._xchg_objs, self._gslot_cache = {}, {}
+            # rows this rank's optimizer updated (upper bounds from the count matrix: no host read), and what the other form would have
+            self.opt_rows = self.opt_rows_owner_form = self.opt_rows_replicated_form = 0
             self._bs_ready = {}          # batches whose metadata phase has been issued ahead: key -> prepared state
             self._bs_parity = 0
             self._bs_done = [torch.cuda.Event(), torch.cuda.Event()]   # main-stream work that last used slot / workspaces of a parity
             self._bs_ahead = self._device_exchange and os.environ.get("EMG_XCHG_AHEAD", "1") != "0"
             self._bs_stream = torch.cuda.Stream(device=self.device) if self._bs_ahead else None
+        self.shard_state = bool(shard_state)
+        if self.shard_state:
+            if not self.batch_sharded or self.opt_id not in (L.OPT_SGD, L.OPT_MOMENTUM, L.OPT_ADAGRAD) or self.reg is not None:
+                raise ValueError("shard_state needs sharded='batch' and SGD / momentum / Adagrad without a regulariser (Keras Adam and the "
+                                 "LP regulariser move every row every step: their state cannot live at the owner alone)")
+            if not self._device_exchange:
+                raise ValueError("shard_state needs the device-resident exchange (EMG_XCHG=device, owner ranges of <= 2^20 rows + 16 per slot)")
+            rank_, world_ = parallel.rank_world()
+            for st_, n_ in ((self.state_ent, self.n_ent), (self.state_rel, self.n_rel)):
+                e0_, e1_ = parallel.entity_range(n_, rank_, world_)
+                if st_[0] is not None:   # this rank's rows only
+                    st_[0] = alloc_table(max(1, e1_ - e0_), k_int, self.device, fill=ADAGRAD_INIT_ACC if optimizer == "adagrad" else None)
         # high priority: the many small kernels must not queue behind the big ones.  TWO side streams used
         # alternately: a preparation chain is latency-bound (each small launch waits for a CU slot), so two
         # chains in flight double the rate at which prepared batches arrive
@@ -815,9 +834,24 @@ class Trainer:
             x.compact = torch.empty((int(pl.cap_u * 1.25) + 64, k), dtype=torch.float32, device=self.device)
         comp = x.compact[:pl.cap_u]
         torch.index_select(x.sums, 0, pl.uniq_local, out=comp)
-        g = x.gather_sums(pl, comp)
-        D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, g, x.world * pl.cap_u, False, hyper, x.ws_rep[parity],
-                        lp_accum=lp_accum)
+        if self.shard_state:
+            # the OWNER applies the optimizer to its rows (its shard of the state), the UPDATED rows are all-gathered and every
+            # replica copies them into its table: one update per touched row in the whole job instead of one per replica
+            own = table[x.e0:x.e1]
+            dest_local = torch.where(pl.mine < x.n_rows, pl.mine - x.e0, torch.full_like(pl.mine, x.e1 - x.e0))   # padding: outside the range
+            x.ws_own = self._grown(getattr(x, "ws_own", None), D.apply_workspace_bytes(pl.cap_u, max(1, x.e1 - x.e0), k), self.device)
+            D.apply_rows(self.opt_id, own, k, state[0], state[1], None, self.step_count, comp, dest_local, pl.cap_u, hyper, x.ws_own)
+            torch.index_select(own[:, :k], 0, pl.uniq_local, out=comp)          # (padding entries: row 0 of the range; their ids are skipped)
+            g = x.gather_sums(pl, comp)
+            D.scatter_rows(table, k, g, pl.ids_all)
+            self.opt_rows += pl.rows_mine
+        else:
+            g = x.gather_sums(pl, comp)
+            D.apply_grouped(self.opt_id, table, k, state[0], state[1], tag, self.step_count, g, x.world * pl.cap_u, False, hyper, x.ws_rep[parity],
+                            lp_accum=lp_accum)
+            self.opt_rows += pl.rows_all
+        self.opt_rows_owner_form += pl.rows_mine
+        self.opt_rows_replicated_form += pl.rows_all
         self.xgmi_bytes += pl.sent_bytes + pl.recv_bytes
 
     def _exchange_apply(self, table, n_rows, state, tag, dest, gslot, rows, hyper, which, lp_accum=None):

@@ -345,6 +345,11 @@ int emg_lp_grad_rows(const float* table, int64_t n_rows, int64_t ld, int32_t k_i
 
 /* ---- K9: optional row-norm clip after a batch (EmbeddingModel.py:1371-1380, clip_by_norm axes=1) */
 int emg_clip_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, float max_norm, void* stream);
+/* rows[j] -> table[ids[j]] for 0 <= ids[j] < n_rows (distinct ids; others skipped): the multi-GPU batch-sharded step with the
+ * optimizer state sharded by OWNER writes the owners' updated rows into every replica with it (no reference counterpart: the
+ * reference has no distributed code; the update itself is training/{sgd,momentum,adagrad}.py) */
+int emg_scatter_rows(float* table, int64_t n_rows, int64_t ld, int32_t k_int, const float* rows, int64_t ldr,
+                     const int32_t* ids, int64_t n, void* stream);
 /* initializers/{glorot_uniform,uniform,normal}.py on the device: kind 0 = U[a, b), 1 = N(mean a, std b); element (r, c)
  * takes word (c & 3) of Philox4x32-10(counter (r * k_int + c) / 4, stream_id, seed), so a table is a pure function of
  * (seed, stream_id, shape) — the same on any number of GPUs.  The reference draws from TensorFlow's generators (cannot

@@ -260,7 +260,7 @@ def row_exchange_worker(rank, world, out_dir):
     np.save(os.path.join(out_dir, "W_%d.npy" % rank), W)
 
 
-def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt, reg=None):
+def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt, reg=None, shard_state=False):
     """the REAL batch-sharded training step (HIP kernels + exchange), two ranks sharing cuda:0 over gloo"""
     import torch
 
@@ -274,14 +274,16 @@ def batch_sharded_fit_worker(rank, world, out_dir, name, loss, opt, reg=None):
     kw = dict(k=10, eta=3, epochs=2, batches_count=3, seed=3, loss=loss, optimizer=opt, optimizer_params={"lr": 0.05})
     if reg is not None:
         kw.update(regularizer="LP", regularizer_params=reg)
-    emp = {"sharding": "batch"}
+    emp = {"sharding": "batch", "shard_state": shard_state}
     if name == "TransE_L2":
         m = models.TransE(embedding_model_params=dict(emp, norm=2), **kw)
     else:
         m = getattr(models, name)(embedding_model_params=emp, **kw)
     m.fit(X[:803])       # 803 rows / 3 batches = 268 per batch (last one 267): odd splits over two ranks
     np.savez(os.path.join(out_dir, "res_%d.npz" % rank), E=m.trained_model_params[0], R=m.trained_model_params[1],
-             pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes), losses=np.array(m.epoch_losses))
+             pred=m.predict(X[800:]), xgmi=np.array(m._trainer.xgmi_bytes), losses=np.array(m.epoch_losses),
+             opt_rows=np.array(m._trainer.opt_rows),
+             state_rows=np.array(-1 if m._trainer.state_ent[0] is None else m._trainer.state_ent[0].shape[0]))
 
 
 def sharded_overflow_worker(rank, world, out_dir):

@@ -145,6 +145,40 @@ def test_batch_sharded_fit_two_ranks_equals_single_process(tmp_path, name, loss,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "sgd"), ("TransE_L2", "pairwise", "adagrad"), ("HolE", "multiclass_nll", "momentum")])
+def test_batch_sharded_fit_with_the_state_sharded_by_owner_equals_the_replicated_form(tmp_path, name, loss, opt):
+    """SURVEY 8e's ZeRO-1 form of the batch plan (`shard_state`): every rank holds the optimizer state of ITS id range only, the
+    owner applies the optimizer to the summed gradients of its rows and the UPDATED rows are all-gathered (emg_scatter_rows writes
+    them into every replica).  Same sums, same rule, applied once: tables, predictions and losses must equal the replicated form's
+    bit for bit (and thereby one GPU's); the state arrays hold half the rows; the optimizer touches about half as many rows."""
+    rep, own = tmp_path / "rep", tmp_path / "own"
+    rep.mkdir(); own.mkdir()
+    _spawn(W.batch_sharded_fit_worker, 2, rep, name, loss, opt, None, False)
+    _spawn(W.batch_sharded_fit_worker, 2, own, name, loss, opt, None, True)
+    a = [np.load(os.path.join(rep, "res_%d.npz" % r)) for r in range(2)]
+    b = [np.load(os.path.join(own, "res_%d.npz" % r)) for r in range(2)]
+    for key in ("E", "R", "pred", "losses"):
+        np.testing.assert_array_equal(b[0][key], b[1][key])     # replicas stay identical
+        np.testing.assert_array_equal(b[0][key], a[0][key])     # and equal the replicated form
+    assert int(b[0]["xgmi"]) == int(a[0]["xgmi"])               # the same bytes on the links
+    if opt != "sgd":
+        assert int(a[0]["state_rows"]) == 80 and int(b[0]["state_rows"]) == 40 and int(b[1]["state_rows"]) == 40
+    assert int(b[0]["opt_rows"]) + int(b[1]["opt_rows"]) == int(a[0]["opt_rows"]) == int(a[1]["opt_rows"])
+
+
+@pytest.mark.gpu
+def test_shard_state_refuses_what_moves_every_row():
+    """Keras Adam decays every row every step and a folded LP regulariser moves every row: their state cannot live at the owner"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    E, R = np.zeros((8, 4), np.float32), np.zeros((2, 4), np.float32)
+    for kw in (dict(optimizer="adam", sharded="batch"), dict(optimizer="adagrad", sharded=False),
+               dict(optimizer="adagrad", sharded="batch", regularizer="LP", regularizer_params={"lambda": 1e-3, "p": 2})):
+        with pytest.raises(ValueError, match="shard_state"):
+            Trainer(L.DISTMULT, 4, 1.0, E, R, 2, shard_state=True, **kw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,loss,opt", [("ComplEx", "nll", "adam"), ("TransE_L2", "pairwise", "sgd"),
                                            ("HolE", "multiclass_nll", "adagrad"), ("DistMult", "nll", "momentum")])
 def test_sharded_fit_and_eval_two_ranks_match_single_process(tmp_path, name, loss, opt):
@@ -245,6 +279,9 @@ def test_bench_runs_at_two_ranks_and_prints_both_plans(sharding):
     for name in want:
         pl = d["plans"][name]
         assert pl["value"] > 0 and pl["ms_per_step"] > 0 and pl["xgmi_bytes_per_step_per_rank"] > 0
+    if "batch" in want:   # rows a rank's optimizer updates: all of the global batch's with replicated state, its own range's with sharded state
+        rows = d["plans"]["batch"]["optimizer_rows_per_step_per_rank"]
+        assert 0 < rows["owner_sharded_state"] < rows["replicated_state"]
     assert d["value"] == max(pl["value"] for pl in d["plans"].values())
     assert d["xgmi_bytes_per_step_per_rank"] == d["plans"][d["plan"]]["xgmi_bytes_per_step_per_rank"]
     assert d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"]
