@@ -413,3 +413,38 @@ def test_no_hand_written_kernel_spills_to_scratch():
     assert not spilling, spilling
     fused = [k for k in ours if "train_fused_riders_kernel" in k[0]]
     assert len(fused) >= 100 and max(v for _, _, v in fused) <= 512
+
+
+def test_installed_filter_is_remembered_by_content_not_by_identity():
+    """evaluate_performance maps the filter triples through the label dictionaries and indexes them on every call (45 of 107 ms at
+    1M filter triples); the mapped set and its FilterIndex are remembered by a digest of the array's CONTENT together with the
+    dictionaries' identity: an equal array (another object) hits, a changed one or other mappings miss"""
+    from types import SimpleNamespace
+    from emgraph_amd.datasets import NumpyDatasetAdapter
+    from emgraph_amd.evaluation import protocol as P
+    rs = np.random.RandomState(0)
+    F = np.stack([rs.randint(0, 50, 400), rs.randint(0, 5, 400), rs.randint(0, 50, 400)], 1)
+    ent = {i: i for i in range(50)}
+    rel = {i: i for i in range(5)}
+    model = SimpleNamespace(ent_to_idx=ent, rel_to_idx=rel, set_filter_for_eval=lambda: None)
+
+    def install(arr, m=model):
+        ad = NumpyDatasetAdapter()
+        ad.use_mappings(m.rel_to_idx, m.ent_to_idx)
+        P._install_filter(ad, False, arr, m, True, False)
+        return ad
+    P._FILTER_CACHE.clear()
+    a, b = install(F), install(F.copy())
+    assert a.filter_index is b.filter_index and a.filter_adapter is b.filter_adapter
+    np.testing.assert_array_equal(a.filter_adapter, F)
+    b.cleanup()                                                              # an adapter's cleanup does not break the remembered index
+    assert install(F).filter_index is a.filter_index
+    G = F.copy()
+    G[7, 0] = (G[7, 0] + 1) % 50
+    c = install(G)
+    assert c.filter_index is not a.filter_index
+    np.testing.assert_array_equal(c.filter_adapter, G)
+    other = SimpleNamespace(ent_to_idx=dict(ent), rel_to_idx=rel, set_filter_for_eval=lambda: None)   # an equal but different dictionary
+    assert install(F, other).filter_index is not a.filter_index
+    labels = np.array([["a", "r", "b"], ["b", "r", "a"]], dtype=object)      # object arrays are not digested: never cached
+    assert P._array_digest(labels) is None
