@@ -1184,12 +1184,14 @@ __device__ unsigned long long emg_trace_buf[4 * 65536];
 // rule, no regulariser).  The run-time form walks opt_update_elem's four branches and lp_fold's test for EVERY element — scalar
 // compares and branches that a wave issues in line with its vector work: per-wave stamps put an item of C1 / C2 at 4 - 5 us where
 // its round trips are 0.3 us each (TCP->TCC latency counters), i.e. at the SIMD's instruction issue.
+constexpr int kFixSgdLp2 = 100;   // FIX: plain SGD with the LP regulariser at p = 2 folded in (C3 + LP: the reference's default regulariser)
 template <bool PLAIN, bool HALF, int FIX = 0>
 __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float* __restrict__ partial, int64_t ldp, int64_t gw,
                                                      int64_t nw, int lane, int64_t heavy = 0, int64_t relief = 0) {
     OptParams opt = P.opt;
     if constexpr (PLAIN) { opt.opt = EMG_OPT_SGD; opt.lp_lambda = 0.f; }   // (known at compile time: the update folds to w - lr g)
-    if constexpr (FIX != 0) { opt.opt = FIX; opt.lp_lambda = 0.f; }
+    if constexpr (FIX == kFixSgdLp2) { opt.opt = EMG_OPT_SGD; opt.lp_p = 2; }   // (lambda stays a run-time value: the tables' may differ)
+    else if constexpr (FIX != 0) { opt.opt = FIX; opt.lp_lambda = 0.f; }
     int32_t step = P.step;
     if (P.ctl) {   // the step's number and learning rates from the device record (a captured graph cannot bake them)
         const float* h = P.which ? P.ctl->hyper_rel : P.ctl->hyper_ent;
@@ -1490,7 +1492,7 @@ static int apply_setup(const emg_apply_args* a, ApplyParams& P, ApplyLaunch& A) 
 // tools/trace_waves.py, C3: 5120 of 8192 waves start at 0 and live 38 us, the other 3072 start at 34-41 us: 78 us for
 // 1.6 rounds of work) — so never launch more than fit.
 typedef void (*SegmentsKernel)(const SegmentsLaunch, const Riders);
-// fix: 0 run-time optimizer switch, 1 Adam without regulariser, 2 Adagrad without regulariser (compile-time forms of the stateful kernel)
+// fix: 0 run-time optimizer switch, 1 Adam without regulariser, 2 Adagrad without regulariser, 3 plain SGD + LP at p = 2 (compile-time forms)
 static SegmentsKernel segments_kernel(bool plain, bool ride, bool half, int fix = 0) {
     static const SegmentsKernel fns[8] = {
         apply_segments_kernel<false, false, false>, apply_segments_kernel<false, false, true>,
@@ -1503,6 +1505,10 @@ static SegmentsKernel segments_kernel(bool plain, bool ride, bool half, int fix 
     static const SegmentsKernel adagrad[4] = {
         apply_segments_kernel<false, false, false, EMG_OPT_ADAGRAD>, apply_segments_kernel<false, false, true, EMG_OPT_ADAGRAD>,
         apply_segments_kernel<false, true, false, EMG_OPT_ADAGRAD>,  apply_segments_kernel<false, true, true, EMG_OPT_ADAGRAD>};
+    static const SegmentsKernel sgdlp2[4] = {
+        apply_segments_kernel<false, false, false, kFixSgdLp2>, apply_segments_kernel<false, false, true, kFixSgdLp2>,
+        apply_segments_kernel<false, true, false, kFixSgdLp2>,  apply_segments_kernel<false, true, true, kFixSgdLp2>};
+    if (!plain && fix == 3) return sgdlp2[(ride ? 2 : 0) + (half ? 1 : 0)];
     if (!plain && fix == 1) return adam[(ride ? 2 : 0) + (half ? 1 : 0)];
     if (!plain && fix == 2) return adagrad[(ride ? 2 : 0) + (half ? 1 : 0)];
     return fns[(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)];
@@ -1511,11 +1517,12 @@ static bool segments_half(const ApplyParams& P) { return P.half_rows && P.k_int 
 // which compile-time optimizer form serves this table (EMG_APPLY_FIX = 0: the run-time switch everywhere — A/B aid)
 static int segments_fix(const ApplyParams& P) {
     static const bool off = getenv("EMG_APPLY_FIX") && atoi(getenv("EMG_APPLY_FIX")) == 0;
-    if (off || P.opt.lp_lambda != 0.f) return 0;
+    if (off) return 0;
+    if (P.opt.lp_lambda != 0.f) return (P.opt.opt == EMG_OPT_SGD && P.opt.lp_p == 2) ? 3 : 0;
     return P.opt.opt == EMG_OPT_ADAM ? 1 : (P.opt.opt == EMG_OPT_ADAGRAD ? 2 : 0);
 }
 static unsigned segments_capacity(bool plain, bool ride, bool half, int fix) {
-    static std::atomic<unsigned> cached[3][8][64];
+    static std::atomic<unsigned> cached[4][8][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024u;
     std::atomic<unsigned>& c = cached[plain ? 0 : fix][(plain ? 4 : 0) + (ride ? 2 : 0) + (half ? 1 : 0)][dev & 63];

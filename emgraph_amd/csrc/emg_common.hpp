@@ -206,17 +206,7 @@ __device__ __forceinline__ float lp_grad(const OptParams& P, float w) {
     const float a = fabsf(w);
     return P.lp_lambda * (float)P.lp_p * (P.lp_p == 1 ? 1.f : lp_pow(a, P.lp_p - 1)) * sgnf(w);
 }
-// the same for p in {1, 2, 3} only (the fused kernel's in-place form: no powf, whose inlined code costs it a wave per SIMD);
-// same expressions, same bits as lp_fold for these p
-__device__ __forceinline__ void lp_fold_p123(const OptParams& P, float w, float& g, float& lp_acc) {
-#pragma clang fp contract(off)
-    const float a = fabsf(w);
-    const float a2 = a * a;
-    const float pm1 = P.lp_p == 1 ? 1.f : (P.lp_p == 2 ? a : a2);          // |w|^(p-1)
-    g += P.lp_lambda * (float)P.lp_p * pm1 * sgnf(w);
-    lp_acc += P.lp_p == 1 ? a : (P.lp_p == 2 ? a2 : a2 * a);
-}
-// p == 2 at compile time (the reference's default, regularizers/_regularizer_constants.py): lambda * 2 * |w| * sgn(w) is fl(2 lambda * w)
+// p == 2 (the reference's default, regularizers/_regularizer_constants.py), taken by lp_fold / lp_fold_p123 themselves: lambda * 2 * |w| * sgn(w) is fl(2 lambda * w)
 // — the product with the sign is exact and rounding is sign-symmetric, signed zeros included — and |w|^2 is fl(w * w): two
 // multiplications where the generic form spends an abs, a square, two selects, three multiplications and the sign's med3.  SAME bits
 // as lp_fold / lp_fold_p123 at p = 2 (the deferred replay is bound by exactly this arithmetic: DESIGN 7)
@@ -225,10 +215,22 @@ __device__ __forceinline__ void lp_fold_p2(const OptParams& P, float w, float& g
     g += (P.lp_lambda * 2.f) * w;
     lp_acc += w * w;
 }
+// the same for p in {1, 2, 3} only (the fused kernel's in-place form: no powf, whose inlined code costs it a wave per SIMD);
+// same expressions, same bits as lp_fold for these p
+__device__ __forceinline__ void lp_fold_p123(const OptParams& P, float w, float& g, float& lp_acc) {
+#pragma clang fp contract(off)
+    if (P.lp_p == 2) { lp_fold_p2(P, w, g, lp_acc); return; }   // (same bits; a uniform branch, folded where p is a compile-time constant)
+    const float a = fabsf(w);
+    const float a2 = a * a;
+    const float pm1 = P.lp_p == 1 ? 1.f : (P.lp_p == 2 ? a : a2);          // |w|^(p-1)
+    g += P.lp_lambda * (float)P.lp_p * pm1 * sgnf(w);
+    lp_acc += P.lp_p == 1 ? a : (P.lp_p == 2 ? a2 : a2 * a);
+}
 // every row's update sees the gradient of the WHOLE loss: data term (summed contributions, 0 for a row no triple of
 // the batch touches) + the regulariser's, both evaluated at the pre-update value (EmbeddingModel.py:786-820)
 __device__ __forceinline__ void lp_fold(const OptParams& P, float w, float& g, float& lp_acc) {
     if (P.lp_lambda != 0.f) {
+        if (P.lp_p == 2) { lp_fold_p2(P, w, g, lp_acc); return; }   // (same bits)
         g += lp_grad(P, w);
         lp_acc += lp_pow(fabsf(w), P.lp_p);
     }

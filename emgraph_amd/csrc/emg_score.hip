@@ -40,6 +40,7 @@ static void launch_group(Pass pass, const GroupParams& P, hipStream_t st, const 
         // window (emg_backward_args.inplace_window): the window forms — the state rows travel with the table rows (ip 4 / 5; 6: Adam
         // whose dense pass is deferred, emg_backward_args.lr_hist); run_group_pass has checked the shape
         if (ip == 2 && P.window) ip = P.lr_hist ? 6 : ((P.opt.opt == EMG_OPT_ADAM || P.opt.opt == EMG_OPT_ADAM_LAZY) ? 5 : 4);
+        if (ip == 3 && P.lr_hist) ip = 7;   // SGD + LP under the deferred dense pass: lagging singleton negatives replayed in registers
 #define EMG_BW(F, I) hipLaunchKernelGGL((train_backward_kernel<MODEL, W, NV, LPG, F, I>), dim3(grid), dim3(kThreads), 0, st, P)
         if constexpr (W == 4) {
             if (fused) {   // the fused forms, with or without riders: one translation unit per model
@@ -71,7 +72,7 @@ static bool dispatch_model(Pass pass, GroupParams& P, bool vec, hipStream_t st, 
         // lane reduction's extra levels add zeros.
         static const int wide_env = getenv("EMG_WIDE_GROUPS") ? atoi(getenv("EMG_WIDE_GROUPS")) : -1;   // A/B aid
         // (in-place updates of a stateful optimizer: always a wave per group — the form whose state rows travel with the table rows)
-        const bool stateful_ip = pass == Pass::Fused && P.single_ent && P.window;
+        const bool stateful_ip = pass == Pass::Fused && P.single_ent && (P.window || P.lr_hist);   // (ip 7 too: a wave per group)
         // (stateful_ip wins over the A/B switch: forms 4 / 5 / 6 exist for LPG = 64 only — with EMG_WIDE_GROUPS=0 a narrow row would
         // otherwise reach a shape that launches nothing)
         const bool wide = pass != Pass::Forward && (stateful_ip || (wide_env >= 0 ? wide_env != 0 : P.B <= 2048));
@@ -441,7 +442,15 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
             P.lp_accum = a->lp_accum;
         }
     }
-    if (a->lr_hist) {   // Adam's dense pass is deferred: singletons among the negatives lag and are replayed in the kernel (ip 6)
+    if (a->lr_hist && a->opt == EMG_OPT_SGD) {   // SGD + LP under the deferred dense pass: lagging singleton negatives replayed in the kernel (ip 7)
+        EMG_REQUIRE(a->single_ent && !a->inplace_window && a->hyper[6] != 0.f && a->tag_ent && fused && a->step >= 1 && !a->ctl,
+                    "emg_train_backward_ex: lr_hist with EMG_OPT_SGD is for the fused kernel with in-place updates and a folded LP regulariser");
+        const bool cplx = a->model == EMG_COMPLEX || a->model == EMG_HOLE;
+        const int n = cplx ? a->k_int / 2 : a->k_int;
+        EMG_REQUIRE(n % 4 == 0 && n / 4 <= 128 && a->ld_ent % 4 == 0 && aligned16(a->ent),
+                    "emg_train_backward_ex: lr_hist needs 16-byte rows of at most 128 chunks (per half for complex models)");
+        P.lr_hist = a->lr_hist; P.upto = a->step - 1;
+    } else if (a->lr_hist) {   // Adam's dense pass is deferred: singletons among the negatives lag and are replayed in the kernel (ip 6)
         EMG_REQUIRE(a->single_ent && a->inplace_window && a->opt == EMG_OPT_ADAM && a->hyper[6] == 0.f && a->tag_ent && fused && a->step >= 1,
                     "emg_train_backward_ex: lr_hist (lagging singletons) is for the fused kernel with in-place EMG_OPT_ADAM updates, no regulariser");
         const bool cplx = a->model == EMG_COMPLEX || a->model == EMG_HOLE;

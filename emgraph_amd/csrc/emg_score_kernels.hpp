@@ -195,7 +195,12 @@ struct ip_traits {
     static constexpr bool window_state = n_state != 0;
     static constexpr bool replay = IP == 6;
     static constexpr bool so_inplace = IP != 0;              // the subject / object slots' singletons are updated in place too
-    static constexpr int chunkwise = (IP == 4 || IP == 5) ? 2 : IP;   // the form inplace_update runs for the s / o slots
+    // 7 (round 5): form 3 — plain SGD with the LP regulariser folded in — under the DEFERRED dense pass: a singleton negative's row is as
+    // of tag[row]; the regulariser's steps it missed (w -= lr_i * lambda p |w|^(p-1) sgn w, step by step: the dense pass's bits) are
+    // replayed on the row in registers before it is scored, then form 3's update writes it: the row is read once and written once
+    // where emg_deferred_catchup read and wrote it first (two row moves per singleton, 0.56 GB of C3 + LP's step)
+    static constexpr bool lp_replay = IP == 7;
+    static constexpr int chunkwise = (IP == 4 || IP == 5) ? 2 : (IP == 7 ? 3 : IP);   // the form inplace_update runs (negatives of 1 / 2 / 3 / 7, s / o slots)
 };
 
 #ifndef EMG_BW_THREADS
@@ -261,6 +266,42 @@ __global__ __launch_bounds__(kThreads) void train_forward_kernel(const GroupPara
 // ---------------------------------------------------------------------------------------------
 //   IP == 1: plain SGD (no state; stays lean)   IP == 2: any optimizer (state RMW; elements are fenced with
 //   sched_barrier so the compiler does not interleave eight sqrt/div expansions and blow up the VGPR budget)
+// IP 7: the LP regulariser's missed steps from + 1 .. P.upto of a lagging row, in registers — emg_apply.hip::replay_finish's arithmetic
+// for plain SGD (g = the regulariser's gradient alone, w -= lr_i g; sum |w|^p of every replayed step into lp_acc), so the dense pass's
+// bits.  `from` is wave-uniform: the learning rates come by scalar loads (no vector-memory operation joins the row window's queue).
+template <int MODEL, int W, int NV, int LPG>
+__device__ __forceinline__ void lp_replay_row(const GroupParams& P, int from, float lr_lane, Row<MODEL, W, NV>& r, int lg, float& lp_acc) {
+    constexpr int E = W * NV;
+    constexpr int HALVES = is_complex<MODEL>::value ? 2 : 1;
+    OptParams opt = P.opt;
+    float accs[HALVES * NV];   // (per 16-byte chunk of the lane, over all steps: replay_finish's association)
+#pragma unroll
+    for (int q = 0; q < HALVES * NV; ++q) accs[q] = 0.f;
+    for (int i = from + 1; i <= P.upto; ++i) {
+        // lane l of the group holds the learning rate of step upto - l (one vector load per GROUP, in its prologue): a step's rate is a
+        // v_readlane; only a row that lags by more than 64 steps reads the table (a scalar load per step, its latency exposed — the
+        // first version did that for every step: the kernel 0.268 -> 0.322 ms at C3 + LP)
+        const int back = P.upto - i;
+        opt.lr = back < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lr_lane), back)) : P.lr_hist[i];
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+            for (int it = 0; it < NV; ++it)
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    float& x = r.x[h * E + it * W + w];
+                    float g = 0.f;
+                    if (opt.lp_p == 2) lp_fold_p2(opt, x, g, accs[h * NV + it]); else lp_fold_p123(opt, x, g, accs[h * NV + it]);
+                    x = opt_sgd_elem(opt, x, g);
+                }
+    }
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h)
+#pragma unroll
+        for (int it = 0; it < NV; ++it)
+            lp_acc += (lg + it * LPG < P.nchunks) ? accs[h * NV + it] : 0.f;   // (lanes past the row's end hold copies: replayed harmlessly, uncounted)
+}
+
 template <int MODEL, int W, int NV, int LPG, int IP>
 __device__ __forceinline__ void inplace_update(const GroupParams& P, int64_t row, const Row<MODEL, W, NV>& cur,
                                                const Row<MODEL, W, NV>& grad, int lg, float& lp_acc) {
@@ -581,6 +622,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     using IT = ip_traits<IP>;
     constexpr int NS = IT::n_state;
     static_assert(!IT::window_state || (W == 4 && LPG == 64 && FUSED), "IP 4 / 5 / 6: fused kernels of 16-byte rows, a wave per group");
+    static_assert(!IT::lp_replay || (W == 4 && LPG == 64 && FUSED), "IP 7: fused kernels of 16-byte rows, a wave per group");
     int my_code = 0, my_flag = 0, my_pos = 0, my_flag_so = 0;   // my_pos: where the negative's factor goes (its slot's sorted position)
     int my_tag = 0;                                              // IP 6: the step the singleton's row was last written at
     auto gather = [&](int c0) {
@@ -588,9 +630,11 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         my_code = j < P.eta ? P.codes[(int64_t)j * B + g] : 0;
         if (kBilinear && P.fac.coef) my_pos = j < P.eta ? (int)P.fac.pos_of_slot[(int64_t)j * B + g] : 0;
         if constexpr (IP != 0) my_flag = j < P.eta ? (int)P.single_ent[2 * B + (int64_t)j * B + g] : 0;
-        if constexpr (IT::replay) my_tag = (j < P.eta && my_flag) ? P.tag_ent[my_code & 0x7fffffff] : P.upto;
+        if constexpr (IT::replay || IT::lp_replay) my_tag = (j < P.eta && my_flag) ? P.tag_ent[my_code & 0x7fffffff] : P.upto;
     };
     gather(0);
+    float lr_lane = 0.f;   // IP 7: the learning rates of the last 64 steps (lane l: step upto - l), fetched with the group's first gather
+    if constexpr (IT::lp_replay) lr_lane = P.lr_hist[max(P.upto - lg, 0)];
     if constexpr (IT::so_inplace) { if (lg < 2) my_flag_so = P.single_ent[(int64_t)lg * B + g]; }
     OptParams wopt = P.opt;   // (the window forms know their optimizer family: the update's switch folds away)
     if constexpr (NS == 2) wopt.opt = EMG_OPT_ADAM;
@@ -822,6 +866,10 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             if constexpr (IT::replay) {   // a singleton behind the table's step: replay the steps it missed, THEN score it
                 if (flag_of(j) && tg[u] > 0 && tg[u] < P.upto) replay_in_window<MODEL, W, NV, LPG>(P, wopt, tg[u], lrv[u], re[u], st0[u], st1[u], lg);
             }
+            if constexpr (IT::lp_replay) {   // (the tag is the group's — a wave per group — so the step loop and its learning rates are scalar)
+                const int from = __builtin_amdgcn_readfirstlane(group_lane_value<LPG>(my_tag, first, j - chunk0));
+                if (from < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, from, lr_lane, re[u], lg, lp_acc);
+            }
             float nrm = 0.f;
             if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
                 if (MODEL == EMG_TRANSE_L2 && P.bw_scores_neg) {
@@ -931,7 +979,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + eg) * P.ldc, lg, P.nchunks, P.khalf);
         }
     }
-    if constexpr (IP == 3) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated in place
+    if constexpr (IP == 3 || IP == 7) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated (and replayed) in place
     if constexpr (FUSED) {
         // loss: one value per group (lane 0), block-reduced in double, one atomic per block
         double v = (active && lg == 0) ? (double)loss_acc : 0.0;

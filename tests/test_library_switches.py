@@ -16,12 +16,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, tag, env_over, name, k, loss, opt):
+def _run(tmp_path, tag, env_over, name, k, loss, opt, *extra):
     out = str(tmp_path / ("%s.npz" % tag))
     env = dict(os.environ)
     env.update(env_over)
     env["EMG_GRAPH"] = env_over.get("EMG_GRAPH", "1")
-    subprocess.run([sys.executable, "-m", "tests._switch_worker", out, name, str(k), loss, opt], cwd=ROOT, env=env, check=True, timeout=600)
+    subprocess.run([sys.executable, "-m", "tests._switch_worker", out, name, str(k), loss, opt] + list(extra), cwd=ROOT, env=env, check=True, timeout=600)
     return dict(np.load(out))
 
 
@@ -49,3 +49,18 @@ def test_compile_time_optimizer_forms_of_the_apply_give_the_same_bits(tmp_path, 
     _same(a, b)
     c = _run(tmp_path, "nograph", {"EMG_APPLY_FIX": "1", "EMG_GRAPH": "0"}, name, k, loss, opt)   # (and as single steps)
     _same(a, c)
+
+
+@pytest.mark.parametrize("name,k,loss,p", [("ComplEx", 100, "nll", 2), ("DistMult", 200, "pairwise", 2), ("TransE", 100, "nll", 3)])
+def test_sgd_with_the_lp_regulariser_folds_the_same_bits_in_every_form(tmp_path, name, k, loss, p):
+    """plain SGD + LP: the apply's compile-time form for p = 2 (apply_segments_kernel<..., kFixSgdLp2>) against the run-time switch,
+    and the two-multiplication fold lp_fold_p2 that every p = 2 path takes since round 5 (lambda 2 |w| sgn w = fl(2 lambda w)) — the
+    tables byte for byte; the regulariser's value is a sum of double atomics from several kernels: equal to 1e-12.  p = 3 keeps the
+    generic fold in both legs (the switch must not touch it)."""
+    a = _run(tmp_path, "fix", {"EMG_APPLY_FIX": "1"}, name, k, loss, "sgd", "lp%d" % p)
+    b = _run(tmp_path, "switch", {"EMG_APPLY_FIX": "0"}, name, k, loss, "sgd", "lp%d" % p)
+    c = _run(tmp_path, "noinplace", {"EMG_APPLY_FIX": "1", "EMG_INPLACE": "0", "EMG_GRAPH": "0"}, name, k, loss, "sgd", "lp%d" % p)   # every row through the apply
+    for other in (b, c):
+        for key in ("E", "R"):
+            assert a[key].tobytes() == other[key].tobytes(), "%s differs" % key
+        np.testing.assert_allclose(a["losses"], other["losses"], rtol=1e-12)
