@@ -59,7 +59,7 @@ BucketGeo bucket_geometry(int64_t N, int64_t R) {
 
 bool group_backend_bucket(int64_t n_ent) {
     const char* e = getenv("EMG_GROUPING");   // (read per call: tests switch it inside one process)
-    if (e && e[0]) return strcmp(e, "bucket") == 0;   // count / sort: never
+    if (e && e[0]) return strcmp(e, "bucket") == 0 && n_ent > kDenseHereMaxRows;   // count / sort: never; forced: wherever it is valid
     return n_ent >= kBucketMinRows;
 }
 

@@ -74,7 +74,11 @@ constexpr int kBucketChunksMax = 512;  // chunks per batch = entries of a row of
 constexpr int kBucketRowsMax = 2048;   // table rows per bucket (the LDS row table of the bucket kernel)
 constexpr int kBucketMaxNB = 4096;     // buckets per table (the LDS histogram of the id kernel)
 constexpr int kBucketCap = 4096;       // contributions of a bucket sorted in LDS; a fuller bucket is sorted through global memory
-constexpr int64_t kBucketMinRows = 65536;  // smaller tables keep the counting grouping: their row arrays live in L2
+// Tables of up to kDenseHereMaxRows rows may run Keras Adam's dense pass INSIDE the descriptor-driven apply launch, which finds the
+// untouched rows in the counting grouping's offset array (emg_apply.hip: dense_here) — an array the bucket grouping never writes.  So
+// the bucket grouping starts ABOVE that size, forced or not (smaller tables keep the counting grouping: their row arrays live in L2).
+constexpr int64_t kDenseHereMaxRows = 131072;
+constexpr int64_t kBucketMinRows = 2 * kDenseHereMaxRows;
 struct BucketGeo { int sh, nb, chunk_log; bool ok; };   // bucket = row >> sh; nb buckets; chunks of 1 << chunk_log slots
 BucketGeo bucket_geometry(int64_t N, int64_t R);
 // 0: counting grouping as ever; 1: bucket grouping where eligible (default); EMG_GROUPING=count|bucket|sort

@@ -1,4 +1,4 @@
-"""The BUCKET form of emg_prepare_batch (csrc/emg_group_bucket.hip: tables of >= 65536 rows) against the counting form
+"""The BUCKET form of emg_prepare_batch (csrc/emg_group_bucket.hip: tables of more than 131072 rows; default from 262144) against the counting form
 (EMG_GROUPING=count) on the same inputs: Philox codes, destination arrays, sorted keys, the stable order, singleton flags,
 factored source rows and positions must be IDENTICAL, the segment descriptors (singleton / segment / block-task lists) equal as
 sets — and an apply from either grouping gives the same table bits.  Shapes: C3's own (1M x 1k, B 16384, eta 20), hub rows,
@@ -118,8 +118,8 @@ CASES = {
     "hubs": (16384, 6, (2,), 500_000, 50, "zipf"),
     "restricted_pool": (8192, 10, (2,), 300_000, 7, "pool"),
     "tiny_batch_big_table": (37, 1, (1,), 1_000_000, 3, "uniform"),      # (the largest table the counting layout takes for 111 rows)
-    "one_relation": (5000, 2, (2,), 70_000, 1, "uniform"),
-    "dense_small_rows": (20000, 30, (2,), 65_536, 2000, "uniform"),
+    "one_relation": (5000, 2, (2,), 140_000, 1, "uniform"),
+    "dense_small_rows": (20000, 30, (2,), 131_073, 2000, "uniform"),      # the smallest table the bucket grouping takes
     "big_batch_wide_chunks": (70000, 12, (2,), 400_000, 100, "uniform"),      # 980 k contributions: chunks of 2048 slots
 }
 
@@ -152,7 +152,7 @@ def test_bucket_grouping_equals_counting_grouping(case, factored):
 def test_bucket_grouping_drops_ids_outside_the_table_and_follows_sharded_and_injected_draws():
     d = dev()
     rs = np.random.RandomState(11)
-    B, eta, n_ent, n_rel = 3000, 4, 100_000, 20
+    B, eta, n_ent, n_rel = 3000, 4, 150_000, 20
     pos = np.stack([rs.randint(0, n_ent, B), rs.randint(0, n_rel, B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
     pos[::17, 0] = n_ent + 5          # ids outside the table (subject / relation): dropped, their flags 0
     pos[::29, 1] = n_rel + 1
@@ -206,3 +206,37 @@ def test_apply_from_the_bucket_grouping_gives_the_counting_grouping_bits(opt):
     for x, y in zip(out["count"], out["bucket"]):
         np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
     assert not np.array_equal(out["count"][0], W0)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_fit_on_a_large_table_gives_the_same_bits_under_either_grouping(monkeypatch, opt):
+    """the plan's step on a table of more than 131072 rows (bucket grouping) with a SHORT last batch — the workspaces are laid out for the
+    plan's capacity (layout_B > B) — and a restricted look-ahead: tables, optimizer state and loss equal the counting grouping's"""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    d = dev()
+    del d
+    rs = np.random.RandomState(9)
+    n_ent, n_rel, k, eta, nb = 140_000, 6, 36, 7, 3
+    E0 = (rs.randn(n_ent, 2 * k) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, 2 * k) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, 1000), rs.randint(0, n_rel, 1000), rs.randint(0, n_ent, 1000)], 1).astype(np.int32)
+    X[:300, 0] = 4242                     # a hub row: block tasks
+
+    def run(mode):
+        monkeypatch.setenv("EMG_GROUPING", mode)
+        tr = Trainer(L.COMPLEX, 2 * k, 1.0, E0, R0, eta, loss="nll", optimizer=opt, optimizer_params={"lr": 0.01}, batches_count=nb, seed=2)
+        tr.set_training_set(X, 334)
+        for ep in (1, 2):
+            for b, (s, n) in enumerate(((0, 334), (334, 333), (667, 333))):
+                tr.step(s, n, epoch=ep, batch=b + 1, prefetch=[((s + n) % 1000, 333 if b < 2 else 334, ep + (b == 2), (b + 1) % 3 + 1)])
+        Et, Rt = tr.tables_numpy()
+        return Et, Rt, [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None], tr.read_loss()
+
+    a, b = run("bucket"), run("count")
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    assert a[3] == b[3]
+    assert not np.array_equal(a[0], E0)
