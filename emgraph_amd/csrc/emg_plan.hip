@@ -171,8 +171,8 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     // of such a row together, replays its missed steps in registers and updates it (emg_backward_args.lr_hist); the catch-up and
     // the apply handle every other destination of the batch (s / o slots, rows hit more than once)
     const bool lag_ip = c.lr_t_hist && c.inplace == 2 && c.opt == EMG_OPT_ADAM;
-    // SGD + LP in place under the deferred pass (round 5, form 7): the singleton NEGATIVES' rows are replayed by the scoring kernel as it
-    // gathers them; the catch-up walks the rows hit more than once and the subject / object slots' singletons (slots below 2 B)
+    // SGD + LP in place under the deferred pass (round 5, form 7): every singleton's row is replayed by the scoring kernel as it gathers
+    // it; the catch-up walks the rows hit more than once
     const int n_cols = (c.model == EMG_COMPLEX || c.model == EMG_HOLE) ? c.k_int / 2 : c.k_int;
     static const bool lp_ip_env = [] { const char* e = getenv("EMG_LP_REPLAY"); return !(e && e[0] == '0'); }();   // A/B aid
     const bool lp_ip = c.lr_t_hist && c.inplace == 1 && c.opt == EMG_OPT_SGD && c.lp_lambda_ent != 0.f && c.lp_p <= 3 && c.fused && !P->ctl &&
@@ -183,7 +183,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
         Timed t(P, ST_CATCHUP, main);
         rc = emg_deferred_catchup(c.opt, c.ent, c.n_ent, c.ld_ent, c.k_int, c.ent_state0, c.ent_state1, c.tag_ent, he, c.lr_t_hist, step - 1,
                                   lp ? c.lp_sum : nullptr, sl.buf.ws_ent, sl.buf.ws_ent_bytes, (2 + (int64_t)et) * c.cap_B, w_only,
-                                  lag_ip ? 0 : (lp_ip ? 2 * B : -1), main);   // (the scoring kernel replays every singleton / the negatives' singletons itself)
+                                  (lag_ip || lp_ip) ? 0 : -1, main);   // (the scoring kernel replays every singleton itself)
         if (rc != EMG_OK) return rc;
         rc = emg_deferred_catchup(c.opt, c.rel, c.n_rel, c.ld_rel, c.k_int, c.rel_state0, c.rel_state1, c.tag_rel, hr, c.lr_t_hist, step - 1,
                                   lp ? c.lp_sum + 1 : nullptr, sl.buf.ws_rel, sl.buf.ws_rel_bytes, c.cap_B, w_only, -1, main);

@@ -648,6 +648,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
     constexpr bool SOP = IT::window_state;
     float* stash = nullptr;
     int fso0 = 0, fso1 = 0;
+    int tso0 = 0, tso1 = 0;   // IP 7: the steps a singleton subject / object row was last written at (P.upto: nothing to replay)
     if constexpr (SOP) {
         __shared__ float so_stash_mem[kThreads / 64][2 * (1 + NS)][R::N][64];
         stash = &so_stash_mem[threadIdx.x >> 6][0][0][0];
@@ -684,6 +685,17 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             }
             park(0, rs); park(1, ms); park(1 + NS, ro); park(2 + NS, mo);
             if constexpr (NS == 2) { park(2, vs); park(5, vo); }
+        }
+        if constexpr (IT::lp_replay) {   // a lagging singleton subject / object row: the regulariser's missed steps BEFORE the queries are built from it
+            int my_tag_so = P.upto;
+            if (lg < 2) my_tag_so = P.tag_ent[lg == 0 ? s : o];
+            fso0 = group_lane_value<LPG>(my_flag_so, first, 0); fso1 = group_lane_value<LPG>(my_flag_so, first, 1);
+            tso0 = fso0 ? __builtin_amdgcn_readfirstlane(group_lane_value<LPG>(my_tag_so, first, 0)) : P.upto;
+            tso1 = fso1 ? __builtin_amdgcn_readfirstlane(group_lane_value<LPG>(my_tag_so, first, 1)) : P.upto;
+            float counted = 0.f;
+            if (tso0 < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, tso0, lr_lane, rs, lg, counted);
+            if (tso1 < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, tso1, lr_lane, ro, lg, counted);
+            if (active) lp_acc += counted;   // (a group past the batch's end is a copy of the last one: its replayed steps are not counted twice)
         }
         make_queries<MODEL, W, NV>(rs, rp, ro, qo, qs);
         if constexpr (KEEP) { ks = rs; kp = rp; ko = ro; }
@@ -868,7 +880,9 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             }
             if constexpr (IT::lp_replay) {   // (the tag is the group's — a wave per group — so the step loop and its learning rates are scalar)
                 const int from = __builtin_amdgcn_readfirstlane(group_lane_value<LPG>(my_tag, first, j - chunk0));
-                if (from < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, from, lr_lane, re[u], lg, lp_acc);
+                float counted = 0.f;
+                if (from < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, from, lr_lane, re[u], lg, counted);
+                if (active) lp_acc += counted;
             }
             float nrm = 0.f;
             if constexpr (FUSED || MODEL == EMG_TRANSE_L2) {
@@ -964,6 +978,11 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
         if constexpr (IT::replay) {   // (a singleton's table row still lags: its replayed row is the parked one)
             if (fso0) unpark(0, rs);
             if (fso1) unpark(1 + NS, ro);
+        }
+        if constexpr (IT::lp_replay && !KEEP) {   // (re-read rows still lag: the same replay again — ~130 instructions a row —, its loss terms counted once, above)
+            float uncounted = 0.f;
+            if (tso0 < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, tso0, lr_lane, rs, lg, uncounted);
+            if (tso1 < P.upto) lp_replay_row<MODEL, W, NV, LPG>(P, tso1, lr_lane, ro, lg, uncounted);
         }
         finish_grads<MODEL, W, NV>(rs, rp, ro, Ao, As, inner_coef<MODEL>(gpos, pos_nrm, P.scale), gs, gp, go);
         store_row<MODEL, W, NV, LPG>(gp, P.contrib_rel + eg * P.ldc, lg, P.nchunks, P.khalf);
