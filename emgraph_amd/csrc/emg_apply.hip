@@ -984,7 +984,7 @@ __device__ __forceinline__ Src segment_sources(const ApplyParams& P, uint32_t st
     return (uint32_t)lane < len ? contrib_src(P, (int64_t)start + lane) : Src{0u, 0.f};
 }
 
-template <int DEPTH, bool PLAIN>   // contribution rows in flight per trip; PLAIN: SGD without state / regulariser
+template <int DEPTH, bool PLAIN>   // contribution rows in flight per trip; PLAIN: no optimizer state rows (SGD; the caller decides the regulariser through opt)
 __device__ __forceinline__ void segment_update(const ApplyParams& P, const OptParams& opt, int32_t step, uint32_t dest, int len,
                                                const Src mine, int lane, int nchunks, float& lp_acc) {
     float* wrow = P.table + (int64_t)dest * P.ld;
@@ -1192,6 +1192,9 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     if constexpr (PLAIN) { opt.opt = EMG_OPT_SGD; opt.lp_lambda = 0.f; }   // (known at compile time: the update folds to w - lr g)
     if constexpr (FIX == kFixSgdLp2) { opt.opt = EMG_OPT_SGD; opt.lp_p = 2; }   // (lambda stays a run-time value: the tables' may differ)
     else if constexpr (FIX != 0) { opt.opt = FIX; opt.lp_lambda = 0.f; }
+    // plain SGD has no optimizer state, with or without the regulariser: the segment forms then carry no state rows, no Adam lag and
+    // no dense pass (the registers of eight float4 state values per lane are what kept this form at 102 VGPRs beside PLAIN's 78)
+    constexpr bool NS = PLAIN || FIX == kFixSgdLp2;
     int32_t step = P.step;
     if (P.ctl) {   // the step's number and learning rates from the device record (a captured graph cannot bake them)
         const float* h = P.which ? P.ctl->hyper_rel : P.ctl->hyper_ent;
@@ -1206,7 +1209,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
     if (n_tasks && partial) {
         const unsigned per = waves_per_task(P, nchunks);
         for (int64_t i2 = gw; i2 < (int64_t)n_tasks * per; i2 += nw)
-            long_task_wave<4, 8, 4, PLAIN>(P, opt, step, partial, ldp, P.tasks[i2 / per], (unsigned)(i2 % per), per, lane, lp_acc);
+            long_task_wave<4, 8, 4, NS>(P, opt, step, partial, ldp, P.tasks[i2 / per], (unsigned)(i2 % per), per, lane, lp_acc);
     } else if (n_tasks) {
         for (int64_t i = gw; i < (int64_t)n_tasks; i += nw) {
             const LongTask tk = P.tasks[i];
@@ -1254,7 +1257,7 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                 const bool on = on_n;
                 const Src mine = nxt;
                 if (k + 2 < cnt) nxt = item(k + 2, len_n, dest_n, on_n);
-                segment_update_half<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, on, mine, lane, nchunks, lp_acc);
+                segment_update_half<EMG_SEG_DEPTH, NS>(P, opt, step, dest, (int)len, on, mine, lane, nchunks, lp_acc);
             }
         } else {
         Src nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, 0), (uint32_t)__builtin_amdgcn_readlane((int)sg.len, 0), lane);
@@ -1266,12 +1269,12 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
                 nxt = segment_sources(P, (uint32_t)__builtin_amdgcn_readlane((int)sg.start, k + 1),
                                       (uint32_t)__builtin_amdgcn_readlane((int)sg.len, k + 1), lane);
             if ((int64_t)dest >= P.n_rows) continue;   // defensive: never write outside the table
-            segment_update<EMG_SEG_DEPTH, PLAIN>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
+            segment_update<EMG_SEG_DEPTH, NS>(P, opt, step, dest, (int)len, mine, lane, nchunks, lp_acc);
         }
         }
     }
     if (P.which == 0) EMG_STAMP(3);   // (trace builds: the entity table's items done, its untouched rows next)
-    if constexpr (!PLAIN) if (P.dense_here) {   // the rows nothing touched: 64 rows' counts in one load, then a wave per untouched row
+    if constexpr (!NS) if (P.dense_here) {   // the rows nothing touched: 64 rows' counts in one load, then a wave per untouched row
         ApplyParams Q = P;
         Q.opt = opt;
         const bool vec = untouched_vec(P);
@@ -1337,7 +1340,7 @@ struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int
 #define EMG_SEG_MINWAVES 1   // A/B aid: waves per SIMD the stateful instantiations are compiled for (a register cap)
 #endif
 template <bool PLAIN, bool RIDE, bool HALF = false, int FIX = 0>   // HALF: rows of 17..32 chunks, two items per wave (segment_update_half)
-__global__ __launch_bounds__(256, (PLAIN ? 1 : EMG_SEG_MINWAVES)) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
+__global__ __launch_bounds__(256, ((PLAIN || FIX == kFixSgdLp2) ? 1 : EMG_SEG_MINWAVES)) void apply_segments_kernel(const SegmentsLaunch K, const Riders riders) {
     // RIDE: the first workgroups of the launch do preparation stages of the next batches (emg_group_kernels.hpp)
     unsigned bx = blockIdx.x, nbx = gridDim.x;
     if constexpr (RIDE) {
