@@ -6,7 +6,7 @@ OUT="${HERE}/../lib"
 OBJ="${HERE}/_obj"
 mkdir -p "${OUT}" "${OBJ}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"${HERE}/../../include" -Wall -Wno-unused-function ${EMG_EXTRA_FLAGS:-})   # EMG_EXTRA_FLAGS: timing ablations (tools/ablate_v4.sh)
 # the hash of every kernel source goes into the library (emg_source_hash): profiles/ name the binary they measured
 SRC_HASH="$(cd "${HERE}" && cat emg_*.hip emg_*.hpp emg_*.inc ../../include/emgraph_hip.h | sha256sum | cut -c1-16)"
 if [[ ! -f "${OBJ}/src_hash.txt" || "$(cat "${OBJ}/src_hash.txt")" != "${SRC_HASH}" ]]; then rm -f "${OBJ}/emg_abi.o"; echo "${SRC_HASH}" > "${OBJ}/src_hash.txt"; fi

@@ -22,6 +22,7 @@
 #include "emg_common.hpp"
 #include <atomic>
 #include <type_traits>
+#include <utility>
 
 namespace emg {
 
@@ -852,6 +853,360 @@ static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
     return EMG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// v4 count kernel: 64 query rows per wave, ONE wave per SIMD, the entity stream entity-group-major.
+//
+// Measured on v3: every one of its eight waves reads the whole entity slice from LDS for its 32 query rows —
+// 8 x 16 KB per 16 KB streamed, the LDS pipe as busy as the MFMA pipe — and the two waves of a SIMD reach the tile's compare
+// epilogue together, behind the same barriers: MFMA busy 47 %.  Here a wave owns 64 query rows (two 32-row halves: 2 x NQ x 4
+// registers of fragments in the AGPRs — a wave addresses 256 VGPRs + 256 AGPRs, an MFMA reads its A operand from either), so a
+// B fragment read from LDS feeds TWO MFMAs and a workgroup of four waves covers the same 256 rows with half the LDS reads.
+// With no second wave to hide behind, the epilogue is interleaved with the MFMAs by construction: the stream is reordered so
+// that a STAGE is 32 entities x the whole contraction (a quarter tile, all k), a stage's 2 NQ MFMAs accumulate 64 x 32 scores
+// in 32 VGPRs, and the compare-and-count of the PREVIOUS stage's 32 registers sits in the slots between this stage's MFMAs.
+// Accumulators ping-pong between two VGPR sets (the stage loop is unrolled twice); the first MFMA of a stage takes srcC = 0.
+// What the first version (compiler-scheduled builtins) measured, and what this one does about it:
+//   * hipcc puts the MFMA results in AGPRs and copies all 32 to VGPRs at the stage's end (v_accvgpr_read x 32 behind the last
+//     MFMA's latency), answers every use of a ds_read with s_waitcnt lgkmcnt(0) (the fragments read AHEAD drained with it) and
+//     gives a counted value v_cmp -> s_and -> v_cndmask -> v_add: the 143 VALU instructions of a stage were NOT hidden (2 NQ MFMAs
+//     = 1650 cycles, the stage took 3000).  Here the MFMAs, the LDS reads and the compare-and-count are inline asm: the
+//     accumulators are VGPR operands of the MFMA itself, LDS reads are counted by hand (they return in order: "at most N younger
+//     reads outstanding" is a fragment's arrival), a counted value is v_cmp + v_addc (the lane's carry-in IS the comparison).
+//     The compiler knows none of the MFMA hazards inside asm; the schedule keeps every dependent pair apart by construction
+//     (an accumulator is read by the VALU a whole MFMA after its last write at the earliest, B fragments arrive through
+//     s_waitcnt, nothing else writes an MFMA operand).
+//   * one barrier per stage with all four waves arriving together and the next stage's first fragments read behind it cost
+//     ~550 cycles per stage: the barrier now stands PF k-steps before the stage's end and the next stage's first PF fragments
+//     are read across it.
+//   * the refill was one owner wave per stage behind a branch in every slot: every wave now issues its share of every stage's
+//     LDS-DMA instructions (instruction j by wave j mod 4, the odd ones out twice), branch-free, a constant vmcnt.
+// LDS: rows of 2 NQ + 1 sixteen-byte slots (an ODD pitch: conflict-free ds_read_b128 without a swizzle: 0 conflicts by PMC), a
+// stage = NQ + 1 LDS-DMA instructions of 1 KB (the last one half padding), a ring of NS stages (6 at NQ = 25: 156 KB).
+// The MFMA k-order per score is v3's (k-steps ascending into one accumulator): the same bits, the same counts — tests compare.
+// The prefilter's pairs go to TWO segments per wave (one per 32-row half): the pair buffer keeps v3's geometry (eight
+// segments of 32 query rows per 256-row workgroup), the re-scoring pass sees no difference.
+template <class F, int... I> __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int OFF> __device__ __forceinline__ void lds_read16(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+template <bool F16, bool FIRST> __device__ __forceinline__ void mfma_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    if constexpr (FIRST) {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b));
+    } else {
+        if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+    }
+}
+constexpr int v4_ring(int nq) {   // B-fragment ring: the smallest divisor of NQ that is >= 4 (a stage then starts at ring index 0)
+    for (int r = 4; r <= nq; ++r)
+        if (nq % r == 0) return r;
+    return nq;
+}
+template <int NQ> struct V4Geo {
+    static constexpr int SLOTS = 2 * NQ + 1;            // 16-byte slots per LDS row
+    static constexpr int PITCH = 16 * SLOTS;
+    static constexpr int INSTR = NQ + 1;                // LDS-DMA instructions (1 KB each) per stage of 32 rows
+    static constexpr int FI = (INSTR + 3) / 4;          // ... per wave
+    static constexpr int STAGE = 1024 * INSTR;
+    static constexpr int NS_FIT = (160 * 1024 - 2048) / STAGE;
+    static constexpr int NS = NS_FIT > 8 ? 8 : NS_FIT;  // ring slots
+    static constexpr int RB = v4_ring(NQ);              // B fragments held
+    static constexpr int PF = RB - 1 > 6 ? 6 : RB - 1;  // ... read ahead (k-steps; <= 15 outstanding LDS reads encode)
+    static_assert(NS >= 4 && FI * (NS - 2) <= 63 && PF >= 1 && PF < NQ, "v4: ring too short / vmcnt does not encode");
+};
+constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }   // s_waitcnt vmcnt(n), gfx9 encoding (6 bits, split)
+
+#ifndef V4_ABLATE
+#define V4_ABLATE 0  // timing experiments only (wrong results): 1 no refills, 2 no compare epilogue, 4 no MFMAs, 8 no LDS reads, 16 no wait / barrier
+#endif
+template <int NQ, int MODE>   // MODE 0 both counters | 1 one | 2 prefilter (see v3)
+__global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountBf16Params P) {
+    using G = V4Geo<NQ>;
+    constexpr bool ONE = MODE == 1, PRE = MODE == 2;
+    constexpr int NS = G::NS, STAGE = G::STAGE, INSTR = G::INSTR, FI = G::FI, SLOTS = G::SLOTS, PF = G::PF, RB = G::RB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ring | thresholds
+    float* thr_s = reinterpret_cast<float*>(smem + NS * STAGE);             // [0,256): gt, [256,512): ge
+
+    const int64_t id = blockIdx.x;
+    const int64_t xcd = id & 7, slot_id = id >> 3;
+    const int64_t qb = slot_id % P.n_qb;
+    const int64_t cb = xcd + 8 * (slot_id / P.n_qb);
+    if (cb >= P.n_cb) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int64_t n_cand = P.n_cand, ld_ent = P.ld_ent;
+
+    // ---- one-time: thresholds -> LDS -> registers, this wave's query fragments -> AGPRs --------------------
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int64_t qr = qb * 256 + tid;
+        float t = INFINITY;  // rows past the end count nothing
+        if (PRE && P.thr_direct != nullptr) {
+            if (qr < P.n_rows) t = P.thr_direct[(half ? P.n_rows : 0) + qr];
+        } else if (qr < P.n_rows) {
+            const int p = P.pos_int[qr];
+            const bool want_gt = ONE ? P.need == 2 : half == 0;
+            t = acc_threshold(want_gt ? gt_threshold(p) : ge_threshold(p), P.cmul);
+            if constexpr (PRE) {   // widened by the band, outwards (v3)
+                const float b = P.band[qr] + 1e-6f * fabsf(t) + 1e-30f;
+                t = want_gt ? nextafterf(t + b, INFINITY) : nextafterf(t - b, -INFINITY);
+            }
+        }
+        thr_s[half * 256 + tid] = t;
+    }
+    bf16x8 A[2][NQ];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t qr = min(qb * 256 + wave * 64 + 32 * h + l31, P.n_rows - 1);
+        const uint16_t* qp = P.Q + qr * P.ldq + 8 * lhi;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) A[h][q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + q * 16));
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): from here on only LDS-DMA (and pair stores) are in the VMEM queue
+    __syncthreads();
+    f32x4 gth[2][4], eth[2][4];   // this lane's rows: 64 w + 32 h + 8 j + i + 4 lhi
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r0 = wave * 64 + 32 * h + 8 * j + 4 * lhi;
+            gth[h][j] = *reinterpret_cast<const f32x4*>(thr_s + r0);
+            if constexpr (!ONE) eth[h][j] = *reinterpret_cast<const f32x4*>(thr_s + 256 + r0);
+        }
+
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // compiler-visible lgkmcnt(0): no LDS read of the compiler's is pending inside the stage loop
+                                          // (it would answer each use there with an s_waitcnt lgkmcnt(0) that drains the hand-counted reads)
+    unsigned cgt[2][16];   // per accumulator register: how often its score reached the first threshold (<= 4 x tiles_per_chunk)
+    unsigned ceq[2][4];    // MODE 0: ties, four packed 8-bit counters per register quadruple (rare)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cgt[h][r] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ceq[h][j] = 0u;
+    }
+
+    // ---- LDS-DMA producer: every wave issues its share (instruction j by wave j mod 4) of every stage ---------
+    const int64_t tile0 = cb * P.tiles_per_chunk;
+    const int ntile = (int)(min(tile0 + (int64_t)P.tiles_per_chunk, P.n_tiles) - tile0);
+    const int rot = (int)(qb % ntile);   // tiles are visited in a per-block rotated order (v2)
+    unsigned off[FI];                    // byte offset of this lane's piece of my fill instruction i from the stage's first row
+    unsigned ldo[FI];                    // ... and its 1 KB place in the stage (scalar)
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        int j = wave + 4 * i;
+        if (j >= INSTR) j -= 4;          // (the odd ones out: an instruction of mine again — the same bytes to the same place)
+        const int p = 64 * j + lane;
+        off[i] = (unsigned)min(p / SLOTS, 31) * (unsigned)(ld_ent * 2) + (unsigned)min(p % SLOTS, 2 * NQ - 1) * 16u;
+        ldo[i] = (unsigned)__builtin_amdgcn_readfirstlane(1024 * j);
+    }
+    // (the table's last rows: a stage that would run past them is SHIFTED back to end at the last row — every fetched row exists,
+    //  nothing is clamped per lane; the epilogue masks the rows it has seen in the stage before and names entities from the shifted base)
+    int ftile = rot, ftb = 0, fslot = 0;   // chunk-local tile / quarter / ring slot of the next stage to fill
+    const unsigned char* fsrc = nullptr;
+    unsigned fbase = 0u;
+    const unsigned ring0 = (unsigned)(uintptr_t)smem;
+    auto fill_point = [&]() __attribute__((always_inline)) {
+        const int64_t row0 = min((tile0 + ftile) * V3_BN + 32 * ftb, n_cand - 32);
+        fsrc = reinterpret_cast<const unsigned char*>(P.ent) + row0 * ld_ent * 2;
+        fbase = __builtin_amdgcn_readfirstlane(ring0 + (unsigned)fslot * STAGE);
+    };
+    auto fill_one = [&](int i) __attribute__((always_inline)) {
+        if (!(V4_ABLATE & 1)) glds16(reinterpret_cast<const uint16_t*>(fsrc + off[i]), fbase + ldo[i]);
+    };
+    auto fill_next = [&]() __attribute__((always_inline)) {
+        ftb = (ftb + 1) & 3;
+        if (ftb == 0) ftile = ftile + 1 == ntile ? 0 : ftile + 1;
+        fslot = fslot + 1 == NS ? 0 : fslot + 1;
+    };
+#pragma unroll 1
+    for (int t = 0; t < NS - 1; ++t) {   // stages 0 .. NS-2 (the stream wraps around the chunk; fills past its end are never read)
+        fill_point();
+#pragma unroll
+        for (int i = 0; i < FI; ++i) fill_one(i);
+        fill_next();
+    }
+
+    // ---- consumer ---------------------------------------------------------------------------------------
+    const unsigned rd_base = ring0 + (unsigned)(l31 * G::PITCH + 16 * lhi);
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[h][r] = 0.f; accB[h][r] = 0.f; }
+    int cslot = 0;
+    uint64_t cokP = 0ull;   // lanes whose entity of the PREVIOUS stage is new (none before the first stage)
+    bool fullP = false;     // ... all of them (else: patch)
+    uint32_t colP = 0u;     // global id of that stage's first entity
+    unsigned pair_n[2] = {0u, 0u}, pair_over = 0u;
+    uint64_t* pair_base[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        pair_base[h] = PRE ? P.pairs + ((uint64_t)blockIdx.x * 8u + (unsigned)(2 * wave + h)) * P.pair_cap : nullptr;
+    const uint32_t row_s = (uint32_t)(qb * 256 + wave * 64);
+    const unsigned lhi4 = 4u * (unsigned)lhi;
+
+    auto emit_mask = [&](uint64_t m, int h, int r) __attribute__((always_inline)) {   // (v3's emission; r = 4 j + i: row = row_s + 32 h + 8 j + i + 4 lhi)
+        const unsigned n = (unsigned)__builtin_popcountll(m);
+        if (pair_n[h] + n > P.pair_cap) { pair_over = 1u; return; }   // the caller redoes this query tile with the exact kernel
+        const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        // (the lane terms are made opaque: otherwise the 32 lane-dependent row sums are hoisted out of the stage loop and held in
+        // vector registers for an emission that may never come)
+        unsigned lv = (unsigned)l31, hv = lhi4;
+        asm volatile("" : "+v"(lv), "+v"(hv));
+        if (__builtin_amdgcn_inverse_ballot_w64(m))   // low word: entity, high word: query row
+            *reinterpret_cast<uint2*>(pair_base[h] + pair_n[h] + before) =
+                make_uint2(colP + lv, row_s + (unsigned)(32 * h + 8 * (r >> 2) + (r & 3)) + hv);
+        pair_n[h] = (unsigned)__builtin_amdgcn_readfirstlane((int)(pair_n[h] + n));
+    };
+    // one accumulator register of the previous stage: compare and count; v = 16 h + 4 j + i.  Two counters / the prefilter: what
+    // the two lane masks say — a tie, an undecided candidate — is looked at ONE VALUE LATER (resolve): the scalar test of masks
+    // the VALU has just produced would stall the wave, and the MFMA behind it, for the compare's latency.
+    uint64_t smg = 0ull, sme = 0ull;
+    auto resolve = [&](int v) __attribute__((always_inline)) {
+        const int h = v >> 4, r = v & 15, j = r >> 2, i = r & 3;
+        const uint64_t mu = sme & ~smg;
+        if (mu) {   // wave-uniform; ties are rare, the prefilter's undecided are a few per stage
+            if constexpr (PRE) emit_mask(mu, h, r);
+            else ceq[h][j] += __builtin_amdgcn_inverse_ballot_w64(mu) ? (1u << (8 * i)) : 0u;
+        }
+    };
+    auto judge = [&](f32x16 (&aP)[2], int v) __attribute__((always_inline)) {
+        const int h = v >> 4, r = v & 15, j = r >> 2, i = r & 3;
+        const float x = aP[h][r];
+        if constexpr (ONE) {
+            asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cgt[h][r]) : "v"(x), "v"(gth[h][j][i]) : "vcc");
+        } else {
+            if (v > 0) resolve(v - 1);
+            asm volatile("v_cmp_ge_f32_e64 %1, %3, %4\n\tv_cmp_ge_f32_e64 %2, %3, %5\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %1"
+                         : "+v"(cgt[h][r]), "=&s"(smg), "=&s"(sme) : "v"(x), "v"(gth[h][j][i]), "v"(eth[h][j][i]) : "vcc");
+        }
+    };
+    auto judge_flush = [&]() __attribute__((always_inline)) {   // the stage's last value (before colP moves on)
+        if constexpr (!ONE) resolve(31);
+    };
+
+    // The table's last stage was shifted back over rows the stage before has counted: their lanes get a NaN score — it reaches no
+    // threshold — and the compare-and-count needs no mask.  (An accumulator the VALU writes behind an MFMA's back: the nops let
+    // the stage's last MFMA retire first; once per table.)
+    auto patch = [&](f32x16 (&aP)[2]) __attribute__((always_inline)) {
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(aP[0]), "+v"(aP[1]));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aP[h][r] = __builtin_amdgcn_inverse_ballot_w64(cokP) ? aP[h][r] : __builtin_nanf("");
+        asm volatile("" : "+v"(aP[0]), "+v"(aP[1]));
+    };
+    // the compare-and-count of the previous stage goes into the slots 1 .. JS - 1, the refill's instructions behind the barrier
+    constexpr int JS = 2 * (NQ - PF) > 2 ? 2 * (NQ - PF) : 2;
+    auto run_stage = [&](f32x16 (&aC)[2], f32x16 (&aP)[2], bf16x8 (&B)[RB], int s) __attribute__((always_inline)) {
+        if (!fullP) patch(aP);   // (block-uniform, the table's last stage only)
+        const unsigned rd = rd_base + (unsigned)cslot * STAGE;
+        cslot = cslot + 1 == NS ? 0 : cslot + 1;
+        const unsigned rdn = rd_base + (unsigned)cslot * STAGE;
+        static_for([&](auto Qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(Qc)::value;
+            if constexpr (q == NQ - PF) {
+                // the next stage has landed (mine: at most the NS - 3 younger batches still fly; the barrier: everyone's), and
+                // every wave is done with the stage BEFORE this one: its slot is refilled behind the barrier
+                if constexpr (!(V4_ABLATE & 16)) {
+                    __builtin_amdgcn_s_waitcnt(vmcnt_imm(FI * (NS - 3)));
+                    __builtin_amdgcn_s_barrier();
+                }
+                fill_point();
+            }
+            if constexpr (!(V4_ABLATE & 8)) {
+                if constexpr (q + PF < NQ) lds_read16<32 * (q + PF)>(B[(q + PF) % RB], rd);
+                else lds_read16<32 * (q + PF - NQ)>(B[(q + PF) % RB], rdn);   // the next stage's first fragments, across the barrier
+            }
+            lds_wait<PF>(B[q % RB]);   // this k-step's fragment has arrived; the PF younger reads fly on
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if constexpr (!(V4_ABLATE & 4)) mfma_asm<PRE, q == 0>(aC[hh], A[hh][q], B[q % RB]);
+                // the slot behind this MFMA
+                const int sl = 2 * q + hh;
+                if (sl >= 1 && sl < JS && !(V4_ABLATE & 2)) {
+#pragma unroll
+                    for (int v = (sl - 1) * 32 / (JS - 1); v < sl * 32 / (JS - 1); ++v) judge(aP, v);
+                }
+                if (sl == JS && !(V4_ABLATE & 2)) judge_flush();
+                if (sl >= JS || JS == 2 * NQ) {
+                    const int u = JS == 2 * NQ ? sl : sl - JS, nu = 2 * NQ - (JS == 2 * NQ ? 0 : JS);
+#pragma unroll
+                    for (int i = u * FI / nu; i < (u + 1) * FI / nu; ++i) fill_one(i);
+                }
+            }
+        }, std::make_integer_sequence<int, NQ>{});
+        fill_next();
+        const int tb = s & 3, ti = s >> 2;
+        const int ctile = rot + ti >= ntile ? rot + ti - ntile : rot + ti;
+        const int64_t col0 = (tile0 + ctile) * V3_BN + 32 * tb, col0s = min(col0, n_cand - 32);   // (shifted like the fill)
+        fullP = col0s == col0;
+        cokP = __builtin_amdgcn_ballot_w64(col0s + l31 >= col0);
+        colP = (uint32_t)(P.ent_offset + col0s);
+    };
+    // stage 0 has landed; its first PF fragments
+    bf16x8 B[RB];
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(FI * (NS - 2)));
+    __builtin_amdgcn_s_barrier();
+    static_for([&](auto Qc) __attribute__((always_inline)) { constexpr int q = decltype(Qc)::value; lds_read16<32 * q>(B[q], rd_base); }, std::make_integer_sequence<int, PF>{});
+#pragma unroll 1
+    for (int s = 0; s < 4 * ntile; s += 2) {
+        run_stage(accA, accB, B, s);
+        run_stage(accB, accA, B, s + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragments read past the last stage)
+    if (!fullP) patch(accB);
+#pragma unroll
+    for (int v = 0; v < 32; ++v) judge(accB, v);   // the last stage's
+    judge_flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
+    if constexpr (PRE) {
+        if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) P.pair_count[blockIdx.x * 8u + (unsigned)(2 * wave + h)] = pair_n[h];
+            if (pair_over) atomicOr(P.pair_count + P.n_segments, 1u);
+        }
+    }
+    // ---- rows are private to the wave: lane shuffle, one global atomic per row and counter ----------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned c = cgt[h][r] | (((ceq[h][r >> 2] >> (8 * (r & 3))) & 0xffu) << 16);  // gt | eq << 16: room for the 32-lane sum
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (l31 == 0) {
+                const int64_t qr = qb * 256 + wave * 64 + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (qr < P.n_rows) {
+                    if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
+                    if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
+                }
+            }
+        }
+}
+
+template <int NQ, int MODE>
+static int launch_v4(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
+    const size_t lds_bytes = (size_t)V4Geo<NQ>::NS * V4Geo<NQ>::STAGE + 2 * 256 * sizeof(float);
+    static std::atomic<uint64_t> devices_done{0};  // one flag per template instance and device
+    int rc = allow_full_lds((const void*)count_mfma_bf16_v4_kernel<NQ, MODE>, devices_done);
+    if (rc != EMG_OK) return rc;
+    hipLaunchKernelGGL((count_mfma_bf16_v4_kernel<NQ, MODE>), dim3((unsigned)nblk), dim3(256), lds_bytes, st, P);
+    return EMG_OK;
+}
+static int v4_mode() {   // EMG_BF16_V4: 0 the v3 kernel everywhere, 1 (default) v4 where it wins (one counter), 2 v4 in every mode at 400 columns (A/B, tests)
+    const char* e = getenv("EMG_BF16_V4");
+    return e ? atoi(e) : 1;
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // the true entity of every query row (the row's own candidate)
@@ -985,6 +1340,14 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
             else if (nq == 38) rc = launch_v3<38, 4, 2, 4>(P, wblk, st);
             else if (nq == 44) rc = launch_v3<44, 4, 2, 4>(P, wblk, st);
             else rc = launch_v3<50, 4, 2, 4>(P, wblk, st);
+        }
+        else if (md == 1 && v4_mode() >= 1 && P.n_cand >= V3_BN) {   // one counter: 64 query rows per wave (v4: -9 % at 400 columns)
+            if (nq == 25) rc = launch_v4<25, 1>(P, nblk, st);
+            else if (nq == 13) rc = launch_v4<13, 1>(P, nblk, st);
+            else rc = launch_v4<8, 1>(P, nblk, st);
+        }
+        else if (nq == 25 && v4_mode() == 2 && P.n_cand >= V3_BN) {   // A/B only: v4 loses to v3 with two counters / as the prefilter
+            rc = md == 2 ? launch_v4<25, 2>(P, nblk, st) : launch_v4<25, 0>(P, nblk, st);
         }
         else if (nq == 25) rc = EMG_V3(25);
         else if (nq == 13) rc = EMG_V3(13);

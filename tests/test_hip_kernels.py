@@ -740,6 +740,69 @@ def test_bf16_stationary_kernel_equals_tile_kernel(model, k, n_ent, nq):
     np.testing.assert_array_equal(got.cpu().numpy(), exp.cpu().numpy())
 
 
+@pytest.mark.parametrize("model,k,n_ent,nq", [("ComplEx", 200, 5000, 300), ("HolE", 200, 4127, 290), ("ComplEx", 200, 131, 140),
+                                              ("ComplEx", 64, 1500, 100), ("ComplEx", 100, 4000, 200)])
+def test_bf16_wide_wave_kernel_equals_register_stationary_kernel(model, k, n_ent, nq, monkeypatch):
+    """v4 (64 query rows per wave, one wave per SIMD, entity-group-major stages, inline-asm MFMA / LDS reads / compare-and-count)
+    against v3 in every mode it is instantiated for: both counters and the half-precision prefilter at 400 columns
+    (EMG_BF16_V4=2: A/B forms, v3 stays the default there), one counter at 400 / 208 / 128 columns (EMG_BF16_V4=1, the
+    default).  Same MFMA k-order: counters bit for bit, the prefilter's undecided pairs as a set.  Tables whose row count is
+    not a multiple of 32 exercise the shifted last stage (NaN-patched lanes), row counts that are not multiples of 256 the
+    clamped query rows, planted duplicates the ties."""
+    d = dev()
+    from emgraph_amd.evaluation import ranking as RK
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k + n_ent, scale=0.2)
+    rs = np.random.RandomState(k + 1)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    for j in range(0, nq, 3):
+        E[rs.randint(0, n_ent, 2)] = E[T[j, 2]]
+        E[rs.randint(0, n_ent, 1)] = E[T[j, 0]]
+    sc = scale_of(model, k)
+    Q, pos_f32 = d.eval_build_queries(MID[model], cu(E), cu(R), ki, sc, cu(T), 3)
+    ld = d.bf16_ld(ki)
+    Eb, Qb = d.to_bf16(cu(E), ki, ld_dst=ld), d.to_bf16(Q, ki, ld_dst=ld)
+    pos_int, self_ent = d.eval_pos_int_bf16(MID[model], Eb, ki, sc, cu(T), 3, Qb)
+    n_rows = Qb.shape[0]
+
+    def counts(v4, need):
+        monkeypatch.setenv("EMG_BF16_V4", str(v4))
+        c = torch.zeros((2, n_rows), dtype=torch.int32, device="cuda")
+        d.eval_count_bf16(MID[model], Qb, pos_int, self_ent, Eb, ki, sc, c[0], c[1], need=need)
+        torch.cuda.synchronize()
+        return c.cpu().numpy()[: (2 if need == 0 else 1)]
+
+    for need in (1, 2, 0):
+        np.testing.assert_array_equal(counts(2, need), counts(0, need), err_msg="need=%d" % need)
+    if ki != 400 or n_ent < 128:
+        return
+    # the prefilter (IEEE half operands, a rigorous band per query row)
+    ldh = d.prefilter_ld(ki)
+    Eh, Qh = d.to_f16(cu(E), ki, ld_dst=ldh), d.to_f16(Q, ki, ld_dst=ldh)
+    band = RK.prefilter_band(Q, Qh, ki, RK.table_norm_bounds(cu(E), Eh, ki))
+    n_seg = d.eval_prefilter_segments(n_rows, n_ent, ki)
+
+    def prefilter(v4):
+        monkeypatch.setenv("EMG_BF16_V4", str(v4))
+        pairs, pcount = RK._pair_buffer(torch.device("cuda"), n_seg)
+        cg = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+        d.eval_prefilter_f16(MID[model], Qh, pos_f32, band, Eh, 0, ki, sc, cg, pairs, pcount)
+        torch.cuda.synchronize()
+        pc = pcount.cpu().numpy()
+        assert pc[n_seg] == 0
+        cap = pairs.numel() // n_seg
+        pn = pairs.cpu().numpy()
+        got = [np.sort(pn[i * cap: i * cap + pc[i]]) for i in range(n_seg)]   # per segment: the same pairs in any order
+        return cg.cpu().numpy(), pc[:n_seg].copy(), got
+
+    g4, c4, p4 = prefilter(2)
+    g3, c3, p3 = prefilter(0)
+    np.testing.assert_array_equal(g4, g3)
+    np.testing.assert_array_equal(c4, c3)
+    for a, b in zip(p4, p3):
+        np.testing.assert_array_equal(a, b)
+    assert c3.sum() > 0
+
+
 @pytest.mark.parametrize("model,k,n_ent", [("ComplEx", 200, 6000), ("DistMult", 200, 3000), ("HolE", 100, 2500),
                                            ("ComplEx", 64, 1500)])
 def test_bf16_filter_counts_are_what_the_count_kernel_counted(model, k, n_ent):
