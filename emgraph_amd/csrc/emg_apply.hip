@@ -683,7 +683,7 @@ __device__ __forceinline__ void untouched_rows_body(const ApplyParams& P0, int64
         if (P.tag[r] == P.step) continue;
         untouched_row_update(P, r, lane, vec, lp_acc);
     }
-    if (P.opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
+    if (P.opt.lp_lambda != 0.f) block_add_double(P.lp_accum, lp_acc);   // (every thread of the workgroup arrives here)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -753,21 +753,6 @@ __device__ __forceinline__ void replay_row(const ReplayParams& P, int64_t r, int
         }
     }
     if (lane == 0) P.tag[r] = P.upto;
-}
-
-// the regulariser's partial sums of a workgroup's waves -> ONE double atomic (a launch of 16 k waves adding to one address one
-// by one took longer than the replay itself)
-__device__ __forceinline__ void block_add_double(double* dst, float partial) {
-    __shared__ double s_part[4];
-    double v = (double)partial;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (dst && t != 0.0) atomicAdd(dst, t);
-    }
 }
 
 // the rows a prepared batch will read and update = the destinations of its grouping's lists (each exactly once).  A wave takes
@@ -1330,7 +1315,9 @@ __device__ __forceinline__ void apply_segments_table(const ApplyParams& P, float
             }
         }
     }
-    if (opt.lp_lambda != 0.f) wave_add_double(P.lp_accum, lp_acc);
+    // (every wave of the persistent grid ends here at the same moment: one double atomic per WAVE to one address was 54 us of
+    //  C3 + LP's 124 us apply — same-address device-scope atomics retire one per ~10 ns; block_add_double: one per workgroup)
+    if (opt.lp_lambda != 0.f) block_add_double(P.lp_accum, lp_acc);
 }
 
 struct SegmentsLaunch { ApplyParams P[2]; float* partial[2]; int64_t ldp[2]; int32_t n_tables; int32_t relief; };

@@ -394,6 +394,23 @@ __device__ __forceinline__ void wave_add_double(double* dst, float partial) {
     if (dst && (threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
 }
 
+// the regulariser's partial sums of a workgroup's waves -> ONE double atomic (a launch of 16 k waves adding to one address one
+// by one took longer than the replay itself)
+__device__ __forceinline__ void block_add_double(double* dst, float partial) {
+    __shared__ double s_part[16];   // (workgroups of up to 1024 threads)
+    double v = (double)partial;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t += s_part[w];
+        if (dst && t != 0.0) atomicAdd(dst, t);
+    }
+    __syncthreads();   // (s_part may be written again by the next call of the same launch)
+}
+
 // ---------------------------------------------------------------------------------------------
 // Hand-off of rows between waves of ONE launch that may sit on different CUs / XCDs (whose L2s are not coherent):
 // the producer writes THROUGH to memory (sc1), waits until its stores have left (s_waitcnt vmcnt(0)) and bumps a

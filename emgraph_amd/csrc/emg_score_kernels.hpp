@@ -998,7 +998,9 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             else store_row<MODEL, W, NV, LPG>(go, P.contrib_ent + (B + eg) * P.ldc, lg, P.nchunks, P.khalf);
         }
     }
-    if constexpr (IP == 3 || IP == 7) wave_add_double(P.lp_accum, lp_acc);   // the regulariser's value over the rows updated (and replayed) in place
+    // the regulariser's value over the rows updated (and replayed) in place: one double atomic per WORKGROUP (per wave — 16 k
+    // adds to one address per launch, one retiring per ~10 ns — they were 58 us of C3 + LP's 311 us scoring kernel)
+    if constexpr (IP == 3 || IP == 7) block_add_double(P.lp_accum, lp_acc);
     if constexpr (FUSED) {
         // loss: one value per group (lane 0), block-reduced in double, one atomic per block
         double v = (active && lg == 0) ? (double)loss_acc : 0.0;
