@@ -472,7 +472,7 @@ def run_eval(r, args):
     out["bf16"] = {"value": round(n_ranks / dtb, 1), "unit": "ranks/s", "seconds": round(dtb, 4),
                    "precision": "bf16 operands, f32 accumulate (v_mfma_f32_32x32x16_bf16)",
                    "median_rel_rank_error_vs_exact": float(np.median(np.abs(rb - ranks) / (2.0 * w["n_ent"]))),
-                   "roofline": {"bound": "mfma", "kernel": "count_mfma_bf16_v3_kernel",
+                   "roofline": {"bound": "mfma", "kernel": "count_mfma_bf16_v4_kernel<25,1> (one counter: 64 query rows per wave; v3 with two counters)",
                                 "achieved": round(kflops / ktb / 1e12, 2), "peak": MFMA_BF16_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": round(kflops / ktb / 1e12 / MFMA_BF16_PEAK_TF, 4),
                                 "launches": stb["count_launches"], "kernel_ms": round(stb["count_ms"], 3),

@@ -3,7 +3,7 @@
 #   gpurun_out/TAG_bench.json                 python3 bench.py --gpus 1 --steps 20 --warmup 5          (the driver's command)
 #   gpurun_out/TAG_<wl>_kernel_stats.md       rocprofv3 --kernel-trace --stats of each workload ALONE (C3 C3a C3g C1 C2 C5)
 #   gpurun_out/TAG_pmc_traffic.json           tools/pmc_traffic.sh (C3: the file bench.py's roofline.traffic reads)
-#   gpurun_out/TAG_pmc_traffic_all.json       tools/pmc_traffic_all.sh (FETCH_SIZE / WRITE_SIZE of every kernel of C3 C3a C3g C1 C2 C5)
+#   gpurun_out/TAG_pmc_traffic_all.json       tools/pmc_traffic_all.sh (FETCH_SIZE / WRITE_SIZE of every kernel of C3 C3a C3g C3r C1 C2 C5)
 TAG="${1:-r5_x}"
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -19,5 +19,5 @@ for wl in C3a C3g C3r C1 C2 C5; do
 done
 bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.log 2>&1
 rm -rf gpurun_out/pmc_traffic
-bash tools/pmc_traffic_all.sh gpurun_out/${TAG}_pmc_traffic_all.json > gpurun_out/${TAG}_pmc_traffic_all.log 2>&1
+bash tools/pmc_traffic_all.sh gpurun_out/${TAG}_pmc_traffic_all.json C3 C3a C3g C3r C1 C2 C5 > gpurun_out/${TAG}_pmc_traffic_all.log 2>&1
 tail -c 600 gpurun_out/${TAG}_bench.json
