@@ -252,6 +252,7 @@ class PrefilterTables:
         self.k_int = k_int
         self._bounds = {}
         self._ent = ent
+        self.undecided = {}   # (slab, side) -> undecided fraction a probe of the run's query rows found (_prefilter_probe)
 
     def bounds(self, e0, n):
         if (e0, n) not in self._bounds:
@@ -313,7 +314,7 @@ def _pair_buffer(device, n_seg):
     """(pairs int64 [cap], per-segment counts int32 [n_seg + 1]) scratch of the prefilter, cached per device.
     A wave of the prefilter covers 32 query rows x up to 4096 entities; 2048 entries hold 1.5 % of them undecided
     (random positives on Gaussian tables leave ~0.7 %, a trained model a tenth of that); at most 1 GiB in total."""
-    per = max(64, min(2048, (1 << 27) // max(n_seg, 1)))
+    per = max(64, min(int(os.environ.get("EMG_PAIR_CAP", "2048")), (1 << int(os.environ.get("EMG_PAIR_LOG2", "27"))) // max(n_seg, 1)))
     cap = n_seg * per
     key = (device.type, device.index)
     buf = _pair_buffers.get(key)
@@ -353,6 +354,34 @@ def _rescore(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg,
         except L.EmgError:   # rows that are not 16-byte aligned / an image that does not fit LDS: the segment form
             pass
     D.eval_rescore_pairs(model_id, Q, pos_int, slab, e0, k_int, scale, pairs, pcount, n_seg, cnt[0], cnt[1], waves, rows)
+
+
+# A table whose candidates the half-precision band cannot decide (a freshly initialised model, the first epochs of a fit: the
+# scores crowd around the positive's) overflows the pair buffer in every tile: the prefilter pass is wasted and the exact kernel
+# runs anyway (72 instead of 55 ms per 8192 x 1M pass).  So precision 2 asks first: ONE workgroup's worth of the call's query
+# rows (128 triples) through the prefilter alone, the undecided fraction read back (~0.3 ms, remembered on the PrefilterTables
+# of the evaluation run).  Above the fraction the pair buffer holds with room to spare the whole call takes the exact kernel.
+_PROBE_TRIPLES = 128
+_PROBE_MAX_UNDECIDED = 0.011   # (a wave's segment of the pair buffer holds 1.56 % of its 32 x 4096 candidates)
+
+
+def _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds):
+    Tt = torch.from_numpy(np.ascontiguousarray(T[:_PROBE_TRIPLES])).to(ent.device)
+    Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
+    n_rows, n_cand = Q.shape[0], slab.shape[0]
+    if n_rows <= 128 or n_cand == 0:
+        return 0.0   # (the register-stationary kernel wants more than 128 rows: such calls take the exact kernel tile by tile)
+    Qb = D.to_f16(Q, k_int, ld_dst=D.prefilter_ld(k_int))
+    band = prefilter_band(Q, Qb, k_int, bounds)
+    n_seg = D.eval_prefilter_segments(n_rows, n_cand, k_int)
+    pairs, pcount = _pair_buffer(ent.device, n_seg)
+    cnt = torch.zeros(n_rows, dtype=torch.int32, device=ent.device)
+    try:
+        D.eval_prefilter_f16(model_id, Qb, pos_int, band, ent_f16[e0:e0 + n_cand], e0, k_int, scale, cnt, pairs, pcount)
+    except L.EmgError:
+        return 0.0
+    over, n_pairs = (int(v) for v in torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]).cpu())
+    return 1.0 if over else n_pairs / float(n_rows * n_cand)
 
 
 def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_side="s,o", strategy="worst",
@@ -433,12 +462,26 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
         tabs = ent_f16 if isinstance(ent_f16, L2Tables) else L2Tables(ent, k_int)
         ent_f16, bounds = tabs.ent_f16, tabs.bounds(e0, slab.shape[0])
     elif precision == 2:
-        if isinstance(ent_f16, PrefilterTables):   # built once per evaluation run by the caller
-            bounds, ent_f16 = ent_f16.bounds(e0, slab.shape[0]), ent_f16.ent_f16
+        tabs = ent_f16 if isinstance(ent_f16, PrefilterTables) else None
+        if tabs is not None:   # built once per evaluation run by the caller
+            bounds, ent_f16 = tabs.bounds(e0, slab.shape[0]), tabs.ent_f16
         else:
             if ent_f16 is None:   # half-precision copy of the table for the prefilter
                 ent_f16 = D.to_f16(ent, k_int, ld_dst=D.prefilter_ld(k_int))
             bounds = table_norm_bounds(slab, ent_f16[e0:e0 + slab.shape[0]], k_int)
+        if cand is None and n >= _PROBE_TRIPLES and slab.shape[0] > 0 and os.environ.get("EMG_PREFILTER_PROBE", "1") != "0":
+            key = (e0, slab.shape[0], side_mode)
+            und = tabs.undecided.get(key) if tabs is not None else None
+            if und is None:
+                und = _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds)
+                if tabs is not None:
+                    tabs.undecided[key] = und
+            if stats is not None:
+                stats["probe_undecided"] = und
+            if und > _PROBE_MAX_UNDECIDED:   # the band decides too little here: every tile of the call by the exact kernel
+                precision = 0
+                if stats is not None:
+                    stats["fallback"] = stats.get("fallback", 0) + (n + query_chunk - 1) // query_chunk
     pending = []  # (counters on the device, nq) per chunk: every launch is asynchronous, ONE D2H at the end
     for c0 in range(0, n, query_chunk):
         Tc = T[c0:c0 + query_chunk]

@@ -1271,6 +1271,44 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
 
 
+def test_prefilter_probe_sends_an_undecidable_table_to_the_exact_kernel(monkeypatch):
+    """precision 2 first runs 128 of the call's triples through the prefilter alone and reads the undecided fraction
+    (ranking._prefilter_probe).  A table whose rows are all but equal (a freshly initialised model looks like this to the band)
+    leaves every candidate undecided: the whole call then takes the exact kernel — ONE pass instead of a wasted prefilter pass, an
+    overflowing pair buffer and the exact pass after it — and says so in stats; a table the band does decide keeps the prefilter.
+    Ranks equal the exact path's either way, with the probe or without it (EMG_PREFILTER_PROBE=0: the old behaviour)."""
+    from emgraph_amd.evaluation import rank_triples_device
+    from emgraph_amd.evaluation import ranking as RK
+    n_ent, k, nq = 40000, 200, 300
+    rs = np.random.RandomState(5)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 3, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    E0, R, ki = make_tables("ComplEx", k, n_ent, 3, seed=11, scale=0.1)
+    crowd = (E0[:1] + 1e-4 * E0).astype(np.float32)     # every row = one row + a ten-thousandth of its own: scores crowd together
+    for name, E, undecidable in (("crowded", crowd, True), ("spread", E0, False)):
+        Et, Rt = cu(E), cu(R)
+        exact = rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst")
+        tabs = RK.PrefilterTables(Et, ki)
+        st = {}
+        fast = rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst", precision=2, ent_f16=tabs, stats=st)
+        np.testing.assert_array_equal(fast, exact, err_msg=name)
+        assert (st["probe_undecided"] > RK._PROBE_MAX_UNDECIDED) == undecidable, (name, st)
+        if undecidable:
+            assert st["fallback"] == 1 and st.get("pairs", 0) == 0 and st["count_launches"] == 1, st
+        else:
+            assert st.get("fallback", 0) == 0 and st["pairs"] > 0, st
+        assert len(tabs.undecided) == 1                       # remembered on the run's tables: the next call does not probe again
+        st2 = {}
+        again = rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst", precision=2, ent_f16=tabs, stats=st2)
+        np.testing.assert_array_equal(again, exact)
+        assert st2["probe_undecided"] == st["probe_undecided"]
+        monkeypatch.setenv("EMG_PREFILTER_PROBE", "0")
+        st3 = {}
+        old = rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst", precision=2, stats=st3)
+        monkeypatch.delenv("EMG_PREFILTER_PROBE")
+        np.testing.assert_array_equal(old, exact)
+        assert "probe_undecided" not in st3
+
+
 @pytest.mark.parametrize("k,n_ent,nq,scale", [(200, 30000, 300, 0.1), (100, 9000, 200, 1.0), (50, 20000, 150, 0.002),
                                               (37, 5000, 140, 0.3), (16, 40000, 130, 0.05), (200, 5000, 40, 0.1), (3, 9, 6, 0.5),
                                               (1, 130, 3, 0.5), (520, 1500, 70, 0.05)])
