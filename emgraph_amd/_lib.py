@@ -87,7 +87,7 @@ class BackwardArgs(C.Structure):
         ("layout_B", _i64), ("ctl", _p),
         ("lp_accum", _p),
         ("lr_hist", _p),
-        ("inplace_window", _i32), ("reserved2", _i32),
+        ("inplace_window", _i32), ("loss_slots", _i32),
     ]
 
 
@@ -215,7 +215,7 @@ class PlanConfig(C.Structure):
         ("cap_B", _i64),
         ("scores", _p), ("g", _p), ("contrib_ent", _p), ("contrib_rel", _p), ("ldc", _i64),
         ("loss_accum", _p), ("lp_sum", _p),
-        ("factored", _i32), ("reserved0", _i32),
+        ("factored", _i32), ("loss_slots", _i32),
         ("lp_lambda_ent", _f32), ("lp_lambda_rel", _f32), ("lp_p", _i32),
         ("fused", _i32), ("inplace", _i32), ("normalize", _i32),
         ("n_slots", _i32), ("slots", PlanSlot * 4),

@@ -149,7 +149,7 @@ static int compute(Plan* P, SlotState& sl, const emg_plan_batch& b, int32_t step
     emg_backward_args ba{};
     ba.model = c.model; ba.k_int = c.k_int; ba.scale = c.scale; ba.eta = et;
     ba.ent = c.ent; ba.n_ent = c.n_ent; ba.ld_ent = c.ld_ent; ba.rel = c.rel; ba.n_rel = c.n_rel; ba.ld_rel = c.ld_rel;
-    ba.pos = pos; ba.B = B; ba.codes = sl.buf.codes; ba.margin = c.margin; ba.loss_accum = c.loss_accum;
+    ba.pos = pos; ba.B = B; ba.codes = sl.buf.codes; ba.margin = c.margin; ba.loss_accum = c.loss_accum; ba.loss_slots = c.loss_slots;
     ba.contrib_ent = c.contrib_ent; ba.contrib_rel = c.contrib_rel; ba.ldc = c.ldc;
     ba.single_ent = c.inplace ? sl.buf.single : nullptr; ba.opt = c.opt; ba.step = step;
     ba.inplace_window = c.inplace == 2 ? 1 : 0;   // (a stateful optimizer's window form)

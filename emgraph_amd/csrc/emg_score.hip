@@ -409,6 +409,9 @@ int emg::train_backward_impl(const emg_backward_args* a, const Riders* riders, v
     P.k_int = a->k_int; P.scale = a->scale; P.pos = a->pos; P.B = a->B; P.eta = a->eta; P.codes = a->codes;
     P.g_pos = a->g_pos; P.g_neg = a->g_neg; P.bw_scores_pos = a->bw_scores_pos; P.bw_scores_neg = a->bw_scores_neg;
     P.fused_loss = a->fused_loss; P.margin = a->margin; P.loss_accum = a->loss_accum;
+    EMG_REQUIRE(a->loss_slots >= 0 && a->loss_slots <= 4096 && (a->loss_slots & (a->loss_slots - 1)) == 0,
+                "emg_train_backward_ex: loss_slots must be 0 or a power of two <= 4096");
+    P.loss_mask = a->loss_slots > 1 ? (uint32_t)a->loss_slots - 1u : 0u;
     P.scores_pos = a->scores_pos_out; P.scores_neg = a->scores_neg_out;
     P.contrib_ent = a->contrib_ent; P.contrib_rel = a->contrib_rel; P.ldc = a->ldc;
     if (a->fac_ws_ent) {

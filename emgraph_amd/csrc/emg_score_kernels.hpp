@@ -161,7 +161,7 @@ struct GroupParams {
     // backward / fused
     const float* g_pos; const float* g_neg;              // external dL/dscore (fused_loss < 0)
     const float* bw_scores_pos; const float* bw_scores_neg;  // global final scores (TransE-L2 on a k-slice)
-    int32_t fused_loss; float margin; double* loss_accum;
+    int32_t fused_loss; float margin; double* loss_accum; uint32_t loss_mask;   // loss_mask: workgroup b adds to loss_accum[b & loss_mask]
     float* contrib_ent; float* contrib_rel; int64_t ldc;
     const uint8_t* single_ent;                           // per entity-contribution slot: 1 = update in place
     float* ent_rw; float* ent_state0; float* ent_state1; int32_t* tag_ent; int32_t step;
@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void train_backward_body(const GroupParams& P0, unsig
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < kThreads / 64; ++w) t += part[w];
-            if (t != 0.0) atomicAdd(P.loss_accum, t);
+            if (t != 0.0) atomicAdd(P.loss_accum + (bx & P.loss_mask), t);   // (slots: emg_backward_args.loss_slots)
         }
     }
 }

@@ -183,12 +183,13 @@ def build_dest(pos, eta, codes, dest_ent, dest_rel):
 def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib_ent, contrib_rel, fused_loss=-1,
                       margin=1.0, loss_accum=None, g_pos=None, g_neg=None, bw_scores_pos=None, bw_scores_neg=None,
                       scores_pos_out=None, scores_neg_out=None, single_ent=None, opt_id=0, step=0, hyper=None,
-                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None, lp_accum=None):
+                      ent_state0=None, ent_state1=None, tag_ent=None, fac_ws_ent=None, lp_accum=None, loss_slots=0):
     """emg_train_backward_ex: fused (fused_loss>=0) or external-gradient backward, optional in-place
     singleton updates (single_ent flags from group_dest).  ``fac_ws_ent`` (bilinear models): FACTORED entity
     contributions — the entity workspace of ``prepare_batch(..., factored=True)`` for this batch; ``contrib_ent`` then
     holds 4*B rows (see include/emgraph_hip.h) and the entity apply is ``apply_grouped(..., factored=True)``.
-    ``hyper`` of 8 values + ``lp_accum`` (plain SGD only): the LP regulariser folded into the in-place updates."""
+    ``hyper`` of 8 values + ``lp_accum`` (plain SGD only): the LP regulariser folded into the in-place updates.
+    ``loss_slots`` (a power of two > 1): ``loss_accum`` holds that many doubles, the loss is their sum."""
     lib = L.load()
     B = pos.shape[0]
     a = L.BackwardArgs()
@@ -198,7 +199,8 @@ def train_backward_ex(model_id, ent, rel, k_int, scale, pos, eta, codes, contrib
     a.pos, a.B = _chk_vec(pos, torch.int32, "pos", 3 * B), B
     a.codes = _chk_vec(codes, torch.int32, "codes", B * eta) if eta else None
     a.fused_loss, a.margin = fused_loss, margin
-    a.loss_accum = _chk_vec(loss_accum, torch.float64, "loss_accum", 1) if loss_accum is not None else None
+    a.loss_accum = _chk_vec(loss_accum, torch.float64, "loss_accum", max(1, int(loss_slots))) if loss_accum is not None else None
+    a.loss_slots = int(loss_slots)
     a.g_pos = _chk_vec(g_pos, torch.float32, "g_pos", B)
     a.g_neg = _chk_vec(g_neg, torch.float32, "g_neg", B * eta) if eta else None
     a.bw_scores_pos = _chk_vec(bw_scores_pos, torch.float32, "bw_scores_pos", B)

@@ -84,6 +84,7 @@ def alloc_table(rows, k_int, device, init=None, fill=None):
 # batches prepared ahead of the one computing (= side streams = extra batch slots); see Trainer.step.
 # Two, not more: main + apply_rel stream + 2 side streams = 4 = the HIP runtime's hardware queues per device;
 # a fifth stream is multiplexed onto them and the step got SLOWER (measured 0.47 -> 0.67 ms at 3, 0.73 at 4).
+LOSS_SLOTS = int(os.environ.get("EMG_LOSS_SLOTS", "64"))   # doubles the fused kernel spreads the batch loss over (1: one, the old form; A/B aid)
 LOOKAHEAD = int(os.environ.get("EMG_LOOKAHEAD", "2"))
 GRAPH_MAX_ROWS = int(os.environ.get("EMG_GRAPH_MAX_ROWS", "200000"))   # entity contribution rows per batch up to which steps run as graph replays
 AUX_MIN_ROWS = int(os.environ.get("EMG_AUX_MIN_ROWS", "100000"))  # (env: A/B aid) entity contribution rows per batch above which apply_rel gets its own stream
@@ -172,7 +173,10 @@ class Trainer:
 
         self.plan = None
         self.graph = False
-        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # the data loss: LOSS_SLOTS doubles, workgroup b of the fused kernel adds to slot b mod LOSS_SLOTS (same-address atomics of a
+        # short launch queue up behind each other: include/emgraph_hip.h, emg_backward_args.loss_slots); every other producer adds to
+        # slot 0; read_loss sums
+        self.loss_accum = torch.zeros(LOSS_SLOTS, dtype=torch.float64, device=self.device)
         self.reg_accum = torch.zeros(1, dtype=torch.float64, device=self.device)  # LP term (column-local when sharded)
         # sum |w|^p per table, accumulated by the kernels that fold the regulariser (scaled by lambda in read_loss)
         self.lp_sum = torch.zeros(2, dtype=torch.float64, device=self.device)
@@ -381,6 +385,7 @@ class Trainer:
         c.scores, c.g = self.scores_all.data_ptr(), self.g_all.data_ptr()
         c.contrib_ent, c.contrib_rel, c.ldc = self.contrib_ent.data_ptr(), self.contrib_rel.data_ptr(), self.contrib_ent.stride(0)
         c.loss_accum, c.lp_sum = self.loss_accum.data_ptr(), self.lp_sum.data_ptr()
+        c.loss_slots = LOSS_SLOTS
         c.factored = int(self.factored)
         if self.reg is not None:
             c.lp_lambda_ent, c.lp_lambda_rel, c.lp_p = self.reg[0], self.reg[1], self.reg[2]
@@ -620,7 +625,7 @@ class Trainer:
         if self.fused:
             self._timed("fused", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr,
-                fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum, **inplace_kw))
+                fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum, loss_slots=LOSS_SLOTS, **inplace_kw))
         else:
             sall = self.scores_all[:B * (1 + et)]
             sp, sn = sall[:B], sall[B:]
@@ -638,7 +643,7 @@ class Trainer:
                 bw = dict(bw_scores_pos=sp, bw_scores_neg=sn)
             gp, gn = self.g_pos[:B], self.g_neg[:B * et]
             self._timed("loss", lambda: D.loss(self.loss_id, sp, sn, B, eta, self.n_sides, self.margin, self.alpha,
-                                               self.loss_accum, gp, gn))
+                                               self.loss_accum[0:1], gp, gn))
             self._timed("backward", lambda: D.train_backward_ex(
                 self.model_id, self.ent, self.rel, self.k_int, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
                 g_pos=gp, g_neg=gn, **bw, **inplace_kw))
@@ -730,13 +735,13 @@ class Trainer:
             ce, cr = self.contrib_ent[:n_ce], self.contrib_rel[:Bl]
             if self.fused:
                 D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr,
-                                    fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum)
+                                    fused_loss=self.loss_id, margin=self.margin, loss_accum=self.loss_accum, loss_slots=LOSS_SLOTS)
             else:
                 sall = self.scores_all[:Bl * (1 + et)]
                 sp, sn = sall[:Bl], sall[Bl:]
                 D.train_forward(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, scores_pos=sp, scores_neg=sn)
                 gp, gn = self.g_pos[:Bl], self.g_neg[:Bl * et]
-                D.loss(self.loss_id, sp, sn, Bl, eta, self.n_sides, self.margin, self.alpha, self.loss_accum, gp, gn)
+                D.loss(self.loss_id, sp, sn, Bl, eta, self.n_sides, self.margin, self.alpha, self.loss_accum[0:1], gp, gn)
                 D.train_backward_ex(self.model_id, self.ent, self.rel, k, self.scale, pos, et, codes, ce, cr, fused_loss=-1,
                                     g_pos=gp, g_neg=gn)
             dest_e, dest_r = sl["dest_ent"][:n_ce], sl["dest_rel"][:Bl]
@@ -910,7 +915,7 @@ class Trainer:
             reg = parallel.allreduce_sum_(self.reg_accum.clone())
         if self.batch_sharded:  # every rank saw its rows of each batch only; the LP term was computed by every replica
             data = parallel.allreduce_sum_(self.loss_accum.clone())
-        v = float(data.item()) + float(reg.item())
+        v = float(data.sum().item()) + float(reg.item())
         if self.reg is not None:   # (batch-sharded: every replica folded the regulariser over the full tables itself)
             lp = self.lp_sum if not self.sharded else parallel.allreduce_sum_(self.lp_sum.clone())
             lp = lp.cpu()

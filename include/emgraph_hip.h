@@ -232,7 +232,12 @@ typedef struct emg_backward_args {
      * waits for nothing (0: the state is read chunk by chunk at the update).  The subject / object singletons are updated in place too
      * (without lr_hist: at the group's end, state read chunk by chunk; with lr_hist: replayed at the group's start, parked in LDS,
      * updated at its end): finish with skip_single = 1.  Required by lr_hist. */
-    int32_t inplace_window; int32_t reserved2;
+    int32_t inplace_window;
+    /* loss_slots: 0 / 1: loss_accum is ONE double.  A power of two n > 1: loss_accum points to n doubles, workgroup b of the fused
+     * kernel adds its partial sum to loss_accum[b & (n - 1)], the batch's loss is their sum.  (One double atomic per workgroup to
+     * ONE address retires one per ~10 ns at the memory side of the eight L2s: the 680 workgroups of a 20 us launch — the reference's
+     * own configurations — all arrive within its last microseconds; measured 5 of C2's 22 us.) */
+    int32_t loss_slots;
 } emg_backward_args;
 /* hyper[6] = lambda, hyper[7] = p of an LP regulariser folded into the update (see emg_apply_grouped): with single_ent != NULL
  * only for opt = EMG_OPT_SGD — a singleton row is then updated in place with g + lambda p |w|^(p-1) sign(w), the rule the
@@ -640,7 +645,8 @@ typedef struct emg_plan_config {
     int64_t cap_B;
     float* scores; float* g; float* contrib_ent; float* contrib_rel; int64_t ldc;
     double* loss_accum; double* lp_sum;              /* lp_sum[2]: sum |w|^p of the entity / relation table */
-    int32_t factored; int32_t reserved0;             /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows */
+    int32_t factored;                                /* 1: factored entity contributions (emg_prepare_args / emg_backward_args); contrib_ent then needs 4 * cap_B rows */
+    int32_t loss_slots;                              /* loss_accum points to this many doubles (emg_backward_args.loss_slots; 0 / 1: one) */
     float lp_lambda_ent; float lp_lambda_rel; int32_t lp_p;   /* folded LP regulariser (0 = none; excludes inplace) */
     int32_t fused; int32_t inplace; int32_t normalize;   /* inplace: 0 off, 1 singletons in place, 2 the same through a stateful optimizer's
                                                             window form (emg_backward_args.inplace_window; with lr_t_hist: Adam's singleton

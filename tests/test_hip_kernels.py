@@ -1044,7 +1044,7 @@ def test_train_step_one_call_matches_trainer(model, loss, opt, sides):
     for b in range(3):
         tr.step(b * B, B, epoch=1, batch=b + 1)
         tr2.step_count += 1
-        d.train_step(MID[model], tr2.ent, tr2.rel, ki, sc, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum,
+        d.train_step(MID[model], tr2.ent, tr2.rel, ki, sc, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum[0:1],
                      tr2.opt_id, tr2.step_count, tr2._hyper(tr2.lr), ws, margin=tr2.margin, alpha=tr2.alpha,
                      states=(tr2.state_ent[0], tr2.state_ent[1], tr2.state_rel[0], tr2.state_rel[1]),
                      tags=(tr2.tag_ent, tr2.tag_rel), n_choices=n_ent, seed=5, counter0=b * len(sides), inplace=tr.inplace)
@@ -1075,7 +1075,7 @@ def test_train_step_one_call_transe_any_norm(order, loss, opt):
     for b in range(3):
         tr.step(b * B, B, epoch=1, batch=b + 1)
         tr2.step_count += 1
-        d.train_step(L.TRANSE_P, tr2.ent, tr2.rel, ki, order, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum,
+        d.train_step(L.TRANSE_P, tr2.ent, tr2.rel, ki, order, Xt[b * B:(b + 1) * B], eta, tr2.sides, tr2.loss_id, tr2.loss_accum[0:1],
                      tr2.opt_id, tr2.step_count, tr2._hyper(tr2.lr), ws, margin=tr2.margin, alpha=tr2.alpha,
                      states=(tr2.state_ent[0], tr2.state_ent[1], tr2.state_rel[0], tr2.state_rel[1]),
                      tags=(tr2.tag_ent, tr2.tag_rel), n_choices=n_ent, seed=5, counter0=b, inplace=True)   # (inplace is ignored for this model)

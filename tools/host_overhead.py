@@ -36,7 +36,7 @@ hyper = tr._hyper(5e-4) if tr.step_count else None
 tr.step_count = max(tr.step_count, 1)
 hyper = tr._hyper(5e-4)
 timeit("train_backward_ex call", lambda: D.train_backward_ex(L.COMPLEX, tr.ent, tr.rel, k_int, 1.0, pos, eta, codes, ce, cr,
-                                                             fused_loss=tr.loss_id, margin=1.0, loss_accum=tr.loss_accum,
+                                                             fused_loss=tr.loss_id, margin=1.0, loss_accum=tr.loss_accum[0:1],
                                                              single_ent=sl["single"][:n_ce], opt_id=tr.opt_id, step=1, hyper=hyper,
                                                              ent_state0=None, ent_state1=None, tag_ent=tr.tag_ent), 50)
 timeit("apply_grouped(ent) call", lambda: D.apply_grouped(tr.opt_id, tr.ent, k_int, None, None, tr.tag_ent, 1, ce, n_ce, True, hyper, sl["ws_ent"]), 50)
