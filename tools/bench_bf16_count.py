@@ -72,9 +72,9 @@ def main():
         return best, cnt.cpu().numpy()
 
     ms2, c2 = run(None)
-    print("v2 query-stationary: %.3f ms  %.1f TFLOP/s" % (ms2, flop / ms2 * 1e-9))
+    print("both counters (v3 register-stationary kernel; EMG_BF16_V4=2: v4): %.3f ms  %.1f TFLOP/s" % (ms2, flop / ms2 * 1e-9))
     ms3, c3 = run(None, need=1)
-    print("  one comparison ('worst'): %.3f ms  %.1f TFLOP/s  (#(>=) equals gt+eq: %s)"
+    print("one counter ('worst'; v4 by default, EMG_BF16_V4=0: v3): %.3f ms  %.1f TFLOP/s  (#(>=) equals gt+eq: %s)"
           % (ms3, flop / ms3 * 1e-9, bool(np.array_equal(c3[0], c2[0] + c2[1]))))
     if a.v1:
         ms1, c1 = run(torch.arange(a.ent, dtype=torch.int32, device=dev))
