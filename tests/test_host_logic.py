@@ -415,6 +415,38 @@ def test_no_hand_written_kernel_spills_to_scratch():
     assert len(fused) >= 100 and max(v for _, _, v in fused) <= 512
 
 
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """the argument structures cross the C-ABI by pointer: the ctypes mirrors in emgraph_amd/_lib.py must have the size of the
+    structs in include/emgraph_hip.h and every field at the header's offset (a field added on one side only would shift everything
+    behind it silently).  A C program that includes the header prints sizeof / offsetof; gcc is part of the image."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from emgraph_amd import _lib as L
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = [("emg_backward_args", L.BackwardArgs), ("emg_prepare_args", L.PrepareArgs), ("emg_step_args", L.StepArgs),
+             ("emg_apply_args", L.ApplyArgs), ("emg_plan_slot", L.PlanSlot), ("emg_plan_config", L.PlanConfig),
+             ("emg_plan_batch", L.PlanBatch)]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "emgraph_hip.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs:
+        assert got[(cname, "sizeof")] == C.sizeof(cls), (cname, got[(cname, "sizeof")], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_installed_filter_is_remembered_by_content_not_by_identity():
     """evaluate_performance maps the filter triples through the label dictionaries and indexes them on every call (45 of 107 ms at
     1M filter triples); the mapped set and its FilterIndex are remembered by a digest of the array's CONTENT together with the
