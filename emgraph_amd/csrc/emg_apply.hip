@@ -1537,7 +1537,7 @@ static unsigned segments_grid(unsigned wanted, bool plain, bool ride, bool half,
 static bool dense_in_segments(const ApplyParams& P, const ApplyLaunch& A) {
     static const int env = getenv("EMG_DENSE_FUSED") ? atoi(getenv("EMG_DENSE_FUSED")) : -1;
     if (!(A.any && A.segs && A.dense) || P.opt.lp_lambda != 0.f) return false;
-    return (env >= 0 ? env != 0 : true) && P.n_rows <= kDenseHereMaxRows;   // (never above: the bucket grouping of larger tables writes no offset array)
+    return (env >= 0 ? env != 0 : true) && P.n_rows <= kDenseHereMaxRows;   // (never above: the bucket grouping writes the offset array only for tables of up to this size — emg_group_bucket.hip: BucketTable::off)
 }
 
 static int apply_launch(const ApplyParams& P0, const ApplyLaunch& A0, hipStream_t st) {

@@ -208,8 +208,12 @@ __device__ __forceinline__ float lp_grad(const OptParams& P, float w) {
 }
 // p == 2 (the reference's default, regularizers/_regularizer_constants.py), taken by lp_fold / lp_fold_p123 themselves: lambda * 2 * |w| * sgn(w) is fl(2 lambda * w)
 // — the product with the sign is exact and rounding is sign-symmetric, signed zeros included — and |w|^2 is fl(w * w): two
-// multiplications where the generic form spends an abs, a square, two selects, three multiplications and the sign's med3.  SAME bits
-// as lp_fold / lp_fold_p123 at p = 2 (the deferred replay is bound by exactly this arithmetic: DESIGN 7)
+// multiplications where the generic form spends an abs, a square, two selects, three multiplications and the sign's med3.  The same
+// VALUE as the generic expressions at p = 2 and the same bits up to the sign of a zero: for w = -0 the generic product is +0 (the
+// sign function returns 0), this one -0, which shows only when the data gradient is itself -0.  Every device path takes THIS form at
+// p = 2 (lp_fold and lp_fold_p123 branch here), so the paths agree with each other bit for bit; against the oracle's generic numpy
+// expression the comparison is by value (tests/test_hip_kernels.py::test_lp_fold_forms_agree...).  (The deferred replay is bound by
+// exactly this arithmetic: DESIGN 7)
 __device__ __forceinline__ void lp_fold_p2(const OptParams& P, float w, float& g, float& lp_acc) {
 #pragma clang fp contract(off)
     g += (P.lp_lambda * 2.f) * w;
@@ -253,9 +257,10 @@ __device__ __forceinline__ float opt_sgd_elem(const OptParams& P, float w, float
 __device__ __forceinline__ float opt_ratio(float num, float root, float eps) {
 #pragma clang fp contract(off)
 #if EMG_OPT_FAST_RECIP
-    // (the max changes nothing for eps >= 1e-7 — Keras' value, the only one the package passes; with a denormal or zero eps from a
-    // C-ABI caller and root == 0 (an untouched row of the dense pass) v_rcp_f32 would return inf and 0 * inf poison the table)
-    return num * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(root) + eps, 1.17549435e-38f));
+    // (eps >= FLT_MIN by construction — make_opt_params raises a denormal or zero eps of a C-ABI caller to it, so that root == 0, an
+    // untouched row of the dense pass, never meets v_rcp_f32's flushed argument: inf, and 0 * inf would poison the table — and there
+    // is NO max on the device side: a NaN root or state stays a NaN here, as in Keras, instead of becoming a huge finite step)
+    return num * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(root) + eps);
 #else
     return num / (sqrtf(root) + eps);
 #endif
@@ -433,6 +438,7 @@ static inline OptParams make_opt_params(int opt, const float* hyper) {
     OptParams o;
     o.opt = opt == EMG_OPT_ADAM_LAZY ? EMG_OPT_ADAM : opt;
     o.lr = hyper[0]; o.mu = hyper[1]; o.beta1 = hyper[2]; o.beta2 = hyper[3]; o.eps = hyper[4]; o.lr_t = hyper[5];
+    if (o.eps >= 0.f && o.eps < 1.17549435e-38f) o.eps = 1.17549435e-38f;   // opt_ratio's reciprocal needs a normal denominator (a NaN eps stays a NaN)
     o.lp_lambda = hyper[6]; o.lp_p = (int)hyper[7];
     return o;
 }

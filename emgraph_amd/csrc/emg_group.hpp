@@ -75,8 +75,10 @@ constexpr int kBucketRowsMax = 2048;   // table rows per bucket (the LDS row tab
 constexpr int kBucketMaxNB = 4096;     // buckets per table (the LDS histogram of the id kernel)
 constexpr int kBucketCap = 4096;       // contributions of a bucket sorted in LDS; a fuller bucket is sorted through global memory
 // Tables of up to kDenseHereMaxRows rows may run Keras Adam's dense pass INSIDE the descriptor-driven apply launch, which finds the
-// untouched rows in the counting grouping's offset array (emg_apply.hip: dense_here) — an array the bucket grouping never writes.  So
-// the bucket grouping starts ABOVE that size, forced or not (smaller tables keep the counting grouping: their row arrays live in L2).
+// untouched rows in the grouping's offset array (emg_apply.hip: dense_here).  The bucket grouping starts ABOVE that size for the
+// ENTITY table, forced or not (smaller tables keep the counting grouping: their row arrays live in L2) — but it groups the
+// RELATION table of the same batch too, which usually IS that small: for such a table its sort kernel writes the offset array
+// as well (BucketTable::off; round 6, the round-5 advisor's finding: a standalone relation apply read an array nobody wrote).
 constexpr int64_t kDenseHereMaxRows = 131072;
 constexpr int64_t kBucketMinRows = 2 * kDenseHereMaxRows;
 struct BucketGeo { int sh, nb, chunk_log; bool ok; };   // bucket = row >> sh; nb buckets; chunks of 1 << chunk_log slots

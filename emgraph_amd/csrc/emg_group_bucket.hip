@@ -39,6 +39,7 @@ struct BucketTable {
     Seg* multi; uint32_t* single; LongTask* tasks; uint32_t task_cap;
     int32_t* arrive; uint32_t* counters;
     uint8_t* flags; const int32_t* fac_codes;   // factored contributions: the batch's codes (sign bit: which query row a negative points at)
+    uint32_t* off;               // tables of <= kDenseHereMaxRows rows: the exclusive row offsets [R + 1] the apply's in-launch dense pass reads (else nullptr)
 };
 struct BucketLaunch { BucketTable t[2]; int64_t B, n_ce; uint32_t cap_lds; int32_t chunk_log; };
 
@@ -271,6 +272,7 @@ __device__ __forceinline__ void bucket_sort_body(const BucketTable& T, BucketLds
     for (int j = 0; j < RPT; ++j) {
         if (!(j < rpt && row0 + j < RB)) continue;
         S.ends[row0 + j] = run0;   // the scatter cursor
+        if (T.off && (int64_t)r0 + row0 + j < T.R) T.off[r0 + row0 + j] = g0 + run0;
         if (cj[j] > (uint32_t)kDeferSegment) longs[atomicAdd(&S.misc[4], 1u)] = (uint16_t)(row0 + j);
         run0 += cj[j];
     }
@@ -437,8 +439,11 @@ __global__ __launch_bounds__(kBT) void bucket_sort_kernel(const BucketLaunch L) 
     for (int w = 0; w < kBT / 64; ++w) g0 += S.misc[8 + w];
     __syncthreads();
     const uint32_t count = block_scan_inplace(S.coff, kBucketChunksMax, s_part);   // (everything in lower buckets, over all chunks: g0)
-    if (b == T.nb - 1 && threadIdx.x == 0) T.counters[GC_VALID] = g0 + count;
-    if (count == 0u) return;
+    if (b == T.nb - 1 && threadIdx.x == 0) { T.counters[GC_VALID] = g0 + count; if (T.off) T.off[T.R] = g0 + count; }
+    if (count == 0u) {   // (an empty bucket still owns its stretch of the offset array)
+        if (T.off) for (int64_t r = ((int64_t)b << T.sh) + threadIdx.x; r < min(T.R, ((int64_t)b + 1) << T.sh); r += kBT) T.off[r] = g0;
+        return;
+    }
     if (count <= L.cap_lds) bucket_sort_body<true>(T, S, b, nchunks, L.chunk_log, g0, count, L.B);
     else bucket_sort_body<false>(T, S, b, nchunks, L.chunk_log, g0, count, L.B);
 }
@@ -450,6 +455,7 @@ static void fill_bucket_table(BucketTable& T, const GroupWs& w, const BucketGeo&
     T.keys = w.keys; T.vals = w.vals; T.srcrow = w.srcrow; T.pos_of_slot = w.pos_of_slot; T.coef = w.coef;
     T.multi = w.multi; T.single = w.single; T.tasks = w.tasks; T.task_cap = w.task_cap;
     T.arrive = w.arrive; T.counters = w.counters; T.flags = flags; T.fac_codes = fac_codes;
+    T.off = R <= kDenseHereMaxRows ? w.off : nullptr;   // (emg_apply.hip::dense_in_segments: the same bound)
 }
 
 // the bucket form of emg_prepare_batch (S: its validated stages); false = not eligible, the counting form runs

@@ -269,7 +269,7 @@ def _test_adapter(X, model, filter_unseen, verbose):
     return adapter, False
 
 
-_FILTER_CACHE = []   # [(key, mapped int64 [n, 3], FilterIndex)] of the filter sets most recently installed (at most 2)
+_FILTER_CACHE = []   # [(key, mapped int64 [n, 3], FilterIndex, ent_to_idx, rel_to_idx)] of the filter sets most recently installed (at most 2)
 
 
 def _array_digest(a):
@@ -293,19 +293,27 @@ def _mapped_filter(adapter, filter_triples, model, filter_unseen, verbose):
     array + identity and fingerprint of the two label dictionaries): early stopping and repeated evaluations pass the same
     filter every time.  A changed array, or changed mappings, miss."""
     dg = _array_digest(filter_triples)
-    key = None if dg is None else (dg, bool(filter_unseen), id(model.ent_to_idx), len(model.ent_to_idx), _fingerprint(model.ent_to_idx),
-                                   id(model.rel_to_idx), len(model.rel_to_idx), _fingerprint(model.rel_to_idx))
+    # the two dictionaries are HELD by the entry and compared with `is` (an id() alone can be reused by a later dictionary of the
+    # same size and end items once the model is gone: round-5 advisor); at most two entries live here, clear_filter_cache() drops them
+    key = None if dg is None else (dg, bool(filter_unseen), len(model.ent_to_idx), _fingerprint(model.ent_to_idx),
+                                   len(model.rel_to_idx), _fingerprint(model.rel_to_idx))
     if key is not None:
         for ent in _FILTER_CACHE:
-            if ent[0] == key:
+            if ent[0] == key and ent[3] is model.ent_to_idx and ent[4] is model.rel_to_idx:
                 adapter.filter_adapter, adapter.filter_index = ent[1], ent[2]
                 return
     if filter_unseen:
         filter_triples = filter_unseen_entities(filter_triples, model, verbose=verbose)
     adapter.set_filter(filter_triples)
     if key is not None and getattr(adapter, "filter_index", None) is not None:
-        _FILTER_CACHE.insert(0, (key, adapter.filter_adapter, adapter.filter_index))
+        _FILTER_CACHE.insert(0, (key, adapter.filter_adapter, adapter.filter_index, model.ent_to_idx, model.rel_to_idx))
         del _FILTER_CACHE[2:]
+
+
+def clear_filter_cache():
+    """drop the remembered mapped filters, their indices and the label dictionaries they were mapped through"""
+    del _FILTER_CACHE[:]
+    del _LOOKUP_CACHE[:]
 
 
 def _install_filter(adapter, own_adapter, filter_triples, model, filter_unseen, verbose):

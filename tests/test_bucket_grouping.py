@@ -253,3 +253,54 @@ def test_fit_on_a_large_table_gives_the_same_bits_under_either_grouping(monkeypa
     else:
         assert a[3] == b[3]
     assert not np.array_equal(a[0], E0)
+
+
+def test_standalone_relation_apply_with_adams_dense_pass_after_a_bucket_grouping():
+    """Keras Adam's dense pass INSIDE the descriptor-driven apply (emg_apply.hip: dense_here, tables of <= 131072 rows) finds the
+    untouched rows in the grouping's offset array.  emg_prepare_batch's bucket form groups BOTH tables whenever the ENTITY table is
+    large, so the relation table's offsets must be written by it too (round 5 advisor: they were not — a standalone apply of the
+    relation table then read whatever the workspace held).  The workspaces start as garbage outside their control region, as the
+    product's torch.empty ones do; bits must equal the counting grouping's and every untouched row must have decayed exactly once.
+    Reference: Keras Adam updates every row of a table each step (training/adam.py:31-48)."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(21)
+    B, eta, n_ent, k = 5000, 3, 300_000, 40
+    for n_rel in (700, 5, 3000):
+        pos = np.stack([rs.randint(0, n_ent, B), rs.randint(0, max(1, n_rel // 2), B), rs.randint(0, n_ent, B)], 1).astype(np.int32)
+        n_ce = (2 + eta) * B
+        contrib = cu(rs.randn(B, k).astype(F32))
+        W0, M0, V0 = rs.randn(n_rel, k).astype(F32), (rs.randn(n_rel, k) * 0.01).astype(F32), (rs.rand(n_rel, k) * 0.01).astype(F32)
+        out = {}
+        for mode in ("count", "bucket"):
+            os.environ["EMG_GROUPING"] = mode
+            try:
+                we = torch.zeros(d.apply_workspace_bytes(n_ce, n_ent, k), dtype=torch.uint8, device="cuda")
+                wr = torch.full((d.apply_workspace_bytes(B, n_rel, k),), 0xA5, dtype=torch.uint8, device="cuda")
+                # the control region (zero before the first grouping) lies between the descriptor lists and the offsets: take it from a zero workspace's prepare
+                wr_zero = torch.zeros_like(wr)
+                codes = torch.empty(B * eta, dtype=torch.int32, device="cuda")
+                de = torch.empty(n_ce, dtype=torch.int32, device="cuda")
+                dr = torch.empty(B, dtype=torch.int32, device="cuda")
+                d.prepare_batch(cu(pos), eta, [2], n_ent, codes, de, dr, n_ent, n_rel, we, wr_zero, seed=5, counter0=3)
+                torch.cuda.synchronize()
+                # second grouping into the SAME (now warm) workspace after scribbling over everything a grouping must rewrite:
+                # the offset array included (its bytes: whatever follows the control region)
+                kb = al(4 * B)
+                clean_off = 6 * kb + al(12 * (B // 2 + 1)) + kb + al(12 * (B // 8 + 2))
+                clean_len = al(4 * (B // 64 + 2)) + al(4 * 64) + (al(8 * ((n_rel + 1 + 4095) // 4096)) + al(4 * (n_rel + 1)))
+                wr_zero[clean_off + clean_len:] = 0xA5
+                d.prepare_batch(cu(pos), eta, [2], n_ent, codes, de, dr, n_ent, n_rel, we, wr_zero, seed=5, counter0=3)
+            finally:
+                os.environ.pop("EMG_GROUPING", None)
+            W, M, V = cu(W0.copy()), cu(M0.copy()), cu(V0.copy())
+            tag = torch.zeros(n_rel, dtype=torch.int32, device="cuda")
+            d.apply_grouped(L.OPT_ADAM, W, k, M, V, tag, 3, contrib, B, 0, (0.01, 0.0, 0.9, 0.999, 1e-7, 0.0123), wr_zero)
+            torch.cuda.synchronize()
+            out[mode] = [t.cpu().numpy() for t in (W, M, V)]
+        for x, y in zip(out["count"], out["bucket"]):
+            np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+        untouched = np.setdiff1d(np.arange(n_rel), pos[:, 1])
+        assert untouched.size > 0
+        np.testing.assert_array_equal(out["bucket"][1][untouched], (np.float32(0.9) * M0[untouched]).astype(F32))   # one decay, no more
+        assert not np.array_equal(out["bucket"][0][untouched], W0[untouched])

@@ -407,6 +407,83 @@ def test_apply_rows_vs_oracle(opt):
         np.testing.assert_array_equal(Wt.cpu().numpy()[30:], W[30:])  # untouched rows bit-identical
 
 
+def test_opt_ratio_keeps_a_nan_and_survives_a_zero_epsilon():
+    """emg_common.hpp::opt_ratio is num * rcp(sqrt(root) + eps) on the hardware's v_rcp_f32, which flushes a denormal argument: a
+    zero / denormal eps of a C-ABI caller is raised to FLT_MIN on the HOST (make_opt_params), so an untouched row of Keras Adam's
+    dense pass (m = v = 0) stays finite — and there is no max on the device side, so a NaN in the state reaches the weights as a NaN
+    (round-5 advisor: an fmaxf there turned it into a huge finite step, hiding a diverged model from fit()'s NaN check).
+    Reference rule: training/adam.py:31-48 (Keras Adam)."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    rs = np.random.RandomState(4)
+    n_rows, k, n_c = 40, 8, 30
+    W = rs.randn(n_rows, k).astype(F32)
+    dest = rs.randint(0, 20, n_c).astype(np.int32)          # rows 20.. untouched
+    dest[0] = 3
+    contrib = rs.randn(n_c, k).astype(F32)
+    for eps in (0.0, 1e-42):
+        Wt, m, v = cu(W), torch.zeros(n_rows, k, device="cuda"), torch.zeros(n_rows, k, device="cuda")
+        ws = torch.empty(d.apply_workspace_bytes(n_c, n_rows), dtype=torch.uint8, device="cuda")
+        tag = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+        d.apply_rows(L.OPT_ADAM, Wt, k, m, v, tag, 1, cu(contrib), cu(dest), n_c, (0.05, 0.0, 0.9, 0.999, eps, 0.05), ws)
+        got = Wt.cpu().numpy()
+        assert np.isfinite(got).all(), eps
+        np.testing.assert_array_equal(got[20:], W[20:])       # m = v = 0, g = 0: the step is 0 / FLT_MIN = 0
+        assert not np.array_equal(got[:20], W[:20])
+    Wt, m, v = cu(W), torch.zeros(n_rows, k, device="cuda"), torch.zeros(n_rows, k, device="cuda")
+    v[3, 2] = float("nan")        # a touched row
+    v[30, 5] = float("nan")       # an untouched row (dense pass)
+    d.apply_rows(L.OPT_ADAM, Wt, k, m, v, torch.zeros(n_rows, dtype=torch.int32, device="cuda"), 1, cu(contrib), cu(dest), n_c, (0.05, 0.0, 0.9, 0.999, 1e-7, 0.05), ws)
+    got = Wt.cpu().numpy()
+    assert np.isnan(got[3, 2]) and np.isnan(got[30, 5]) and np.isnan(got).sum() == 2
+
+
+def test_lp_fold_forms_agree_by_value_on_signed_zeros_and_denormals():
+    """lp_fold_p2 (every device path at p = 2) is (2 lambda) * w where regularizers/lp.py:107-113 reads lambda * p * |w|^(p-1) * sign(w):
+    the same value everywhere, the same bits up to the sign of a zero.  Weights of +-0, denormals, tiny and huge values with data
+    gradients of +-0 / non-zero: SGD + LP through the apply equals the generic numpy expression BY VALUE (array_equal: -0 == +0),
+    for p = 1, 2, 3, and the regulariser's value equals the sum of |w|^p."""
+    d = dev()
+    from emgraph_amd import _lib as L
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, -3e-39, 1.17549435e-38, -1.17549435e-38, 1e-20, -1e-20, 1.0, -1.0, 3e12, -3e12, 0.5, -0.25], F32)
+    k = special.size
+    n_rows = 6
+    W = np.tile(special, (n_rows, 1))
+    dest = np.array([0, 1, 1, 2], np.int32)                       # row 3.. untouched (dense pass), row 1 a segment of two
+    contrib = np.zeros((4, k), F32)
+    contrib[0] = -0.0                                              # g = -0 on row 0: where the two forms' bits may differ
+    contrib[1], contrib[2] = 0.25, -0.25                           # g = +0 by cancellation on row 1
+    contrib[3] = np.linspace(-1, 1, k).astype(F32)
+    lr, lam = F32(0.05), F32(0.01)
+    for p in (1, 2, 3):
+        Wt = cu(W)
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ws = torch.empty(d.apply_workspace_bytes(4, n_rows), dtype=torch.uint8, device="cuda")
+        d.group_dest(cu(dest), 4, n_rows, ws)
+        tag = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+        d.apply_grouped(L.OPT_SGD, Wt, k, None, None, tag, 1, cu(contrib), 4, 0, (float(lr), 0, 0, 0, 0, 0, float(lam), p), ws, lp_accum=acc)
+        G = np.zeros((n_rows, k), F32)
+        for i, r in enumerate(dest):
+            G[r] = G[r] + contrib[i]
+        with np.errstate(over="ignore", under="ignore"):
+            a = np.abs(W)
+            pm1 = np.ones_like(a) if p == 1 else (a if p == 2 else a * a)
+            g = (G + (lam * F32(p) * pm1) * np.sign(W)).astype(F32)
+            exp = (W - lr * g).astype(F32)
+            val = (a.astype(np.float64) ** p).sum() if p == 1 else (lp_pow32(a, p)).astype(np.float64).sum()
+        got = Wt.cpu().numpy()
+        # (the device runs with denormals ON for f32 — gfx950's default mode — so denormal weights are not flushed)
+        np.testing.assert_array_equal(got, exp, err_msg="p=%d" % p)
+        np.testing.assert_allclose(acc.item(), val, rtol=1e-6)
+
+
+def lp_pow32(a, p):
+    out = a.copy()
+    for _ in range(p - 1):
+        out = (out * a).astype(F32)
+    return out
+
+
 @pytest.mark.parametrize("k,n_rows,n_c,hot", [(12, 40, 3000, 0), (50, 300, 5000, 0), (100, 64, 20000, 0), (200, 500, 9000, 0),
                                               (400, 200, 6000, 0), (7, 33, 2000, 0), (30, 50, 700, 0), (52, 2000, 40000, 500)])
 def test_apply_rows_sums_in_contribution_order(k, n_rows, n_c, hot):

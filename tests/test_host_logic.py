@@ -480,3 +480,16 @@ def test_installed_filter_is_remembered_by_content_not_by_identity():
     assert install(F, other).filter_index is not a.filter_index
     labels = np.array([["a", "r", "b"], ["b", "r", "a"]], dtype=object)      # object arrays are not digested: never cached
     assert P._array_digest(labels) is None
+    # same size, same first / last items, another interior mapping (a refit with another insertion order): a miss, and the mapped
+    # filter follows the new ids — the entry holds its dictionaries, so an address reused after a model is gone cannot alias it
+    swapped = dict(ent)
+    swapped[3], swapped[4] = ent[4], ent[3]
+    d = install(F, SimpleNamespace(ent_to_idx=swapped, rel_to_idx=rel, set_filter_for_eval=lambda: None))
+    assert d.filter_index is not a.filter_index
+    expect = F.copy()
+    for col in (0, 2):
+        expect[:, col] = np.where(F[:, col] == 3, 4, np.where(F[:, col] == 4, 3, F[:, col]))
+    np.testing.assert_array_equal(d.filter_adapter, expect)
+    assert all(e[3] is not None and e[4] is not None for e in P._FILTER_CACHE)
+    P.clear_filter_cache()
+    assert P._FILTER_CACHE == [] and P._LOOKUP_CACHE == []
