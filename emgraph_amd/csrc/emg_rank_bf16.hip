@@ -540,11 +540,22 @@ constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
 // WAVES = 8: 256 query rows per workgroup, two waves per SIMD (<= 256 registers: NQ <= 25, k_int <= 400).  WAVES = 4 (the
 // prefilter above k_int = 400): 128 query rows, ONE wave per SIMD with the whole 512-register file — NQ up to 50 query
 // fragments (200 registers) beside the accumulators; every streamed entity byte is used by half as many rows.
-template <int NQ, int SQ, int MODE, int WAVES = 8>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter
+//
+// MODE 3 (round 6): the prefilter WITHOUT emission.  Measured on MODE 2 (profiles/r6_b_eval_kernel_stats.md): the same MFMAs take
+// 5.7 ms with one counter, 7.2 ms as the prefilter of a trained-like table (0.08 % undecided) and 9.0 ms on random positives
+// (0.72 %): the per-group scalar branches and the emission — 37 % of the accumulator registers hold an undecided candidate on
+// random positives — stall the wave, and its pair stores sit in the same counted queue as the LDS-DMA fills.  Here a tile's
+// epilogue is branch-free: per value two compares, each shifted into a 32-bit word of the lane by its own carry
+// (v_cmp + v_addc w, w, w: w = 2 w + bit), then count += popcount(greater word), undecided = greater-or-equal word XOR greater
+// word, and ONE 8-byte store per lane and tile of the undecided BITMAP — into the wave's own segment of the pair buffer
+// (64 lanes x 8 B x <= 32 tiles = the segment's 16 KB at 2048 entries).  prefilter_compact_kernel then turns each segment's
+// bitmap into the (row, entity) pairs the re-scoring kernels read, in place (a wave per segment reads the 16 KB, then writes).
+template <int NQ, int SQ, int MODE, int WAVES = 8>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter | 3 prefilter, bitmap
 __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
     constexpr int V3_BM = 32 * WAVES;           // query rows per workgroup
     constexpr bool ONE = MODE == 1;
-    constexpr bool PRE = MODE == 2;
+    constexpr bool PRE = MODE >= 2;
+    constexpr bool BMP = MODE == 3;
     constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
     constexpr int SPR = SQ * 2;                 // 16-byte slots per slice row
     constexpr int RPB = 256 / RB;               // rows per 256-byte LDS bank row
@@ -596,11 +607,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
     __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): from here on only LDS-DMA is in the VMEM queue
     __syncthreads();
 
-    // per PAIR of accumulator registers (= two query rows of this lane) four packed 8-bit counters:
-    // gt(r even) | eq(r even) << 8 | gt(r odd) << 16 | eq(r odd) << 24; each <= 4 x tiles_per_chunk (<= 32) = 128
-    unsigned cnt[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) cnt[r] = 0u;
+    // TRANSPOSED products (round 6): the entity fragment is the MFMA's A operand, the query fragment its B operand, so an
+    // accumulator tile is [entity][query row] and lane l holds query row l & 31 in ALL of its registers (16 entities each:
+    // 8 (r >> 2) + (r & 3) + 4 (l >> 5) of the 32-entity block).  One lane, one row: the row's two thresholds are two registers
+    // (no LDS reads in the epilogue), a counted value is v_cmp + v_addc into ONE 32-bit counter per lane (was: compare, select,
+    // add into packed 8-bit counters per register pair), and the lanes l / l + 32 of a row meet in one shuffle at the end.
+    // The products a[m][k] b[k][n] and their k order are those of the untransposed form: the same scores bit for bit.
+    const float g_l = thr_s[wave * 32 + l31], e_l = thr_s[V3_BM + wave * 32 + l31];
+    unsigned cgt = 0u, cge = 0u;   // scores that reached the first threshold; MODE 0: ... the second (ties = cge - cgt)
+    [[maybe_unused]] unsigned ucnt = 0u;   // MODE 3: undecided candidates of this lane
 
     // ---- LDS-DMA producer: this lane's 16-byte pieces of every slice -------------------------------------
     const int64_t tile0 = cb * P.tiles_per_chunk;
@@ -665,8 +680,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
         for (int tb = 0; tb < 4; ++tb) {
             // the prefilter's operands are IEEE half (11 significant bits: an 8x narrower error band than bf16, same
             // MFMA rate); the fragments are bit containers, only the instruction differs
-            if constexpr (PRE) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[tb]), acc[tb], 0, 0, 0);
-            else acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[tb], acc[tb], 0, 0, 0);
+            // (entity fragment first: the transposed tile, see the counters above)
+            if constexpr (PRE) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bq[tb]), __builtin_bit_cast(f16x8, a), acc[tb], 0, 0, 0);
+            else acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[tb], a, acc[tb], 0, 0, 0);
         }
     };
     __builtin_amdgcn_s_waitcnt(0x0F70 | (G * (NS - 2)));  // slice 0 landed (mine) ...
@@ -714,85 +730,80 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
         // pairs so far + v_mbcnt of the mask — so no per-lane bitmap, prefix scan or bit loop is ever built.
         const uint32_t row_s = (uint32_t)(qb * V3_BM + wave * 32), col_s = (uint32_t)(P.ent_offset + (tile0 + ctile) * V3_BN);   // scalars
         const unsigned lhi4 = 4u * (unsigned)lhi;
-        auto emit_mask = [&](uint64_t m, int r, int tb) {   // r = 4 j + i: row = row0 + 8 j + i, entity = col0 + 32 tb
+        [[maybe_unused]] auto emit_mask = [&](uint64_t m, int r, int tb) {   // register r of block tb: entity = col0 + 32 tb + 8 (r >> 2) + (r & 3) + 4 lhi, row = row0 + l31
             const unsigned n = (unsigned)__builtin_popcountll(m);
             if (pair_n + n > P.pair_cap) { pair_over = 1u; return; }   // the caller redoes this query tile with the exact kernel
             const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            // (the scalar halves are made opaque: otherwise the 16 + 4 lane-dependent sums are hoisted out of the tile loop and
+            // (the scalar halves are made opaque: otherwise the lane-dependent sums are hoisted out of the tile loop and
             // held in — spilled — vector registers for an emission that may never come)
-            unsigned hi_s = row_s + (unsigned)(8 * (r >> 2) + (r & 3)), lo_s = col_s + 32u * (unsigned)tb;
+            unsigned hi_s = row_s, lo_s = col_s + (unsigned)(32 * tb + 8 * (r >> 2) + (r & 3));
             asm volatile("" : "+s"(hi_s), "+s"(lo_s));
             if (__builtin_amdgcn_inverse_ballot_w64(m))   // low word: entity, high word: query row
-                *reinterpret_cast<uint2*>(pair_base + pair_n + before) = make_uint2(lo_s + (unsigned)l31, hi_s + lhi4);
+                *reinterpret_cast<uint2*>(pair_base + pair_n + before) = make_uint2(lo_s + lhi4, hi_s + (unsigned)l31);
             pair_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(pair_n + n));
         };
         // ---- tile epilogue: compare-and-count, clear -----------------------------------------------------
         auto epilogue = [&](auto FULL) {
+            const int64_t ent0 = (tile0 + ctile) * V3_BN + 4 * lhi;   // this lane's first entity of the tile
+            if constexpr (BMP) {
+                // value i = 16 (tb & 1) + r of word tb >> 1 ends at bit 31 - i (32 shifts: whatever the word held before is gone)
+                unsigned wg[2] = {0u, 0u}, we[2] = {0u, 0u};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r0 = wave * 32 + 8 * j + 4 * lhi;  // query rows of accumulator registers 4j..4j+3
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(thr_s + r0);
-                const f32x4 e4 = *reinterpret_cast<const f32x4*>(thr_s + V3_BM + r0);
-                if constexpr (ONE) {
+                for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) {
-                        const bool cok = FULL.value || (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            cnt[2 * j + (i >> 1)] += (cok && acc[tb][4 * j + i] >= g4[i]) ? (1u << (16 * (i & 1))) : 0u;
+                    for (int r = 0; r < 16; ++r) {
+                        // (the table's last, partial tile: a NaN reaches no threshold — one code path, no mask)
+                        const float v = (FULL.value || ent0 + 32 * tb + 8 * (r >> 2) + (r & 3) < n_cand) ? acc[tb][r] : __builtin_nanf("");
+                        asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                     "v_cmp_ge_f32 vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                                     : "+v"(wg[tb >> 1]), "+v"(we[tb >> 1]) : "v"(v), "v"(g_l), "v"(e_l) : "vcc");
                     }
-                } else if constexpr (PRE) {
+                const unsigned u0 = we[0] ^ wg[0], u1 = we[1] ^ wg[1];   // (the first threshold is the higher one: greater implies greater-or-equal)
+                cgt += (unsigned)__builtin_popcount(wg[0]) + (unsigned)__builtin_popcount(wg[1]);
+                ucnt += (unsigned)__builtin_popcount(u0) + (unsigned)__builtin_popcount(u1);
+                reinterpret_cast<uint2*>(pair_base)[ctile * 64 + lane] = make_uint2(u0, u1);
 #pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) {
-                        const uint64_t cokm = FULL.value ? ~0ull : __builtin_amdgcn_ballot_w64((tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand);
-                        uint64_t mu[4], any = 0ull;
+                for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = acc[tb][4 * j + i];
-                            const uint64_t mg = __builtin_amdgcn_ballot_w64(v >= g4[i]) & cokm;
-                            const uint64_t me = __builtin_amdgcn_ballot_w64(v >= e4[i]) & cokm;
-                            cnt[2 * j + (i >> 1)] += __builtin_amdgcn_inverse_ballot_w64(mg) ? (1u << (16 * (i & 1))) : 0u;
+                    for (int r = 0; r < 16; ++r) acc[tb][r] = 0.f;
+                return;
+            }
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    [[maybe_unused]] uint64_t mu[4], any = 0ull;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = acc[tb][4 * j + i];
+                        const bool cok = FULL.value || ent0 + 32 * tb + 8 * j + i < n_cand;
+                        if constexpr (PRE) {
+                            // the two compares leave LANE MASKS in scalar registers: `undecided` is one s_andn2 of them, the count
+                            // the first mask as the carry of a v_addc, and "any in these four registers" a scalar branch
+                            uint64_t mg, me;
+                            if constexpr (FULL.value) {   // (as v4's: hipcc turns the mask back into a select and an add)
+                                asm volatile("v_cmp_ge_f32_e64 %1, %3, %4\n\tv_cmp_ge_f32_e64 %2, %3, %5\n\tv_addc_co_u32_e64 %0, vcc, 0, %0, %1"
+                                             : "+v"(cgt), "=&s"(mg), "=&s"(me) : "v"(v), "v"(g_l), "v"(e_l) : "vcc");
+                            } else {
+                                const uint64_t cokm = __builtin_amdgcn_ballot_w64(cok);
+                                mg = __builtin_amdgcn_ballot_w64(v >= g_l) & cokm; me = __builtin_amdgcn_ballot_w64(v >= e_l) & cokm;
+                                cgt += __builtin_amdgcn_inverse_ballot_w64(mg) ? 1u : 0u;
+                            }
                             mu[i] = me & ~mg;
                             any |= mu[i];
+                        } else {
+                            cgt += (cok && v >= g_l) ? 1u : 0u;
+                            if constexpr (!ONE) cge += (cok && v >= e_l) ? 1u : 0u;
                         }
-                        // (count here: left to itself the compiler defers the 64 counter updates of a tile to its end and
-                        // carries their 64 lane masks there — 128 scalar registers it does not have)
-                        asm volatile("" : "+v"(cnt[2 * j]), "+v"(cnt[2 * j + 1]));
+                    }
+                    if constexpr (PRE) {
+                        // (count here: left to itself the compiler defers the counter updates of a tile to its end and carries
+                        // their lane masks there — scalar registers it does not have)
+                        asm volatile("" : "+v"(cgt));
                         if (any) {   // wave-uniform
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 if (mu[i]) emit_mask(mu[i], 4 * j + i, tb);
-                        }
-                    }
-                } else if constexpr (FULL.value) {
-                    unsigned long long tie = 0ull;  // lanes holding a score equal to the positive's (rare)
-#pragma unroll
-                    for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = acc[tb][4 * j + i];
-                            cnt[2 * j + (i >> 1)] += (v >= g4[i]) ? (1u << (16 * (i & 1))) : 0u;
-                            tie |= __builtin_amdgcn_fcmpf(v, g4[i], 3) ^ __builtin_amdgcn_fcmpf(v, e4[i], 3);
-                        }
-                    if (tie) {
-#pragma unroll
-                        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = acc[tb][4 * j + i];
-                                cnt[2 * j + (i >> 1)] += (v >= e4[i] && !(v >= g4[i])) ? (0x100u << (16 * (i & 1))) : 0u;
-                            }
-                    }
-                } else {
-#pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) {
-                        const bool cok = (tile0 + ctile) * V3_BN + tb * 32 + l31 < n_cand;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = acc[tb][4 * j + i];
-                            const bool gt = v >= g4[i], ge = v >= e4[i];
-                            cnt[2 * j + (i >> 1)] += (cok && gt) ? (1u << (16 * (i & 1))) : 0u;
-                            cnt[2 * j + (i >> 1)] += (cok && ge && !gt) ? (0x100u << (16 * (i & 1))) : 0u;
                         }
                     }
                 }
@@ -806,6 +817,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
         else epilogue(std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
+    if constexpr (BMP) {   // the segment's undecided candidates: the wave's sum (the bitmap holds them whatever their number)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ucnt += __shfl_xor(ucnt, off, 64);
+        // more than the re-scoring pass's segment holds: the caller redoes this query tile exactly, and the segment counts as EMPTY
+        // (its words stay a bitmap: nothing may read them as pairs)
+        pair_over = ucnt > P.pair_cap ? 1u : 0u;
+        pair_n = pair_over ? 0u : ucnt;
+    }
     if constexpr (PRE) {
         if (lane == 0) {
             P.pair_count[blockIdx.x * (unsigned)WAVES + (unsigned)wave] = pair_n;
@@ -813,19 +832,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
         }
     }
 
-    // ---- rows are private to the wave: lane shuffle, one global atomic per row and counter ----------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned pk = cnt[r >> 1] >> (16 * (r & 1));
-        unsigned c = (pk & 0xffu) | ((pk & 0xff00u) << 8);  // gt | eq << 16: room for the 32-lane sum
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-        if (l31 == 0) {
-            const int64_t qr = qb * V3_BM + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (qr < P.n_rows) {
-                if (c & 0xffffu) atomicAdd(&P.cnt_gt[qr], (int)(c & 0xffffu));
-                if (c >> 16) atomicAdd(&P.cnt_eq[qr], (int)(c >> 16));
-            }
+    // ---- rows are private to the wave, a row to the lanes l and l + 32: one shuffle, one global atomic per row and counter ----
+    {
+        unsigned ceq = (ONE || PRE) ? 0u : cge - cgt;   // (the second threshold is the lower one: every score counted in cgt is in cge)
+        cgt += __shfl_xor(cgt, 32, 64);
+        ceq += __shfl_xor(ceq, 32, 64);
+        const int64_t qr = qb * V3_BM + wave * 32 + l31;
+        if (lhi == 0 && qr < P.n_rows) {
+            if (cgt) atomicAdd(&P.cnt_gt[qr], (int)cgt);
+            if (ceq) atomicAdd(&P.cnt_eq[qr], (int)ceq);
         }
     }
 }
@@ -851,6 +866,56 @@ static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
     if (rc != EMG_OK) return rc;
     hipLaunchKernelGGL((count_mfma_bf16_v3_kernel<NQ, SQ, MODE, WAVES>), dim3((unsigned)nblk), dim3(64 * WAVES), lds_bytes, st, P);
     return EMG_OK;
+}
+
+// MODE 3's second half: a segment's undecided bitmap -> its (row << 32 | entity) pairs, IN PLACE.  One wave per segment: all of the
+// segment's words are in registers (32 x 8 bytes per lane) before the first pair is written over them; per tile a lane's pairs go
+// behind those of the lanes below it (wave scan of the popcounts), tiles ascending — the order the re-scoring kernels sweep in.
+struct CompactParams {
+    uint64_t* pairs; const uint32_t* pair_count; uint32_t pair_cap, n_segments;
+    int64_t n_qb, n_cb, n_tiles, ent_offset; int32_t tiles_per_chunk, waves;
+};
+__global__ __launch_bounds__(256) void prefilter_compact_kernel(const CompactParams C) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg >= C.n_segments) return;
+    const uint32_t n = C.pair_count[seg];
+    if (n == 0u || n > C.pair_cap) return;   // (nothing to re-score; an overflowing segment was recorded as empty)
+    const int64_t blk = seg / (uint32_t)C.waves;
+    const int wave = (int)(seg % (uint32_t)C.waves);
+    const int64_t xcd = blk & 7, slot_id = blk >> 3, qb = slot_id % C.n_qb, cb = xcd + 8 * (slot_id / C.n_qb);   // (the prefilter's block -> tile map)
+    const int64_t tile0 = cb * C.tiles_per_chunk;
+    const int ntile = (int)(min(tile0 + (int64_t)C.tiles_per_chunk, C.n_tiles) - tile0);
+    uint64_t* const base = C.pairs + (uint64_t)seg * C.pair_cap;
+    const uint2* const bm = reinterpret_cast<const uint2*>(base);
+    uint2 w[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) w[t] = t < ntile ? bm[t * 64 + lane] : make_uint2(0u, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every word has been read before the first pair overwrites one
+    const uint64_t row_hi = (uint64_t)(uint32_t)(qb * 32 * C.waves + wave * 32 + (lane & 31)) << 32;
+    const uint32_t lhi4 = 4u * (uint32_t)(lane >> 5);
+    uint32_t done = 0u;   // pairs written so far (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const uint32_t c = (uint32_t)__builtin_popcount(w[t].x) + (uint32_t)__builtin_popcount(w[t].y);
+        if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;   // wave-uniform
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+        uint32_t at = done + incl - c;
+        const uint32_t col = (uint32_t)(C.ent_offset + (tile0 + t) * V3_BN) + lhi4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t m = h ? w[t].y : w[t].x;
+            while (m) {
+                const int b = 31 - __builtin_clz(m);      // bit 31 - i holds value i = 16 (tb & 1) + r of blocks 2 h, 2 h + 1: ascending entities first
+                m &= ~(1u << b);
+                const int i = 31 - b, r = i & 15;
+                base[at++] = row_hi | (uint64_t)(col + (uint32_t)(32 * (2 * h + (i >> 4)) + 8 * (r >> 2) + (r & 3)));
+            }
+        }
+        done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1327,8 +1392,14 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const int64_t nblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
         EMG_REQUIRE(nblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
         int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
-        const int md = P.pairs ? 2 : (P.need != 0 ? 1 : 0);
-#define EMG_V3(NQ_) (md == 2 ? launch_v3<NQ_, 4, 2>(P, nblk, st) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
+        // the prefilter as a bitmap (MODE 3) wherever a wave's segment of the pair buffer holds its tiles' words (64 entries per tile:
+        // 2048 entries at 32 tiles — what ranking.py allocates up to 65536 segments); EMG_PRE_BITMAP=0: the emitting form (A/B)
+        static const bool bitmap_ok = !(getenv("EMG_PRE_BITMAP") && atoi(getenv("EMG_PRE_BITMAP")) == 0);
+        const bool bmp = P.pairs && bitmap_ok && (int64_t)P.pair_cap >= 64 * (int64_t)P.tiles_per_chunk &&
+                         !(v4_mode() == 2 && v3_prefilter_steps(P.k16) == 25);   // (EMG_BF16_V4=2: the v4 kernel's emitting prefilter, an A/B form)
+        const int md = P.pairs ? (bmp ? 3 : 2) : (P.need != 0 ? 1 : 0);
+#define EMG_V3P(NQ_) (md == 3 ? launch_v3<NQ_, 4, 3>(P, nblk, st) : launch_v3<NQ_, 4, 2>(P, nblk, st))
+#define EMG_V3(NQ_) (md >= 2 ? EMG_V3P(NQ_) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
         // the prefilter (exact-fast mode, what evaluate_performance uses by default) at EVERY width up to 400: the next
         // instantiated step count, the extra k-steps multiply the rows' zero padding (exact zeros: nothing changes)
         const int nq = P.pairs != nullptr ? v3_prefilter_steps(P.k16) : P.k16;
@@ -1336,10 +1407,12 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
             P.n_qb = cdiv(P.n_rows, 128);
             const int64_t wblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
             EMG_REQUIRE(wblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
-            if (nq == 32) rc = launch_v3<32, 4, 2, 4>(P, wblk, st);
-            else if (nq == 38) rc = launch_v3<38, 4, 2, 4>(P, wblk, st);
-            else if (nq == 44) rc = launch_v3<44, 4, 2, 4>(P, wblk, st);
-            else rc = launch_v3<50, 4, 2, 4>(P, wblk, st);
+#define EMG_V3W(NQ_) (md == 3 ? launch_v3<NQ_, 4, 3, 4>(P, wblk, st) : launch_v3<NQ_, 4, 2, 4>(P, wblk, st))
+            if (nq == 32) rc = EMG_V3W(32);
+            else if (nq == 38) rc = EMG_V3W(38);
+            else if (nq == 44) rc = EMG_V3W(44);
+            else rc = EMG_V3W(50);
+#undef EMG_V3W
         }
         else if (md == 1 && v4_mode() >= 1 && P.n_cand >= V3_BN) {   // one counter: 64 query rows per wave (v4: -9 % at 400 columns)
             if (nq == 25) rc = launch_v4<25, 1>(P, nblk, st);
@@ -1352,14 +1425,23 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         else if (nq == 25) rc = EMG_V3(25);
         else if (nq == 13) rc = EMG_V3(13);
         else if (nq == 8) rc = EMG_V3(8);
-        else if (nq == 4) rc = launch_v3<4, 4, 2>(P, nblk, st);
-        else if (nq == 7) rc = launch_v3<7, 4, 2>(P, nblk, st);
-        else if (nq == 10) rc = launch_v3<10, 4, 2>(P, nblk, st);
-        else if (nq == 16) rc = launch_v3<16, 4, 2>(P, nblk, st);
-        else if (nq == 19) rc = launch_v3<19, 4, 2>(P, nblk, st);
-        else rc = launch_v3<22, 4, 2>(P, nblk, st);
+        else if (nq == 4) rc = EMG_V3P(4);
+        else if (nq == 7) rc = EMG_V3P(7);
+        else if (nq == 10) rc = EMG_V3P(10);
+        else if (nq == 16) rc = EMG_V3P(16);
+        else if (nq == 19) rc = EMG_V3P(19);
+        else rc = EMG_V3P(22);
 #undef EMG_V3
+#undef EMG_V3P
         if (rc != EMG_OK) return rc;
+        if (md == 3) {   // the segments' bitmaps -> pairs, in place
+            EMG_LAUNCH_CHECK();
+            CompactParams C{};
+            C.pairs = P.pairs; C.pair_count = P.pair_count; C.pair_cap = P.pair_cap; C.n_segments = P.n_segments;
+            C.n_qb = P.n_qb; C.n_cb = P.n_cb; C.n_tiles = P.n_tiles; C.ent_offset = P.ent_offset; C.tiles_per_chunk = P.tiles_per_chunk;
+            C.waves = nq >= V3_WIDE_FROM ? 4 : 8;
+            hipLaunchKernelGGL(prefilter_compact_kernel, dim3((unsigned)cdiv((int64_t)P.n_segments, 4)), dim3(256), 0, st, C);
+        }
     } else if (P.pairs) {
         return fail(EMG_ENOSUP, "bf16 prefilter: contraction widths up to 400 on rows of at least emg_eval_prefilter_ld columns, more than 128 query rows, no candidate list");
     } else if (P.cand == nullptr && P.k_pad <= V2_KPAD_MAX && P.cmul > 0.f && P.cmul < INFINITY) {
