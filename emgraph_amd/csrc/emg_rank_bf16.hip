@@ -1394,7 +1394,8 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         int rc;  // 64-wide slices (SQ = 4): one barrier per 16 MFMAs measured 1.5-3.5 % faster than 32-wide
         // the prefilter as a bitmap (MODE 3) wherever a wave's segment of the pair buffer holds its tiles' words (64 entries per tile:
         // 2048 entries at 32 tiles — what ranking.py allocates up to 65536 segments); EMG_PRE_BITMAP=0: the emitting form (A/B)
-        static const bool bitmap_ok = !(getenv("EMG_PRE_BITMAP") && atoi(getenv("EMG_PRE_BITMAP")) == 0);
+        const char* bm_env = getenv("EMG_PRE_BITMAP");   // (read per call: tests compare the two forms inside one process)
+        const bool bitmap_ok = !(bm_env && bm_env[0] && atoi(bm_env) == 0);
         const bool bmp = P.pairs && bitmap_ok && (int64_t)P.pair_cap >= 64 * (int64_t)P.tiles_per_chunk &&
                          !(v4_mode() == 2 && v3_prefilter_steps(P.k16) == 25);   // (EMG_BF16_V4=2: the v4 kernel's emitting prefilter, an A/B form)
         const int md = P.pairs ? (bmp ? 3 : 2) : (P.need != 0 ? 1 : 0);

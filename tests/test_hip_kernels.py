@@ -1348,6 +1348,68 @@ def test_prefilter_ranks_equal_exact_ranks(model, k, n_ent, nq, scale):
         assert used > 0        # the prefilter ran and handed candidates (at least the ties) to the exact re-scoring
 
 
+@pytest.mark.parametrize("k,n_ent,nq,crowd", [(200, 9000, 300, 0.0), (200, 4096 * 3 + 77, 140, 0.0), (64, 130000, 200, 0.0),
+                                               (300, 5000, 130, 0.0), (200, 12000, 200, 1e-4)])
+def test_prefilter_bitmap_form_equals_the_emitting_form(monkeypatch, k, n_ent, nq, crowd):
+    """the prefilter kernel's two forms on the same inputs (csrc/emg_rank_bf16.hip, MODE 3 + prefilter_compact_kernel against MODE 2,
+    EMG_PRE_BITMAP=0): the decided counts are identical, every segment holds the same SET of (row, entity) pairs and the same
+    count; a table whose scores crowd around the positives' overflows its segments — the bitmap form then records such a segment as
+    EMPTY and raises the overflow flag (the caller redoes the tile exactly), never a count that would make the re-scoring pass read
+    bitmap words as pairs.  Shapes: a last tile that is not full, a last chunk that is not full (4096 x 3 + 77 entities), several
+    chunks, the wide form above 400 columns (k = 300: four waves x 128 query rows), query rows that end inside a workgroup.
+    Reference behaviour behind both: perform_comparision's counts (EmbeddingModel.py:2010-2033)."""
+    d = dev()
+    from emgraph_amd.evaluation import ranking as RK
+    E, R, ki = make_tables("ComplEx", k, n_ent, 3, seed=k + nq, scale=0.1)
+    if crowd:
+        E = (E[:1] + crowd * E).astype(F32)
+    rs = np.random.RandomState(nq)
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 3, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    Et, Rt = cu(E), cu(R)
+    tabs = RK.PrefilterTables(Et, ki)
+    Q, pos_int = d.eval_build_queries(MID["ComplEx"], Et, Rt, ki, 1.0, cu(T), 3)
+    Qb = d.to_f16(Q, ki, ld_dst=d.prefilter_ld(ki))
+    band = RK.prefilter_band(Q, Qb, ki, tabs.bounds(0, n_ent))
+    n_rows = Q.shape[0]
+    n_seg = d.eval_prefilter_segments(n_rows, n_ent, ki)
+    cap = 2048
+    out = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("EMG_PRE_BITMAP", form)
+        pairs = torch.full((n_seg * cap,), -1, dtype=torch.int64, device="cuda")
+        pcount = torch.full((n_seg + 1,), 77, dtype=torch.int32, device="cuda")      # (the call clears it)
+        cnt = torch.zeros(n_rows, dtype=torch.int32, device="cuda")
+        d.eval_prefilter_f16(MID["ComplEx"], Qb, pos_int, band, tabs.ent_f16, 0, ki, 1.0, cnt, pairs, pcount)
+        torch.cuda.synchronize()
+        out[form] = (cnt.cpu().numpy(), pairs.cpu().numpy().reshape(n_seg, cap), pcount.cpu().numpy())
+    monkeypatch.delenv("EMG_PRE_BITMAP")
+    (c0, p0, n0), (c1, p1, n1) = out["0"], out["1"]
+    if not crowd:
+        assert n0[n_seg] == 0 and n1[n_seg] == 0
+        np.testing.assert_array_equal(c1, c0)
+        np.testing.assert_array_equal(n1, n0)
+        assert n0[:n_seg].sum() > 0
+        for sgm in np.nonzero(n0[:n_seg])[0]:
+            a, b = np.sort(p0[sgm, :n0[sgm]]), np.sort(p1[sgm, :n1[sgm]])
+            np.testing.assert_array_equal(b, a, err_msg="segment %d" % sgm)
+            rows, ents = b >> 32, b & 0xffffffff
+            assert rows.max() < n_rows and ents.max() < n_ent
+            assert np.all(np.diff((p1[sgm, :n1[sgm]] & 0xffffffff) >> 7) >= 0)     # tiles ascending: the order the re-scoring kernels sweep in
+    else:
+        assert n0[n_seg] != 0 and n1[n_seg] != 0                 # both forms say: redo this query tile exactly
+        np.testing.assert_array_equal(c1, c0)                    # (the decided counts do not depend on the room for pairs)
+        over = np.nonzero(n1[:n_seg] == 0)[0]
+        assert over.size > 0 and n1[:n_seg].max() <= cap
+        # ... and the public path returns the exact kernel's ranks on this table
+        from emgraph_amd.evaluation import rank_triples_device
+        monkeypatch.setenv("EMG_PREFILTER_PROBE", "0")
+        st = {}
+        fast = rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst", precision=2, ent_f16=tabs, stats=st)
+        monkeypatch.delenv("EMG_PREFILTER_PROBE")
+        np.testing.assert_array_equal(fast, rank_triples_device(MID["ComplEx"], Et, Rt, ki, 1.0, T, "s,o", "worst"))
+        assert st["fallback"] >= 1
+
+
 def test_prefilter_probe_sends_an_undecidable_table_to_the_exact_kernel(monkeypatch):
     """precision 2 first runs 128 of the call's triples through the prefilter alone and reads the undecided fraction
     (ranking._prefilter_probe).  A table whose rows are all but equal (a freshly initialised model looks like this to the band)
