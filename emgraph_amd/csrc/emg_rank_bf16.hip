@@ -874,6 +874,7 @@ static int launch_v3(const CountBf16Params& P, int64_t nblk, hipStream_t st) {
 struct CompactParams {
     uint64_t* pairs; const uint32_t* pair_count; uint32_t pair_cap, n_segments;
     int64_t n_qb, n_cb, n_tiles, ent_offset; int32_t tiles_per_chunk, waves;
+    int64_t last32;   // v4 (its stage of 32 entities never runs past the table: it is shifted back to end there): n_cand - 32; v3: INT64_MAX
 };
 __global__ __launch_bounds__(256) void prefilter_compact_kernel(const CompactParams C) {
     const int lane = threadIdx.x & 63;
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(256) void prefilter_compact_kernel(const CompactPar
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
         uint32_t at = done + incl - c;
-        const uint32_t col = (uint32_t)(C.ent_offset + (tile0 + t) * V3_BN) + lhi4;
+        const int64_t col = (tile0 + t) * V3_BN;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint32_t m = h ? w[t].y : w[t].x;
@@ -911,7 +912,8 @@ __global__ __launch_bounds__(256) void prefilter_compact_kernel(const CompactPar
                 const int b = 31 - __builtin_clz(m);      // bit 31 - i holds value i = 16 (tb & 1) + r of blocks 2 h, 2 h + 1: ascending entities first
                 m &= ~(1u << b);
                 const int i = 31 - b, r = i & 15;
-                base[at++] = row_hi | (uint64_t)(col + (uint32_t)(32 * (2 * h + (i >> 4)) + 8 * (r >> 2) + (r & 3)));
+                const int64_t blk0 = min(col + 32 * (2 * h + (i >> 4)), C.last32);   // the block's first entity (v4: shifted back at the table's end)
+                base[at++] = row_hi | (uint64_t)((uint32_t)(C.ent_offset + blk0) + lhi4 + (uint32_t)(8 * (r >> 2) + (r & 3)));
             }
         }
         done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -959,6 +961,11 @@ template <int OFF> __device__ __forceinline__ void lds_read16(bf16x8& dst, unsig
 template <int N> __device__ __forceinline__ void lds_wait(bf16x8& frag) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
+// (entity fragment as the A operand, query fragment — an AGPR — as B: the transposed tile of MODE 3, one query row per lane)
+template <bool FIRST> __device__ __forceinline__ void mfma_asm_t(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %1, 0" : "=v"(acc) : "a"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+v"(acc) : "a"(a), "v"(b));
+}
 template <bool F16, bool FIRST> __device__ __forceinline__ void mfma_asm(f32x16& acc, const bf16x8& a, const bf16x8& b) {
     if constexpr (FIRST) {
         if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(a), "v"(b));
@@ -990,10 +997,16 @@ constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); } 
 #ifndef V4_ABLATE
 #define V4_ABLATE 0  // timing experiments only (wrong results): 1 no refills, 2 no compare epilogue, 4 no MFMAs, 8 no LDS reads, 16 no wait / barrier
 #endif
-template <int NQ, int MODE>   // MODE 0 both counters | 1 one | 2 prefilter (see v3)
+// MODE 3 (round 6): the prefilter as a BITMAP, as v3's MODE 3 — the products transposed (the query fragment is the MFMA's B
+// operand: lane = query row, the stage's 32 entities in the accumulator registers), per value two compares shifted into two words
+// of the lane by their own carries (4 VALU instructions, no scalar work, no branch: they sit in the slots between the MFMAs like
+// the one-counter form's two), and after every second stage of a tile — 32 values per word — count += popcount, undecided =
+// XOR, one 4-byte store per lane and half into the half's segment of the pair buffer ([tile][lane][word], v3's layout:
+// prefilter_compact_kernel reads both).  The thresholds are two registers per half (64 in the other modes).
+template <int NQ, int MODE>   // MODE 0 both counters | 1 one | 2 prefilter | 3 prefilter, bitmap (see v3)
 __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountBf16Params P) {
     using G = V4Geo<NQ>;
-    constexpr bool ONE = MODE == 1, PRE = MODE == 2;
+    constexpr bool ONE = MODE == 1, PRE = MODE >= 2, BMP = MODE == 3;
     constexpr int NS = G::NS, STAGE = G::STAGE, INSTR = G::INSTR, FI = G::FI, SLOTS = G::SLOTS, PF = G::PF, RB = G::RB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // ring | thresholds
     float* thr_s = reinterpret_cast<float*>(smem + NS * STAGE);             // [0,256): gt, [256,512): ge
@@ -1037,6 +1050,11 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
     __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): from here on only LDS-DMA (and pair stores) are in the VMEM queue
     __syncthreads();
     f32x4 gth[2][4], eth[2][4];   // this lane's rows: 64 w + 32 h + 8 j + i + 4 lhi
+    float g_t[2] = {0.f, 0.f}, e_t[2] = {0.f, 0.f};   // MODE 3: this lane's ROW 64 w + 32 h + l31
+    if constexpr (BMP) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { g_t[h] = thr_s[wave * 64 + 32 * h + l31]; e_t[h] = thr_s[256 + wave * 64 + 32 * h + l31]; }
+    } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1045,6 +1063,7 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
             gth[h][j] = *reinterpret_cast<const f32x4*>(thr_s + r0);
             if constexpr (!ONE) eth[h][j] = *reinterpret_cast<const f32x4*>(thr_s + 256 + r0);
         }
+    }
 
     __builtin_amdgcn_s_waitcnt(0xC07F);   // compiler-visible lgkmcnt(0): no LDS read of the compiler's is pending inside the stage loop
                                           // (it would answer each use there with an s_waitcnt lgkmcnt(0) that drains the hand-counted reads)
@@ -1057,6 +1076,8 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
 #pragma unroll
         for (int j = 0; j < 4; ++j) ceq[h][j] = 0u;
     }
+    // MODE 3: the words the compares are shifted into (32 values = two stages fill one), the lane's counts
+    unsigned bw_g[2] = {0u, 0u}, bw_e[2] = {0u, 0u}, bc_gt[2] = {0u, 0u}, bc_un[2] = {0u, 0u};
 
     // ---- LDS-DMA producer: every wave issues its share (instruction j by wave j mod 4) of every stage ---------
     const int64_t tile0 = cb * P.tiles_per_chunk;
@@ -1110,6 +1131,8 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
     uint64_t cokP = 0ull;   // lanes whose entity of the PREVIOUS stage is new (none before the first stage)
     bool fullP = false;     // ... all of them (else: patch)
     uint32_t colP = 0u;     // global id of that stage's first entity
+    int shiftP = 64;        // MODE 3: entities of the previous stage the stage before has seen (its rows were shifted back; 64: all — no stage yet)
+    int slotP = -1;         // MODE 3: 2 x (the previous stage's tile in the chunk) + its word (tb >> 1); -1: none
     unsigned pair_n[2] = {0u, 0u}, pair_over = 0u;
     uint64_t* pair_base[2];
 #pragma unroll
@@ -1146,7 +1169,13 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
     auto judge = [&](f32x16 (&aP)[2], int v) __attribute__((always_inline)) {
         const int h = v >> 4, r = v & 15, j = r >> 2, i = r & 3;
         const float x = aP[h][r];
-        if constexpr (ONE) {
+        if constexpr (BMP) {
+            // (both compares first, into scalar pairs: a carry is not read by the instruction right behind the compare that made it)
+            uint64_t c0_, c1_;
+            asm volatile("v_cmp_ge_f32_e64 %2, %4, %5\n\tv_cmp_ge_f32_e64 %3, %4, %6\n\t"
+                         "v_addc_co_u32_e64 %0, vcc, %0, %0, %2\n\tv_addc_co_u32_e64 %1, vcc, %1, %1, %3"
+                         : "+v"(bw_g[h]), "+v"(bw_e[h]), "=&s"(c0_), "=&s"(c1_) : "v"(x), "v"(g_t[h]), "v"(e_t[h]) : "vcc");
+        } else if constexpr (ONE) {
             asm volatile("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(cgt[h][r]) : "v"(x), "v"(gth[h][j][i]) : "vcc");
         } else {
             if (v > 0) resolve(v - 1);
@@ -1154,8 +1183,21 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
                          : "+v"(cgt[h][r]), "=&s"(smg), "=&s"(sme) : "v"(x), "v"(gth[h][j][i]), "v"(eth[h][j][i]) : "vcc");
         }
     };
+    uint32_t* const bm32[2] = {reinterpret_cast<uint32_t*>(pair_base[0]), reinterpret_cast<uint32_t*>(pair_base[1])};
     auto judge_flush = [&]() __attribute__((always_inline)) {   // the stage's last value (before colP moves on)
-        if constexpr (!ONE) resolve(31);
+        if constexpr (BMP) {
+            // a word is full after the tile's second and fourth stage: count, undecided, store ([tile][lane][word] of the half's segment)
+            if (slotP >= 0 && (slotP & 0x10000)) {   // (wave-uniform; bit 16: the previous stage was an odd one)
+                const int sl_ = slotP & 0xffff;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned u = bw_e[h] ^ bw_g[h];   // (the first threshold is the higher one)
+                    bc_gt[h] += (unsigned)__builtin_popcount(bw_g[h]);
+                    bc_un[h] += (unsigned)__builtin_popcount(u);
+                    bm32[h][((sl_ >> 1) * 64 + lane) * 2 + (sl_ & 1)] = u;
+                }
+            }
+        } else if constexpr (!ONE) resolve(31);
     };
 
     // The table's last stage was shifted back over rows the stage before has counted: their lanes get a NaN score — it reaches no
@@ -1166,7 +1208,10 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) aP[h][r] = __builtin_amdgcn_inverse_ballot_w64(cokP) ? aP[h][r] : __builtin_nanf("");
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (BMP) aP[h][r] = 8 * (r >> 2) + (r & 3) + 4 * lhi >= shiftP ? aP[h][r] : __builtin_nanf("");   // (transposed: the entities are registers)
+                else aP[h][r] = __builtin_amdgcn_inverse_ballot_w64(cokP) ? aP[h][r] : __builtin_nanf("");
+            }
         asm volatile("" : "+v"(aP[0]), "+v"(aP[1]));
     };
     // the compare-and-count of the previous stage goes into the slots 1 .. JS - 1, the refill's instructions behind the barrier
@@ -1194,7 +1239,10 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
             lds_wait<PF>(B[q % RB]);   // this k-step's fragment has arrived; the PF younger reads fly on
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                if constexpr (!(V4_ABLATE & 4)) mfma_asm<PRE, q == 0>(aC[hh], A[hh][q], B[q % RB]);
+                if constexpr (!(V4_ABLATE & 4)) {
+                    if constexpr (BMP) mfma_asm_t<q == 0>(aC[hh], A[hh][q], B[q % RB]);
+                    else mfma_asm<PRE, q == 0>(aC[hh], A[hh][q], B[q % RB]);
+                }
                 // the slot behind this MFMA
                 const int sl = 2 * q + hh;
                 if (sl >= 1 && sl < JS && !(V4_ABLATE & 2)) {
@@ -1216,6 +1264,8 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
         fullP = col0s == col0;
         cokP = __builtin_amdgcn_ballot_w64(col0s + l31 >= col0);
         colP = (uint32_t)(P.ent_offset + col0s);
+        shiftP = (int)(col0 - col0s);
+        slotP = 2 * ctile + (tb >> 1) + ((tb & 1) << 16);
     };
     // stage 0 has landed; its first PF fragments
     bf16x8 B[RB];
@@ -1233,12 +1283,32 @@ __global__ __launch_bounds__(256, 1) void count_mfma_bf16_v4_kernel(const CountB
     for (int v = 0; v < 32; ++v) judge(accB, v);   // the last stage's
     judge_flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land after this workgroup has left
+    if constexpr (BMP) {   // a half's undecided candidates: the wave's sum; more than the segment's entries: the segment counts as EMPTY (v3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned u = bc_un[h];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o, 64);
+            if (u > P.pair_cap) { pair_over = 1u; u = 0u; }
+            pair_n[h] = u;
+        }
+    }
     if constexpr (PRE) {
         if (lane == 0) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) P.pair_count[blockIdx.x * 8u + (unsigned)(2 * wave + h)] = pair_n[h];
             if (pair_over) atomicOr(P.pair_count + P.n_segments, 1u);
         }
+    }
+    if constexpr (BMP) {   // a row is the lanes l and l + 32 of its half
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned c = bc_gt[h];
+            c += __shfl_xor(c, 32, 64);
+            const int64_t qr = qb * 256 + wave * 64 + 32 * h + l31;
+            if (lhi == 0 && qr < P.n_rows && c) atomicAdd(&P.cnt_gt[qr], (int)c);
+        }
+        return;
     }
     // ---- rows are private to the wave: lane shuffle, one global atomic per row and counter ----------------
 #pragma unroll
@@ -1399,6 +1469,9 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const bool bmp = P.pairs && bitmap_ok && (int64_t)P.pair_cap >= 64 * (int64_t)P.tiles_per_chunk &&
                          !(v4_mode() == 2 && v3_prefilter_steps(P.k16) == 25);   // (EMG_BF16_V4=2: the v4 kernel's emitting prefilter, an A/B form)
         const int md = P.pairs ? (bmp ? 3 : 2) : (P.need != 0 ? 1 : 0);
+        const char* pv4 = getenv("EMG_PRE_V4");   // 0: the bitmap prefilter through v3 at every width (A/B; read per call)
+        const bool pre_v4 = !(pv4 && pv4[0] && atoi(pv4) == 0);
+        bool bmp_v4 = false;
 #define EMG_V3P(NQ_) (md == 3 ? launch_v3<NQ_, 4, 3>(P, nblk, st) : launch_v3<NQ_, 4, 2>(P, nblk, st))
 #define EMG_V3(NQ_) (md >= 2 ? EMG_V3P(NQ_) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
         // the prefilter (exact-fast mode, what evaluate_performance uses by default) at EVERY width up to 400: the next
@@ -1419,6 +1492,10 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
             if (nq == 25) rc = launch_v4<25, 1>(P, nblk, st);
             else if (nq == 13) rc = launch_v4<13, 1>(P, nblk, st);
             else rc = launch_v4<8, 1>(P, nblk, st);
+        }
+        else if (md == 3 && v4_mode() >= 1 && pre_v4 && P.n_cand >= V3_BN && (nq == 25 || nq == 13)) {   // the bitmap prefilter, 64 query rows per wave
+            rc = nq == 25 ? launch_v4<25, 3>(P, nblk, st) : launch_v4<13, 3>(P, nblk, st);
+            bmp_v4 = true;
         }
         else if (nq == 25 && v4_mode() == 2 && P.n_cand >= V3_BN) {   // A/B only: v4 loses to v3 with two counters / as the prefilter
             rc = md == 2 ? launch_v4<25, 2>(P, nblk, st) : launch_v4<25, 0>(P, nblk, st);
@@ -1441,6 +1518,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
             C.pairs = P.pairs; C.pair_count = P.pair_count; C.pair_cap = P.pair_cap; C.n_segments = P.n_segments;
             C.n_qb = P.n_qb; C.n_cb = P.n_cb; C.n_tiles = P.n_tiles; C.ent_offset = P.ent_offset; C.tiles_per_chunk = P.tiles_per_chunk;
             C.waves = nq >= V3_WIDE_FROM ? 4 : 8;
+            C.last32 = bmp_v4 ? P.n_cand - 32 : INT64_MAX;
             hipLaunchKernelGGL(prefilter_compact_kernel, dim3((unsigned)cdiv((int64_t)P.n_segments, 4)), dim3(256), 0, st, C);
         }
     } else if (P.pairs) {
