@@ -498,7 +498,7 @@ def run_eval(r, args):
                      "equal_to_exact_f32_ranks": True, "exact_f32_ranks_per_s": round(n_ranks / dt, 1),
                      "undecided_pairs": stf.get("pairs", 0), "undecided_fraction": round(stf.get("pairs", 0) / (n_ranks * w["n_ent"] / world), 6),
                      "tiles_redone_by_exact_kernel": stf.get("fallback", 0), "kernel_ms": round(stf["count_ms"], 3),
-                     "kernels": "count_mfma_bf16_v3_kernel<25,4,2> (v_mfma_f32_32x32x16_f16) + rescore_segment_kernel (segments of >= 512 pairs: query rows in LDS) / rescore_pairs_kernel"}
+                     "kernels": "count_mfma_bf16_v4_kernel<25,3> (v_mfma_f32_32x32x16_f16, transposed products, undecided candidates as a bitmap) + prefilter_compact_kernel + rescore_segment_kernel (segments of >= 512 pairs: query rows in LDS) / rescore_pairs_kernel"}
     # what the API call pays when nothing is cached (get_ranks / early stopping pass no tables: the half-precision copy, the
     # norm bounds and the range are rebuilt inside the call) — the figures above build them once per evaluation run, outside
     ru, dtu, _ = timed(T, precision=2)
@@ -586,7 +586,7 @@ def run_eval(r, args):
                 "value": round(2 * len(T2) / dt3, 1), "unit": "ranks/s", "equal_to_exact_f32_ranks": bool(np.array_equal(fast_2, exact_2)),
                 "undecided_pairs": int(st3.get("pairs", 0)), "undecided_fraction": round(st3.get("pairs", 0) / (2.0 * len(T2) * w["n_ent"] / world), 6),
                 "tiles_redone_by_exact_kernel": int(st3.get("fallback", 0)), "kernel_ms": round(st3["count_ms"], 3),
-                "kernels": "count_mfma_bf16_v3_kernel<13,4,2> (v_mfma_f32_32x32x16_f16 over [2q|-1|-1].[e|n_hi|n_lo]) + rescore_pairs_kernel",
+                "kernels": "count_mfma_bf16_v4_kernel<13,3> (v_mfma_f32_32x32x16_f16 over [2q|-1|-1].[e|n_hi|n_lo], bitmap form) + prefilter_compact_kernel + rescore_pairs_kernel",
                 "roofline": {"bound": "mfma", "achieved": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
                              "unit": "TFLOP/s (kernel_ms includes the re-scoring)",
                              "frac": round(mfma_flops / (st3["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4)}}}
@@ -622,7 +622,7 @@ def run_eval(r, args):
                            "equal_to_exact_f32_ranks": bool(np.array_equal(res_w[0][0], res_w[2][0])),
                            "undecided_pairs": int(res_w[2][2].get("pairs", 0)), "tiles_redone_by_exact_kernel": int(res_w[2][2].get("fallback", 0)),
                            "kernel_ms": round(res_w[2][2]["count_ms"], 3), "mean_rank": float(np.mean(res_w[2][0])),
-                           "kernels": "count_mfma_bf16_v3_kernel<50,4,2,4> (4 waves x 128 query rows) + rescore_segment_kernel<0,4> / rescore_pairs_kernel"}}
+                           "kernels": "count_mfma_bf16_v3_kernel<50,4,3,4> (4 waves x 128 query rows, bitmap form) + prefilter_compact_kernel + rescore_segment_kernel<0,4> / rescore_pairs_kernel"}}
     return out
 
 
