@@ -498,6 +498,9 @@ def run_eval(r, args):
                      "equal_to_exact_f32_ranks": True, "exact_f32_ranks_per_s": round(n_ranks / dt, 1),
                      "undecided_pairs": stf.get("pairs", 0), "undecided_fraction": round(stf.get("pairs", 0) / (n_ranks * w["n_ent"] / world), 6),
                      "tiles_redone_by_exact_kernel": stf.get("fallback", 0), "kernel_ms": round(stf["count_ms"], 3),
+                     # the contraction's flops over ALL the mode's kernels (prefilter + compaction + re-scoring): the fraction of the
+                     # half-precision dense peak at which this parity-exact mode delivers the 1-vs-all product
+                     "mfma_frac_all_kernels": round(kflops / (stf["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
                      "kernels": "count_mfma_bf16_v4_kernel<25,3> (v_mfma_f32_32x32x16_f16, transposed products, undecided candidates as a bitmap) + prefilter_compact_kernel + rescore_segment_kernel (segments of >= 512 pairs: query rows in LDS) / rescore_pairs_kernel"}
     # what the API call pays when nothing is cached (get_ranks / early stopping pass no tables: the half-precision copy, the
     # norm bounds and the range are rebuilt inside the call) — the figures above build them once per evaluation run, outside
@@ -754,7 +757,7 @@ def summary_line(line, detail_file=DETAIL_FILE):
         for label, short in (("random_positives", "exact_fast_random"), ("planted_positives", "exact_fast_planted")):
             x = ev.get("exact_fast", {}).get(label)
             if x:
-                e[short] = _pick(x, "value", "equal_to_exact_f32_ranks", "undecided_fraction", "kernel_ms")
+                e[short] = _pick(x, "value", "equal_to_exact_f32_ranks", "undecided_fraction", "kernel_ms", "mfma_frac_all_kernels")
         s["eval"] = e
     cpu = line.get("cpu_baseline")
     if cpu:

@@ -363,7 +363,10 @@ def evaluate_performance(X, model, filter_triples=None, verbose=False, filter_un
             wanted = set(entities_subset)
             settings["corruption_entities"] = np.asarray([i for label, i in model.ent_to_idx.items() if label in wanted])
         model.configure_evaluation_protocol(settings)
-        ranks = np.array(model.get_ranks(adapter))
+        if getattr(model, "_ranks_as_array", False):   # this package's models hand the array over as it is
+            ranks = np.asarray(model.get_ranks(adapter, as_array=True))
+        else:                                          # any other model: the reference's lists
+            ranks = np.array(model.get_ranks(adapter))
     except BaseException:
         model.end_evaluation()
         if adapter is not None:
