@@ -313,8 +313,10 @@ _pair_buffers = {}
 def _pair_buffer(device, n_seg):
     """(pairs int64 [cap], per-segment counts int32 [n_seg + 1]) scratch of the prefilter, cached per device.
     A wave of the prefilter covers 32 query rows x up to 4096 entities; 2048 entries hold 1.5 % of them undecided
-    (random positives on Gaussian tables leave ~0.7 %, a trained model a tenth of that); at most 1 GiB in total."""
-    per = max(64, min(int(os.environ.get("EMG_PAIR_CAP", "2048")), (1 << int(os.environ.get("EMG_PAIR_LOG2", "27"))) // max(n_seg, 1)))
+    (random positives on Gaussian tables leave ~0.7 %, a trained model a tenth of that) — and 2048 entries are what the
+    prefilter's bitmap form needs of a segment (64 per entity tile, emg_rank_bf16.hip MODE 3; below it the slower emitting form
+    runs): the buffer grows with the call, 1 GiB at 8192 query rows x 1M entities, at most 4 GiB (EMG_PAIR_LOG2 = log2 entries)."""
+    per = max(64, min(int(os.environ.get("EMG_PAIR_CAP", "2048")), (1 << int(os.environ.get("EMG_PAIR_LOG2", "29"))) // max(n_seg, 1)))
     cap = n_seg * per
     key = (device.type, device.index)
     buf = _pair_buffers.get(key)

@@ -465,7 +465,13 @@ int emg_eval_prefilter_band(const float* q, int64_t n_rows, int64_t ldq, const v
  * (row << 32 | global entity id) into `pairs`: the buffer is cut into emg_eval_prefilter_segments(n_rows, n_cand)
  * segments of pairs_capacity / segments entries, one per wave of the kernel (no atomics); pair_count[s] = entries
  * written to segment s, pair_count[segments] != 0 if some wave ran out of room (then the caller must use
- * emg_eval_count for these rows instead).  pair_count (uint32 [segments + 1]) is zeroed by the call.  EMG_ENOSUP for
+ * emg_eval_count for these rows instead).  pair_count (uint32 [segments + 1]) is zeroed by the call.
+ * Round 6 (ABI unchanged): with at least 2048 entries per segment (64 per entity tile of the chunk) the kernel first writes each
+ * segment's undecided candidates as a BITMAP into the segment itself (64 lanes x 8 bytes per tile, branch-free) and a second
+ * launch inside the same call turns every segment's bitmap into its pairs in place, entity tiles ascending; a segment with more
+ * undecided candidates than entries is then recorded with pair_count[s] = 0 (its words stay a bitmap) beside the overflow flag.
+ * What the caller sees after the call is as before; smaller segments take the emitting kernel (EMG_PRE_BITMAP=0 forces it).
+ * EMG_ENOSUP for
  * shapes the register-stationary kernel does not cover.  emg_eval_rescore_pairs scores the pairs with the parity
  * path's arithmetic (k-ordered fmaf chain, int32(score*1e5)) and adds them to cnt_gt / cnt_eq, reading the counts
  * on the device (no host round trip between the two calls).  The resulting counters equal
