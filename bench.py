@@ -442,7 +442,10 @@ def run_eval(r, args):
         # launch loads its code object and sets its LDS attribute (~30 ms once per process for the prefilter + re-scoring pair)
         # (half of the test set: long enough segments for the segment-wise re-scoring kernel too — with 192 triples it was sometimes
         # first launched inside the timed call: 164 k instead of 406 k ranks/s in one run of round 4)
-        rank_triples_device(mid, ent, rel, k_int, r.scale, T_[:max(192, len(T_) // 2)], "s+o", "worst", filter_triples=F, shard=shard, **kw)
+        # (precision 2: the WHOLE test set — its pair buffer is sized by the call, 1 GiB at 8192 query rows x 1M entities, and a
+        # half-size warm-up left that allocation inside the timed call: 180 k instead of 530 k ranks/s in one run of round 6)
+        warm = T_ if kw.get("precision") == 2 else T_[:max(192, len(T_) // 2)]
+        rank_triples_device(mid, ent, rel, k_int, r.scale, warm, "s+o", "worst", filter_triples=F, shard=shard, **kw)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
