@@ -1539,6 +1539,45 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+def test_contraction_prefilter_random_shapes_equal_exact(seed, monkeypatch):
+    """soak of the half-precision MFMA prefilter in its three forms — the bitmap form in the 64-rows-per-wave kernel (400 / 208
+    columns), the bitmap form in the register-stationary kernel (every other width, EMG_PRE_V4=0 everywhere) and the emitting form
+    (EMG_PRE_BITMAP=0) — on random shapes: DistMult / ComplEx / HolE, widths 3 … 400 (6 … 800 columns), tables of 1500 … 70 000
+    rows (one chunk, several chunks, a last tile that is not full), 130 … 700 test triples (query rows that end inside a
+    workgroup), scales over four decades, heavy-tailed tables, few distinct query entities and copies of them elsewhere in the
+    table (exact ties): precision 2 must return the ranks of precision 0 for a random side / strategy / filter."""
+    from emgraph_amd.evaluation import rank_triples_device
+    dev()
+    rs = np.random.RandomState(5000 + seed)
+    for _ in range(4):
+        model = ("DistMult", "ComplEx", "HolE")[rs.randint(0, 3)]
+        k = int(rs.choice([200, 104, 100, 52])) if rs.randint(0, 3) == 0 else int(rs.randint(3, 401))   # (a third of the draws: the v4 widths)
+        if model == "DistMult" and rs.randint(0, 2):
+            k = min(2 * k, 800)
+        n_ent, nq = int(rs.randint(1500, 70000)), int(rs.randint(130, 700))
+        scale = 10.0 ** rs.uniform(-3, 0.5)
+        E, R, ki = make_tables(model, k, n_ent, 6, seed=seed * 7 + k, scale=scale)
+        if rs.randint(0, 2):
+            E = (rs.standard_t(3, E.shape).astype(F32) * F32(scale)).astype(F32)
+        pool = rs.randint(0, n_ent, 60)
+        T = np.stack([rs.choice(pool, nq), rs.randint(0, 6, nq), rs.choice(pool, nq)], 1).astype(np.int32)
+        E[rs.randint(0, n_ent, 30)] = E[rs.choice(pool, 30)]
+        side = ("s,o", "s+o", "s", "o")[rs.randint(0, 4)]
+        strategy = ("worst", "best", "middle")[rs.randint(0, 3)]
+        filt = np.concatenate([T, np.stack([rs.randint(0, n_ent, 3000), rs.randint(0, 6, 3000), rs.randint(0, n_ent, 3000)], 1)]).astype(np.int32) if rs.randint(0, 2) else None
+        sc = scale_of(model, k)
+        Et, Rt = cu(E), cu(R)
+        exact = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt)
+        for env in ({}, {"EMG_PRE_V4": "0"}, {"EMG_PRE_BITMAP": "0"}):
+            for kk, vv in env.items():
+                monkeypatch.setenv(kk, vv)
+            fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2)
+            for kk in env:
+                monkeypatch.delenv(kk)
+            np.testing.assert_array_equal(fast, exact, err_msg=str((model, k, n_ent, nq, scale, side, strategy, filt is not None, env)))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_transe_prefilters_random_shapes_equal_exact(seed):
     """soak of both TransE prefilters: random widths, table scales over four decades, heavy-tailed tables, relation scales
     far from the entity scale, query sets with many repeated entities — precision 2 must return the ranks of precision 0"""
