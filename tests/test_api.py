@@ -257,8 +257,32 @@ def test_fit_random_configurations_match_oracle_training_loop(seed):
     np.testing.assert_allclose(m.predict(Xt), orc.score_triples(omodel, m.trained_model_params[0], m.trained_model_params[1],
                                                                 Xt.astype(np.int32), k=k), rtol=1e-4, atol=1e-5, err_msg=what)
     if opt != "adam":
-        np.testing.assert_allclose(m.trained_model_params[0], E, rtol=2e-3, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(m.trained_model_params[1], R, rtol=2e-3, atol=2e-5, err_msg=what)
+        gE, gR = m.trained_model_params
+        offE = ~np.isclose(gE, E, rtol=2e-3, atol=2e-5)
+        if name == "TransE" and norm == 1 and offE.any():
+            # TransE-L1's gradient is sgn(e_s + e_p - e_o) per coordinate: where a coordinate of that difference is within rounding of
+            # zero its sign is not determined — the two arithmetics (sums in another order in an earlier step) may disagree, the update
+            # of three rows then differs by 2 lr g in ONE coordinate, and every later step carries it on: training drives exactly
+            # these differences towards zero, and a softmax loss (multiclass_nll) hands a changed score to every negative of its group.
+            # Three of 3000 seeds of the round-6 soak (883, 1139, 1819; `tools/dbg_fuzz_seed.py SEED` prints the rows): all TransE-L1
+            # with multiclass_nll; after the FIRST epoch none, one or two coordinates differ, in +- pairs.  Such a run is accepted as
+            # that signature only: the first epoch alone must match (strictly, or in at most 0.1 % of the elements, each within a few
+            # flipped unit gradients, with the epoch's loss equal), the whole run must stay within a few flipped gradients per step
+            # and its losses within 2e-3.
+            bound = 4.0 * lr * epochs * bc
+            m1 = _models()[name](k=k, eta=eta, epochs=1, batches_count=bc, seed=seed, loss=loss, optimizer=opt,
+                                 optimizer_params={"lr": lr}, embedding_model_params=emp, initializer="constant",
+                                 initializer_params={"entity": ent0, "relation": rel0}, **reg_kw)
+            m1.fit(X)
+            E1, R1, l1 = oracle_fit(omodel, k, X.astype(np.int32), ent0, rel0, eta, 1, bc, seed, loss, None, opt, lr, sides=sides, reg=reg)
+            off1 = ~np.isclose(m1.trained_model_params[0], E1, rtol=2e-3, atol=2e-5)
+            assert off1.mean() <= 0.001 and np.abs(m1.trained_model_params[0] - E1).max() <= 4.0 * lr * bc, what
+            np.testing.assert_allclose(m1.epoch_losses, l1, rtol=2e-4, atol=1e-6, err_msg=what)
+            assert np.abs(gE - E).max() <= bound and np.abs(gR - R).max() <= bound, what
+            np.testing.assert_allclose(m.epoch_losses, losses, rtol=2e-3, err_msg=what)
+            return
+        np.testing.assert_allclose(gE, E, rtol=2e-3, atol=2e-5, err_msg=what)
+        np.testing.assert_allclose(gR, R, rtol=2e-3, atol=2e-5, err_msg=what)
         np.testing.assert_allclose(m.epoch_losses, losses, rtol=2e-4, atol=1e-6, err_msg=what)
     else:
         # Keras Adam moves a weight by ~lr * g / (|g| + 1e-7): where the true gradient is exactly zero (equal and opposite
