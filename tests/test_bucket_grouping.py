@@ -304,3 +304,101 @@ def test_standalone_relation_apply_with_adams_dense_pass_after_a_bucket_grouping
         assert untouched.size > 0
         np.testing.assert_array_equal(out["bucket"][1][untouched], (np.float32(0.9) * M0[untouched]).astype(F32))   # one decay, no more
         assert not np.array_equal(out["bucket"][0][untouched], W0[untouched])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+def test_bucket_grouping_random_shapes_equal_counting_grouping(seed):
+    """soak of the bucket grouping against the counting grouping: random batch size (1 ... 40 000), eta, corruption sides, table
+    sizes from the smallest the bucket form takes (131 073 rows) to 3 M, 1 ... 5000 relations, uniform / hub-heavy / pooled
+    destinations, factored or full-row contributions, now and then the global-memory form of every bucket (EMG_BUCKET_CAP) —
+    codes, destinations, sorted keys, the stable order, flags, factored source rows and the descriptor lists must agree (`compare`)."""
+    d = dev()
+    rs = np.random.RandomState(9000 + seed)
+    B = int(rs.choice([1, 7, 64, 300, 1725, 2722, 5000, 16384, 40000]))
+    eta = int(rs.choice([1, 2, 5, 10, 20]))
+    sides = [(2,), (0,), (1,), (0, 1)][rs.randint(0, 4)]
+    n_ent = int(rs.choice([131_073, 200_000, 262_144, 1_000_000, 3_000_000]))
+    n_rel = int(rs.choice([1, 3, 237, 1000, 5000]))
+    if (2 + eta * len(sides)) * B > 1_200_000:
+        B = 1_200_000 // (2 + eta * len(sides))
+    if n_ent > 16 * (2 + eta * len(sides)) * B + (1 << 20):   # (beyond it the workspace has the radix-sort layout: neither grouping runs)
+        n_ent = 1_000_000
+    kind = rs.randint(0, 3)
+    if kind == 0:
+        s, o = rs.randint(0, n_ent, B), rs.randint(0, n_ent, B)
+    elif kind == 1:      # hubs: a few entities carry most of the batch
+        hubs = rs.randint(0, n_ent, 5)
+        s = np.where(rs.rand(B) < 0.6, hubs[rs.randint(0, 5, B)], rs.randint(0, n_ent, B))
+        o = np.where(rs.rand(B) < 0.3, hubs[rs.randint(0, 5, B)], rs.randint(0, n_ent, B))
+    else:                # one neighbourhood: everything falls into one or two buckets
+        base = int(rs.randint(0, n_ent - 3000))
+        s, o = base + rs.randint(0, 3000, B), base + rs.randint(0, 3000, B)
+    pos = np.stack([s, rs.randint(0, n_rel, B), o], 1).astype(np.int32)
+    factored = bool(rs.randint(0, 2))
+    kw = {}
+    if rs.randint(0, 4) == 0:
+        pool = (int(rs.randint(0, n_ent - 500)) + rs.permutation(500)[:int(rs.randint(2, 200))]).astype(np.int32)
+        kw = dict(entities_list=cu(pool), n_choices=len(pool))
+    cap = int(rs.choice([48, 300])) if rs.randint(0, 4) == 0 else None
+    ref = run_prepare(d, "count", pos, eta, sides, n_ent, n_rel, factored, **dict(kw))
+    got = run_prepare(d, "bucket", pos, eta, sides, n_ent, n_rel, factored, cap=cap, **dict(kw))
+    compare(got, ref, B, factored, n_ent, n_rel)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
+def test_fit_on_a_large_table_random_configurations_same_bits_under_either_grouping(monkeypatch, seed):
+    """soak of the training step on tables the bucket grouping takes: a random model, optimizer (Keras Adam with its dense pass inside
+    the apply launch for the relation table, deferred or not; Adagrad; momentum; SGD with the in-place forms), regulariser, width,
+    eta, batch split (a short last batch) and graph shape per seed — tables, optimizer state and loss must carry the counting
+    grouping's bits (what `test_fit_on_a_large_table_gives_the_same_bits_under_either_grouping` checks for seven hand-picked cases)."""
+    from emgraph_amd import _lib as L
+    from emgraph_amd.training import Trainer
+    dev()
+    rs = np.random.RandomState(11000 + seed)
+    model = ("ComplEx", "DistMult", "TransE", "HolE")[rs.randint(0, 4)]
+    opt = ("sgd", "adam", "adagrad", "momentum")[rs.randint(0, 4)]
+    deferred = [None, False, True][rs.randint(0, 3)] if opt in ("adam",) else (True if rs.randint(0, 2) else None)
+    reg = {"lambda": float(rs.choice([1e-3, 1e-2])), "p": int(rs.choice([1, 2, 3]))} if rs.randint(0, 3) == 0 else None
+    if reg is None and opt != "adam":
+        deferred = None
+    n_ent = int(rs.choice([131_073, 140_000, 300_000]))
+    n_rel, k, eta = int(rs.choice([1, 6, 300, 3000])), int(rs.choice([8, 36, 50, 100])), int(rs.choice([1, 3, 7, 20]))
+    n = int(rs.choice([200, 1000, 4000]))
+    cplx = model in ("ComplEx", "HolE")
+    ki = 2 * k if cplx else k
+    mid = {"ComplEx": L.COMPLEX, "DistMult": L.DISTMULT, "TransE": [L.TRANSE_L1, L.TRANSE_L2][rs.randint(0, 2)], "HolE": L.HOLE}[model]
+    scale = 2.0 / k if model == "HolE" else 1.0
+    E0 = (rs.randn(n_ent, ki) * 0.3).astype(F32)
+    R0 = (rs.randn(n_rel, ki) * 0.3).astype(F32)
+    X = np.stack([rs.randint(0, n_ent, n), rs.randint(0, n_rel, n), rs.randint(0, n_ent, n)], 1).astype(np.int32)
+    if rs.randint(0, 2):
+        X[: n // 3, 0] = int(rs.randint(0, n_ent))     # a hub row: block tasks
+    loss = ("pairwise", "nll", "self_adversarial", "multiclass_nll")[rs.randint(0, 4)]
+    kw = dict(regularizer="LP", regularizer_params=reg) if reg else {}
+    b0 = (n + 2) // 3
+    splits = ((0, b0), (b0, b0), (2 * b0, n - 2 * b0))
+    what = str((model, mid, opt, deferred, reg, n_ent, n_rel, k, eta, n, loss))
+
+    def run(mode):
+        monkeypatch.setenv("EMG_GROUPING", mode)
+        tr = Trainer(mid, ki, scale, E0, R0, eta, loss=loss, optimizer=opt, optimizer_params={"lr": 0.01},
+                     batches_count=3, seed=2, deferred_dense=deferred, **kw)
+        tr.set_training_set(X, b0)
+        for ep in (1, 2):
+            for b, (s, m_) in enumerate(splits):
+                nxt = splits[(b + 1) % 3]
+                tr.step(s, m_, epoch=ep, batch=b + 1, prefetch=[(nxt[0], nxt[1], ep + (b == 2), (b + 1) % 3 + 1)])
+        loss_v = tr.read_loss()
+        Et, Rt = tr.tables_numpy()
+        return Et, Rt, [t.cpu().numpy().copy() for t in tr.state_ent + tr.state_rel if t is not None], loss_v
+
+    a, b = run("bucket"), run("count")
+    np.testing.assert_array_equal(a[0], b[0], err_msg=what)
+    np.testing.assert_array_equal(a[1], b[1], err_msg=what)
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y, err_msg=what)
+    if reg:   # (the regulariser's value: FLOAT partial sums per wave of the apply, added as doubles — the partition of the rows over the
+        #  waves follows the grouping's lists, so the partials differ in their last bits: 1.6e-11 relative in one seed)
+        assert a[3] == pytest.approx(b[3], rel=1e-8), what
+    else:
+        assert a[3] == b[3], what
