@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EMGRAPH_HIP_LIB") or os.path.join(_HERE, "lib", "libemgraph_hip.so")
 
 # ---- constants mirrored from include/emgraph_hip.h -------------------------------------------
-ABI_VERSION = 7
+ABI_VERSION = 8
 TRANSE_L1, TRANSE_L2, DISTMULT, COMPLEX, HOLE, TRANSE_P = range(6)
 SIDE_S, SIDE_O, SIDE_SO = range(3)
 LOSS_PAIRWISE, LOSS_NLL, LOSS_ABSOLUTE_MARGIN, LOSS_SELF_ADVERSARIAL, LOSS_MULTICLASS_NLL = range(5)
@@ -130,6 +130,7 @@ SIGNATURES.update({
     "emg_eval_prefilter_bounds": (_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "emg_eval_prefilter_band": (_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p, _p]),
     "emg_eval_prefilter_f16": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _i64, _p]),
+    "emg_eval_prefilter_f16_ties": (_int, [_int, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i32, _f32, _p, _p, _p, _p, _i64, _p]),
     "emg_eval_prefilter_segments": (_i64, [_i64, _i64]),
     "emg_eval_prefilter_segments_k": (_i64, [_i64, _i64, _i32]),
     "emg_eval_prefilter_waves": (_i32, [_i32]),

@@ -52,6 +52,7 @@ struct CountBf16Params {
     uint32_t* pair_count;      //   wave w of the grid owns pairs[w * pair_cap ...), pair_count[w] = how many it wrote
     uint32_t pair_cap;         //   (no atomics: a returning atomic per emission cost more than the MFMAs of the tile);
     uint32_t n_segments;       //   pair_count[n_segments] != 0: some wave ran out of room
+    int32_t ties;              // prefilter, MODE 4: candidates PROVEN to tie with the positive are counted into cnt_eq (see the kernel)
 };
 
 constexpr int HBM_ = 128, HBN_ = 128, HBK_ = 64;
@@ -550,12 +551,24 @@ constexpr int V3_BM = 256, V3_BN = 128, V3_RING = 128 * 1024;
 // word, and ONE 8-byte store per lane and tile of the undecided BITMAP — into the wave's own segment of the pair buffer
 // (64 lanes x 8 B x <= 32 tiles = the segment's 16 KB at 2048 entries).  prefilter_compact_kernel then turns each segment's
 // bitmap into the (row, entity) pairs the re-scoring kernels read, in place (a wave per segment reads the 16 KB, then writes).
-template <int NQ, int SQ, int MODE, int WAVES = 8>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter | 3 prefilter, bitmap
+//
+// MODE 4 (round 6): MODE 3 that also PROVES TIES.  The reference compares int32(score * 1e5) (EmbeddingModel.py:2010-2014): a table
+// whose scores are small against 1e-5 — a freshly initialised model, the first epochs of a fit, what early stopping evaluates —
+// has EVERY candidate tie with the positive, and modes 2 / 3 call every tie undecided (its accumulator lies between the `>` and the
+// `>=` threshold): the pair buffer overflows and the exact kernel does the tile (47 ms per 8192 x 1M pass).  But a tie can be
+// decided like the other two outcomes: the integer cell of the positive is [E, G) in the accumulator domain, and an accumulator in
+// [E + band, G - band) belongs to a score inside the cell whatever the rounding.  Four thresholds per row — E - b, E + b, G - b, G + b
+// —, four compare-and-shift pairs per value; greater = above G + b, EQUAL = in [E + b, G - b) (counted into cnt_eq), undecided = the
+// two bands around E and G; where the band is wider than the cell (E + b > G - b: any table with scores of order one) the equal zone is
+// empty and the two bands merge into mode 3's.  Eight VALU instructions per value instead of four: the host runs this form only
+// where mode 3's probe found too many undecided candidates (ranking.py).
+template <int NQ, int SQ, int MODE, int WAVES = 8>  // NQ: 16-wide k-steps per row; SQ: k-steps per slice (2 or 4); MODE 0 both | 1 one | 2 prefilter | 3 prefilter, bitmap | 4 ... proving ties
 __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const CountBf16Params P) {
     constexpr int V3_BM = 32 * WAVES;           // query rows per workgroup
     constexpr bool ONE = MODE == 1;
     constexpr bool PRE = MODE >= 2;
-    constexpr bool BMP = MODE == 3;
+    constexpr bool BMP = MODE >= 3;
+    constexpr bool TIES = MODE == 4;
     constexpr int RB = SQ * 32;                 // slice row bytes (64 / 128)
     constexpr int SPR = SQ * 2;                 // 16-byte slots per slice row
     constexpr int RPB = 256 / RB;               // rows per 256-byte LDS bank row
@@ -616,6 +629,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
     const float g_l = thr_s[wave * 32 + l31], e_l = thr_s[V3_BM + wave * 32 + l31];
     unsigned cgt = 0u, cge = 0u;   // scores that reached the first threshold; MODE 0: ... the second (ties = cge - cgt)
     [[maybe_unused]] unsigned ucnt = 0u;   // MODE 3: undecided candidates of this lane
+    // MODE 4: the INNER thresholds of this lane's row (rows past the end: +inf, nothing is ever equal) and its proven ties
+    [[maybe_unused]] float gi_l = INFINITY, ei_l = INFINITY;
+    [[maybe_unused]] unsigned ceq_l = 0u;
+    if constexpr (TIES) {
+        const int64_t qr = qb * V3_BM + wave * 32 + l31;
+        if (qr < P.n_rows) {
+            const int p = P.pos_int[qr];
+            const float tg = acc_threshold(gt_threshold(p), P.cmul), te = acc_threshold(ge_threshold(p), P.cmul);
+            const float bg = P.band[qr] + 1e-6f * fabsf(tg) + 1e-30f, be = P.band[qr] + 1e-6f * fabsf(te) + 1e-30f;
+            gi_l = nextafterf(tg - bg, -INFINITY);   // an accumulator below it: the score is below the `>` threshold for certain
+            ei_l = nextafterf(te + be, INFINITY);    // an accumulator at or above it: the score reaches the `>=` threshold for certain
+        }
+    }
 
     // ---- LDS-DMA producer: this lane's 16-byte pieces of every slice -------------------------------------
     const int64_t tile0 = cb * P.tiles_per_chunk;
@@ -748,6 +774,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
             if constexpr (BMP) {
                 // value i = 16 (tb & 1) + r of word tb >> 1 ends at bit 31 - i (32 shifts: whatever the word held before is gone)
                 unsigned wg[2] = {0u, 0u}, we[2] = {0u, 0u};
+                [[maybe_unused]] unsigned wgi[2] = {0u, 0u}, wei[2] = {0u, 0u};
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -757,8 +784,17 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
                         asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
                                      "v_cmp_ge_f32 vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
                                      : "+v"(wg[tb >> 1]), "+v"(we[tb >> 1]) : "v"(v), "v"(g_l), "v"(e_l) : "vcc");
+                        if constexpr (TIES)
+                            asm volatile("v_cmp_ge_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                         "v_cmp_ge_f32 vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                                         : "+v"(wgi[tb >> 1]), "+v"(wei[tb >> 1]) : "v"(v), "v"(gi_l), "v"(ei_l) : "vcc");
                     }
-                const unsigned u0 = we[0] ^ wg[0], u1 = we[1] ^ wg[1];   // (the first threshold is the higher one: greater implies greater-or-equal)
+                // (the thresholds are ordered E - b <= E + b, G - b <= G + b: each inner word is a subset of its outer one)
+                unsigned u0 = we[0] ^ wg[0], u1 = we[1] ^ wg[1];   // modes 3: between the outer thresholds
+                if constexpr (TIES) {
+                    u0 = (we[0] ^ wei[0]) | (wgi[0] ^ wg[0]); u1 = (we[1] ^ wei[1]) | (wgi[1] ^ wg[1]);   // the two bands around E and G
+                    ceq_l += (unsigned)__builtin_popcount(wei[0] & ~wgi[0]) + (unsigned)__builtin_popcount(wei[1] & ~wgi[1]);   // [E + b, G - b)
+                }
                 cgt += (unsigned)__builtin_popcount(wg[0]) + (unsigned)__builtin_popcount(wg[1]);
                 ucnt += (unsigned)__builtin_popcount(u0) + (unsigned)__builtin_popcount(u1);
                 reinterpret_cast<uint2*>(pair_base)[ctile * 64 + lane] = make_uint2(u0, u1);
@@ -834,7 +870,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void count_mfma_bf16_v3_kernel(const
 
     // ---- rows are private to the wave, a row to the lanes l and l + 32: one shuffle, one global atomic per row and counter ----
     {
-        unsigned ceq = (ONE || PRE) ? 0u : cge - cgt;   // (the second threshold is the lower one: every score counted in cgt is in cge)
+        unsigned ceq = TIES ? ceq_l : ((ONE || PRE) ? 0u : cge - cgt);   // (the second threshold is the lower one: every score counted in cgt is in cge)
         cgt += __shfl_xor(cgt, 32, 64);
         ceq += __shfl_xor(ceq, 32, 64);
         const int64_t qr = qb * V3_BM + wave * 32 + l31;
@@ -1468,11 +1504,12 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
         const bool bitmap_ok = !(bm_env && bm_env[0] && atoi(bm_env) == 0);
         const bool bmp = P.pairs && bitmap_ok && (int64_t)P.pair_cap >= 64 * (int64_t)P.tiles_per_chunk &&
                          !(v4_mode() == 2 && v3_prefilter_steps(P.k16) == 25);   // (EMG_BF16_V4=2: the v4 kernel's emitting prefilter, an A/B form)
-        const int md = P.pairs ? (bmp ? 3 : 2) : (P.need != 0 ? 1 : 0);
+        EMG_REQUIRE(!P.ties || bmp, "bf16 prefilter (ties form): a wave's segment must hold its bitmap (64 entries per entity tile)");
+        const int md = P.pairs ? (P.ties ? 4 : (bmp ? 3 : 2)) : (P.need != 0 ? 1 : 0);
         const char* pv4 = getenv("EMG_PRE_V4");   // 0: the bitmap prefilter through v3 at every width (A/B; read per call)
         const bool pre_v4 = !(pv4 && pv4[0] && atoi(pv4) == 0);
         bool bmp_v4 = false;
-#define EMG_V3P(NQ_) (md == 3 ? launch_v3<NQ_, 4, 3>(P, nblk, st) : launch_v3<NQ_, 4, 2>(P, nblk, st))
+#define EMG_V3P(NQ_) (md == 4 ? launch_v3<NQ_, 4, 4>(P, nblk, st) : md == 3 ? launch_v3<NQ_, 4, 3>(P, nblk, st) : launch_v3<NQ_, 4, 2>(P, nblk, st))
 #define EMG_V3(NQ_) (md >= 2 ? EMG_V3P(NQ_) : md == 1 ? launch_v3<NQ_, 4, 1>(P, nblk, st) : launch_v3<NQ_, 4, 0>(P, nblk, st))
         // the prefilter (exact-fast mode, what evaluate_performance uses by default) at EVERY width up to 400: the next
         // instantiated step count, the extra k-steps multiply the rows' zero padding (exact zeros: nothing changes)
@@ -1481,7 +1518,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
             P.n_qb = cdiv(P.n_rows, 128);
             const int64_t wblk = 8 * P.n_qb * cdiv(P.n_cb, 8);
             EMG_REQUIRE(wblk < ((int64_t)1 << 31), "bf16 eval: grid too large");
-#define EMG_V3W(NQ_) (md == 3 ? launch_v3<NQ_, 4, 3, 4>(P, wblk, st) : launch_v3<NQ_, 4, 2, 4>(P, wblk, st))
+#define EMG_V3W(NQ_) (md == 4 ? launch_v3<NQ_, 4, 4, 4>(P, wblk, st) : md == 3 ? launch_v3<NQ_, 4, 3, 4>(P, wblk, st) : launch_v3<NQ_, 4, 2, 4>(P, wblk, st))
             if (nq == 32) rc = EMG_V3W(32);
             else if (nq == 38) rc = EMG_V3W(38);
             else if (nq == 44) rc = EMG_V3W(44);
@@ -1512,7 +1549,7 @@ static int launch_bf16(int mode, CountBf16Params& P, hipStream_t st) {
 #undef EMG_V3
 #undef EMG_V3P
         if (rc != EMG_OK) return rc;
-        if (md == 3) {   // the segments' bitmaps -> pairs, in place
+        if (md >= 3) {   // the segments' bitmaps -> pairs, in place
             EMG_LAUNCH_CHECK();
             CompactParams C{};
             C.pairs = P.pairs; C.pair_count = P.pair_count; C.pair_cap = P.pair_cap; C.n_segments = P.n_segments;
@@ -1623,6 +1660,25 @@ extern "C" int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq,
     P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_gt; P.need = 0;
     P.band = band; P.pairs = pairs; P.pair_count = pair_count; P.pair_cap = (uint32_t)(pairs_capacity / n_seg);
     P.n_segments = (uint32_t)n_seg;
+    EMG_HIP(hipMemsetAsync(pair_count, 0, (size_t)(n_seg + 1) * sizeof(uint32_t), (hipStream_t)stream));
+    return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
+}
+
+extern "C" int emg_eval_prefilter_f16_ties(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
+                                           int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent,
+                                           int64_t ent_offset, int32_t k_pad, float scale, int32_t* cnt_gt, int32_t* cnt_eq,
+                                           uint64_t* pairs, uint32_t* pair_count, int64_t pairs_capacity, void* stream) {
+    EMG_REQUIRE(q_f16 && pos_int && band && ent_f16 && cnt_gt && cnt_eq && pairs && pair_count, "emg_eval_prefilter_f16_ties: null pointer");
+    EMG_REQUIRE(n_rows < ((int64_t)1 << 31) && ent_offset + n_cand < ((int64_t)1 << 31), "emg_eval_prefilter_f16_ties: ids must fit 31 bits");
+    if (n_rows == 0 || n_cand == 0) return EMG_OK;
+    const int64_t n_seg = emg_eval_prefilter_segments_k(n_rows, n_cand, k_pad);
+    EMG_REQUIRE(pairs_capacity >= n_seg && pairs_capacity / n_seg < ((int64_t)1 << 31), "emg_eval_prefilter_f16_ties: pair buffer smaller than one entry per wave (%lld)", (long long)n_seg);
+    CountBf16Params P{};
+    P.Q = (const uint16_t*)q_f16; P.ldq = ldq; P.pos_int = pos_int; P.n_rows = n_rows;
+    P.ent = (const uint16_t*)ent_f16; P.n_cand = n_cand; P.ld_ent = ld_ent; P.ent_offset = ent_offset;
+    P.k_pad = k_pad; P.scale = scale; P.model = model; P.cnt_gt = cnt_gt; P.cnt_eq = cnt_eq; P.need = 0;
+    P.band = band; P.pairs = pairs; P.pair_count = pair_count; P.pair_cap = (uint32_t)(pairs_capacity / n_seg);
+    P.n_segments = (uint32_t)n_seg; P.ties = 1;
     EMG_HIP(hipMemsetAsync(pair_count, 0, (size_t)(n_seg + 1) * sizeof(uint32_t), (hipStream_t)stream));
     return launch_bf16(BF_COUNT, P, (hipStream_t)stream);
 }

@@ -582,14 +582,24 @@ def prefilter_max_cols():
     return int(L.load().emg_eval_prefilter_max_cols())
 
 
-def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_int, scale, cnt_gt, pairs, pair_count):
+def eval_prefilter_f16(model_id, q_f16, pos_int, band, ent_f16, ent_offset, k_int, scale, cnt_gt, pairs, pair_count, cnt_eq=None):
     """half-precision MFMA prefilter of precision mode 2: definite `>` counts into cnt_gt, undecided (row, entity)
     pairs into ``pairs`` (int64 [capacity]), per-segment counts + overflow flag into ``pair_count`` (int32
-    [segments + 1]).  Raises EmgError(EMG_ENOSUP) for shapes the register-stationary kernel does not cover."""
+    [segments + 1]).  Raises EmgError(EMG_ENOSUP) for shapes the register-stationary kernel does not cover.
+    ``cnt_eq``: the form that also PROVES TIES (emg_eval_prefilter_f16_ties): candidates inside the positive's integer cell by more
+    than the band are counted there, only the two bands around the cell's ends become pairs."""
     lib = L.load()
     pq, n_rows, ldq = _chk_f16(q_f16, "q_f16")
     pe, ne, lde = _chk_f16(ent_f16, "ent_f16")
     n_seg = eval_prefilter_segments(n_rows, ne, k_int)
+    if cnt_eq is not None:
+        L.check(lib.emg_eval_prefilter_f16_ties(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
+                                                _chk_vec(band, torch.float32, "band", n_rows), n_rows, pe, ne, lde, ent_offset,
+                                                bf16_pad(k_int), scale, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),
+                                                _chk_vec(cnt_eq, torch.int32, "cnt_eq", n_rows),
+                                                _chk_vec(pairs, torch.int64, "pairs"), _chk_vec(pair_count, torch.int32, "pair_count", n_seg + 1),
+                                                pairs.numel(), _stream()), "emg_eval_prefilter_f16_ties")
+        return n_seg
     L.check(lib.emg_eval_prefilter_f16(model_id, pq, ldq, _chk_vec(pos_int, torch.int32, "pos_int", n_rows),
                                        _chk_vec(band, torch.float32, "band", n_rows), n_rows, pe, ne, lde, ent_offset,
                                        bf16_pad(k_int), scale, _chk_vec(cnt_gt, torch.int32, "cnt_gt", n_rows),

@@ -367,7 +367,7 @@ _PROBE_TRIPLES = 128
 _PROBE_MAX_UNDECIDED = 0.011   # (a wave's segment of the pair buffer holds 1.56 % of its 32 x 4096 candidates)
 
 
-def _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds):
+def _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds, ties=False):
     Tt = torch.from_numpy(np.ascontiguousarray(T[:_PROBE_TRIPLES])).to(ent.device)
     Q, pos_int = D.eval_build_queries(model_id, ent, rel, k_int, scale, Tt, side_mode)
     n_rows, n_cand = Q.shape[0], slab.shape[0]
@@ -377,11 +377,12 @@ def _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, e
     band = prefilter_band(Q, Qb, k_int, bounds)
     n_seg = D.eval_prefilter_segments(n_rows, n_cand, k_int)
     pairs, pcount = _pair_buffer(ent.device, n_seg)
-    cnt = torch.zeros(n_rows, dtype=torch.int32, device=ent.device)
+    cnt = torch.zeros((2, n_rows), dtype=torch.int32, device=ent.device)
     try:
-        D.eval_prefilter_f16(model_id, Qb, pos_int, band, ent_f16[e0:e0 + n_cand], e0, k_int, scale, cnt, pairs, pcount)
+        D.eval_prefilter_f16(model_id, Qb, pos_int, band, ent_f16[e0:e0 + n_cand], e0, k_int, scale, cnt[0], pairs, pcount,
+                             cnt_eq=cnt[1] if ties else None)
     except L.EmgError:
-        return 0.0
+        return 1.0 if ties else 0.0   # (the ties form needs segments that hold the bitmap: without it, the exact kernel)
     over, n_pairs = (int(v) for v in torch.stack([pcount[n_seg].long(), pcount[:n_seg].sum()]).cpu())
     return 1.0 if over else n_pairs / float(n_rows * n_cand)
 
@@ -454,6 +455,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
     if filter_triples is not None:
         findex = filter_triples if isinstance(filter_triples, FilterIndex) else FilterIndex(filter_triples)
     bounds = None
+    prove_ties = False   # precision 2, contraction models: the prefilter form that also counts proven ties (set by the probe below)
     if sad:
         if isinstance(ent_f16, SadTables):
             sad_range, ent_u16 = ent_f16.range, ent_f16.ent_u16
@@ -476,10 +478,19 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             und = tabs.undecided.get(key) if tabs is not None else None
             if und is None:
                 und = _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds)
+                if und > _PROBE_MAX_UNDECIDED and os.environ.get("EMG_PREFILTER_TIES", "1") != "0":
+                    # too many undecided candidates — on a table whose scores are small against the comparison's quantum (a fresh model,
+                    # the first epochs of a fit) they are TIES with the positive, which the second form of the prefilter proves as it
+                    # proves the other two outcomes (emg_rank_bf16.hip MODE 4): probe it too
+                    und_t = _prefilter_probe(model_id, ent, rel, slab, e0, k_int, scale, T, side_mode, ent_f16, bounds, ties=True)
+                    if und_t <= _PROBE_MAX_UNDECIDED:
+                        und = -1.0 - und_t   # (negative: "the ties form decides this table", remembered like the fraction)
                 if tabs is not None:
                     tabs.undecided[key] = und
+            prove_ties = und < 0.0
             if stats is not None:
-                stats["probe_undecided"] = und
+                stats["probe_undecided"] = -1.0 - und if prove_ties else und
+                stats["prove_ties"] = prove_ties
             if und > _PROBE_MAX_UNDECIDED:   # the band decides too little here: every tile of the call by the exact kernel
                 precision = 0
                 if stats is not None:
@@ -551,7 +562,7 @@ def rank_triples_device(model_id, ent, rel, k_int, scale, test_triples, corrupt_
             ev = _ev_start(stats)
             try:
                 D.eval_prefilter_f16(model_id, Qb, pos_int, band, ent_f16[e0:e0 + slab.shape[0]], e0, k_int, scale, cnt[0],
-                                     pairs, pcount)
+                                     pairs, pcount, cnt_eq=cnt[1] if prove_ties else None)
             except L.EmgError:      # shape outside the register-stationary kernel: the exact kernel does this tile
                 pre = None
             else:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EMG_ABI_VERSION 7
+#define EMG_ABI_VERSION 8
 
 #define EMG_OK 0
 #define EMG_EINVAL (-1)   /* bad argument */
@@ -493,6 +493,18 @@ int emg_eval_prefilter_f16(int model, const void* q_f16, int64_t ldq, const int3
                            int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset,
                            int32_t k_pad, float scale, int32_t* cnt_gt, uint64_t* pairs, uint32_t* pair_count,
                            int64_t pairs_capacity, void* stream);
+/* The same pass PROVING TIES (ABI 8, round 6).  The reference compares int32(score * 1e5) (EmbeddingModel.py:2010-2014): on a table
+ * whose scores are small against 1e-5 — a freshly initialised model, the first epochs of a fit — every candidate ties with the
+ * positive, and emg_eval_prefilter_f16 calls every tie undecided (its accumulator lies between the `>` and the `>=` threshold).
+ * Here a candidate whose accumulator lies inside the positive's integer cell by more than the band is counted into cnt_eq, one
+ * above it into cnt_gt, and only the two bands around the cell's ends are written as pairs.  With a band wider than the cell
+ * (scores of order one) the result is emg_eval_prefilter_f16's.  Eight instead of four VALU instructions per score: for tables the
+ * plain form cannot decide.  Needs segments that hold the bitmap form (pairs_capacity / segments >= 2048 at 32 tiles per chunk:
+ * EMG_EINVAL otherwise); cnt_gt / cnt_eq as emg_eval_rescore_pairs continues them. */
+int emg_eval_prefilter_f16_ties(int model, const void* q_f16, int64_t ldq, const int32_t* pos_int, const float* band,
+                                int64_t n_rows, const void* ent_f16, int64_t n_cand, int64_t ld_ent, int64_t ent_offset,
+                                int32_t k_pad, float scale, int32_t* cnt_gt, int32_t* cnt_eq, uint64_t* pairs,
+                                uint32_t* pair_count, int64_t pairs_capacity, void* stream);
 int emg_eval_rescore_pairs(int model, const float* Q, int64_t ldq, const int32_t* pos_int, const float* ent,
                            int64_t ld_ent, int64_t ent_offset, int32_t k_int, float scale, const uint64_t* pairs,
                            int64_t pairs_capacity, const uint32_t* pair_count, int64_t n_segments, int32_t* cnt_gt,

@@ -303,10 +303,15 @@ def sharded_overflow_worker(rank, world, out_dir):
     dev0 = torch.device("cuda")
     ent, rel = alloc_table(n_ent, 2 * k, dev0, init=E), alloc_table(n_rel, 2 * k, dev0, init=R)
     T = np.stack([rs.randint(0, n_ent, 160), rs.randint(0, n_rel, 160), rs.randint(0, n_ent, 160)], 1).astype(np.int32)
-    st = {}
+    st, st_t = {}, {}
+    os.environ["EMG_PREFILTER_TIES"] = "0"      # (round 6: the prefilter's second form PROVES such ties; off here: the overflow path is what this test is about)
     got = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision=2,
                               shard=(rank, world), stats=st)
+    os.environ.pop("EMG_PREFILTER_TIES")
     auto = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision="auto",
                                shard=(rank, world))
+    ties = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision=2,
+                               shard=(rank, world), stats=st_t)      # ... and on: the same ranks, no tile redone
     want = rank_triples_device(L.COMPLEX, ent, rel, 2 * k, 1.0, T, "s,o", "worst", filter_triples=T, precision=0)
-    np.savez(os.path.join(out_dir, "res_%d.npz" % rank), got=got, auto=auto, want=want, fallback=st.get("fallback", 0))
+    np.savez(os.path.join(out_dir, "res_%d.npz" % rank), got=got, auto=auto, want=want, ties=ties, fallback=st.get("fallback", 0),
+             ties_fallback=st_t.get("fallback", 0), ties_taken=int(bool(st_t.get("prove_ties"))))

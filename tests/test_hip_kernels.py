@@ -1410,6 +1410,52 @@ def test_prefilter_bitmap_form_equals_the_emitting_form(monkeypatch, k, n_ent, n
         assert st["fallback"] >= 1
 
 
+@pytest.mark.parametrize("model,k,scale", [("ComplEx", 200, 2.45e-3), ("DistMult", 200, 4e-3), ("HolE", 100, 3e-3), ("DistMult", 300, 2e-3),
+                                           ("ComplEx", 200, 0.02), ("DistMult", 64, 0.05)])
+def test_prefilter_proves_ties_on_tables_of_small_scores(monkeypatch, model, k, scale):
+    """The reference compares int32(score * 1e5) (EmbeddingModel.py:2010-2014): on a freshly initialised table (Glorot limit 2.45e-3 at
+    1M x 400) every score truncates to 0 and EVERY candidate ties with the positive.  The prefilter's plain form calls a tie undecided;
+    its second form (emg_eval_prefilter_f16_ties, MODE 4 of csrc/emg_rank_bf16.hip) proves it: an accumulator inside the positive's
+    integer cell by more than the band is counted into cnt_eq.  precision 2 must (a) return the exact kernel's ranks for every side /
+    strategy / filter, (b) have taken the ties form without a single tile redone by the exact kernel (tables of scale 2e-3 ... 5e-2:
+    all ties, or a mix of ties and decided candidates), and (c) fall back exactly as before with EMG_PREFILTER_TIES=0.
+    Planted: rows scaled up so that some candidates are decided greater / smaller, duplicates of the positive's row (exact ties)."""
+    from emgraph_amd.evaluation import rank_triples_device
+    from emgraph_amd.evaluation import ranking as RK
+    d = dev()
+    n_ent, nq = 30000, 260
+    E, R, ki = make_tables(model, k, n_ent, 4, seed=k, scale=scale)
+    rs = np.random.RandomState(k)
+    if scale >= 3e-3:                                # (the pure case — every candidate a tie — must not redo a single tile)
+        big = rs.randint(0, n_ent, 300)
+        E[big] *= 30.0                               # a few hundred entities whose scores reach the cell's ends or leave it
+    T = np.stack([rs.randint(0, n_ent, nq), rs.randint(0, 4, nq), rs.randint(0, n_ent, nq)], 1).astype(np.int32)
+    E[rs.randint(0, n_ent, 20)] = E[T[:20, 2]]       # exact duplicates of some true objects
+    F = np.concatenate([T, np.stack([rs.randint(0, n_ent, 3000), rs.randint(0, 4, 3000), rs.randint(0, n_ent, 3000)], 1)]).astype(np.int32)
+    sc = scale_of(model, k)
+    Et, Rt = cu(E), cu(R)
+    tabs = RK.PrefilterTables(Et, ki)
+    took = 0
+    for side in ("s,o", "s+o", "o"):
+        for strategy in ("worst", "best", "middle"):
+            for filt in (None, F):
+                exact = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt)
+                st = {}
+                fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, ent_f16=tabs, stats=st)
+                np.testing.assert_array_equal(fast, exact, err_msg=str((side, strategy, filt is not None, st)))
+                if st.get("prove_ties"):
+                    took += 1
+                    if scale < 3e-3:
+                        assert st.get("fallback", 0) == 0 and st.get("pairs", 0) < 0.001 * fast.size * n_ent, st
+    assert took > 0 or scale >= 3e-3, "the ties form was never taken on a table of tiny scores"
+    monkeypatch.setenv("EMG_PREFILTER_TIES", "0")
+    st = {}
+    old = rank_triples_device(MID[model], Et, Rt, ki, sc, T, "s,o", "worst", precision=2, stats=st)
+    monkeypatch.delenv("EMG_PREFILTER_TIES")
+    np.testing.assert_array_equal(old, rank_triples_device(MID[model], Et, Rt, ki, sc, T, "s,o", "worst"))
+    assert not st.get("prove_ties")
+
+
 def test_prefilter_probe_sends_an_undecidable_table_to_the_exact_kernel(monkeypatch):
     """precision 2 first runs 128 of the call's triples through the prefilter alone and reads the undecided fraction
     (ranking._prefilter_probe).  A table whose rows are all but equal (a freshly initialised model looks like this to the band)

@@ -223,6 +223,8 @@ def test_sharded_exact_fast_ranking_survives_pair_buffer_overflow(tmp_path):
         assert int(r["fallback"]) >= 1, "the test is meant to overflow the pair buffer"
         np.testing.assert_array_equal(r["got"], r["want"])
         np.testing.assert_array_equal(r["auto"], r["want"])
+        np.testing.assert_array_equal(r["ties"], r["want"])
+        assert int(r["ties_taken"]) == 1 and int(r["ties_fallback"]) == 0, "the ties form of the prefilter decides this table on every rank"
 
 
 @pytest.mark.gpu
