@@ -505,6 +505,28 @@ def run_eval(r, args):
                      # half-precision dense peak at which this parity-exact mode delivers the 1-vs-all product
                      "mfma_frac_all_kernels": round(kflops / (stf["count_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
                      "kernels": "count_mfma_bf16_v4_kernel<25,3> (v_mfma_f32_32x32x16_f16, transposed products, undecided candidates as a bitmap) + prefilter_compact_kernel + rescore_segment_kernel (segments of >= 512 pairs: query rows in LDS) / rescore_pairs_kernel"}
+    # a FRESH model (round 6): Glorot-scale tables (limit 2.45e-3 at 1M x 400) — every score truncates to the comparison integer 0, every
+    # candidate ties with the positive; the prefilter's second form proves the ties (emg_eval_prefilter_f16_ties), the plain form could
+    # only hand the whole tile to the exact kernel.  What early stopping's first evaluations and a one-epoch model see.
+    fresh_e = alloc_table(w["n_ent"], k_int, dev, init=None)
+    fresh_r = alloc_table(w["n_rel"], k_int, dev, init=None)
+    with torch.no_grad():
+        fresh_e.uniform_(-2.45e-3, 2.45e-3, generator=torch.Generator(device=dev).manual_seed(11))
+        fresh_r.uniform_(-7.7e-2, 7.7e-2, generator=torch.Generator(device=dev).manual_seed(12))
+    ent_keep, rel_keep = ent, rel
+    ent, rel = fresh_e, fresh_r
+    try:
+        rx, dtx, stx = timed(T)
+        rt_, dtt, stt = timed(T, precision=2, ent_f16=PrefilterTables(ent, k_int))
+        assert np.array_equal(rt_, rx), "precision 2 ranks differ from the exact path on the fresh table"
+        ex["fresh_model"] = {"value": round(n_ranks / dtt, 1), "unit": "ranks/s", "seconds": round(dtt, 4), "equal_to_exact_f32_ranks": True,
+                             "exact_f32_ranks_per_s": round(n_ranks / dtx, 1), "proved_ties": bool(stt.get("prove_ties")),
+                             "tiles_redone_by_exact_kernel": stt.get("fallback", 0), "undecided_pairs": stt.get("pairs", 0),
+                             "kernel_ms": round(stt["count_ms"], 3),
+                             "kernels": "count_mfma_bf16_v3_kernel<25,4,4> (four thresholds per row: greater | proven tie | the two bands) + prefilter_compact_kernel + rescore_pairs_kernel"}
+    finally:
+        ent, rel = ent_keep, rel_keep
+        del fresh_e, fresh_r
     # what the API call pays when nothing is cached (get_ranks / early stopping pass no tables: the half-precision copy, the
     # norm bounds and the range are rebuilt inside the call) — the figures above build them once per evaluation run, outside
     ru, dtu, _ = timed(T, precision=2)
@@ -757,10 +779,10 @@ def summary_line(line, detail_file=DETAIL_FILE):
             sw = b.get("query_tile_sweep")
             if sw:
                 e["bf16"]["frac_by_query_tile"] = {k.replace("B_q=", ""): v.get("MFMA_frac") for k, v in sw.items()}
-        for label, short in (("random_positives", "exact_fast_random"), ("planted_positives", "exact_fast_planted")):
+        for label, short in (("random_positives", "exact_fast_random"), ("planted_positives", "exact_fast_planted"), ("fresh_model", "exact_fast_fresh")):
             x = ev.get("exact_fast", {}).get(label)
             if x:
-                e[short] = _pick(x, "value", "equal_to_exact_f32_ranks", "undecided_fraction", "kernel_ms", "mfma_frac_all_kernels")
+                e[short] = _pick(x, "value", "equal_to_exact_f32_ranks", "undecided_fraction", "kernel_ms", "mfma_frac_all_kernels", "exact_f32_ranks_per_s", "proved_ties")
         s["eval"] = e
     cpu = line.get("cpu_baseline")
     if cpu:
