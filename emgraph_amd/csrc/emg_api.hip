@@ -173,6 +173,22 @@ extern "C" int emg_rank_1vsall(int model, const float* ent, int64_t n_ent, int64
                                  hipStreamSynchronize(st) != hipSuccess))
                 rc = fail(EMG_EHIP, "emg_rank_1vsall: reading the prefilter's overflow flag failed");
             exact = over != 0;
+            if (rc == EMG_OK && exact && !l2 && !sad && pair_cap / n_seg >= 2048) {
+                // too many undecided candidates: on a table of small scores they are TIES with the positive, which the prefilter's second
+                // form proves (emg_eval_prefilter_f16_ties: the fresh model, the first epochs) — once more through it before the exact kernel
+                if (hipMemsetAsync(cnt, 0, (size_t)2 * n_rows * 4, st) != hipSuccess) rc = fail(EMG_EHIP, "emg_rank_1vsall: memset failed");
+                const int r = rc != EMG_OK ? rc : emg_eval_prefilter_f16_ties(model, Qh, ldb, pos_int, band, n_rows, Eh, n_ent, ldb, 0, (k_int + 15) / 16 * 16,
+                                                                              scale, cnt, cnt + n_rows, pairs, pcount, pair_cap, stream);
+                if (r == EMG_OK) {
+                    step(emg_eval_rescore_pairs_rows(model, Q, ldq, pos_int, ent, ld_ent, 0, k_int, scale, pairs, pair_cap, pcount, n_seg,
+                                                     emg_eval_prefilter_waves((k_int + 15) / 16 * 16), 32, cnt, cnt + n_rows, stream));
+                    over = 0;
+                    if (rc == EMG_OK && (hipMemcpyAsync(&over, pcount + n_seg, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                         hipStreamSynchronize(st) != hipSuccess))
+                        rc = fail(EMG_EHIP, "emg_rank_1vsall: reading the prefilter's overflow flag failed");
+                    exact = over != 0;
+                }   // (any error of the second form: the exact kernel, below)
+            }
         }
         if (rc == EMG_OK && exact) {
             if (hipMemsetAsync(cnt, 0, (size_t)2 * n_rows * 4, st) != hipSuccess) rc = fail(EMG_EHIP, "emg_rank_1vsall: memset failed");

@@ -1081,8 +1081,10 @@ def test_rank_1vsall_one_call_precision_2_equals_precision_0(model, k, n_ent, nq
 
 @pytest.mark.parametrize("model,k", [("TransE_L1", 200), ("TransE_L2", 198), ("DistMult", 200)])
 def test_rank_1vsall_one_call_precision_2_overflow_falls_back_to_the_exact_kernel(model, k):
-    """tables so small that every comparison integer is 0: every candidate is undecided, the pair buffer overflows and
-    emg_rank_1vsall(precision_mode = 2) must redo the tile with the exact kernel — same ranks as precision_mode 0"""
+    """tables so small that every comparison integer is 0: every candidate is undecided for the plain prefilter, the pair buffer
+    overflows and emg_rank_1vsall(precision_mode = 2) must get the ranks of precision_mode 0 all the same — TransE: by redoing the
+    tile with the exact kernel; DistMult (round 6): by the prefilter's second form, which proves the ties, and the exact kernel
+    only if that overflows too"""
     from emgraph_amd import _lib as L
     d = dev()
     n_ent, nq = 12000, 200
