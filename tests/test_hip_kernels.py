@@ -1458,6 +1458,40 @@ def test_prefilter_proves_ties_on_tables_of_small_scores(monkeypatch, model, k, 
     assert not st.get("prove_ties")
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+def test_ties_prefilter_random_tables_equal_exact(seed):
+    """soak of the ties-proving prefilter: tables between "every score truncates to the comparison integer 0" and "a few ties":
+    scales 1e-4 ... 5e-2, a random share of rows scaled up by 3 ... 100 (scores at the cell's ends, outside it, far outside it),
+    duplicates of true entities, random model / width / table size / side / strategy / filter — precision 2 (whichever form its
+    probes pick) must return the ranks of precision 0"""
+    from emgraph_amd.evaluation import rank_triples_device
+    dev()
+    rs = np.random.RandomState(21000 + seed)
+    for _ in range(3):
+        model = ("DistMult", "ComplEx", "HolE")[rs.randint(0, 3)]
+        k = int(rs.choice([16, 50, 100, 104, 200, 300]))
+        n_ent, nq = int(rs.randint(4200, 60000)), int(rs.randint(130, 500))
+        scale = 10.0 ** rs.uniform(-4, -1.3)
+        E, R, ki = make_tables(model, k, n_ent, 5, seed=seed * 11 + k, scale=scale)
+        if rs.randint(0, 2):
+            R = (R * F32(10.0 ** rs.uniform(0, 1.5))).astype(F32)                     # (Glorot relations are larger than Glorot entities)
+        nbig = int(rs.choice([0, 0, 30, 1000, n_ent // 4]))
+        if nbig:
+            E[rs.randint(0, n_ent, nbig)] *= F32(rs.choice([3.0, 10.0, 30.0, 100.0]))
+        pool = rs.randint(0, n_ent, 80)
+        T = np.stack([rs.choice(pool, nq), rs.randint(0, 5, nq), rs.choice(pool, nq)], 1).astype(np.int32)
+        E[rs.randint(0, n_ent, 25)] = E[rs.choice(pool, 25)]
+        side = ("s,o", "s+o", "s", "o")[rs.randint(0, 4)]
+        strategy = ("worst", "best", "middle")[rs.randint(0, 3)]
+        filt = np.concatenate([T, np.stack([rs.randint(0, n_ent, 2000), rs.randint(0, 5, 2000), rs.randint(0, n_ent, 2000)], 1)]).astype(np.int32) if rs.randint(0, 2) else None
+        sc = scale_of(model, k)
+        Et, Rt = cu(E), cu(R)
+        exact = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt)
+        st = {}
+        fast = rank_triples_device(MID[model], Et, Rt, ki, sc, T, side, strategy, filter_triples=filt, precision=2, stats=st)
+        np.testing.assert_array_equal(fast, exact, err_msg=str((model, k, n_ent, nq, scale, nbig, side, strategy, filt is not None, st)))
+
+
 def test_prefilter_probe_sends_an_undecidable_table_to_the_exact_kernel(monkeypatch):
     """precision 2 first runs 128 of the call's triples through the prefilter alone and reads the undecided fraction
     (ranking._prefilter_probe).  A table whose rows are all but equal (a freshly initialised model looks like this to the band)
