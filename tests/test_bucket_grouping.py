@@ -249,7 +249,8 @@ def test_fit_on_a_large_table_gives_the_same_bits_under_either_grouping(monkeypa
     for x, y in zip(a[2], b[2]):
         np.testing.assert_array_equal(x, y)
     if reg:
-        assert a[3] == pytest.approx(b[3], rel=1e-12)     # (the regulariser's value: double atomics from several kernels)
+        assert a[3] == pytest.approx(b[3], rel=1e-8)      # (the regulariser's value: FLOAT partial sums per wave added as doubles, and the partition
+        #  of the rows over the waves follows the grouping's lists: 1.6e-11 apart in the round-6 soak, once past 1e-12 in a full-suite run)
     else:
         assert a[3] == b[3]
     assert not np.array_equal(a[0], E0)

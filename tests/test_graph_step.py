@@ -49,7 +49,11 @@ def test_graph_steps_equal_single_steps_bit_for_bit(monkeypatch, name, k, loss, 
     Es, Rs, Ls, ms = _fit(monkeypatch, False, name, k, X, ent0, rel0, **kw)
     np.testing.assert_array_equal(Eg, Es)
     np.testing.assert_array_equal(Rg, Rs)
-    assert Lg == Ls
+    if "regularizer" in extra:   # (the regulariser's value: FLOAT partial sums per wave added as doubles — the riders of a graph step change
+        #  which wave holds which rows: equal to ~1e-12, not always to the last bit; the soak below found 1 in 50 runs off)
+        np.testing.assert_allclose(Lg, Ls, rtol=1e-9)
+    else:
+        assert Lg == Ls
     assert mg._trainer.step_count == ms._trainer.step_count == 18
     # a second fit of the same object (plan re-created) reproduces the first: the refit-determinism the reference tests
     # (tests/emgraph/models/test_models.py:338-367)

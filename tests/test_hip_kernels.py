@@ -1131,7 +1131,9 @@ def test_train_step_one_call_matches_trainer(model, loss, opt, sides):
     assert torch.equal(tr.ent, tr2.ent) and torch.equal(tr.rel, tr2.rel)
     for a_, b_ in zip(tr.state_ent + tr.state_rel, tr2.state_ent + tr2.state_rel):
         assert (a_ is None and b_ is None) or torch.equal(a_, b_)
-    assert tr.read_loss() == tr2.read_loss()
+    # (fused-loss path: float-valued partials, exact in any order; separate-loss path — multiclass_nll, self_adversarial — double partials whose
+    #  last bit follows the arrival order of the workgroups: 7 of 40 000 runs of the round-6 soak)
+    assert tr.read_loss() == pytest.approx(tr2.read_loss(), rel=1e-12)
 
 
 @pytest.mark.parametrize("order,loss,opt", [(3.0, "pairwise", "adagrad"), (float("inf"), "nll", "sgd")])
@@ -1161,7 +1163,9 @@ def test_train_step_one_call_transe_any_norm(order, loss, opt):
     torch.cuda.synchronize()
     assert torch.equal(tr.ent, tr2.ent) and torch.equal(tr.rel, tr2.rel)
     assert not torch.equal(tr.ent[:, :ki].cpu(), torch.from_numpy(E))
-    assert tr.read_loss() == tr2.read_loss()
+    # (fused-loss path: float-valued partials, exact in any order; separate-loss path — multiclass_nll, self_adversarial — double partials whose
+    #  last bit follows the arrival order of the workgroups: 7 of 40 000 runs of the round-6 soak)
+    assert tr.read_loss() == pytest.approx(tr2.read_loss(), rel=1e-12)
 
 
 # ------------------------------------------------------------------------------------------------

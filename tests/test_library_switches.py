@@ -55,7 +55,7 @@ def test_compile_time_optimizer_forms_of_the_apply_give_the_same_bits(tmp_path, 
 def test_sgd_with_the_lp_regulariser_folds_the_same_bits_in_every_form(tmp_path, name, k, loss, p):
     """plain SGD + LP: the apply's compile-time form for p = 2 (apply_segments_kernel<..., kFixSgdLp2>) against the run-time switch,
     and the two-multiplication fold lp_fold_p2 that every p = 2 path takes since round 5 (lambda 2 |w| sgn w = fl(2 lambda w)) — the
-    tables byte for byte; the regulariser's value is a sum of double atomics from several kernels: equal to 1e-12.  p = 3 keeps the
+    tables byte for byte; the regulariser's value is a sum of float partials added as double atomics from several kernels: equal to 1e-9.  p = 3 keeps the
     generic fold in both legs (the switch must not touch it)."""
     a = _run(tmp_path, "fix", {"EMG_APPLY_FIX": "1"}, name, k, loss, "sgd", "lp%d" % p)
     b = _run(tmp_path, "switch", {"EMG_APPLY_FIX": "0"}, name, k, loss, "sgd", "lp%d" % p)
@@ -63,4 +63,4 @@ def test_sgd_with_the_lp_regulariser_folds_the_same_bits_in_every_form(tmp_path,
     for other in (b, c):
         for key in ("E", "R"):
             assert a[key].tobytes() == other[key].tobytes(), "%s differs" % key
-        np.testing.assert_allclose(a["losses"], other["losses"], rtol=1e-12)
+        np.testing.assert_allclose(a["losses"], other["losses"], rtol=1e-9)   # (float partials per wave, added as doubles: the partition of the rows over the waves differs between the forms)
