@@ -409,8 +409,12 @@ class EmbeddingModel(abc.ABC):  # noqa: B024
             tr.run_batches([batch_args(epoch, batch) for batch in range(1, self.batches_count + 1)])
             loss_epoch = tr.read_loss()
             self.epoch_losses.append(loss_epoch)
-            if np.isnan(loss_epoch) or np.isinf(loss_epoch):  # EmbeddingModel.py:1422-1427 (per epoch here)
-                msg = "Loss is {}. Please change the hyperparameters.".format(loss_epoch)
+            # EmbeddingModel.py:1422-1427 (per epoch here).  The reference's loss is a float32 tensor: a loss beyond float32's range IS inf
+            # there; the device accumulates the epoch in a double, which would let such a run pass (seed 96078 of the round-6 soak)
+            with np.errstate(over="ignore"):
+                loss32 = np.float32(loss_epoch)
+            if np.isnan(loss32) or np.isinf(loss32):
+                msg = "Loss is {}. Please change the hyperparameters.".format(loss32)
                 logger.error(msg)
                 raise ValueError(msg)
             if self.verbose:
