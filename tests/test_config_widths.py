@@ -785,7 +785,7 @@ def test_inplace_forms_random_configurations_do_not_change_bits(monkeypatch, see
             np.testing.assert_array_equal(x, y, err_msg=what)
         if reg:
             assert a[4] == pytest.approx(other[4], rel=1e-8), what
-        elif abs(a[4]) > 1e15:   # a diverged run (seed 2248: -8.8e24): float partials that far apart no longer add exactly in a double
+        elif abs(a[4]) > 1e9:    # a diverged run (seeds 2248: -8.8e24, 4193 / 10036: 1e13): float partials that far apart no longer add exactly in a double
             assert a[4] == pytest.approx(other[4], rel=1e-12), what
         else:
             assert a[4] == other[4], what
