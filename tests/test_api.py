@@ -229,11 +229,11 @@ def test_fit_transe_any_norm_matches_oracle_training_loop(norm, loss, opt):
     np.testing.assert_allclose(m.predict(Xt), orc.score_triples(omodel, got_E, got_R, Xt.astype(np.int32)), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_FUZZ_SEEDS", "10"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_FUZZ_OFFSET", "0")), int(os.environ.get("EMG_FUZZ_OFFSET", "0")) + int(os.environ.get("EMG_FUZZ_SEEDS", "10"))))
 def test_fit_random_configurations_match_oracle_training_loop(seed):
     """soak over the configuration space of fit(): a random model / width / eta / loss / optimizer / corruption-side list /
     graph shape (uniform or hub-heavy) per seed, trained for a few batches and compared with the oracle loop driven by the
-    same Philox draws (same tolerances as the hand-picked cases above).  EMG_FUZZ_SEEDS widens it."""
+    same Philox draws (same tolerances as the hand-picked cases above).  EMG_FUZZ_SEEDS widens it, EMG_FUZZ_OFFSET starts it elsewhere."""
     rs = np.random.RandomState(7000 + seed)
     name = str(rs.choice(["TransE", "TransE", "DistMult", "ComplEx", "HolE"]))
     norm = int(rs.choice([1, 2]))
