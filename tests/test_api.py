@@ -36,7 +36,7 @@ def synth_graph(n_ent=60, n_rel=4, n=600, seed=0):
 # ------------------------------------------------------------------------------------------------
 def _kink_distance(model, E, R, xb, x_negs, eta, loss, reg, k):
     """how close this step comes to a point where the loss's (sub)gradient jumps: the hinge of pairwise / absolute_margin at 0
-    (pairwise.py:66-70, absolute_margin.py), TransE-L1's sign per coordinate (TransE.py:208-216), the LP regulariser's sign at p = 1
+    (pairwise.py:66-70, absolute_margin.py), TransE-L1's sign per coordinate and TransE-L2's direction at distance zero (TransE.py:208-216), the LP regulariser's sign at p = 1
     (lp.py:107-113).  Relative: a score distance over 1 + |score|, a coordinate distance over the coordinate scale."""
     d = np.inf
     if loss in ("pairwise", "absolute_margin"):
@@ -51,6 +51,12 @@ def _kink_distance(model, E, R, xb, x_negs, eta, loss, reg, k):
             nz = np.abs(dd[dd != 0])          # (an exact zero has gradient 0 in both arithmetics: s == o collisions)
             if nz.size:
                 d = min(d, float(nz.min() / max(1e-30, np.abs(E).mean())))
+    if model == "TransE_L2":     # the norm's gradient d / ||d|| has no direction at d = 0 (TransE.py:208-216, ord = 2)
+        for xx in [xb] + list(x_negs):
+            nn = np.linalg.norm(((E[xx[:, 0]] + R[xx[:, 1]]) - E[xx[:, 2]]).astype(np.float64), axis=1)
+            nz = nn[nn != 0]
+            if nz.size:
+                d = min(d, float(nz.min() / max(1e-30, np.abs(E).mean() * np.sqrt(E.shape[1]))))
     if reg is not None and reg["p"] == 1:
         for W in (E, R):
             nz = np.abs(W[W != 0])
