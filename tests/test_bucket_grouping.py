@@ -307,7 +307,7 @@ def test_standalone_relation_apply_with_adams_dense_pass_after_a_bucket_grouping
         assert not np.array_equal(out["bucket"][0][untouched], W0[untouched])
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_bucket_grouping_random_shapes_equal_counting_grouping(seed):
     """soak of the bucket grouping against the counting grouping: random batch size (1 ... 40 000), eta, corruption sides, table
     sizes from the smallest the bucket form takes (131 073 rows) to 3 M, 1 ... 5000 relations, uniform / hub-heavy / pooled
@@ -346,7 +346,7 @@ def test_bucket_grouping_random_shapes_equal_counting_grouping(seed):
     compare(got, ref, B, factored, n_ent, n_rel)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
 def test_fit_on_a_large_table_random_configurations_same_bits_under_either_grouping(monkeypatch, seed):
     """soak of the training step on tables the bucket grouping takes: a random model, optimizer (Keras Adam with its dense pass inside
     the apply launch for the relation table, deferred or not; Adagrad; momentum; SGD with the in-place forms), regulariser, width,

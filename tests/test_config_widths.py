@@ -723,7 +723,7 @@ def test_more_negatives_than_lanes_per_group(monkeypatch, model, k, eta, opt):
     assert not np.array_equal(a[0], E0)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
 def test_inplace_forms_random_configurations_do_not_change_bits(monkeypatch, seed):
     """soak of the scoring kernel's in-place forms (csrc/emg_score_kernels.hpp::ip_traits: plain SGD; the stateful optimizers with
     their state rows in the rolling window or read at the update; Keras Adam replayed under the deferred pass; SGD + LP with its

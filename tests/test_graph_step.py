@@ -170,7 +170,7 @@ def test_fit_with_deferred_adam_decay_equals_dense_fit(monkeypatch, name, k):
 import os  # noqa: E402
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "4"))))
 def test_graph_steps_random_configurations_equal_single_steps(monkeypatch, seed):
     """soak of the captured step graph through fit(): a random model, width, eta, loss, optimizer (with an SGD learning-rate schedule
     now and then), regulariser, corruption sides / pool, graph size, batch count (short last batches, one-batch epochs) and epoch

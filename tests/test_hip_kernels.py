@@ -689,7 +689,7 @@ def test_bf16_ranks_exact_on_bf16_representable_data(model):
                 np.testing.assert_array_equal(got, exp, err_msg=str((side, strategy, filt is not None, subset is not None)))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_ranks_random_protocols_equal_literal_oracle(seed):
     """soak of the ranking protocol against the oracle's literal per-triple evaluation (generate_corruptions_for_eval +
     score + perform_comparison + filter lookups): random model, width, side, strategy, filter set, candidate
@@ -1462,7 +1462,7 @@ def test_prefilter_proves_ties_on_tables_of_small_scores(monkeypatch, model, k, 
     assert not st.get("prove_ties")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_ties_prefilter_random_tables_equal_exact(seed):
     """soak of the ties-proving prefilter: tables between "every score truncates to the comparison integer 0" and "a few ties":
     scales 1e-4 ... 5e-2, a random share of rows scaled up by 3 ... 100 (scores at the cell's ends, outside it, far outside it),
@@ -1624,7 +1624,7 @@ def test_l2_prefilter_ranks_equal_exact_ranks_transe_l2(k, n_ent, nq, scale, hug
         assert used > 0        # the prefilter ran
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_contraction_prefilter_random_shapes_equal_exact(seed, monkeypatch):
     """soak of the half-precision MFMA prefilter in its three forms — the bitmap form in the 64-rows-per-wave kernel (400 / 208
     columns), the bitmap form in the register-stationary kernel (every other width, EMG_PRE_V4=0 everywhere) and the emitting form
@@ -1663,7 +1663,7 @@ def test_contraction_prefilter_random_shapes_equal_exact(seed, monkeypatch):
             np.testing.assert_array_equal(fast, exact, err_msg=str((model, k, n_ent, nq, scale, side, strategy, filt is not None, env)))
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EMG_SOAK_OFFSET", "0")), int(os.environ.get("EMG_SOAK_OFFSET", "0")) + int(os.environ.get("EMG_SOAK_SEEDS", "6"))))
 def test_transe_prefilters_random_shapes_equal_exact(seed):
     """soak of both TransE prefilters: random widths, table scales over four decades, heavy-tailed tables, relation scales
     far from the entity scale, query sets with many repeated entities — precision 2 must return the ranks of precision 0"""
